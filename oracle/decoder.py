@@ -1,0 +1,99 @@
+"""Oracle: object-query decoder (fp32, CPU, autograd-capable).  Test infrastructure.
+
+Restates /root/reference/model/tfm_decoder.py (ObjDecoder / Cross_Attention / TransformerDecoder /
+TransformerDecoderLayer.forward_pre with sa_first=True) batch-first.  Dropout is p=0 here: parity is
+defined in eval mode.  The literal `4` of tfm_decoder.py:216 is `T` here
+(identical at T=4).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _ln(x, sd, name, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], eps)
+
+
+def mha(q_in, k_in, v_in, sd, prefix, heads):
+    """nn.MultiheadAttention forward (packed in_proj [q;k;v], scale d^-0.5 on q) -- the op behind
+    tfm_decoder.py:433-441.  Inputs batch-first [B,L,C]; returns [B,Lq,C].  Head-averaged weights
+    (need_weights=True default) are discarded by the caller and not computed."""
+    C = q_in.shape[-1]
+    d = C // heads
+    Wq, Wk, Wv = sd[prefix + ".in_proj_weight"].chunk(3, dim=0)
+    bq, bk, bv = sd[prefix + ".in_proj_bias"].chunk(3, dim=0)
+    B, Lq, Lk = q_in.shape[0], q_in.shape[1], k_in.shape[1]
+    q = F.linear(q_in, Wq, bq).view(B, Lq, heads, d).transpose(1, 2) * (d ** -0.5)
+    k = F.linear(k_in, Wk, bk).view(B, Lk, heads, d).transpose(1, 2)
+    v = F.linear(v_in, Wv, bv).view(B, Lk, heads, d).transpose(1, 2)
+    p = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(B, Lq, C)
+    return F.linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
+
+
+def decoder_layer(tgt, memory, pos, qpos, sd, b, heads):
+    """TransformerDecoderLayer.forward_pre, sa_first -- tfm_decoder.py:430-461 (all LN eps 1e-5)."""
+    a = _ln(tgt, sd, b + "norm1")
+    tgt = tgt + mha(a + qpos, a + qpos, a, sd, b + "self_attn", heads)
+    c = _ln(tgt, sd, b + "norm2")
+    tgt = tgt + mha(c + qpos, memory + pos, memory, sd, b + "multihead_attn", heads)
+    e = _ln(tgt, sd, b + "norm3")
+    ff = F.linear(F.relu(F.linear(e, sd[b + "linear1.weight"], sd[b + "linear1.bias"])),
+                  sd[b + "linear2.weight"], sd[b + "linear2.bias"])
+    return tgt + ff
+
+
+def pos_embed_3d(sd, T, n):
+    """ObjDecoder.construct_3d_pos_embed -- tfm_decoder.py:161-166 -> [T*n, C] (pos_embed[0] unused)."""
+    return (sd["pos_embed"][0, 1:].repeat(T, 1) + sd["temporal_embed"][0, :T].repeat_interleave(n, dim=0))
+
+
+def objdecoder_forward(features, sd, cfg, compute_logits=True):
+    """ObjDecoder.forward -- tfm_decoder.py:183-233 (+ Cross_Attention.forward :76-93,
+    TransformerDecoder.forward :255-295).
+
+    features [B,T,n,F] -> (out dict, hs [L,B,Q,C]).  out['pred_boxes'] [B*T,Q,4] (cx,cy,w,h),
+    out['pred_logits'] [B*T,Q,classes+1], out['aux_outputs'] for layers 0..L-2.
+    """
+    B, T, n, _ = features.shape
+    C, heads, L = cfg.dec_dim, cfg.dec_heads, cfg.dec_layers
+    mem = F.linear(features, sd["proj.weight"]).reshape(B, T * n, C)
+    memory = _ln(mem, sd, "transformer.pre_norm")
+    pos = pos_embed_3d(sd, T, n)[None]
+    qpos = sd["query_embed.weight"][None].expand(B, -1, -1)
+    tgt = torch.zeros_like(qpos)
+    inter = []
+    for l in range(L):
+        tgt = decoder_layer(tgt, memory, pos, qpos, sd, f"transformer.decoder.layers.{l}.", heads)
+        inter.append(_ln(tgt, sd, "transformer.decoder.norm"))
+    hs = torch.stack(inter)                                                   # [L,B,Q,C]
+    Q = hs.shape[2]
+    # frame-conditioned trajectory head (:210-216): cat[hs, frame_index[t]] -> frame_proj
+    fe = sd["frame_index.weight"][:T]
+    cond = torch.cat([hs[:, :, None].expand(L, B, T, Q, C), fe[None, None, :, None, :].expand(L, B, T, Q, C)], -1)
+    cond = F.linear(cond, sd["frame_proj.weight"], sd["frame_proj.bias"]).flatten(1, 2)   # [L,B*T,Q,C]
+    x = cond
+    for i in range(3):
+        x = F.linear(x, sd[f"bbox_embed.layers.{i}.weight"], sd[f"bbox_embed.layers.{i}.bias"])
+        if i < 2:
+            x = F.relu(x)
+    boxes = x.sigmoid()
+    out = {"pred_boxes": boxes[-1]}
+    if compute_logits:
+        logits = F.linear(hs, sd["class_embed.weight"], sd["class_embed.bias"])            # [L,B,Q,K]
+        logits = logits[:, :, None].expand(L, B, T, Q, logits.shape[-1]).flatten(1, 2)
+        out["pred_logits"] = logits[-1]
+        out["aux_outputs"] = [{"pred_logits": logits[l], "pred_boxes": boxes[l]} for l in range(L - 1)]
+    else:
+        out["aux_outputs"] = [{"pred_boxes": boxes[l]} for l in range(L - 1)]
+    return out, hs
+
+
+def txt_proj(x, sd):
+    """ObjDecoder.txt_proj = ReLU -> Linear(768,256) -- tfm_decoder.py:170-171 (ReLU first)."""
+    return F.linear(F.relu(x), sd["txt_proj.1.weight"], sd["txt_proj.1.bias"])
+
+
+def obj_proj(x, sd):
+    """ObjDecoder.obj_proj = Linear -> ReLU -> Linear(256) -- tfm_decoder.py:175-180."""
+    return F.linear(F.relu(F.linear(x, sd["obj_proj.0.weight"], sd["obj_proj.0.bias"])),
+                    sd["obj_proj.2.weight"], sd["obj_proj.2.bias"])

@@ -1,0 +1,116 @@
+"""Emit golden fixtures from the IMPORTED reference (dev container only; needs /root/reference).
+
+    python tests/golden/make_golden.py
+
+Writes tests/golden/step_<cfg>.npz (reduced-width configs that run the identical reference code
+path: D=128, 2 heads of d=64, depth 2, n=256, T in {4,16}; real 512-wide decoder) and
+tests/golden/lsap_scipy.npz (scipy.optimize.linear_sum_assignment known answers incl. ties).
+Inputs/weights are regenerated from seeds by helping_hand_for_egocentric_videos_amd.synth; the
+fixture stores checksums of them so generator drift is detected.  A fixture is data only.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import refglue  # noqa: E402
+from refglue import _refload  # noqa: E402
+from helping_hand_for_egocentric_videos_amd import synth, TINY4, TINY16  # noqa: E402
+
+SEED_W, SEED_B = 4, 9
+
+
+def checksum(t):
+    t = t.double().flatten()
+    return np.array([float(t.sum()), float(t.abs().sum()), float((t * torch.arange(1, t.numel() + 1, dtype=torch.float64) % 7).sum())])
+
+
+def sample(t, k=64):
+    f = t.detach().flatten()
+    idx = torch.linspace(0, f.numel() - 1, min(k, f.numel())).long()
+    return f[idx].numpy()
+
+
+def emit_step(R, cfg, name, B=2):
+    torch.manual_seed(0)
+    esd = synth.encoder_state(cfg, seed=SEED_W)
+    dsd = synth.decoder_state(cfg, seed=SEED_W)
+    batch = synth.make_batch(cfg, B, seed=SEED_B)
+    bb = refglue.build_backbone(R, cfg, esd)
+    dec = refglue.build_decoder(R, cfg, dsd)
+    crit = refglue.build_criterion(R)
+    res = refglue.reference_step(R, bb, dec, crit, batch, cfg)
+    res["total_loss"].backward()
+    out = {"meta_B": np.array(B), "meta_seed_w": np.array(SEED_W), "meta_seed_b": np.array(SEED_B),
+           "in_video_checksum": checksum(batch["video"]), "in_text": batch["text"].numpy(),
+           "in_boxes": batch["boxes"].numpy(), "in_nouns": batch["nouns"].numpy(),
+           "w_enc_checksum": checksum(torch.cat([v.flatten() for v in esd.values()])),
+           "w_dec_checksum": checksum(torch.cat([v.flatten() for v in dsd.values()]))}
+    for k in ("total_loss", "nce_loss", "box_loss_hand", "box_loss_obj", "word_loss", "acc_vt", "acc_tv"):
+        out["loss_" + k] = np.array(float(res[k]))
+    out["fmap_sample"] = res["image_feature_map"][:, ::97, ::7].detach().numpy()
+    out["fmap_checksum"] = checksum(res["image_feature_map"])
+    out["hs"] = res["hs"].detach().numpy()
+    out["pred_boxes"] = res["pred_boxes"].detach().numpy()
+    out["video_embeds"] = res["video_embeds"].detach().numpy()
+    out["text_embeds"] = res["text_embeds"].detach().numpy()
+    out["logits_argmax"] = res["pred_logits"].argmax(-1).numpy()
+    for key in ("idx_hand", "idx_obj"):
+        lens = np.array([len(a) for a, _ in res[key]])
+        out[key + "_len"] = lens
+        out[key + "_rows"] = np.concatenate([a.numpy() for a, _ in res[key]]) if lens.sum() else np.zeros(0, np.int64)
+        out[key + "_cols"] = np.concatenate([b.numpy() for _, b in res[key]]) if lens.sum() else np.zeros(0, np.int64)
+    gn, names = [], []
+    for pname, p in dec.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(pname)
+        gn.append(float(p.grad.norm()))
+        if any(s in pname for s in ("proj.weight", "layers.5.multihead_attn.in_proj_weight", "query_embed", "bbox_embed.layers.2.weight", "layers.0.norm1.weight")):
+            out["grad_sample__" + pname] = sample(p.grad)
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(gn)
+    # EgoMCQ forward (run/test_EgoMCQ.py:56-83) on 2 items with the same weights
+    mcq = synth.make_mcq_item(cfg, 2, seed=SEED_B)
+    with torch.no_grad():
+        q = mcq["video"].shape[0]
+        o = bb(mcq["video"].flatten(0, 1), mcq["text"], return_feature_map=True)
+        grid = o["image_feature_map"][:, 1:].reshape(q * 5, cfg.num_frames, cfg.patches_per_frame, -1)
+        _, hs, _, _ = dec(grid)
+        te = dec.txt_proj(o["text_feature_map"][torch.arange(q), mcq["text"].argmax(-1)])
+        ve = dec.obj_proj(hs[-1])[:, -1].view(q, 5, -1)
+        scores = torch.stack([R.metric.sim_matrix(te[i:i + 1], ve[i])[0] for i in range(q)])
+    out["mcq_scores"] = scores.numpy()
+    np.savez_compressed(os.path.join(HERE, f"step_{name}.npz"), **out)
+    print(name, {k: float(out["loss_" + k]) for k in ("total_loss", "nce_loss", "box_loss_hand", "box_loss_obj", "word_loss")})
+
+
+def emit_lsap():
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(123)
+    costs, shapes, rows, cols, lens = [], [], [], [], []
+    for trial in range(400):
+        nr, nc = [(10, 2), (2, 2), (12, 4), (10, 1), (2, 1), (12, 3), (2, 0), (3, 7), (5, 5), (1, 1)][trial % 10]
+        if trial % 3 == 0:
+            c = rng.integers(0, 3, (nr, nc)).astype(np.float64)
+        elif trial % 3 == 1:
+            c = rng.standard_normal((nr, nc)).astype(np.float32).astype(np.float64)
+        else:
+            c = np.round(rng.standard_normal((nr, nc)), 1)
+        r, k = linear_sum_assignment(c)
+        costs.append(c.flatten()); shapes.append((nr, nc)); rows.append(r); cols.append(k); lens.append(len(r))
+    np.savez_compressed(os.path.join(HERE, "lsap_scipy.npz"), costs=np.concatenate(costs), shapes=np.array(shapes),
+                        rows=np.concatenate(rows), cols=np.concatenate(cols), lens=np.array(lens))
+    print("lsap", len(lens))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    R = _refload.load()
+    emit_step(R, TINY4, "tiny4")
+    emit_step(R, TINY16, "tiny16")
+    emit_lsap()

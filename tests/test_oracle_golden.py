@@ -1,0 +1,81 @@
+"""Oracle vs the committed golden fixtures (emitted by tests/golden/make_golden.py from the imported
+reference).  Runs anywhere (no reference, no GPU): this is what keeps the oracle honest on the GPU box."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helping_hand_for_egocentric_videos_amd import synth, TINY4, TINY16
+from oracle import step as OS
+from oracle.lsap import linear_sum_assignment
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _checksum(t):
+    t = t.double().flatten()
+    return np.array([float(t.sum()), float(t.abs().sum()), float((t * torch.arange(1, t.numel() + 1, dtype=torch.float64) % 7).sum())])
+
+
+def _sample(t, k=64):
+    f = t.detach().flatten()
+    idx = torch.linspace(0, f.numel() - 1, min(k, f.numel())).long()
+    return f[idx].numpy()
+
+
+def test_lsap_known_answers():
+    g = np.load(os.path.join(GOLD, "lsap_scipy.npz"))
+    co, ro, off = 0, 0, 0
+    for (nr, nc), n in zip(g["shapes"], g["lens"]):
+        c = g["costs"][co:co + nr * nc].reshape(nr, nc)
+        co += nr * nc
+        r, k = linear_sum_assignment(c)
+        assert r.dtype == np.int64 and k.dtype == np.int64
+        assert np.array_equal(r, g["rows"][ro:ro + n]) and np.array_equal(k, g["cols"][ro:ro + n])
+        ro += n
+
+
+@pytest.mark.parametrize("cfg,name", [(TINY4, "tiny4"), (TINY16, "tiny16")])
+def test_step_against_reference_golden(cfg, name):
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    g = np.load(os.path.join(GOLD, f"step_{name}.npz"))
+    B = int(g["meta_B"])
+    esd = synth.encoder_state(cfg, seed=int(g["meta_seed_w"]))
+    dsd = synth.decoder_state(cfg, seed=int(g["meta_seed_w"]))
+    batch = synth.make_batch(cfg, B, seed=int(g["meta_seed_b"]))
+    # generator drift guard: inputs and weights are regenerated from seeds
+    np.testing.assert_allclose(_checksum(batch["video"]), g["in_video_checksum"], rtol=1e-9)
+    assert np.array_equal(batch["text"].numpy(), g["in_text"])
+    np.testing.assert_array_equal(batch["boxes"].numpy(), g["in_boxes"])
+    np.testing.assert_allclose(_checksum(torch.cat([v.flatten() for v in esd.values()])), g["w_enc_checksum"], rtol=1e-9)
+    np.testing.assert_allclose(_checksum(torch.cat([v.flatten() for v in dsd.values()])), g["w_dec_checksum"], rtol=1e-9)
+
+    params = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    res = OS.step_losses(esd, params, batch, cfg)
+    for k in ("total_loss", "nce_loss", "box_loss_hand", "box_loss_obj", "word_loss", "acc_vt", "acc_tv"):
+        np.testing.assert_allclose(float(res[k]), float(g["loss_" + k]), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(res["image_feature_map"][:, ::97, ::7].numpy(), g["fmap_sample"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(res["hs"].detach().numpy(), g["hs"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(res["pred_boxes"].detach().numpy(), g["pred_boxes"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(res["video_embeds"].detach().numpy(), g["video_embeds"], rtol=1e-4, atol=1e-5)
+    for key in ("idx_hand", "idx_obj"):
+        rows = np.concatenate([a.numpy() for a, _ in res[key]])
+        cols = np.concatenate([b.numpy() for _, b in res[key]])
+        assert np.array_equal(np.array([len(a) for a, _ in res[key]]), g[key + "_len"])
+        assert np.array_equal(rows, g[key + "_rows"]) and np.array_equal(cols, g[key + "_cols"])
+    res["total_loss"].backward()
+    norms = dict(zip(g["grad_names"].tolist(), g["grad_norms"].tolist()))
+    got = {k for k, p in params.items() if p.grad is not None}
+    assert got == set(norms)
+    for k, v in norms.items():
+        np.testing.assert_allclose(float(params[k].grad.norm()), v, rtol=1e-4, atol=1e-7)
+    for key in g.files:
+        if key.startswith("grad_sample__"):
+            pn = key[len("grad_sample__"):]
+            scale = np.abs(g[key]).max() + 1e-12
+            assert np.abs(_sample(params[pn].grad) - g[key]).max() <= 1e-4 * scale
+    # EgoMCQ forward
+    mcq = synth.make_mcq_item(cfg, 2, seed=int(g["meta_seed_b"]))
+    scores = OS.mcq_forward(esd, dsd, mcq["video"], mcq["text"], cfg)
+    np.testing.assert_allclose(scores.numpy(), g["mcq_scores"], rtol=1e-4, atol=1e-5)
