@@ -1,0 +1,66 @@
+"""ctypes binding of libhh.so (C ABI declared in include/hh.h).  There is NO fallback: if the library is
+missing or a call fails, a RuntimeError is raised (the product path never routes through CPU code)."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhh.so")
+
+c_i64, c_int, c_float, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+
+class GemmEpilogue(ctypes.Structure):
+    _fields_ = [("bias", c_vp), ("resid", c_vp), ("ldr", c_i64), ("colscale", c_float), ("colscale_cols", c_int),
+                ("act", c_int), ("c_dtype", c_int), ("remap_group", c_i64), ("remap_skip", c_i64),
+                ("remap_offset", c_i64)]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); must list every symbol of include/hh.h
+SIGNATURES = {
+    "hh_version": [],
+    "hh_last_error_string": [],
+    "hh_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_float, c_vp],
+    "hh_layernorm_bwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
+    "hh_gemm_bf16": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, ctypes.POINTER(GemmEpilogue), c_vp],
+    "hh_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
+    "hh_cast_bf16_to_f32": [c_vp, c_vp, c_i64, c_vp],
+    "hh_transpose_to_bf16": [c_vp, c_int, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp],
+    "hh_patch_im2col": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp],
+    "hh_embed_ln_pre": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, c_vp],
+    "hh_space_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "hh_time_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "hh_cls_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
+    "hh_xattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "hh_xattn_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp],
+    "hh_match_boxes": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_float, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "hh_lsap_rows": [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
+    "hh_box_loss_fwd": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "hh_box_loss_bwd": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "hh_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_float, c_float, c_float, c_float, c_float, c_int, c_vp],
+}
+_RESTYPES = {"hh_last_error_string": ctypes.c_char_p}
+
+_lib = None
+
+
+def lib():
+    """Load libhh.so (raises if absent -- build it with `python -m helping_hand_for_egocentric_videos_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libhh.so (HIP kernels) is not built: run `python -m helping_hand_for_egocentric_videos_amd.build`. "
+                "There is no CPU fallback for the product path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, c_int)
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().hh_last_error_string()
+        raise RuntimeError("%s failed (status %d): %s" % (what, rc, msg.decode() if msg else "?"))

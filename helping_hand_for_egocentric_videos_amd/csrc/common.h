@@ -1,0 +1,49 @@
+// Shared device/host helpers for libhh (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/hh.h"
+
+typedef __bf16 bf16_t;
+typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+void hh_set_error(const char* fmt, ...);
+int hh_check_launch(const char* what);
+
+#define HH_REQUIRE(cond, code, ...)                 \
+    do {                                            \
+        if (!(cond)) {                              \
+            hh_set_error(__VA_ARGS__);              \
+            return (code);                          \
+        }                                           \
+    } while (0)
+
+#define HH_ALIGNED16(p) ((((uintptr_t)(p)) & 15) == 0)
+
+__device__ __forceinline__ float bf16_lo_to_f32(unsigned int u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi_to_f32(unsigned int u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
+    bf16x2 v;
+    v[0] = (bf16_t)lo;
+    v[1] = (bf16_t)hi;
+    return __builtin_bit_cast(unsigned int, v);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

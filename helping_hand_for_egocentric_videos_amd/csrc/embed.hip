@@ -1,0 +1,109 @@
+// TimeSformer front end: im2col for the 14x14/14 patch convolution and the fused
+// "cls concat + positional/temporal embedding add + ln_pre" pass (model/LaviLa.py:218-223,540-559).
+// HBM-bound; the patch GEMM itself runs on hh_gemm_bf16 (K padded to a multiple of 64).
+#include "common.h"
+
+// patches[(frame*n + py*G + px), k] = video[frame, c, py*P+i, px*P+j], k = c*P*P + i*P + j ; zero for k >= 3*P*P
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ video, bf16_t* __restrict__ patches,
+                                                     int64_t frames, int H, int W, int P, int Kpad) {
+    const int G = W / P, n = (H / P) * G, K = 3 * P * P;
+    const int chunks = Kpad / 8;
+    const int64_t total = frames * n * chunks;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(idx % chunks);
+        const int64_t row = idx / chunks;
+        const int64_t frame = row / n;
+        const int pr = (int)(row % n), py = pr / G, px = pr % G;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = ch * 8 + q;
+            if (k < K) {
+                const int c = k / (P * P), rem = k % (P * P), i = rem / P, jj = rem % P;
+                v[q] = video[((frame * 3 + c) * H + (py * P + i)) * (int64_t)W + (px * P + jj)];
+            } else v[q] = 0.f;
+        }
+        u32x4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+        *(u32x4*)(patches + row * Kpad + ch * 8) = o;
+    }
+}
+
+// one wave per output token row; D <= NV*256 (guarded), D % 4 == 0
+template <int NV>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ tok, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, const float* __restrict__ temporal,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ x, int B, int T, int n, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t N = 1 + (int64_t)T * n;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)B * N) return;
+    const int64_t b = row / N, t = row % N;
+    float v[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (c >= D) {
+        } else if (t == 0) {
+            a = *(const f32x4*)(cls + c) + *(const f32x4*)(pos + c);
+        } else {
+            const int64_t f = (t - 1) / n, pp = (t - 1) % n;
+            a = *(const f32x4*)(tok + ((b * T + f) * n + pp) * D + c) + *(const f32x4*)(pos + (1 + pp) * D + c) +
+                *(const f32x4*)(temporal + f * D + c);
+        }
+        v[i][0] = a[0]; v[i][1] = a[1]; v[i][2] = a[2]; v[i][3] = a[3];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if ((i * 64 + lane) * 4 >= D) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { float d = v[i][j] - mean; q += d * d; }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c >= D) continue;
+        f32x4 g = *(const f32x4*)(gamma + c), bb = *(const f32x4*)(beta + c), o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bb[j];
+        *(f32x4*)(x + row * D + c) = o;
+    }
+}
+
+extern "C" int hh_patch_im2col(const float* video, void* patches, int64_t frames, int H, int W, int P, int Kpad,
+                               hh_stream_t stream) {
+    HH_REQUIRE(frames >= 0 && H > 0 && W > 0 && P > 0 && H % P == 0 && W % P == 0, HH_ERR_SHAPE, "hh_patch_im2col: bad image/patch size");
+    HH_REQUIRE(Kpad % 8 == 0 && Kpad >= 3 * P * P, HH_ERR_SHAPE, "hh_patch_im2col: Kpad=%d must be a multiple of 8 and >= 3*P*P", Kpad);
+    HH_REQUIRE(HH_ALIGNED16(patches), HH_ERR_ALIGN, "hh_patch_im2col: output must be 16-byte aligned");
+    if (frames == 0) return HH_OK;
+    const int64_t total = frames * (H / P) * (W / P) * (Kpad / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, video, (bf16_t*)patches, frames, H, W, P, Kpad);
+    return hh_check_launch("hh_patch_im2col");
+}
+
+extern "C" int hh_embed_ln_pre(const float* tok, const float* cls, const float* pos, const float* temporal,
+                               const float* gamma, const float* beta, float* x, int B, int T, int n, int D, float eps,
+                               hh_stream_t stream) {
+    HH_REQUIRE(B >= 0 && T > 0 && n > 0 && D > 0 && D % 8 == 0 && D <= 2048, HH_ERR_SHAPE, "hh_embed_ln_pre: D=%d must be a multiple of 8, <= 2048", D);
+    HH_REQUIRE(HH_ALIGNED16(tok) && HH_ALIGNED16(cls) && HH_ALIGNED16(pos) && HH_ALIGNED16(temporal) && HH_ALIGNED16(gamma) &&
+               HH_ALIGNED16(beta) && HH_ALIGNED16(x), HH_ERR_ALIGN, "hh_embed_ln_pre: pointers must be 16-byte aligned");
+    if (B == 0) return HH_OK;
+    const int64_t rows = (int64_t)B * (1 + (int64_t)T * n);
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int nv = (D + 255) / 256;
+    if (nv <= 1) hipLaunchKernelGGL(embed_ln_kernel<1>, grid, block, 0, s, tok, cls, pos, temporal, gamma, beta, x, B, T, n, D, eps);
+    else if (nv <= 2) hipLaunchKernelGGL(embed_ln_kernel<2>, grid, block, 0, s, tok, cls, pos, temporal, gamma, beta, x, B, T, n, D, eps);
+    else if (nv <= 4) hipLaunchKernelGGL(embed_ln_kernel<4>, grid, block, 0, s, tok, cls, pos, temporal, gamma, beta, x, B, T, n, D, eps);
+    else hipLaunchKernelGGL(embed_ln_kernel<8>, grid, block, 0, s, tok, cls, pos, temporal, gamma, beta, x, B, T, n, D, eps);
+    return hh_check_launch("hh_embed_ln_pre");
+}

@@ -1,0 +1,183 @@
+// bf16 MFMA GEMM with fused epilogue:  C[m,n] = epi( sum_k A[m,k] * W[n,k] ).
+// Replaces nn.Linear on the hot path (model/LaviLa.py:249 qkv, :281 proj, :186-189 fc1/fc2; tfm_decoder.py:156,
+// nn.MultiheadAttention in-proj :438-441).  MFMA-bound: 2*M*N*K flops per call.
+//
+// Structure (v1): 128x128 block tile, BK=64, 256 threads = 4 waves (2x2), each wave 64x64 as 4x4 MFMA 16x16x32
+// tiles.  Operands are swapped (MFMA A-operand = W rows, B-operand = A rows) so the accumulator holds C^T tiles:
+// a lane owns 4 consecutive n for one m, which makes the epilogue's bias/residual/stores 8- or 16-byte vectors.
+// Both operands are K-contiguous, staged HBM->LDS by LDS-DMA (global_load_lds_dwordx4), double buffered.
+// LDS image: [row][8 chunks of 16 B]; chunk c of row r lives at position c ^ (r & 7) (XOR swizzle applied on the
+// per-lane SOURCE address, LDS destination stays lane-linear) -> ds_read_b128 fragment reads are conflict-free.
+// Block order is XCD-aware: blockIdx % 8 selects the XCD-local stream; each XCD walks groups of 8 m-tiles x all
+// n-tiles so an A tile is re-used from that XCD's L2 across its n-tiles.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define GROUP_M 8
+
+struct GemmParams {
+    const bf16_t* A; int64_t lda;
+    const bf16_t* W; int64_t ldw;
+    void* C; int64_t ldc;
+    int64_t M; int N; int K;
+    int Mt, Nt;
+    hh_gemm_epilogue e;
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A 16 KB | W 16 KB]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- XCD-aware tile assignment
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int per = GROUP_M * p.Nt;
+    const int kg = j / per, r = j % per;
+    const int nt = r / GROUP_M, mi = r % GROUP_M;
+    const int mt = xcd + 8 * (kg * GROUP_M + mi);
+    if (mt >= p.Mt) return;
+    const int64_t m0 = (int64_t)mt * BM;
+    const int n0 = nt * BN;
+
+    // ---- staging: wave w issues 4 LDS-DMA pieces per operand per k-tile; piece i covers tile rows (w*4+i)*8..+8
+    const bf16_t* a_src[4];
+    const bf16_t* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        int64_t gm = m0 + row;
+        if (gm > p.M - 1) gm = p.M - 1;
+        a_src[i] = p.A + gm * p.lda + c * 8;
+        w_src[i] = p.W + (int64_t)(n0 + row) * p.ldw + c * 8;
+    }
+    const int wm = wave >> 1, wn = wave & 1;
+    // fragment read offsets (bytes inside an operand tile): row = base + (lane&15), chunk = ks*4 + (lane>>4)
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_off[2], w_off[2];     // per ks, for tile 0; tile t adds t*16 rows = t*2048 bytes
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ks * 4 + fq;
+        a_off[ks] = (wm * 64 + frow) * 128 + ((c ^ (frow & 7)) << 4);
+        w_off[ks] = (wn * 64 + frow) * 128 + ((c ^ (frow & 7)) << 4);
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * 32768 + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(a_src[i] + (int64_t)kt * BK, base + i * 1024);
+            glds16(w_src[i] + (int64_t)kt * BK, base + 16384 + i * 1024);
+        }
+    };
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* As = smem + (kt & 1) * 32768;
+        const char* Ws = As + 16384;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *(const bf16x8*)(As + a_off[ks] + t * 2048);
+                wf[t] = *(const bf16x8*)(Ws + w_off[ks] + t * 2048);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane owns C[m][n..n+3], m = m0 + wm*64 + tm*16 + (lane&15), n = n0 + wn*64 + tn*16 + 4*(lane>>4)
+    const hh_gemm_epilogue& e = p.e;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        const int64_t m = m0 + wm * 64 + tm * 16 + frow;
+        if (m >= p.M) continue;
+        int64_t orow = m;
+        if (e.remap_group > 0) orow = m + (m / e.remap_group) * e.remap_skip + e.remap_offset;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int n = n0 + wn * 64 + tn * 16 + 4 * fq;
+            f32x4 v = acc[tn][tm];
+            if (e.bias) {
+                f32x4 bb = *(const f32x4*)(e.bias + n);
+                v += bb;
+            }
+            if (n < e.colscale_cols) v *= e.colscale;
+            if (e.act == HH_ACT_QUICKGELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.f + __expf(-1.702f * v[q]));
+            } else if (e.act == HH_ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            if (e.resid) {
+                f32x4 rr = *(const f32x4*)(e.resid + orow * e.ldr + n);
+                v += rr;
+            }
+            if constexpr (OUT_BF16) {
+                u32x2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                *(u32x2*)((bf16_t*)p.C + orow * p.ldc + n) = o;
+            } else {
+                *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
+            }
+        }
+    }
+}
+
+extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                            int64_t M, int N, int K, const hh_gemm_epilogue* epi, hh_stream_t stream) {
+    HH_REQUIRE(epi != nullptr, HH_ERR_SHAPE, "hh_gemm_bf16: epilogue descriptor is NULL");
+    HH_REQUIRE(M >= 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0, HH_ERR_SHAPE,
+               "hh_gemm_bf16: need N %% 128 == 0 and K %% 64 == 0 (M=%lld N=%d K=%d)", (long long)M, N, K);
+    HH_REQUIRE(lda >= K && ldw >= K && ldc >= N && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, HH_ERR_SHAPE,
+               "hh_gemm_bf16: bad leading dimensions lda=%lld ldw=%lld ldc=%lld", (long long)lda, (long long)ldw, (long long)ldc);
+    HH_REQUIRE(HH_ALIGNED16(A) && HH_ALIGNED16(W) && HH_ALIGNED16(C) && HH_ALIGNED16(epi->bias) && HH_ALIGNED16(epi->resid),
+               HH_ERR_ALIGN, "hh_gemm_bf16: pointers must be 16-byte aligned");
+    HH_REQUIRE(epi->c_dtype == HH_F32 || epi->c_dtype == HH_BF16, HH_ERR_DTYPE, "hh_gemm_bf16: bad output dtype");
+    HH_REQUIRE(epi->resid == nullptr || epi->ldr % 4 == 0, HH_ERR_SHAPE, "hh_gemm_bf16: ldr must be a multiple of 4");
+    if (M == 0) return HH_OK;
+    GemmParams p;
+    p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.e = *epi;
+    p.Mt = (int)((M + BM - 1) / BM);
+    p.Nt = N / BN;
+    const int per_xcd_mt = (p.Mt + 7) / 8;
+    const int groups = (per_xcd_mt + GROUP_M - 1) / GROUP_M;
+    const unsigned grid = 8u * (unsigned)groups * GROUP_M * (unsigned)p.Nt;
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)gemm_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute((const void*)gemm_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_done = true;
+    }
+    if (epi->c_dtype == HH_BF16)
+        hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3(grid), dim3(256), 65536, s, p);
+    else
+        hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3(grid), dim3(256), 65536, s, p);
+    return hh_check_launch("hh_gemm_bf16");
+}

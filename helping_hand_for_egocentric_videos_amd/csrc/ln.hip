@@ -1,0 +1,187 @@
+// LayerNorm forward/backward, one wave per row, row held in registers (two-pass mean / variance in fp32).
+// Replaces nn.LayerNorm at model/LaviLa.py:439,456 (norm1/2/3 eps 1e-6, ln_pre 1e-5) and tfm_decoder.py:57.
+// HBM-bound: algorithmic bytes per row = cols*(sizeof(in)+sizeof(out)).
+#include "common.h"
+
+template <int NV, typename TIN>
+__device__ __forceinline__ void load_row(const TIN* x, int cols, int lane, float (&v)[NV][4]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+            if constexpr (sizeof(TIN) == 4) {
+                f32x4 t = *(const f32x4*)(x + c);
+                v[i][0] = t[0]; v[i][1] = t[1]; v[i][2] = t[2]; v[i][3] = t[3];
+            } else {
+                u32x2 t = *(const u32x2*)(x + c);
+                v[i][0] = bf16_lo_to_f32(t[0]); v[i][1] = bf16_hi_to_f32(t[0]);
+                v[i][2] = bf16_lo_to_f32(t[1]); v[i][3] = bf16_hi_to_f32(t[1]);
+            }
+        } else {
+            v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+        }
+    }
+}
+
+template <int NV, typename TIN, typename TOUT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, TOUT* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     int64_t rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NV][4];
+    load_row<NV, TIN>(x + row * cols, cols, lane, v);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (mean_out && lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+            f32x4 g = *(const f32x4*)(gamma + c);
+            f32x4 b = *(const f32x4*)(beta + c);
+            float o0 = (v[i][0] - mean) * rstd * g[0] + b[0];
+            float o1 = (v[i][1] - mean) * rstd * g[1] + b[1];
+            float o2 = (v[i][2] - mean) * rstd * g[2] + b[2];
+            float o3 = (v[i][3] - mean) * rstd * g[3] + b[3];
+            if constexpr (sizeof(TOUT) == 4) {
+                f32x4 o = {o0, o1, o2, o3};
+                *(f32x4*)(y + row * cols + c) = o;
+            } else {
+                u32x2 o = {pack_bf16(o0, o1), pack_bf16(o2, o3)};
+                *(u32x2*)(y + row * cols + c) = o;
+            }
+        }
+    }
+}
+
+// backward: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma; dgamma += dy*xhat, dbeta += dy (atomics per block)
+template <int NV, typename TIN>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TIN* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ dy, float* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int64_t rows, int cols, int rows_per_block) {
+    __shared__ float red[2][4][NV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float ag[NV][4], ab[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    for (int rr = wave; rr < rows_per_block; rr += 4) {
+        const int64_t row = r0 + rr;
+        if (row >= rows) break;
+        float v[NV][4], d[NV][4];
+        load_row<NV, TIN>(x + row * cols, cols, lane, v);
+        load_row<NV, float>(dy + row * cols, cols, lane, d);
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int c = (i * 64 + lane) * 4;
+            if (c < cols) {
+                f32x4 g = *(const f32x4*)(gamma + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float xh = (v[i][j] - mu) * rs;
+                    float gg = d[i][j] * g[j];
+                    s1 += gg;
+                    s2 += gg * xh;
+                    ag[i][j] += d[i][j] * xh;
+                    ab[i][j] += d[i][j];
+                    v[i][j] = xh;
+                    d[i][j] = gg;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)cols;
+        s2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int c = (i * 64 + lane) * 4;
+            if (c < cols) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rs * (d[i][j] - s1 - v[i][j] * s2);
+                *(f32x4*)(dx + row * cols + c) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[0][wave][(i * 64 + lane) * 4 + j] = ag[i][j];
+            red[1][wave][(i * 64 + lane) * 4 + j] = ab[i][j];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        atomicAdd(dgamma + c, a);
+        atomicAdd(dbeta + c, b);
+    }
+}
+
+template <int NV>
+static int ln_fwd_dispatch(const void* x, int xd, const float* g, const float* b, void* y, int yd, float* mo, float* ro,
+                           int64_t rows, int cols, float eps, hipStream_t s) {
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (xd == HH_F32 && yd == HH_BF16)
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, float, bf16_t>), grid, block, 0, s, (const float*)x, g, b, (bf16_t*)y, mo, ro, rows, cols, eps);
+    else if (xd == HH_F32 && yd == HH_F32)
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, float, float>), grid, block, 0, s, (const float*)x, g, b, (float*)y, mo, ro, rows, cols, eps);
+    else if (xd == HH_BF16 && yd == HH_BF16)
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, g, b, (bf16_t*)y, mo, ro, rows, cols, eps);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, float>), grid, block, 0, s, (const bf16_t*)x, g, b, (float*)y, mo, ro, rows, cols, eps);
+    return hh_check_launch("hh_layernorm_fwd");
+}
+
+extern "C" int hh_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                                float* mean_out, float* rstd_out, int64_t rows, int cols, float eps, hh_stream_t stream) {
+    HH_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 2048, HH_ERR_SHAPE, "hh_layernorm_fwd: cols=%d must be a multiple of 8 and <= 2048", cols);
+    HH_REQUIRE((x_dtype == HH_F32 || x_dtype == HH_BF16) && (y_dtype == HH_F32 || y_dtype == HH_BF16), HH_ERR_DTYPE, "hh_layernorm_fwd: bad dtype");
+    HH_REQUIRE(HH_ALIGNED16(x) && HH_ALIGNED16(y) && HH_ALIGNED16(gamma) && HH_ALIGNED16(beta), HH_ERR_ALIGN, "hh_layernorm_fwd: pointers must be 16-byte aligned");
+    HH_REQUIRE((mean_out == nullptr) == (rstd_out == nullptr), HH_ERR_SHAPE, "hh_layernorm_fwd: mean_out/rstd_out must both be set or both NULL");
+    if (rows == 0) return HH_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int nv = (cols + 255) / 256;
+    if (nv <= 2) return ln_fwd_dispatch<2>(x, x_dtype, gamma, beta, y, y_dtype, mean_out, rstd_out, rows, cols, eps, s);
+    if (nv <= 4) return ln_fwd_dispatch<4>(x, x_dtype, gamma, beta, y, y_dtype, mean_out, rstd_out, rows, cols, eps, s);
+    return ln_fwd_dispatch<8>(x, x_dtype, gamma, beta, y, y_dtype, mean_out, rstd_out, rows, cols, eps, s);
+}
+
+extern "C" int hh_layernorm_bwd(const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd,
+                                const float* dy, float* dx, float* dgamma, float* dbeta, int64_t rows, int cols,
+                                hh_stream_t stream) {
+    HH_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 1024, HH_ERR_SHAPE, "hh_layernorm_bwd: cols=%d must be a multiple of 8 and <= 1024", cols);
+    HH_REQUIRE(x_dtype == HH_F32 || x_dtype == HH_BF16, HH_ERR_DTYPE, "hh_layernorm_bwd: bad dtype");
+    HH_REQUIRE(HH_ALIGNED16(x) && HH_ALIGNED16(dy) && HH_ALIGNED16(dx) && HH_ALIGNED16(gamma), HH_ERR_ALIGN, "hh_layernorm_bwd: pointers must be 16-byte aligned");
+    if (rows == 0) return HH_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int rpb = 64;
+    dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(256);
+    int nv = (cols + 255) / 256;
+#define LAUNCH(NV, T) hipLaunchKernelGGL((ln_bwd_kernel<NV, T>), grid, block, 0, s, (const T*)x, gamma, mean, rstd, dy, dx, dgamma, dbeta, rows, cols, rpb)
+    if (x_dtype == HH_F32) { if (nv <= 2) LAUNCH(2, float); else LAUNCH(4, float); }
+    else { if (nv <= 2) LAUNCH(2, bf16_t); else LAUNCH(4, bf16_t); }
+#undef LAUNCH
+    return hh_check_launch("hh_layernorm_bwd");
+}

@@ -1,0 +1,269 @@
+// Hungarian matching and matched-pair box losses on device (model/box_utils.py:43-92,156-173,249-279;
+// utils/box_ops.py:9-61; scipy.optimize.linear_sum_assignment restated as in oracle/lsap.c).
+// Removes the reference's three device->host syncs per step.  Integer/index work must be BIT-EXACT with the
+// reference given identical fp32 boxes, so the fp32 cost is evaluated in the reference's operation order with
+// FMA contraction disabled, and the assignment runs the same shortest-augmenting-path algorithm in fp64.
+// One thread per frame (problems are <= 16 x 8); latency-bound, negligible bytes.
+#include "common.h"
+#pragma clang fp contract(off)
+
+#define MAXQ 16
+#define MAXK 16
+
+struct Box { float x0, y0, x1, y1; };
+
+__device__ __forceinline__ Box to_xyxy(const float* c) {
+    Box b;
+    b.x0 = c[0] - 0.5f * c[2];
+    b.y0 = c[1] - 0.5f * c[3];
+    b.x1 = c[0] + 0.5f * c[2];
+    b.y1 = c[1] + 0.5f * c[3];
+    return b;
+}
+
+// utils/box_ops.py:24-61 (IoU with union+1e-4; GIoU hull term without eps)
+__device__ __forceinline__ float giou_xyxy(const Box& a, const Box& b) {
+    const float area_a = (a.x1 - a.x0) * (a.y1 - a.y0);
+    const float area_b = (b.x1 - b.x0) * (b.y1 - b.y0);
+    const float w = fmaxf(fminf(a.x1, b.x1) - fmaxf(a.x0, b.x0), 0.f);
+    const float h = fmaxf(fminf(a.y1, b.y1) - fmaxf(a.y0, b.y0), 0.f);
+    const float inter = w * h;
+    const float uni = (area_a + area_b) - inter;
+    const float iou = inter / (uni + 0.0001f);
+    const float hw = fmaxf(fmaxf(a.x1, b.x1) - fminf(a.x0, b.x0), 0.f);
+    const float hh = fmaxf(fmaxf(a.y1, b.y1) - fminf(a.y0, b.y0), 0.f);
+    const float hull = hw * hh;
+    return iou - (hull - uni) / hull;
+}
+
+// Rectangular LSAP, nr <= nc, shortest augmenting path (Crouse 2016) as scipy implements it.
+// cost row-major [nr][ldc] (double).  col4row out.  Returns false if infeasible.
+__device__ bool lsap_wide(int nr, int nc, const double* cost, int ldc, int* col4row) {
+    double u[MAXK], v[MAXQ], spc[MAXQ];
+    int path[MAXQ], row4col[MAXQ], remaining[MAXQ];
+    bool SR[MAXK], SC[MAXQ];
+    for (int i = 0; i < nr; ++i) { u[i] = 0.0; col4row[i] = -1; }
+    for (int j = 0; j < nc; ++j) { v[j] = 0.0; path[j] = -1; row4col[j] = -1; }
+    for (int cur = 0; cur < nr; ++cur) {
+        double min_val = 0.0;
+        int i = cur, num_remaining = nc, sink = -1;
+        for (int it = 0; it < nc; ++it) remaining[it] = nc - it - 1;
+        for (int t = 0; t < nr; ++t) SR[t] = false;
+        for (int t = 0; t < nc; ++t) { SC[t] = false; spc[t] = INFINITY; }
+        while (sink == -1) {
+            int index = -1;
+            double lowest = INFINITY;
+            SR[i] = true;
+            for (int it = 0; it < num_remaining; ++it) {
+                const int j = remaining[it];
+                const double r = min_val + cost[i * ldc + j] - u[i] - v[j];
+                if (r < spc[j]) { path[j] = i; spc[j] = r; }
+                if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+            }
+            min_val = lowest;
+            if (min_val == INFINITY) return false;
+            const int j = remaining[index];
+            if (row4col[j] == -1) sink = j; else i = row4col[j];
+            SC[j] = true;
+            remaining[index] = remaining[--num_remaining];
+        }
+        u[cur] += min_val;
+        for (int t = 0; t < nr; ++t) if (SR[t] && t != cur) u[t] += min_val - spc[col4row[t]];
+        for (int t = 0; t < nc; ++t) if (SC[t]) v[t] -= min_val - spc[t];
+        int j = sink;
+        for (;;) {
+            const int ii = path[j];
+            row4col[j] = ii;
+            const int t = col4row[ii]; col4row[ii] = j; j = t;
+            if (ii == cur) break;
+        }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void match_boxes_kernel(const float* __restrict__ pred, int Qtot, int q0, int q,
+                                                         const float* __restrict__ raw, int k, float img, float w_l1,
+                                                         float w_giou, float* __restrict__ tgt, int* __restrict__ tgt_count,
+                                                         int64_t* __restrict__ mp, int64_t* __restrict__ mt,
+                                                         int* __restrict__ mn, int64_t F) {
+    const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (f >= F) return;
+    // ---- prepare_targets (box_utils.py:249-279, center_crop=False): clip to [0,img]/img, keep x1>x0 && y1>y0, -> cxcywh
+    float t[MAXK][4];
+    int cnt = 0;
+    for (int i = 0; i < k; ++i) {
+        const float* r = raw + (f * k + i) * 4;
+        const float x0 = fminf(fmaxf(r[0], 0.f), img) / img, y0 = fminf(fmaxf(r[1], 0.f), img) / img;
+        const float x1 = fminf(fmaxf(r[2], 0.f), img) / img, y1 = fminf(fmaxf(r[3], 0.f), img) / img;
+        if (x1 > x0 && y1 > y0) {
+            t[cnt][0] = (x0 + x1) / 2.f; t[cnt][1] = (y0 + y1) / 2.f; t[cnt][2] = x1 - x0; t[cnt][3] = y1 - y0;
+            ++cnt;
+        }
+    }
+    for (int i = 0; i < k; ++i)
+        for (int c = 0; c < 4; ++c) tgt[(f * k + i) * 4 + c] = (i < cnt) ? t[i][c] : 0.f;
+    tgt_count[f] = cnt;
+    const int nm = cnt < q ? cnt : q;
+    mn[f] = nm;
+    for (int i = 0; i < k; ++i) { mp[f * k + i] = -1; mt[f * k + i] = -1; }
+    if (nm == 0) return;
+    // ---- cost C = w_l1 * cdist_L1 + w_giou * (-GIoU)   (box_utils.py:74-81), fp32, reference op order
+    double cost[MAXQ * MAXK];   // stored [pred][tgt] or transposed [tgt][pred] so that rows <= cols
+    const bool transpose = cnt < q;            // scipy: transpose when nc < nr (rows = preds)
+    for (int i = 0; i < q; ++i) {
+        const float* p = pred + (f * Qtot + q0 + i) * 4;
+        const Box pb = to_xyxy(p);
+        for (int j = 0; j < cnt; ++j) {
+            float l1 = 0.f;
+            for (int c = 0; c < 4; ++c) l1 = l1 + fabsf(p[c] - t[j][c]);
+            const Box tb = to_xyxy(t[j]);
+            const float g = giou_xyxy(pb, tb);
+            const float cst = w_l1 * l1 + w_giou * (-g);
+            if (transpose) cost[j * q + i] = (double)cst; else cost[i * cnt + j] = (double)cst;
+        }
+    }
+    int col4row[MAXK];
+    if (transpose) {
+        // rows = targets (cnt), cols = preds (q); result sorted by pred index
+        lsap_wide(cnt, q, cost, q, col4row);
+        int order[MAXK];
+        for (int i = 0; i < cnt; ++i) order[i] = i;
+        for (int i = 1; i < cnt; ++i) {           // insertion sort by pred index (col4row)
+            const int key = order[i];
+            int j = i - 1;
+            while (j >= 0 && col4row[order[j]] > col4row[key]) { order[j + 1] = order[j]; --j; }
+            order[j + 1] = key;
+        }
+        for (int i = 0; i < cnt; ++i) { mp[f * k + i] = col4row[order[i]]; mt[f * k + i] = order[i]; }
+    } else {
+        lsap_wide(q, cnt, cost, cnt, col4row);
+        for (int i = 0; i < q; ++i) { mp[f * k + i] = i; mt[f * k + i] = col4row[i]; }
+    }
+}
+
+// generic batched LSAP (word loss, loss.py:83-93): rows with row_valid != 0 (in order) x all nc columns
+__global__ __launch_bounds__(64) void lsap_rows_kernel(const float* __restrict__ cost, const unsigned char* __restrict__ row_valid,
+                                                       int64_t* __restrict__ col_of_row, int64_t P, int nr, int nc) {
+    const int64_t p = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (p >= P) return;
+    int rows[MAXK], cnt = 0;
+    for (int r = 0; r < nr; ++r) { col_of_row[p * nr + r] = -1; if (row_valid[p * nr + r]) rows[cnt++] = r; }
+    if (cnt == 0) return;
+    double c[MAXQ * MAXK];
+    int col4row[MAXQ];
+    if (cnt <= nc) {
+        for (int i = 0; i < cnt; ++i) for (int j = 0; j < nc; ++j) c[i * nc + j] = (double)cost[(p * nr + rows[i]) * nc + j];
+        lsap_wide(cnt, nc, c, nc, col4row);
+        for (int i = 0; i < cnt; ++i) col_of_row[p * nr + rows[i]] = col4row[i];
+    } else {
+        for (int i = 0; i < cnt; ++i) for (int j = 0; j < nc; ++j) c[j * cnt + i] = (double)cost[(p * nr + rows[i]) * nc + j];
+        lsap_wide(nc, cnt, c, cnt, col4row);        // col4row[j] = row index assigned to column j
+        for (int j = 0; j < nc; ++j) col_of_row[p * nr + rows[col4row[j]]] = j;
+    }
+}
+
+// matched-pair losses (box_utils.py:156-173): sums[0] += sum |p - t|, sums[1] += sum (1 - GIoU(p,t))
+__global__ __launch_bounds__(64) void box_loss_fwd_kernel(const float* __restrict__ pred, int Qtot, int q0,
+                                                          const float* __restrict__ tgt, int k,
+                                                          const int64_t* __restrict__ mp, const int64_t* __restrict__ mt,
+                                                          const int* __restrict__ mn, float* __restrict__ sums, int64_t F) {
+    const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    float a = 0.f, g = 0.f;
+    if (f < F) {
+        const int nm = mn[f];
+        for (int i = 0; i < nm; ++i) {
+            const float* p = pred + (f * Qtot + q0 + mp[f * k + i]) * 4;
+            const float* t = tgt + (f * k + mt[f * k + i]) * 4;
+            for (int c = 0; c < 4; ++c) a += fabsf(p[c] - t[c]);
+            g += 1.f - giou_xyxy(to_xyxy(p), to_xyxy(t));
+        }
+    }
+    a = wave_sum(a);
+    g = wave_sum(g);
+    if (threadIdx.x == 0) { atomicAdd(sums, a); atomicAdd(sums + 1, g); }
+}
+
+// d(pred) for L = g_l1 * sum|p-t| + g_giou * sum(1-GIoU); dpred [F,Qtot,4] must be zero-initialised by the caller
+__global__ __launch_bounds__(64) void box_loss_bwd_kernel(const float* __restrict__ pred, int Qtot, int q0,
+                                                          const float* __restrict__ tgt, int k,
+                                                          const int64_t* __restrict__ mp, const int64_t* __restrict__ mt,
+                                                          const int* __restrict__ mn, const float* __restrict__ g_l1,
+                                                          const float* __restrict__ g_giou, float* __restrict__ dpred, int64_t F) {
+    const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (f >= F) return;
+    const float gl = *g_l1, gg = *g_giou;
+    const int nm = mn[f];
+    for (int i = 0; i < nm; ++i) {
+        const int64_t pi = (f * Qtot + q0 + mp[f * k + i]) * 4;
+        const float* p = pred + pi;
+        const float* t = tgt + (f * k + mt[f * k + i]) * 4;
+        const Box a = to_xyxy(p), b = to_xyxy(t);
+        const float Ap = (a.x1 - a.x0) * (a.y1 - a.y0), At = (b.x1 - b.x0) * (b.y1 - b.y0);
+        const float dxw = fminf(a.x1, b.x1) - fmaxf(a.x0, b.x0), dyh = fminf(a.y1, b.y1) - fmaxf(a.y0, b.y0);
+        const float iw = fmaxf(dxw, 0.f), ih = fmaxf(dyh, 0.f), inter = iw * ih;
+        const float U = (Ap + At) - inter, Ue = U + 0.0001f;
+        const float hw = fmaxf(fmaxf(a.x1, b.x1) - fminf(a.x0, b.x0), 0.f), hh = fmaxf(fmaxf(a.y1, b.y1) - fminf(a.y0, b.y0), 0.f);
+        const float hull = hw * hh;
+        const float dg_dinter = 1.f / Ue + inter / (Ue * Ue) - 1.f / hull;
+        const float dg_dAp = -inter / (Ue * Ue) + 1.f / hull;
+        const float dg_dhull = -U / (hull * hull);
+        const float s = -gg;
+        float dx0 = s * dg_dAp * (-(a.y1 - a.y0)), dx1 = s * dg_dAp * (a.y1 - a.y0);
+        float dy0 = s * dg_dAp * (-(a.x1 - a.x0)), dy1 = s * dg_dAp * (a.x1 - a.x0);
+        const float d_iw = dxw > 0.f ? s * dg_dinter * ih : 0.f;
+        const float d_ih = dyh > 0.f ? s * dg_dinter * iw : 0.f;
+        if (a.x0 > b.x0) dx0 -= d_iw; else if (a.x0 == b.x0) dx0 -= 0.5f * d_iw;
+        if (a.x1 < b.x1) dx1 += d_iw; else if (a.x1 == b.x1) dx1 += 0.5f * d_iw;
+        if (a.y0 > b.y0) dy0 -= d_ih; else if (a.y0 == b.y0) dy0 -= 0.5f * d_ih;
+        if (a.y1 < b.y1) dy1 += d_ih; else if (a.y1 == b.y1) dy1 += 0.5f * d_ih;
+        const float d_hw = s * dg_dhull * hh, d_hh = s * dg_dhull * hw;
+        if (a.x0 < b.x0) dx0 -= d_hw; else if (a.x0 == b.x0) dx0 -= 0.5f * d_hw;
+        if (a.x1 > b.x1) dx1 += d_hw; else if (a.x1 == b.x1) dx1 += 0.5f * d_hw;
+        if (a.y0 < b.y0) dy0 -= d_hh; else if (a.y0 == b.y0) dy0 -= 0.5f * d_hh;
+        if (a.y1 > b.y1) dy1 += d_hh; else if (a.y1 == b.y1) dy1 += 0.5f * d_hh;
+        float sg[4];
+        for (int c = 0; c < 4; ++c) { const float d = p[c] - t[c]; sg[c] = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+        dpred[pi + 0] += dx0 + dx1 + gl * sg[0];
+        dpred[pi + 1] += dy0 + dy1 + gl * sg[1];
+        dpred[pi + 2] += 0.5f * (dx1 - dx0) + gl * sg[2];
+        dpred[pi + 3] += 0.5f * (dy1 - dy0) + gl * sg[3];
+    }
+}
+
+extern "C" int hh_match_boxes(const float* pred, int Qtot, int q0, int q, const float* raw_boxes, int k, float img,
+                              float w_l1, float w_giou, float* tgt_cxcywh, int32_t* tgt_count, int64_t* match_pred,
+                              int64_t* match_tgt, int32_t* match_n, int64_t F, hh_stream_t stream) {
+    HH_REQUIRE(F >= 0 && q > 0 && q <= MAXQ && k > 0 && k <= MAXK && q0 >= 0 && q0 + q <= Qtot, HH_ERR_SHAPE,
+               "hh_match_boxes: need 0 < q <= %d, 0 < k <= %d, q0+q <= Qtot (q=%d k=%d q0=%d Qtot=%d)", MAXQ, MAXK, q, k, q0, Qtot);
+    if (F == 0) return HH_OK;
+    hipLaunchKernelGGL(match_boxes_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pred, Qtot, q0, q,
+                       raw_boxes, k, img, w_l1, w_giou, tgt_cxcywh, tgt_count, match_pred, match_tgt, match_n, F);
+    return hh_check_launch("hh_match_boxes");
+}
+
+extern "C" int hh_lsap_rows(const float* cost, const uint8_t* row_valid, int64_t* col_of_row, int64_t P, int nr, int nc,
+                            hh_stream_t stream) {
+    HH_REQUIRE(P >= 0 && nr > 0 && nr <= MAXK && nc > 0 && nc <= MAXQ, HH_ERR_SHAPE, "hh_lsap_rows: need nr <= %d, nc <= %d", MAXK, MAXQ);
+    if (P == 0) return HH_OK;
+    hipLaunchKernelGGL(lsap_rows_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, (hipStream_t)stream, cost, row_valid, col_of_row, P, nr, nc);
+    return hh_check_launch("hh_lsap_rows");
+}
+
+extern "C" int hh_box_loss_fwd(const float* pred, int Qtot, int q0, const float* tgt_cxcywh, int k, const int64_t* match_pred,
+                               const int64_t* match_tgt, const int32_t* match_n, float* sums, int64_t F, hh_stream_t stream) {
+    HH_REQUIRE(F >= 0 && k > 0 && k <= MAXK, HH_ERR_SHAPE, "hh_box_loss_fwd: bad shape");
+    if (F == 0) return HH_OK;
+    hipLaunchKernelGGL(box_loss_fwd_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pred, Qtot, q0,
+                       tgt_cxcywh, k, match_pred, match_tgt, match_n, sums, F);
+    return hh_check_launch("hh_box_loss_fwd");
+}
+
+extern "C" int hh_box_loss_bwd(const float* pred, int Qtot, int q0, const float* tgt_cxcywh, int k, const int64_t* match_pred,
+                               const int64_t* match_tgt, const int32_t* match_n, const float* g_l1, const float* g_giou,
+                               float* dpred, int64_t F, hh_stream_t stream) {
+    HH_REQUIRE(F >= 0 && k > 0 && k <= MAXK, HH_ERR_SHAPE, "hh_box_loss_bwd: bad shape");
+    if (F == 0) return HH_OK;
+    hipLaunchKernelGGL(box_loss_bwd_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pred, Qtot, q0,
+                       tgt_cxcywh, k, match_pred, match_tgt, match_n, g_l1, g_giou, dpred, F);
+    return hh_check_launch("hh_box_loss_bwd");
+}

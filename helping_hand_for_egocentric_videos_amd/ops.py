@@ -1,0 +1,244 @@
+"""Python-side operator wrappers over the libhh C ABI (include/hh.h).
+
+Every function validates device / dtype / contiguity in Python (so the C side stays branch-light,
+SURVEY.md section 8b "Error conventions"), allocates outputs as torch tensors, and launches on the
+current torch stream.  Nothing here computes on the CPU: non-GPU tensors raise.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GemmEpilogue
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_QUICKGELU, ACT_RELU = 0, 1, 2
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("libhh: unsupported dtype %s" % t.dtype)
+
+
+def _chk(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("libhh ops need GPU tensors (got device %s); there is no CPU fallback" % t.device)
+        if not t.is_contiguous():
+            raise RuntimeError("libhh ops need contiguous tensors")
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def layernorm(x, gamma, beta, eps, out_dtype=torch.bfloat16, save_stats=False):
+    """LayerNorm over the last dim; x fp32/bf16 [..., cols] -> out_dtype."""
+    _chk(x, gamma, beta)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    _lib.check(L.hh_layernorm_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(y), _dt(y), _p(mean), _p(rstd), rows, cols,
+                                  float(eps), _stream()), "hh_layernorm_fwd")
+    return (y, mean, rstd) if save_stats else y
+
+
+def layernorm_bwd(x, gamma, mean, rstd, dy):
+    _chk(x, gamma, mean, rstd, dy)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    dg = torch.zeros(cols, dtype=torch.float32, device=x.device)
+    db = torch.zeros(cols, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    _lib.check(L.hh_layernorm_bwd(_p(x), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dx), _p(dg), _p(db), rows, cols,
+                                  _stream()), "hh_layernorm_bwd")
+    return dx, dg, db
+
+
+def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, resid=None, colscale=1.0,
+         colscale_cols=0, remap=None, out_rows=None):
+    """C = epilogue(A @ W^T).  a bf16 [M,K], w bf16 [N,K] (nn.Linear weight layout), bias fp32 [N].
+
+    resid fp32 [rows,N] is added after the activation; `out` may alias `resid` (in-place residual update).
+    remap=(group, skip, offset) scatters output row m to m + (m//group)*skip + offset (token-major scatter).
+    """
+    _chk(a, w, bias, resid, out)
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
+        raise TypeError("gemm: A and W must be bf16")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError("gemm: K mismatch %s vs %s" % (tuple(a.shape), tuple(w.shape)))
+    if out is None:
+        out = torch.empty((out_rows if out_rows is not None else M, N), dtype=out_dtype, device=a.device)
+    e = GemmEpilogue()
+    e.bias = bias.data_ptr() if bias is not None else None
+    e.resid = resid.data_ptr() if resid is not None else None
+    e.ldr = resid.stride(0) if resid is not None else 0
+    e.colscale, e.colscale_cols, e.act, e.c_dtype = float(colscale), int(colscale_cols), int(act), _dt(out)
+    e.remap_group, e.remap_skip, e.remap_offset = remap if remap is not None else (0, 0, 0)
+    L = _lib.lib()
+    _lib.check(L.hh_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K, ctypes.byref(e),
+                              _stream()), "hh_gemm_bf16")
+    return out
+
+
+def to_bf16(x):
+    _chk(x)
+    if x.dtype == torch.bfloat16:
+        return x
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().hh_cast_f32_to_bf16(_p(x), _p(y), x.numel(), _stream()), "hh_cast_f32_to_bf16")
+    return y
+
+
+def to_f32(x):
+    _chk(x)
+    if x.dtype == torch.float32:
+        return x
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hh_cast_bf16_to_f32(_p(x), _p(y), x.numel(), _stream()), "hh_cast_bf16_to_f32")
+    return y
+
+
+def transpose_bf16(x, pad_cols_to=1):
+    """x [rows, cols] fp32/bf16 -> bf16 [cols, rows_padded] (rows padded with zeros to a multiple of pad_cols_to)."""
+    _chk(x)
+    rows, cols = x.shape
+    rp = (rows + pad_cols_to - 1) // pad_cols_to * pad_cols_to
+    y = (torch.zeros if rp != rows else torch.empty)((cols, rp), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().hh_transpose_to_bf16(_p(x), _dt(x), x.stride(0), _p(y), rp, rows, cols, _stream()),
+               "hh_transpose_to_bf16")
+    return y
+
+
+def patch_im2col(video, patch, kpad):
+    """video fp32 [B,T,3,H,W] -> bf16 [B*T*n, kpad] patch rows (k = c*P*P + i*P + j)."""
+    _chk(video)
+    B, T, C, H, W = video.shape
+    if C != 3 or video.dtype != torch.float32:
+        raise ValueError("patch_im2col: expected fp32 [B,T,3,H,W]")
+    n = (H // patch) * (W // patch)
+    out = torch.empty((B * T * n, kpad), dtype=torch.bfloat16, device=video.device)
+    _lib.check(_lib.lib().hh_patch_im2col(_p(video), _p(out), B * T, H, W, patch, kpad, _stream()), "hh_patch_im2col")
+    return out
+
+
+def embed_ln_pre(tok, cls, pos, temporal, gamma, beta, B, T, n, eps=1e-5):
+    _chk(tok, cls, pos, temporal, gamma, beta)
+    D = tok.shape[-1]
+    x = torch.empty((B, 1 + T * n, D), dtype=torch.float32, device=tok.device)
+    _lib.check(_lib.lib().hh_embed_ln_pre(_p(tok), _p(cls), _p(pos), _p(temporal), _p(gamma), _p(beta), _p(x), B, T, n, D,
+                                          float(eps), _stream()), "hh_embed_ln_pre")
+    return x
+
+
+def divided_attention(qkv, B, T, n, heads, mode, out=None):
+    """qkv bf16 [B*N, 3D] (q pre-scaled) -> bf16 [B*N, D]: CLS row via hh_cls_attn_fwd, the rest via space/time."""
+    _chk(qkv, out)
+    N = 1 + T * n
+    D = heads * 64
+    if qkv.dtype != torch.bfloat16 or qkv.shape != (B * N, 3 * D):
+        raise ValueError("divided_attention: qkv must be bf16 [B*N, 3*heads*64], got %s" % (tuple(qkv.shape),))
+    if out is None:
+        out = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device)
+    L = _lib.lib()
+    _lib.check(L.hh_cls_attn_fwd(_p(qkv), _p(out), B, N, heads, _stream()), "hh_cls_attn_fwd")
+    if mode == "space":
+        _lib.check(L.hh_space_attn_fwd(_p(qkv), _p(out), B, T, n, heads, _stream()), "hh_space_attn_fwd")
+    elif mode == "time":
+        _lib.check(L.hh_time_attn_fwd(_p(qkv), _p(out), B, T, n, heads, _stream()), "hh_time_attn_fwd")
+    else:
+        raise ValueError(mode)
+    return out
+
+
+def xattn_fwd(q, k, v, heads):
+    """q fp32 [B,Q,C] (pre-scaled); k, v bf16 [B,M,C] views with a common row stride -> (out fp32 [B,Q,C], lse [B,h,Q])."""
+    for t in (q, k, v):
+        if not t.is_cuda:
+            raise RuntimeError("libhh ops need GPU tensors; there is no CPU fallback")
+    B, Q, C = q.shape
+    M = k.shape[1]
+    if k.stride(1) != v.stride(1) or k.stride(2) != 1 or v.stride(2) != 1 or k.stride(0) != M * k.stride(1) or not q.is_contiguous():
+        raise RuntimeError("xattn_fwd: k/v must be row-strided views [B,M,C] with dense batch stride")
+    out = torch.empty_like(q)
+    lse = torch.empty((B, heads, Q), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().hh_xattn_fwd(_p(q), _p(k), _p(v), k.stride(1), _p(out), _p(lse), B, Q, M, heads, _stream()), "hh_xattn_fwd")
+    return out, lse
+
+
+def xattn_bwd(q, k, v, out, lse, dout, dk, dv, heads):
+    """Writes dk/dv (bf16 [B,M,C] row-strided views) in place; returns dq fp32 [B,Q,C]."""
+    B, Q, C = q.shape
+    M = k.shape[1]
+    _chk(q, out, lse, dout)
+    dq = torch.empty_like(q)
+    _lib.check(_lib.lib().hh_xattn_bwd(_p(q), _p(k), _p(v), k.stride(1), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(dv),
+                                       dk.stride(1), B, Q, M, heads, _stream()), "hh_xattn_bwd")
+    return dq
+
+
+def match_boxes(pred, q0, q, raw_boxes, img=224.0, w_l1=5.0, w_giou=2.0):
+    """pred fp32 [F,Qtot,4]; raw_boxes fp32 [F,k,4] -> dict(tgt, count, pred_idx, tgt_idx, n) all on device."""
+    _chk(pred, raw_boxes)
+    F_, Qtot, _ = pred.shape
+    k = raw_boxes.shape[1]
+    dev = pred.device
+    tgt = torch.empty((F_, k, 4), dtype=torch.float32, device=dev)
+    cnt = torch.empty((F_,), dtype=torch.int32, device=dev)
+    mp = torch.empty((F_, k), dtype=torch.int64, device=dev)
+    mt = torch.empty((F_, k), dtype=torch.int64, device=dev)
+    mn = torch.empty((F_,), dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().hh_match_boxes(_p(pred), Qtot, q0, q, _p(raw_boxes), k, float(img), float(w_l1), float(w_giou),
+                                         _p(tgt), _p(cnt), _p(mp), _p(mt), _p(mn), F_, _stream()), "hh_match_boxes")
+    return {"tgt": tgt, "count": cnt, "pred_idx": mp, "tgt_idx": mt, "n": mn}
+
+
+def lsap_rows(cost, row_valid):
+    """cost fp32 [P,nr,nc], row_valid uint8/bool [P,nr] -> int64 [P,nr] assigned column per valid row (-1 otherwise)."""
+    _chk(cost, row_valid)
+    P, nr, nc = cost.shape
+    rv = row_valid.to(torch.uint8).contiguous()
+    out = torch.empty((P, nr), dtype=torch.int64, device=cost.device)
+    _lib.check(_lib.lib().hh_lsap_rows(_p(cost), _p(rv), _p(out), P, nr, nc, _stream()), "hh_lsap_rows")
+    return out
+
+
+def box_loss_fwd(pred, q0, m):
+    _chk(pred)
+    F_, Qtot, _ = pred.shape
+    sums = torch.zeros(2, dtype=torch.float32, device=pred.device)
+    _lib.check(_lib.lib().hh_box_loss_fwd(_p(pred), Qtot, q0, _p(m["tgt"]), m["tgt"].shape[1], _p(m["pred_idx"]),
+                                          _p(m["tgt_idx"]), _p(m["n"]), _p(sums), F_, _stream()), "hh_box_loss_fwd")
+    return sums
+
+
+def box_loss_bwd(pred, q0, m, g_l1, g_giou, dpred):
+    _chk(pred, g_l1, g_giou, dpred)
+    F_, Qtot, _ = pred.shape
+    _lib.check(_lib.lib().hh_box_loss_bwd(_p(pred), Qtot, q0, _p(m["tgt"]), m["tgt"].shape[1], _p(m["pred_idx"]),
+                                          _p(m["tgt_idx"]), _p(m["n"]), _p(g_l1), _p(g_giou), _p(dpred), F_, _stream()),
+               "hh_box_loss_bwd")
+    return dpred
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    _chk(p, g, m, v)
+    _lib.check(_lib.lib().hh_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
+                                        float(eps), float(weight_decay), int(step), _stream()), "hh_adamw_step")

@@ -1,0 +1,134 @@
+/* libhh -- C ABI of the MI355X-native (gfx950) hot path of helping_hand_for_egocentric_videos.
+ *
+ * The reference has no FFI layer: its "operator API" for this path is PyTorch nn.Module.forward
+ * (SURVEY.md section 8b).  Each entry point below names the reference op group it replaces
+ * (file:line into /root/reference).  The Python host (helping_hand_for_egocentric_videos_amd/ops.py)
+ * binds these with ctypes; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the caller.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never allocates,
+ *     never synchronises, keeps no pointer after returning.
+ *   - return 0 on success, negative hh_status otherwise; hh_last_error_string() describes the
+ *     last failure of the calling thread.
+ *   - bf16 = 16-bit brain float (uint16 storage); "rows" are token rows, row-major, last dim contiguous.
+ */
+#ifndef HH_H
+#define HH_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hh_stream_t;
+
+enum hh_status { HH_OK = 0, HH_ERR_SHAPE = -1, HH_ERR_DTYPE = -2, HH_ERR_UNSUPPORTED = -3, HH_ERR_LAUNCH = -4,
+                 HH_ERR_ALIGN = -5 };
+enum hh_dtype { HH_F32 = 0, HH_BF16 = 1 };
+enum hh_act { HH_ACT_NONE = 0, HH_ACT_QUICKGELU = 1, HH_ACT_RELU = 2 };
+
+int hh_version(void);
+const char* hh_last_error_string(void);
+
+/* ---- LayerNorm over the last dim (model/LaviLa.py:439,456 eps 1e-6 / 1e-5; tfm_decoder.py:57,375-377)
+ * y[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta ; x dtype / y dtype in {HH_F32, HH_BF16}; gamma/beta fp32.
+ * cols must be a multiple of 64*... see implementation: cols % 8 == 0 and cols <= 8192.
+ * If mean_out/rstd_out are non-NULL the per-row statistics (fp32) are stored for the backward. */
+int hh_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                     float* mean_out, float* rstd_out, int64_t rows, int cols, float eps, hh_stream_t stream);
+
+/* LayerNorm backward: dx (same dtype as x_dtype... fp32) plus per-column partial sums for dgamma/dbeta.
+ * dgamma_part/dbeta_part: [nparts, cols] fp32 workspace partials, reduced by hh_colsum_f32. */
+int hh_layernorm_bwd(const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd,
+                     const float* dy, float* dx, float* dgamma, float* dbeta, int64_t rows, int cols,
+                     hh_stream_t stream);
+
+/* ---- bf16 MFMA GEMM with fused epilogue (replaces nn.Linear: LaviLa.py:249,281,186-189; tfm_decoder.py:156,
+ * nn.MultiheadAttention in-proj :438-441)
+ *   C[m,n] = epilogue( sum_k A[m,k] * W[n,k] )        A [M,K] bf16 (lda), W [N,K] bf16 (ldw)
+ *   epilogue: (+ bias[n]) -> (* colscale for n < colscale_cols) -> act -> (+ resid[m,n] fp32, ldr) -> store
+ *   out dtype bf16 or fp32, ldc in elements.  Output row remap for token-major scatter:
+ *   out_row = m + (m / remap_group) * remap_skip + remap_offset   (remap_group 0 = identity).
+ *   Requirements: K % 64 == 0, N % 128 == 0, 16-byte aligned pointers/strides.  M arbitrary. */
+typedef struct hh_gemm_epilogue {
+    const float* bias;        /* [N] or NULL */
+    const float* resid;       /* fp32 [M(out rows), ldr] or NULL; may alias C when c_dtype == HH_F32 */
+    int64_t ldr;
+    float colscale;           /* applied to columns < colscale_cols (q *= d^-0.5, LaviLa.py:252) */
+    int colscale_cols;
+    int act;                  /* hh_act */
+    int c_dtype;              /* hh_dtype */
+    int64_t remap_group, remap_skip, remap_offset;
+} hh_gemm_epilogue;
+
+int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                 int64_t M, int N, int K, const hh_gemm_epilogue* epi, hh_stream_t stream);
+
+/* ---- casts / transposes (host-side plumbing for weights and wgrad operands) */
+int hh_cast_f32_to_bf16(const float* x, void* y, int64_t n, hh_stream_t stream);
+int hh_cast_bf16_to_f32(const void* x, float* y, int64_t n, hh_stream_t stream);
+/* y[c, r] = x[r, c]  (bf16, x [rows, cols] with ldx) -> y [cols, rows] with ldy; in_dtype F32 converts on the fly */
+int hh_transpose_to_bf16(const void* x, int x_dtype, int64_t ldx, void* y, int64_t ldy, int64_t rows, int64_t cols,
+                         hh_stream_t stream);
+
+/* ---- TimeSformer patch embedding front end (model/LaviLa.py:218-223,540-559)
+ * im2col: video [B*T,3,H,W] fp32 -> patches bf16 [B*T*n, Kpad] (k = c*P*P + i*P + j, zero padded to Kpad) */
+int hh_patch_im2col(const float* video, void* patches, int64_t frames, int H, int W, int P, int Kpad,
+                    hh_stream_t stream);
+/* x[b,0,:]   = LN(cls + pos[0]) ; x[b,1+f*n+p,:] = LN(tok[(b*T+f)*n+p,:] + pos[1+p] + temporal[f])  (eps, ln_pre)
+ * tok fp32 [B*T*n, D]; x fp32 [B, 1+T*n, D] */
+int hh_embed_ln_pre(const float* tok, const float* cls, const float* pos, const float* temporal,
+                    const float* gamma, const float* beta, float* x, int B, int T, int n, int D, float eps,
+                    hh_stream_t stream);
+
+/* ---- divided space-time attention cores (model/LaviLa.py:246-283, attn() :194-198)
+ * qkv bf16 [B, N=1+T*n, 3*D] (q|k|v, head-major inside D, q pre-scaled), out bf16 [B, N, D]; head dim 64.
+ * space: per (b, head, frame): n queries x (CLS + n) keys.  time: per (b, head, patch): T queries x (CLS + T) keys.
+ * cls: the CLS query attends all N keys (row 0 of out).  Rows 1.. are written by space/time, row 0 by cls. */
+int hh_space_attn_fwd(const void* qkv, void* out, int B, int T, int n, int heads, hh_stream_t stream);
+int hh_time_attn_fwd(const void* qkv, void* out, int B, int T, int n, int heads, hh_stream_t stream);
+int hh_cls_attn_fwd(const void* qkv, void* out, int B, int N, int heads, hh_stream_t stream);
+
+/* ---- decoder cross-attention core (nn.MultiheadAttention inside tfm_decoder.py:438-441; 13 x 4096, 8 heads)
+ * q fp32 [B, Q, C] (already scaled by d^-0.5), k/v bf16 [B, M, ldkv] (head-major columns, C = heads*64 used),
+ * out fp32 [B, Q, C], lse fp32 [B, heads, Q] (log-sum-exp for the backward).  Q <= 16. */
+int hh_xattn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out, float* lse,
+                 int B, int Q, int M, int heads, hh_stream_t stream);
+/* backward: dq fp32 [B,Q,C]; dk/dv bf16 [B, M, lddkv] */
+int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_t ldkv, const float* out, const float* lse,
+                 const float* dout, float* dq, void* dk, void* dv, int64_t lddkv,
+                 int B, int Q, int M, int heads, hh_stream_t stream);
+
+/* ---- Hungarian matching + box losses (model/box_utils.py:43-92,156-173,249-279; utils/box_ops.py:9-61)
+ * pred fp32 [F, Qtot, 4] cxcywh; queries [q0, q0+q) are matched.  raw_boxes fp32 [F, k, 4] xyxy pixels
+ * (zero / degenerate = absent, prepare_targets semantics, img = 224).  Outputs (all device):
+ *   tgt_cxcywh fp32 [F,k,4] compacted valid targets, tgt_count int32 [F],
+ *   match_pred int64 [F,k], match_tgt int64 [F,k] (first min(q,count) entries valid, pred ascending), match_n int32 [F]
+ * Exact shortest-augmenting-path LSAP (scipy.optimize.linear_sum_assignment semantics) in fp64 on the fp32 cost
+ * C = w_l1*L1 - w_giou*GIoU, one thread per frame. q <= 16, k <= 16. */
+int hh_match_boxes(const float* pred, int Qtot, int q0, int q, const float* raw_boxes, int k, float img,
+                   float w_l1, float w_giou, float* tgt_cxcywh, int32_t* tgt_count,
+                   int64_t* match_pred, int64_t* match_tgt, int32_t* match_n, int64_t F, hh_stream_t stream);
+/* generic batched LSAP on fp32 costs [P, nr, nc] (word loss, loss.py:83-93): the rows with row_valid != 0
+ * (kept in order) x all nc columns; out col_of_row int64 [P, nr] (assigned column per row, -1 for invalid /
+ * unassigned rows). nr <= 16, nc <= 16 */
+int hh_lsap_rows(const float* cost, const uint8_t* row_valid, int64_t* col_of_row, int64_t P, int nr, int nc,
+                 hh_stream_t stream);
+/* matched-pair losses: sums over all frames of L1 and (1-GIoU) (un-normalised), and d(pred) given upstream
+ * scalars g_l1, g_giou (dL/d(sum_l1), dL/d(sum_giou)).  sums fp32 [2] must be zeroed by the caller. */
+int hh_box_loss_fwd(const float* pred, int Qtot, int q0, const float* tgt_cxcywh, int k,
+                    const int64_t* match_pred, const int64_t* match_tgt, const int32_t* match_n,
+                    float* sums, int64_t F, hh_stream_t stream);
+int hh_box_loss_bwd(const float* pred, int Qtot, int q0, const float* tgt_cxcywh, int k,
+                    const int64_t* match_pred, const int64_t* match_tgt, const int32_t* match_n,
+                    const float* g_l1, const float* g_giou, float* dpred, int64_t F, hh_stream_t stream);
+
+/* ---- fused AdamW over a flat fp32 parameter arena (torch.optim.AdamW semantics; run/train.py:199-203,520)
+ * p,g,m,v fp32 [n]; decay_mask uint8 [n] or per-segment handled by caller through two calls.  step >= 1. */
+int hh_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, hh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HH_H */

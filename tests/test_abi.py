@@ -1,0 +1,52 @@
+"""CPU-side checks of the C-ABI boundary: libhh.so builds for gfx950, loads, and exports every symbol that
+include/hh.h declares (no compute calls without a GPU); the Python binding table covers the same set."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "hh.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hh_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from helping_hand_for_egocentric_videos_amd import build, _lib
+    path = build.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/hh.h but not exported by libhh.so"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    L = _lib.lib()
+    assert L.hh_version() >= 100
+    assert isinstance(L.hh_last_error_string(), bytes)
+
+
+def test_host_side_argument_validation_needs_no_gpu():
+    """Shape/alignment errors are reported by the C ABI before any launch (status < 0 + message)."""
+    from helping_hand_for_egocentric_videos_amd import _lib
+    L = _lib.lib()
+    e = _lib.GemmEpilogue()
+    rc = L.hh_gemm_bf16(None, 100, None, 100, None, 100, 4, 100, 100, ctypes.byref(e), None)
+    assert rc == -1 and b"hh_gemm_bf16" in L.hh_last_error_string()
+    assert L.hh_space_attn_fwd(None, None, 1, 4, 250, 2, None) == -1
+    assert L.hh_time_attn_fwd(None, None, 1, 5, 256, 2, None) == -3
+    assert L.hh_xattn_fwd(None, None, None, 512, None, None, 1, 17, 4096, 8, None) == -1
+    assert L.hh_adamw_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None) == -1
+
+
+def test_product_ops_refuse_cpu_tensors():
+    import torch
+    from helping_hand_for_egocentric_videos_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.layernorm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64), 1e-5)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(128, 64, dtype=torch.bfloat16))

@@ -1,0 +1,279 @@
+"""GPU parity tests of every libhh kernel (through the C ABI) against plain fp32 PyTorch / the oracle.
+
+Tolerances: kernels consume bf16 operands and accumulate in fp32; references are computed in fp32 on the
+SAME bf16-rounded inputs, so the residual is accumulation order + one bf16 rounding of the output
+(relative 2^-8 = 3.9e-3).  Index work (matching) is bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helping_hand_for_egocentric_videos_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def assert_close_bf16(got, ref, rel=8e-3, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("cols,rows", [(1024, 4097), (512, 1000), (128, 37), (768, 64)])
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.bfloat16), (torch.float32, torch.float32),
+                                     (torch.bfloat16, torch.bfloat16)])
+def test_layernorm(cols, rows, xdt, ydt):
+    x = (rnd(rows, cols, seed=1) * 2 + 0.3).to(xdt)
+    g, b = rnd(cols, seed=2) * 0.1 + 1, rnd(cols, seed=3) * 0.1
+    ref = torch.nn.functional.layer_norm(x.float(), (cols,), g, b, 1e-6)
+    y = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-6, out_dtype=ydt)
+    if ydt == torch.float32:
+        torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-5)
+    else:
+        assert_close_bf16(y, ref, 5e-3, "layernorm")
+
+
+def test_layernorm_bwd():
+    rows, cols = 1031, 512
+    x = rnd(rows, cols, seed=4, scale=2.0)
+    g, b = rnd(cols, seed=5) * 0.1 + 1, rnd(cols, seed=6) * 0.1
+    dy = rnd(rows, cols, seed=7)
+    xr = x.clone().requires_grad_(True)
+    gr = g.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (cols,), gr, br, 1e-5).backward(dy)
+    y, mean, rstd = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, out_dtype=torch.float32, save_stats=True)
+    dx, dg, db = ops.layernorm_bwd(x.to(DEV), g.to(DEV), mean, rstd, dy.to(DEV))
+    torch.testing.assert_close(dx.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(4097, 3072, 1024), (300, 128, 64), (8194, 1024, 4096), (1, 256, 128), (129, 384, 128)])
+def test_gemm_plain_and_epilogues(M, N, K):
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
+    bias = rnd(N, seed=3)
+    ref = a.float() @ w.float().t()
+    A, W, Bv = a.to(DEV), w.to(DEV), bias.to(DEV)
+    assert_close_bf16(ops.gemm(A, W), ref, 8e-3, "plain")
+    out32 = ops.gemm(A, W, Bv, out_dtype=torch.float32)
+    torch.testing.assert_close(out32.cpu(), ref + bias, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+    # qkv epilogue: bias then scale the first N/3.. columns
+    cs = (N // 128 // 3 or 1) * 128
+    r = ref + bias
+    r[:, :cs] *= 0.125
+    assert_close_bf16(ops.gemm(A, W, Bv, colscale=0.125, colscale_cols=cs), r, 8e-3, "qkv")
+    # QuickGELU
+    r = ref + bias
+    assert_close_bf16(ops.gemm(A, W, Bv, act=ops.ACT_QUICKGELU), r * torch.sigmoid(1.702 * r), 8e-3, "gelu")
+    assert_close_bf16(ops.gemm(A, W, Bv, act=ops.ACT_RELU), torch.relu(r), 8e-3, "relu")
+    # fp32 residual, in place
+    res = rnd(M, N, seed=5)
+    R = res.to(DEV)
+    out = ops.gemm(A, W, Bv, out=R, resid=R)
+    assert out.data_ptr() == R.data_ptr()
+    torch.testing.assert_close(R.cpu(), ref + bias + res, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+
+
+def test_gemm_row_remap():
+    B, T, n, K, N = 2, 4, 256, 640, 128
+    a, w = bf(rnd(B * T * n, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
+    out = torch.zeros((B * (1 + T * n), N), dtype=torch.float32, device=DEV)
+    ops.gemm(a.to(DEV), w.to(DEV), out=out, remap=(T * n, 1, 1))
+    ref = (a.float() @ w.float().t()).view(B, T * n, N)
+    got = out.view(B, 1 + T * n, N).cpu()
+    assert got[:, 0].abs().max() == 0
+    torch.testing.assert_close(got[:, 1:], ref, rtol=2e-3, atol=2e-3)
+
+
+def test_cast_transpose():
+    x = rnd(1000, 520, seed=1)
+    X = x.to(DEV)
+    assert torch.equal(ops.to_bf16(X).cpu(), x.to(torch.bfloat16))
+    assert torch.equal(ops.to_f32(ops.to_bf16(X)).cpu(), x.to(torch.bfloat16).float())
+    t = ops.transpose_bf16(X, pad_cols_to=64)
+    assert t.shape == (520, 1024)
+    assert torch.equal(t[:, :1000].cpu(), x.t().to(torch.bfloat16))
+    assert t[:, 1000:].abs().max() == 0
+
+
+def test_patch_embed_front_end():
+    from helping_hand_for_egocentric_videos_amd import synth, TINY4
+    from oracle import encoder as OE
+    cfg = TINY4
+    sd = synth.encoder_state(cfg, seed=1, with_text=False)
+    video = synth.make_batch(cfg, 2, seed=1)["video"]
+    B, T = 2, cfg.num_frames
+    n, D, P = cfg.patches_per_frame, cfg.embed_dim, cfg.patch_size
+    patches = ops.patch_im2col(video.to(DEV), P, 640)
+    ref_p = torch.nn.functional.unfold(video.flatten(0, 1), P, stride=P).transpose(1, 2).reshape(B * T * n, -1)
+    assert torch.equal(patches[:, :588].cpu(), ref_p.to(torch.bfloat16))
+    assert patches[:, 588:].abs().max() == 0
+    w = torch.zeros(D, 640)
+    w[:, :588] = sd["visual.patch_embed.proj.weight"].reshape(D, -1)
+    tok = ops.gemm(patches, bf(w).to(DEV), out_dtype=torch.float32)
+    x = ops.embed_ln_pre(tok, sd["visual.cls_token"].view(-1).to(DEV), sd["visual.pos_embed"][0].contiguous().to(DEV),
+                         sd["visual.temporal_embed"][0].contiguous().to(DEV), sd["visual.ln_pre.weight"].to(DEV),
+                         sd["visual.ln_pre.bias"].to(DEV), B, T, n)
+    ref = OE.embed_tokens(video, sd, cfg)
+    torch.testing.assert_close(x.cpu(), ref, rtol=2e-2, atol=2e-2)      # bf16 patch GEMM operands
+
+
+def _ref_divided(qkv, B, T, n, heads, mode):
+    """fp32 reference of the attention core on the same bf16 qkv (q pre-scaled): oracle maths, LaviLa.py:255-279."""
+    N, D = 1 + T * n, heads * 64
+    q, k, v = qkv.float().view(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    cls = torch.softmax(q[:, :, :1] @ k.transpose(-1, -2), -1) @ v
+    ql, kl, vl = (t[:, :, 1:].reshape(B, heads, T, n, 64) for t in (q, k, v))
+    if mode == "time":
+        ql, kl, vl = (t.transpose(2, 3) for t in (ql, kl, vl))
+    G = ql.shape[2]
+    kl = torch.cat([k[:, :, None, :1].expand(B, heads, G, 1, 64), kl], 3)
+    vl = torch.cat([v[:, :, None, :1].expand(B, heads, G, 1, 64), vl], 3)
+    o = torch.softmax(ql @ kl.transpose(-1, -2), -1) @ vl
+    if mode == "time":
+        o = o.transpose(2, 3)
+    o = torch.cat([cls, o.reshape(B, heads, T * n, 64)], 2)
+    return o.permute(0, 2, 1, 3).reshape(B * N, D)
+
+
+@pytest.mark.parametrize("mode", ["space", "time"])
+@pytest.mark.parametrize("B,T,n,heads", [(2, 4, 256, 2), (1, 16, 256, 16), (1, 2, 576, 2), (1, 32, 64, 2)])
+def test_divided_attention(mode, B, T, n, heads):
+    N, D = 1 + T * n, heads * 64
+    qkv = rnd(B * N, 3 * D, seed=T + n)
+    qkv[:, :D] *= 0.6            # realistic logits (|s| up to ~15)
+    qkv[5, :64] += 6.0            # spike one query
+    qkv = bf(qkv)
+    out = ops.divided_attention(qkv.to(DEV), B, T, n, heads, mode)
+    ref = _ref_divided(qkv, B, T, n, heads, mode)
+    assert_close_bf16(out, ref, 1.2e-2, f"attn-{mode}")
+    # row-wise check so a wrong small-magnitude row cannot hide behind the global scale
+    err = (out.float().cpu() - ref).abs().amax(1)
+    scale = ref.abs().amax(1) + 1e-3
+    assert (err / scale).max() < 5e-2
+
+
+@pytest.mark.parametrize("B,Q,M,heads", [(2, 13, 4096, 8), (3, 5, 1024, 8), (1, 16, 96, 2)])
+def test_xattn_fwd_bwd(B, Q, M, heads):
+    C = heads * 64
+    q = rnd(B, Q, C, seed=1, scale=0.3)
+    kv = bf(rnd(B, M, 2 * C, seed=2))
+    dout = rnd(B, Q, C, seed=3)
+    Kd = kv.to(DEV)
+    k, v = Kd[:, :, :C], Kd[:, :, C:]
+    out, lse = ops.xattn_fwd(q.to(DEV), k, v, heads)
+    qb = bf(q).float().requires_grad_(True)
+    kr = kv[:, :, :C].float().requires_grad_(True)
+    vr = kv[:, :, C:].float().requires_grad_(True)
+    qh = qb.view(B, Q, heads, 64).transpose(1, 2)
+    kh = kr.view(B, M, heads, 64).transpose(1, 2)
+    vh = vr.view(B, M, heads, 64).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2)
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Q, C)
+    assert_close_bf16(out, ref.detach(), 1e-2, "xattn out")
+    torch.testing.assert_close(lse.cpu(), torch.logsumexp(s, -1).detach(), rtol=1e-3, atol=1e-3)
+    ref.backward(dout)
+    dkv = torch.zeros_like(Kd)
+    dq = ops.xattn_bwd(q.to(DEV), k, v, out, lse, dout.to(DEV), dkv[:, :, :C], dkv[:, :, C:], heads)
+    assert_close_bf16(dq, qb.grad, 2e-2, "dq")
+    assert_close_bf16(dkv[:, :, :C], kr.grad, 2e-2, "dk")
+    assert_close_bf16(dkv[:, :, C:], vr.grad, 2e-2, "dv")
+
+
+def test_match_boxes_bit_exact_and_losses():
+    from helping_hand_for_egocentric_videos_amd import synth, TINY4
+    from oracle import losses as OL
+    g = torch.Generator().manual_seed(5)
+    for trial, (q0, q) in enumerate([(0, 2), (2, 10), (0, 2), (2, 2), (1, 12)]):
+        Qtot = 13
+        F_ = 64
+        pred = torch.rand(F_, Qtot, 4, generator=g) * 0.4 + 0.2
+        if trial == 2:                      # near-duplicate predictions: tie-ish costs
+            pred[:, 1] = pred[:, 0] + 1e-7
+        raw = synth.make_batch(TINY4.with_(num_frames=16), 4, seed=trial)["boxes"][:, :, :2].flatten(0, 1)   # [64,2,4]
+        if trial == 3:
+            raw = raw.repeat(1, 2, 1)[:, :3] + torch.rand(F_, 3, 4, generator=g)    # up to 3 targets vs q=2 (wide)
+            raw[..., 2:] = raw[..., :2] + raw[..., 2:].abs() + 1
+        tg = OL.prepare_targets(raw)
+        pb = pred[:, q0:q0 + q]
+        ref_idx = OL.hungarian_match(pb, tg)
+        m = ops.match_boxes(pred.to(DEV), q0, q, raw.to(DEV).contiguous())
+        cnt = m["count"].cpu()
+        mp, mt, mn = m["pred_idx"].cpu(), m["tgt_idx"].cpu(), m["n"].cpu()
+        assert mp.dtype == torch.int64 and mt.dtype == torch.int64
+        for f in range(F_):
+            assert int(cnt[f]) == len(tg[f])
+            torch.testing.assert_close(m["tgt"][f, :len(tg[f])].cpu(), tg[f], rtol=0, atol=0)
+            r, c = ref_idx[f]
+            assert int(mn[f]) == len(r)
+            assert torch.equal(mp[f, :len(r)], r) and torch.equal(mt[f, :len(r)], c), (trial, f)
+        # losses + gradient
+        pr = pred.clone().requires_grad_(True)
+        l1, gi, _ = OL.box_losses(pr[:, q0:q0 + q], tg, ref_idx)
+        nb = max(float(sum(len(t) for t in tg)), 1.0)
+        sums = ops.box_loss_fwd(pred.to(DEV), q0, m).cpu()
+        torch.testing.assert_close(sums[0] / nb, l1.detach(), rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(sums[1] / nb, gi.detach(), rtol=1e-4, atol=1e-6)
+        (3.75 * l1 + 1.5 * gi).backward()
+        dpred = torch.zeros_like(pred, device=DEV)
+        ops.box_loss_bwd(pred.to(DEV), q0, m, torch.tensor([3.75 / nb], device=DEV), torch.tensor([1.5 / nb], device=DEV), dpred)
+        torch.testing.assert_close(dpred.cpu(), pr.grad, rtol=1e-3, atol=1e-5)
+
+
+def test_lsap_rows_matches_scipy_golden():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lsap_scipy.npz"))
+    co, ro = 0, 0
+    for (nr, nc), n in zip(g["shapes"], g["lens"]):
+        c = g["costs"][co:co + nr * nc].reshape(nr, nc)
+        co += nr * nc
+        rows, cols = g["rows"][ro:ro + n], g["cols"][ro:ro + n]
+        ro += n
+        if nr == 0 or nc == 0 or nr > 16 or nc > 16 or not np.array_equal(c.astype(np.float32).astype(np.float64), c):
+            continue
+        out = ops.lsap_rows(torch.tensor(c, dtype=torch.float32, device=DEV)[None], torch.ones(1, nr, dtype=torch.uint8, device=DEV)).cpu()[0]
+        got = {(r, int(out[r])) for r in range(nr) if out[r] >= 0}
+        assert got == set(zip(rows.tolist(), cols.tolist()))
+    # masked rows
+    cost = torch.rand(7, 4, 12, generator=torch.Generator().manual_seed(1))
+    valid = torch.tensor([[1, 1, 0, 0], [1, 0, 1, 0], [0, 0, 0, 0], [1, 1, 1, 1], [0, 1, 1, 1], [1, 0, 0, 0], [0, 0, 0, 1]], dtype=torch.uint8)
+    from oracle.lsap import linear_sum_assignment
+    out = ops.lsap_rows(cost.to(DEV), valid.to(DEV)).cpu()
+    for p in range(7):
+        rows = [r for r in range(4) if valid[p, r]]
+        if rows:
+            _, cols = linear_sum_assignment(cost[p][rows].numpy())
+            assert [int(out[p, r]) for r in rows] == cols.tolist()
+        assert all(int(out[p, r]) == -1 for r in range(4) if not valid[p, r])
+
+
+def test_adamw_step():
+    n = 100003
+    p, g = rnd(n, seed=1), rnd(n, seed=2) * 1e-3
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=3e-5, weight_decay=1e-5)
+    P, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        ref.grad = g * step
+        opt.step()
+        ops.adamw_step(P, (g * step).to(DEV), m, v, 3e-5, 0.9, 0.999, 1e-8, 1e-5, step)
+    torch.testing.assert_close(P.cpu(), ref.detach(), rtol=1e-6, atol=1e-8)
+
+
+def test_errors_are_loud():
+    with pytest.raises(RuntimeError):
+        ops.layernorm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64), 1e-5)          # CPU tensor
+    with pytest.raises(RuntimeError, match="hh_gemm_bf16"):
+        ops.gemm(torch.zeros(4, 32, dtype=torch.bfloat16, device=DEV), torch.zeros(128, 32, dtype=torch.bfloat16, device=DEV))
