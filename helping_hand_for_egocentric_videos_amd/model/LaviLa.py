@@ -1,0 +1,374 @@
+"""Frozen LaViLa dual encoder: TimeSformer vision tower on libhh kernels + CLIP wrapper.
+
+Mirror of /root/reference/model/LaviLa.py for the hot path: `SpaceTimeTransformer` (:393-581), `SpaceTimeBlock`
+(:305-390), `VarAttention` (:226-283), `Mlp` (:175-191), `VideoPatchEmbed` (:200-223), `CLIP` (:586-687).
+Constructor arguments, forward signatures, returned values and state_dict keys are the reference's; factories
+that download weights (:19-172) are out of scope (no network).
+
+MI355X design (not a translation of the reference's op sequence):
+  * the vision tower is inference-only (frozen, run under no_grad at run/train.py:109-110): weights are cached once
+    as bf16 [N,K] operands, the residual stream stays fp32, every Linear runs on the MFMA GEMM with its bias /
+    q-scale / QuickGELU / residual fused into the epilogue, LayerNorms are single-pass wave-per-row kernels,
+  * one token-major activation layout [B*N, D] end to end -- no rearrange/cat/chunk copies (9 per attention call in
+    the reference): the attention kernels read q|k|v straight out of the QKV GEMM output,
+  * supports only what the hot path uses: attention_style 'frozen-in-time', no adapters / tanh gating / drop-path.
+"""
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops
+from .openai_model import QuickGELU, Transformer
+
+
+def _require_gpu(x, who):
+    if not x.is_cuda:
+        raise RuntimeError(f"{who}: the product path runs on libhh HIP kernels only (got a {x.device} tensor); "
+                           "there is no CPU fallback -- use oracle/ for CPU reference numbers")
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+        if not isinstance(self.act, QuickGELU):
+            raise NotImplementedError("Mlp: only QuickGELU is fused into the GEMM epilogue (LaViLa uses QuickGELU)")
+        if drop != 0.:
+            raise NotImplementedError("Mlp: dropout is 0 on the frozen tower")
+
+    def forward(self, x):
+        """x [..., D] fp32/bf16 -> fc2(QuickGELU(fc1(x))) fp32 (unfused standalone form)."""
+        _require_gpu(x, "Mlp")
+        shp = x.shape
+        a = ops.to_bf16(x.reshape(-1, shp[-1]).contiguous())
+        h = ops.gemm(a, ops.to_bf16(self.fc1.weight.detach()), self.fc1.bias.detach(), act=ops.ACT_QUICKGELU)
+        y = ops.gemm(h, ops.to_bf16(self.fc2.weight.detach()), self.fc2.bias.detach(), out_dtype=torch.float32)
+        return y.view(shp)
+
+
+class VideoPatchEmbed(nn.Module):
+    """Video to patch embedding (LaviLa.py:200-223): Conv2d(k=P, s=P) == im2col + GEMM."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, num_frames=8, ln_pre=False):
+        super().__init__()
+        img_size = (img_size, img_size) if not isinstance(img_size, tuple) else img_size
+        patch_size = (patch_size, patch_size) if not isinstance(patch_size, tuple) else patch_size
+        self.img_size, self.patch_size = img_size, patch_size
+        self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0]) * num_frames
+        self.num_frames, self.embed_dim = num_frames, embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=not ln_pre)
+        if in_chans != 3 or patch_size[0] != patch_size[1]:
+            raise NotImplementedError("VideoPatchEmbed: 3-channel square patches only")
+
+    def kpad(self):
+        k = 3 * self.patch_size[0] * self.patch_size[1]
+        return (k + 63) // 64 * 64
+
+    def packed_weight(self):
+        w = self.proj.weight.detach().reshape(self.embed_dim, -1)
+        wp = torch.zeros((self.embed_dim, self.kpad()), dtype=torch.float32, device=w.device)
+        wp[:, :w.shape[1]] = w
+        return ops.to_bf16(wp)
+
+    def forward(self, x):
+        """x [B,F,C,H,W] -> [B*F, embed_dim, H/P, W/P] (reference layout, LaviLa.py:218-223)."""
+        _require_gpu(x, "VideoPatchEmbed")
+        B, Fr, C, H, W = x.shape
+        P = self.patch_size[0]
+        patches = ops.patch_im2col(x.float().contiguous(), P, self.kpad())
+        tok = ops.gemm(patches, self.packed_weight(), self.proj.bias.detach() if self.proj.bias is not None else None,
+                       out_dtype=torch.float32)
+        return tok.view(B * Fr, H // P, W // P, self.embed_dim).permute(0, 3, 1, 2)
+
+
+class VarAttention(nn.Module):
+    """Divided space-time attention (LaviLa.py:226-283)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., initialize='random'):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        if initialize == 'zeros':
+            self.qkv.weight.data.fill_(0)
+            if self.qkv.bias is not None:
+                self.qkv.bias.data.fill_(0)
+            self.proj.weight.data.fill_(1)
+            self.proj.bias.data.fill_(0)
+        self.attn_drop = nn.Dropout(attn_drop)      # never applied by the reference either (LaviLa.py:243)
+        self.proj_drop = nn.Dropout(proj_drop)
+        if head_dim != 64:
+            raise NotImplementedError("VarAttention: libhh attention kernels are specialised for head_dim 64")
+        if proj_drop != 0.:
+            raise NotImplementedError("VarAttention: proj_drop is 0 on the frozen tower")
+
+    def packed(self):
+        """bf16 [N,K] operands + fp32 biases for the fused path."""
+        return {"wqkv": ops.to_bf16(self.qkv.weight.detach()), "bqkv": None if self.qkv.bias is None else self.qkv.bias.detach().float(),
+                "wproj": ops.to_bf16(self.proj.weight.detach()), "bproj": self.proj.bias.detach().float()}
+
+    @staticmethod
+    def _mode(einops_to):
+        return "space" if einops_to.replace(" ", "") == "(bf)nd" else "time"
+
+    def core(self, xn, pk, B, T, n, mode):
+        """xn bf16 [B*N, D] (already normalised) -> attention output bf16 [B*N, D] (before proj)."""
+        D = xn.shape[1]
+        qkv = ops.gemm(xn, pk["wqkv"], pk["bqkv"], colscale=self.scale, colscale_cols=D)
+        return ops.divided_attention(qkv, B, T, n, self.num_heads, mode)
+
+    def forward(self, x, einops_from, einops_to, einops_dims):
+        """x [B, 1+T*n, D] -> proj(attention(x)) [B, N, D] fp32.  einops strings as the reference passes them
+        (LaviLa.py:492-495): '(b f) n d' with f=T -> space, '(b n) f d' with n=patches -> time."""
+        _require_gpu(x, "VarAttention")
+        B, N, D = x.shape
+        mode = self._mode(einops_to)
+        if mode == "space":
+            T = einops_dims["f"]
+            n = (N - 1) // T
+        else:
+            n = einops_dims["n"]
+            T = (N - 1) // n
+        pk = self.packed()
+        a = self.core(ops.to_bf16(x.reshape(B * N, D).contiguous()), pk, B, T, n, mode)
+        return ops.gemm(a, pk["wproj"], pk["bproj"], out_dtype=torch.float32).view(B, N, D)
+
+
+class SpaceTimeBlock(nn.Module):
+    """LaviLa.py:305-390: t = timeattn(norm3(x)); s = attn(norm1(x+t)); y = x + s; out = y + mlp(norm2(y))."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, n_layer=0, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, time_init='zeros',
+                 attention_style='frozen-in-time', is_tanh_gating=False, use_adapter=False):
+        super().__init__()
+        if attention_style != 'frozen-in-time' or is_tanh_gating or use_adapter or drop_path > 0.:
+            raise NotImplementedError("SpaceTimeBlock: only the hot-path configuration of LaViLa is built "
+                                      "(frozen-in-time, no gating / adapters / drop-path)")
+        self.norm1 = norm_layer(dim)
+        self.attn = VarAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.timeattn = VarAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                                     proj_drop=drop, initialize=time_init)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.norm3 = norm_layer(dim)
+        self.attention_style = attention_style
+        self.use_adapter = False
+        self._pack = None
+
+    def packed(self, refresh=False):
+        if self._pack is None or refresh:
+            ln = lambda m: (m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous(), m.eps)
+            self._pack = {"n1": ln(self.norm1), "n2": ln(self.norm2), "n3": ln(self.norm3), "time": self.timeattn.packed(),
+                          "space": self.attn.packed(), "w1": ops.to_bf16(self.mlp.fc1.weight.detach()),
+                          "b1": self.mlp.fc1.bias.detach().float(), "w2": ops.to_bf16(self.mlp.fc2.weight.detach()),
+                          "b2": self.mlp.fc2.bias.detach().float()}
+        return self._pack
+
+    def fused(self, x, B, T, n):
+        """x fp32 [B*N, D] residual stream, updated IN PLACE; returns x."""
+        pk = self.packed()
+        a = self.timeattn.core(ops.layernorm(x, *pk["n3"]), pk["time"], B, T, n, "time")
+        tr = ops.gemm(a, pk["time"]["wproj"], pk["time"]["bproj"], resid=x, out_dtype=torch.float32)          # x + time
+        a = self.attn.core(ops.layernorm(tr, *pk["n1"]), pk["space"], B, T, n, "space")
+        ops.gemm(a, pk["space"]["wproj"], pk["space"]["bproj"], resid=x, out=x)                                 # x + space (A1)
+        h = ops.gemm(ops.layernorm(x, *pk["n2"]), pk["w1"], pk["b1"], act=ops.ACT_QUICKGELU)
+        ops.gemm(h, pk["w2"], pk["b2"], resid=x, out=x)
+        return x
+
+    def forward(self, x, einops_from_space, einops_to_space, einops_from_time, einops_to_time, time_n, space_f,
+                use_checkpoint=False):
+        _require_gpu(x, "SpaceTimeBlock")
+        B, N, D = x.shape
+        y = x.float().reshape(B * N, D).clone()
+        return self.fused(y, B, space_f, time_n).view(B, N, D)
+
+
+class SpaceTimeTransformer(nn.Module):
+    """TimeSformer vision tower (LaviLa.py:393-581).  forward(x [B,T,C,H,W]) -> (x_cls [B,D], x [B,1+T*n,D])."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=True, qk_scale=None, representation_size=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., hybrid_backbone=None, norm_layer=None,
+                 num_frames=8, time_init='rand', attention_style='frozen-in-time', ln_pre=False,
+                 act_layer=nn.GELU, is_tanh_gating=False, use_adapter=False):
+        super().__init__()
+        if hybrid_backbone is not None or representation_size or drop_rate or drop_path_rate or not ln_pre:
+            raise NotImplementedError("SpaceTimeTransformer: only the LaViLa configuration (ln_pre=True, no dropout, "
+                                      "no representation layer) is built")
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.num_frames = num_frames
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        self.patch_embed = VideoPatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                           embed_dim=embed_dim, num_frames=num_frames, ln_pre=ln_pre)
+        self.patches_per_frame = self.patch_embed.num_patches // num_frames
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patches_per_frame + 1, embed_dim))
+        self.temporal_embed = nn.Parameter(torch.zeros(1, num_frames, embed_dim))
+        self.ln_pre = nn.LayerNorm(embed_dim)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.blocks = nn.ModuleList([
+            SpaceTimeBlock(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                           n_layer=i, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=0., norm_layer=norm_layer,
+                           time_init=time_init, attention_style=attention_style, act_layer=act_layer,
+                           is_tanh_gating=is_tanh_gating, use_adapter=use_adapter) for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.pre_logits = nn.Identity()
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        self.einops_from_space, self.einops_to_space = 'b (f n) d', '(b f) n d'
+        self.einops_from_time, self.einops_to_time = 'b (f n) d', '(b n) f d'
+        self._pack = None
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token'}
+
+    def refresh_weights(self):
+        """Re-derive the cached bf16 operands (call after load_state_dict / parameter edits)."""
+        self._pack = None
+        for b in self.blocks:
+            b._pack = None
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self.refresh_weights()
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.refresh_weights()
+        return r
+
+    def packed(self):
+        if self._pack is None:
+            f = lambda t: t.detach().float().contiguous()
+            self._pack = {"wpatch": self.patch_embed.packed_weight(), "cls": f(self.cls_token).view(-1),
+                          "pos": f(self.pos_embed[0]), "tmp": f(self.temporal_embed[0]),
+                          "ln_pre": (f(self.ln_pre.weight), f(self.ln_pre.bias), self.ln_pre.eps),
+                          "norm": (f(self.norm.weight), f(self.norm.bias), self.norm.eps)}
+        return self._pack
+
+    @torch.no_grad()
+    def forward_features(self, x, use_checkpoint=False, cls_at_last=True, out_dtype=torch.float32):
+        """LaviLa.py:537-573.  The tower is frozen in this path (run/train.py:89,109-110): no autograd graph."""
+        _require_gpu(x, "SpaceTimeTransformer")
+        B, T, C, H, W = x.shape
+        if T > self.num_frames:
+            raise ValueError(f"SpaceTimeTransformer: {T} frames > num_frames={self.num_frames}")
+        n, D = self.patches_per_frame, self.embed_dim
+        pk = self.packed()
+        patches = ops.patch_im2col(x.float().contiguous(), self.patch_embed.patch_size[0], self.patch_embed.kpad())
+        tok = ops.gemm(patches, pk["wpatch"], out_dtype=torch.float32)
+        xs = ops.embed_ln_pre(tok, pk["cls"], pk["pos"], pk["tmp"], *pk["ln_pre"][:2], B, T, n, pk["ln_pre"][2])
+        del patches, tok
+        xs = xs.view(B * (1 + T * n), D)
+        for blk in self.blocks:
+            blk.fused(xs, B, T, n)
+        out = ops.layernorm(xs, *pk["norm"], out_dtype=out_dtype).view(B, 1 + T * n, D)     # norm evaluated once (A5)
+        return self.pre_logits(out[:, 0]), out
+
+    def forward(self, x, use_checkpoint=False):
+        x_cls, x = self.forward_features(x, use_checkpoint=use_checkpoint)
+        return self.head(x_cls), x
+
+
+class CLIP(nn.Module):
+    """LaviLa.py:586-687: dual encoder wrapper; forward returns the reference's dict."""
+
+    def __init__(self, embed_dim: int, vision_width: int, vision_model: nn.Module, context_length: int, vocab_size: int,
+                 transformer_width: int, transformer_heads: int, transformer_layers: int, tempearture_init=0.07, **kwargs):
+        super().__init__()
+        self.context_length = context_length
+        self.vision_width = vision_width
+        self.visual = vision_model
+        self.transformer = Transformer(width=transformer_width, layers=transformer_layers, heads=transformer_heads,
+                                       attn_mask=self.build_attention_mask())
+        self.vocab_size = vocab_size
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(self.context_length, transformer_width))
+        self.ln_final = nn.LayerNorm(transformer_width)
+        self.image_projection = nn.Parameter(torch.empty(vision_width, embed_dim))
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / tempearture_init))
+        self.text_autocast = torch.bfloat16          # compute dtype of the stock-op text tower on the GPU
+        self.initialize_parameters()
+
+    def initialize_parameters(self):
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        w, L = self.transformer.width, self.transformer.layers
+        for block in self.transformer.resblocks:
+            nn.init.normal_(block.attn.in_proj_weight, std=w ** -0.5)
+            nn.init.normal_(block.attn.out_proj.weight, std=(w ** -0.5) * ((2 * L) ** -0.5))
+            nn.init.normal_(block.mlp.c_fc.weight, std=(2 * w) ** -0.5)
+            nn.init.normal_(block.mlp.c_proj.weight, std=(w ** -0.5) * ((2 * L) ** -0.5))
+        nn.init.normal_(self.image_projection, std=self.vision_width ** -0.5)
+        nn.init.normal_(self.text_projection, std=w ** -0.5)
+
+    def build_attention_mask(self):
+        mask = torch.empty(self.context_length, self.context_length)
+        mask.fill_(float("-inf"))
+        mask.triu_(1)
+        return mask
+
+    def encode_image(self, image, use_checkpoint=False, apply_project=True):
+        x_cls, x = self.visual(image, use_checkpoint=use_checkpoint)
+        if not apply_project:
+            return x_cls, x
+        return x_cls @ self.image_projection, x
+
+    def encode_text(self, text, use_checkpoint=False):
+        """LaviLa.py:660-670 on stock PyTorch-ROCm ops, bf16 autocast on the GPU."""
+        with torch.autocast("cuda", dtype=self.text_autocast, enabled=text.is_cuda and self.text_autocast is not None):
+            x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]
+            x = self.transformer(x.permute(1, 0, 2), use_checkpoint=use_checkpoint).permute(1, 0, 2)
+            x = self.ln_final(x)
+        x = x.float()
+        x_cls = x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)] @ self.text_projection
+        return x_cls, x
+
+    def forward(self, image, text, use_checkpoint=False, norm_embed=True, return_feature_map=False):
+        image_embed, image_fmap = self.encode_image(image, use_checkpoint=use_checkpoint)
+        text_embed, text_fmap = self.encode_text(text, use_checkpoint=use_checkpoint)
+        if norm_embed:
+            image_embed = F.normalize(image_embed, dim=-1)
+            text_embed = F.normalize(text_embed, dim=-1)
+        out = {'image_embed': image_embed, 'text_embed': text_embed, 'logit_scale': self.logit_scale.exp()}
+        if return_feature_map:
+            out['image_feature_map'] = image_fmap
+            out['text_feature_map'] = text_fmap
+        return out
+
+
+def build_backbone(cfg, state_dict=None, device="cuda"):
+    """Construct CLIP(SpaceTimeTransformer) with the arguments of LaviLa.py:118-129,148-162, bypassing the
+    network-bound factory; optionally load a reference-keyed state dict."""
+    vis = SpaceTimeTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth,
+                               num_heads=cfg.num_heads, num_frames=cfg.num_frames, time_init='zeros',
+                               attention_style='frozen-in-time', ln_pre=True, act_layer=QuickGELU)
+    vis.head = nn.Identity()
+    vis.pre_logits = nn.Identity()
+    vis.fc = nn.Identity()
+    model = CLIP(embed_dim=cfg.project_embed_dim, vision_width=cfg.embed_dim, vision_model=vis,
+                 context_length=cfg.context_length, vocab_size=cfg.vocab_size, transformer_width=cfg.text_width,
+                 transformer_heads=cfg.text_heads, transformer_layers=cfg.text_layers, tempearture_init=0.07)
+    if state_dict is not None:
+        missing, unexpected = model.load_state_dict(state_dict, strict=False)
+        if unexpected or any(not k.endswith("attn_mask") for k in missing):
+            raise RuntimeError(f"backbone state dict mismatch: missing={missing} unexpected={unexpected}")
+    model = model.to(device).eval()
+    for p in model.parameters():
+        p.requires_grad_(False)          # optim_policy freezes the backbone (utils/train_utils.py:42-43)
+    return model
