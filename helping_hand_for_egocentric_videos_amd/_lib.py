@@ -12,7 +12,7 @@ c_i64, c_int, c_float, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctyp
 class GemmEpilogue(ctypes.Structure):
     _fields_ = [("bias", c_vp), ("resid", c_vp), ("ldr", c_i64), ("colscale", c_float), ("colscale_cols", c_int),
                 ("act", c_int), ("c_dtype", c_int), ("remap_group", c_i64), ("remap_skip", c_i64),
-                ("remap_offset", c_i64)]
+                ("remap_offset", c_i64), ("splitk", c_int), ("split_stride", c_i64)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); must list every symbol of include/hh.h
@@ -30,9 +30,10 @@ SIGNATURES = {
     "hh_space_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "hh_time_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "hh_cls_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
-    "hh_xattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
-    "hh_xattn_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp],
-    "hh_match_boxes": [c_vp, c_int, c_int, c_int, c_vp, c_int, c_float, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "hh_xattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
+    "hh_xattn_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_float,
+                     ctypes.c_uint32, c_vp],
+    "hh_match_boxes": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_float, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "hh_lsap_rows": [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
     "hh_box_loss_fwd": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "hh_box_loss_bwd": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],

@@ -78,16 +78,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk_all = p.K / BK;
+    int kt0 = 0, nk = nk_all;
+    char* Cbase = (char*)p.C;
+    if (p.e.splitk > 1) {
+        const int per_split = (nk_all + p.e.splitk - 1) / p.e.splitk;
+        kt0 = blockIdx.y * per_split;
+        nk = nk_all - kt0 < per_split ? nk_all - kt0 : per_split;
+        if (nk < 0) nk = 0;
+        Cbase += (int64_t)blockIdx.y * p.e.split_stride * (OUT_BF16 ? 2 : 4);
+    }
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * 32768 + wave * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            glds16(a_src[i] + (int64_t)kt * BK, base + i * 1024);
-            glds16(w_src[i] + (int64_t)kt * BK, base + 16384 + i * 1024);
+            glds16(a_src[i] + (int64_t)(kt0 + kt) * BK, base + i * 1024);
+            glds16(w_src[i] + (int64_t)(kt0 + kt) * BK, base + 16384 + i * 1024);
         }
     };
-    stage(0, 0);
+    if (nk > 0) stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -140,9 +149,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             }
             if constexpr (OUT_BF16) {
                 u32x2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-                *(u32x2*)((bf16_t*)p.C + orow * p.ldc + n) = o;
+                *(u32x2*)((bf16_t*)Cbase + orow * p.ldc + n) = o;
             } else {
-                *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
+                *(f32x4*)((float*)Cbase + orow * p.ldc + n) = v;
             }
         }
     }
@@ -175,9 +184,12 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         hipFuncSetAttribute((const void*)gemm_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_done = true;
     }
+    const unsigned splits = epi->splitk > 1 ? (unsigned)epi->splitk : 1u;
+    HH_REQUIRE(splits <= 1024, HH_ERR_SHAPE, "hh_gemm_bf16: splitk too large");
+    HH_REQUIRE(splits == 1 || (epi->resid == nullptr && epi->split_stride >= 0), HH_ERR_SHAPE, "hh_gemm_bf16: split-K partials take no residual");
     if (epi->c_dtype == HH_BF16)
-        hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3(grid), dim3(256), 65536, s, p);
+        hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3(grid, splits), dim3(256), 65536, s, p);
     else
-        hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3(grid), dim3(256), 65536, s, p);
+        hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3(grid, splits), dim3(256), 65536, s, p);
     return hh_check_launch("hh_gemm_bf16");
 }

@@ -82,7 +82,8 @@ __device__ bool lsap_wide(int nr, int nc, const double* cost, int ldc, int* col4
 }
 
 __global__ __launch_bounds__(64) void match_boxes_kernel(const float* __restrict__ pred, int Qtot, int q0, int q,
-                                                         const float* __restrict__ raw, int k, float img, float w_l1,
+                                                         const float* __restrict__ raw, const int* __restrict__ given_count,
+                                                         int k, float img, float w_l1,
                                                          float w_giou, float* __restrict__ tgt, int* __restrict__ tgt_count,
                                                          int64_t* __restrict__ mp, int64_t* __restrict__ mt,
                                                          int* __restrict__ mn, int64_t F) {
@@ -91,6 +92,12 @@ __global__ __launch_bounds__(64) void match_boxes_kernel(const float* __restrict
     // ---- prepare_targets (box_utils.py:249-279, center_crop=False): clip to [0,img]/img, keep x1>x0 && y1>y0, -> cxcywh
     float t[MAXK][4];
     int cnt = 0;
+    if (given_count) {
+        cnt = given_count[f];
+        if (cnt > k) cnt = k;
+        for (int i = 0; i < cnt; ++i)
+            for (int c = 0; c < 4; ++c) t[i][c] = raw[(f * k + i) * 4 + c];
+    } else
     for (int i = 0; i < k; ++i) {
         const float* r = raw + (f * k + i) * 4;
         const float x0 = fminf(fmaxf(r[0], 0.f), img) / img, y0 = fminf(fmaxf(r[1], 0.f), img) / img;
@@ -230,14 +237,14 @@ __global__ __launch_bounds__(64) void box_loss_bwd_kernel(const float* __restric
     }
 }
 
-extern "C" int hh_match_boxes(const float* pred, int Qtot, int q0, int q, const float* raw_boxes, int k, float img,
+extern "C" int hh_match_boxes(const float* pred, int Qtot, int q0, int q, const float* raw_boxes, const int32_t* given_count, int k, float img,
                               float w_l1, float w_giou, float* tgt_cxcywh, int32_t* tgt_count, int64_t* match_pred,
                               int64_t* match_tgt, int32_t* match_n, int64_t F, hh_stream_t stream) {
     HH_REQUIRE(F >= 0 && q > 0 && q <= MAXQ && k > 0 && k <= MAXK && q0 >= 0 && q0 + q <= Qtot, HH_ERR_SHAPE,
                "hh_match_boxes: need 0 < q <= %d, 0 < k <= %d, q0+q <= Qtot (q=%d k=%d q0=%d Qtot=%d)", MAXQ, MAXK, q, k, q0, Qtot);
     if (F == 0) return HH_OK;
     hipLaunchKernelGGL(match_boxes_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pred, Qtot, q0, q,
-                       raw_boxes, k, img, w_l1, w_giou, tgt_cxcywh, tgt_count, match_pred, match_tgt, match_n, F);
+                       raw_boxes, given_count, k, img, w_l1, w_giou, tgt_cxcywh, tgt_count, match_pred, match_tgt, match_n, F);
     return hh_check_launch("hh_match_boxes");
 }
 

@@ -15,7 +15,14 @@
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-#define VSTRIDE 36   // bf16 elements per d-row of the wave-private transposed tile (32 keys + 4 pad)
+#define VSTRIDE 36
+
+// counter-based dropout mask for element (clip*heads+head, query, key): keep iff hash >= thresh (thresh = p * 2^32)
+__device__ __forceinline__ bool drop_keep(unsigned seed, unsigned bh, unsigned qq, unsigned key, unsigned thresh) {
+    unsigned h = seed ^ (bh * 0x9E3779B9u) ^ (key * 0x85EBCA6Bu) ^ (qq * 0xC2B2AE35u);
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h >= thresh;
+}   // bf16 elements per d-row of the wave-private transposed tile (32 keys + 4 pad)
 
 __device__ __forceinline__ u32x2 pick4(unsigned a, unsigned b, unsigned c, unsigned d, bool hi) {
     u32x2 r;
@@ -60,7 +67,8 @@ __device__ __forceinline__ bf16x8 load_row_frag_f32(const float* row, bool valid
 
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict__ q, const bf16_t* __restrict__ k,
                                                         const bf16_t* __restrict__ v, int64_t ldkv, float* __restrict__ out,
-                                                        float* __restrict__ lse, int B, int Q, int M, int heads) {
+                                                        float* __restrict__ lse, int B, int Q, int M, int heads, unsigned drop_thresh,
+                                                        float drop_scale, unsigned seed) {
     __shared__ __attribute__((aligned(16))) bf16_t tiles[4][64 * VSTRIDE];
     __shared__ float ml[2][4][16];
     __shared__ __attribute__((aligned(16))) float obuf[4][16][64];
@@ -106,8 +114,9 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[t][r] * LOG2E - mb);
+                float p = __builtin_amdgcn_exp2f(s[t][r] * LOG2E - mb);
                 lsum += p;
+                if (drop_thresh) p = drop_keep(seed, blockIdx.x, ql, k0 + 16 * t + 4 * g + r, drop_thresh) ? p * drop_scale : 0.f;
                 pf[4 * t + r] = (bf16_t)p;
             }
         lsum += __shfl_xor(lsum, 16, 64);
@@ -151,7 +160,8 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
                                                         const bf16_t* __restrict__ v, int64_t ldkv, const float* __restrict__ out,
                                                         const float* __restrict__ lse, const float* __restrict__ dout,
                                                         float* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
-                                                        int64_t lddkv, int B, int Q, int M, int heads) {
+                                                        int64_t lddkv, int B, int Q, int M, int heads, unsigned drop_thresh,
+                                                        float drop_scale, unsigned seed) {
     __shared__ __attribute__((aligned(16))) bf16_t tiles[4][64 * VSTRIDE];
     __shared__ __attribute__((aligned(16))) float qbuf[4][16][64];
     __shared__ float stat[2][16];
@@ -237,8 +247,14 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
             for (int r = 0; r < 4; ++r) {
                 const bool live = (4 * g + r) < Q;
                 const float p = live ? __builtin_amdgcn_exp2f(s[r] * LOG2E - lse_r[r]) : 0.f;
-                pb[r] = (bf16_t)p;
-                dsb[r] = (bf16_t)(p * (dp[r] - del_r[r]));
+                float pd = p, dpm = dp[r];
+                if (drop_thresh) {
+                    const bool keep = drop_keep(seed, blockIdx.x, 4 * g + r, (unsigned)key, drop_thresh);
+                    pd = keep ? p * drop_scale : 0.f;
+                    dpm = keep ? dp[r] * drop_scale : 0.f;
+                }
+                pb[r] = (bf16_t)pd;
+                dsb[r] = (bf16_t)(p * (dpm - del_r[r]));
             }
             const s16x4 pbs = __builtin_bit_cast(s16x4, pb), dsbs = __builtin_bit_cast(s16x4, dsb);
 #pragma unroll
@@ -260,7 +276,9 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float p = (ql < Q) ? __builtin_amdgcn_exp2f(st[r] * LOG2E - lse_l) : 0.f;
-                dsT[4 * t + r] = (bf16_t)(p * (dpt[r] - del_l));
+                float dpm = dpt[r];
+                if (drop_thresh) dpm = drop_keep(seed, blockIdx.x, ql, (unsigned)(k0 + 16 * t + 4 * g + r), drop_thresh) ? dpt[r] * drop_scale : 0.f;
+                dsT[4 * t + r] = (bf16_t)(p * (dpm - del_l));
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -287,27 +305,41 @@ static int xattn_check(const char* what, int B, int Q, int M, int heads, int64_t
     return HH_OK;
 }
 
+static void drop_params(float p, unsigned* thresh, float* scale) {
+    if (p <= 0.f) { *thresh = 0u; *scale = 1.f; return; }
+    double t = (double)p * 4294967296.0;
+    *thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    if (*thresh == 0u) *thresh = 1u;
+    *scale = 1.f / (1.f - p);
+}
+
 extern "C" int hh_xattn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out, float* lse,
-                            int B, int Q, int M, int heads, hh_stream_t stream) {
+                            int B, int Q, int M, int heads, float dropout_p, uint32_t seed, hh_stream_t stream) {
     int rc = xattn_check("hh_xattn_fwd", B, Q, M, heads, ldkv);
     if (rc) return rc;
     HH_REQUIRE(HH_ALIGNED16(q) && HH_ALIGNED16(k) && HH_ALIGNED16(v) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_xattn_fwd: pointers must be 16-byte aligned");
+    HH_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, HH_ERR_SHAPE, "hh_xattn_fwd: dropout_p must be in [0,1)");
     if (B == 0) return HH_OK;
+    unsigned thr; float sc;
+    drop_params(dropout_p, &thr, &sc);
     hipLaunchKernelGGL(xattn_fwd_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)k,
-                       (const bf16_t*)v, ldkv, out, lse, B, Q, M, heads);
+                       (const bf16_t*)v, ldkv, out, lse, B, Q, M, heads, thr, sc, seed);
     return hh_check_launch("hh_xattn_fwd");
 }
 
 extern "C" int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_t ldkv, const float* out, const float* lse,
                             const float* dout, float* dq, void* dk, void* dv, int64_t lddkv, int B, int Q, int M, int heads,
-                            hh_stream_t stream) {
+                            float dropout_p, uint32_t seed, hh_stream_t stream) {
     int rc = xattn_check("hh_xattn_bwd", B, Q, M, heads, ldkv);
     if (rc) return rc;
     HH_REQUIRE(lddkv >= heads * 64 && lddkv % 8 == 0, HH_ERR_SHAPE, "hh_xattn_bwd: bad lddkv");
     HH_REQUIRE(HH_ALIGNED16(q) && HH_ALIGNED16(k) && HH_ALIGNED16(v) && HH_ALIGNED16(dout) && HH_ALIGNED16(dk) && HH_ALIGNED16(dv) &&
                HH_ALIGNED16(out) && HH_ALIGNED16(dq), HH_ERR_ALIGN, "hh_xattn_bwd: pointers must be 16-byte aligned");
+    HH_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, HH_ERR_SHAPE, "hh_xattn_bwd: dropout_p must be in [0,1)");
     if (B == 0) return HH_OK;
+    unsigned thr; float sc;
+    drop_params(dropout_p, &thr, &sc);
     hipLaunchKernelGGL(xattn_bwd_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)k,
-                       (const bf16_t*)v, ldkv, out, lse, dout, dq, (bf16_t*)dk, (bf16_t*)dv, lddkv, B, Q, M, heads);
+                       (const bf16_t*)v, ldkv, out, lse, dout, dq, (bf16_t*)dk, (bf16_t*)dv, lddkv, B, Q, M, heads, thr, sc, seed);
     return hh_check_launch("hh_xattn_bwd");
 }

@@ -1,0 +1,32 @@
+"""Metrics on the hot path: mirror of /root/reference/model/metric.py:363-392,209-225 (sim_matrix,
+compute_tv_accuracy, egomcq_accuracy_metrics).  Legacy retrieval metrics of the reference are out of scope."""
+import torch
+
+
+def sim_matrix(a, b, eps=1e-8, norm=True):
+    """Cosine similarity with eps-clamped norms (metric.py:363-375); 2-D -> mm, 3-D -> bmm."""
+    if norm:
+        a = a / a.norm(dim=-1, keepdim=True).clamp_min(eps)
+        b = b / b.norm(dim=-1, keepdim=True).clamp_min(eps)
+    return a @ b.transpose(-1, -2)
+
+
+def compute_tv_accuracy(similarity, text_embeds, sim_v, sim_n, num_samples, device=None):
+    """metric.py:378-392: top-1 text<->video accuracy counting verb/noun-sharing and duplicate-text clips as hits
+    (`[::5]` = first of the 5 rephrases).  Stays on device, no host sync."""
+    tv_argmax = similarity.argmax(dim=-1)
+    vt_argmax = similarity.argmax(dim=0)
+    same = sim_matrix(text_embeds[::5], text_embeds[::5]) > 0.99
+    ar = torch.arange(num_samples, device=similarity.device)
+    same[ar, ar] = False
+    pos = (((sim_v * sim_n) + torch.eye(num_samples, device=similarity.device)) + same) > 0
+    return pos[vt_argmax, ar].float().mean(), pos[ar, tv_argmax].float().mean()
+
+
+def egomcq_accuracy_metrics(preds, labels, types):
+    """metric.py:209-225: accuracy per question type (1 = Inter... group names as in the reference)."""
+    metrics = {}
+    for type_i, group_i in zip(torch.unique(types), ["Intra-video", "Inter-video"]):
+        m = types == type_i
+        metrics[group_i] = float((preds[m].argmax(-1) == labels[m]).float().mean()) * 100
+    return metrics

@@ -1,0 +1,393 @@
+"""Object-query decoder (trainable) on libhh kernels: mirror of /root/reference/model/tfm_decoder.py.
+
+Classes / ctor arguments / forward signatures / state_dict keys follow the reference: `ObjDecoder` (:111-241),
+`Cross_Attention` (:50-93), `TransformerDecoder` (:246-295), `TransformerDecoderLayer` (:358-479, the live path
+is forward_pre with sa_first=True :430-461), `MLP` (:96-108).  Dead code of the reference (PositionEmbeddingSine,
+TransformerEncoderLayer, forward_post -- unusable) is not built.
+
+MI355X design:
+  * memory side (99 % of decoder FLOPs): proj GEMM -> fused LayerNorm -> ONE batched K/V in-projection of the
+    4096 memory tokens for all 6 layers ([B*M,512] x [512, 6*1024], memory is layer-invariant) on the MFMA GEMM;
+    backward = two dgrad GEMMs (second one accumulates through the fp32 residual epilogue), split-K wgrad GEMMs
+    and the LayerNorm backward kernel.  K/V and their gradients live in one [B*M, 6144] bf16 buffer each; the six
+    cross-attention backward kernels write their column slices directly (no autograd slice/accumulate copies).
+  * cross-attention core: hh_xattn_fwd / hh_xattn_bwd (13 x 4096 per clip and head), attention-dropout inside.
+  * query side (13 rows per clip, < 1 % of FLOPs): stock PyTorch-ROCm ops under autograd.
+  * the frame-conditioning `cat[hs, frame_index] -> frame_proj` is evaluated in its exact decomposed form
+    hs.W[:, :C]^T + (frame_index.W[:, C:]^T + b)[t]  (T x fewer FLOPs).
+"""
+import copy
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn, Tensor
+
+from .. import ops
+
+
+def _require_gpu(x, who):
+    if not x.is_cuda:
+        raise RuntimeError(f"{who}: the product path runs on libhh HIP kernels only (got a {x.device} tensor); "
+                           "there is no CPU fallback -- use oracle/ for CPU reference numbers")
+
+
+class _KVHolder:
+    """K/V of all layers [B*M, 2*L*C] bf16 (K columns first) and its gradient buffer."""
+
+    def __init__(self):
+        self.kv = None
+        self.dkv = None
+        self.B = self.M = self.C = self.L = 0
+        self.seed = 0
+
+
+def _splitk_for(tiles, k):
+    s = max(1, min(64, 512 // max(tiles, 1), k // 512))
+    return s
+
+
+class _MemorySide(torch.autograd.Function):
+    """features -> proj -> pre_norm -> (+pos) -> K/V in-projection of every layer.  Returns a 1-element token that
+    the cross-attention nodes consume, so that this node's backward runs after all of them have written holder.dkv."""
+
+    @staticmethod
+    def forward(ctx, feat_b, w_proj, g_pre, b_pre, pos, holder, eps, *in_wb):
+        L = len(in_wb) // 2
+        in_w, in_b = in_wb[:L], in_wb[L:]
+        C = w_proj.shape[0]
+        BM = feat_b.shape[0]
+        M = pos.shape[0]
+        B = BM // M
+        mem0 = ops.gemm(feat_b, ops.to_bf16(w_proj.detach()), out_dtype=torch.float32)                   # [BM, C]
+        memory, mean, rstd = ops.layernorm(mem0, g_pre.detach().float(), b_pre.detach().float(), eps, save_stats=True)
+        mem_pos = (memory.view(B, M, C).float() + pos.detach()).to(torch.bfloat16).view(BM, C)
+        wk = torch.cat([w.detach()[C:2 * C] for w in in_w])                                               # [L*C, C]
+        wv = torch.cat([w.detach()[2 * C:] for w in in_w])
+        bk = torch.cat([b.detach()[C:2 * C] for b in in_b]).float()
+        bv = torch.cat([b.detach()[2 * C:] for b in in_b]).float()
+        kv = torch.empty((BM, 2 * L * C), dtype=torch.bfloat16, device=feat_b.device)
+        ops.gemm(mem_pos, ops.to_bf16(wk), bk, out=kv[:, :L * C])
+        ops.gemm(memory, ops.to_bf16(wv), bv, out=kv[:, L * C:])
+        holder.kv, holder.dkv = kv, None
+        holder.B, holder.M, holder.C, holder.L = B, M, C, L
+        ctx.holder, ctx.L, ctx.C = holder, L, C
+        ctx.save_for_backward(feat_b, mem0, mean, rstd, memory, mem_pos, g_pre, wk, wv)
+        return torch.zeros(1, dtype=torch.float32, device=feat_b.device)
+
+    @staticmethod
+    def backward(ctx, _gtoken):
+        feat_b, mem0, mean, rstd, memory, mem_pos, g_pre, wk, wv = ctx.saved_tensors
+        h, L, C = ctx.holder, ctx.L, ctx.C
+        BM = feat_b.shape[0]
+        if h.dkv is None:                      # no cross-attention gradient reached us
+            h.dkv = torch.zeros_like(h.kv)
+        dk_all, dv_all = h.dkv[:, :L * C], h.dkv[:, L * C:]
+        # dgrad: d(mem_pos) = dK.Wk ; d(memory) = dV.Wv + d(mem_pos)
+        dmem_pos = ops.gemm(dk_all, ops.transpose_bf16(wk), out_dtype=torch.float32)                      # [BM, C]
+        dmem = ops.gemm(dv_all, ops.transpose_bf16(wv), resid=dmem_pos, out_dtype=torch.float32)
+        dpos = dmem_pos.view(h.B, h.M, C).sum(0)
+        # wgrad (contraction over B*M tokens): transposed bf16 operands + split-K
+        sk = _splitk_for((L * C // 128) * (C // 128), BM)
+        dwk = ops.gemm(ops.transpose_bf16(dk_all), ops.transpose_bf16(mem_pos), splitk=sk)               # [L*C, C]
+        dwv = ops.gemm(ops.transpose_bf16(dv_all), ops.transpose_bf16(memory), splitk=sk)
+        dbk = torch.sum(dk_all, dim=0, dtype=torch.float32)
+        dbv = torch.sum(dv_all, dim=0, dtype=torch.float32)
+        del dmem_pos
+        dmem0, dg, db = ops.layernorm_bwd(mem0, g_pre.detach().float(), mean, rstd, dmem)
+        sk2 = _splitk_for((C // 128) * (feat_b.shape[1] // 128), BM)
+        dw_proj = ops.gemm(ops.transpose_bf16(dmem0), ops.transpose_bf16(feat_b), splitk=sk2)            # [C, F]
+        h.kv = h.dkv = None
+        gw, gb = [], []
+        for l in range(L):
+            w = torch.zeros((3 * C, C), dtype=torch.float32, device=feat_b.device)
+            w[C:2 * C] = dwk[l * C:(l + 1) * C]
+            w[2 * C:] = dwv[l * C:(l + 1) * C]
+            b = torch.zeros((3 * C,), dtype=torch.float32, device=feat_b.device)
+            b[C:2 * C] = dbk[l * C:(l + 1) * C]
+            b[2 * C:] = dbv[l * C:(l + 1) * C]
+            gw.append(w)
+            gb.append(b)
+        return (None, dw_proj, dg, db, dpos, None, None, *gw, *gb)
+
+
+class _XAttn(torch.autograd.Function):
+    """softmax(q.K^T).V of one layer on the holder's K/V column slices (q fp32 [B,Q,C], pre-scaled)."""
+
+    @staticmethod
+    def forward(ctx, q, token, holder, layer, heads, dropout_p, seed):
+        B, M, C, L = holder.B, holder.M, holder.C, holder.L
+        kvv = holder.kv.view(B, M, 2 * L * C)
+        k, v = kvv[:, :, layer * C:(layer + 1) * C], kvv[:, :, (L + layer) * C:(L + layer + 1) * C]
+        q = q.contiguous()
+        out, lse = ops.xattn_fwd(q, k, v, heads, dropout_p, seed)
+        ctx.holder, ctx.layer, ctx.heads, ctx.p, ctx.seed = holder, layer, heads, dropout_p, seed
+        ctx.save_for_backward(q, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, out, lse = ctx.saved_tensors
+        h, l = ctx.holder, ctx.layer
+        B, M, C, L = h.B, h.M, h.C, h.L
+        if h.dkv is None:
+            h.dkv = torch.empty_like(h.kv)
+        kvv, dkvv = h.kv.view(B, M, 2 * L * C), h.dkv.view(B, M, 2 * L * C)
+        k, v = kvv[:, :, l * C:(l + 1) * C], kvv[:, :, (L + l) * C:(L + l + 1) * C]
+        dk, dv = dkvv[:, :, l * C:(l + 1) * C], dkvv[:, :, (L + l) * C:(L + l + 1) * C]
+        dq = ops.xattn_bwd(q, k, v, out, lse, dout.contiguous(), dk, dv, ctx.heads, ctx.p, ctx.seed)
+        return dq, torch.zeros(1, dtype=torch.float32, device=q.device), None, None, None, None, None
+
+
+class MLP(nn.Module):
+    """Simple multi-layer perceptron (tfm_decoder.py:96-108)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+        return x
+
+
+class TransformerDecoderLayer(nn.Module):
+    """tfm_decoder.py:358-479.  Only normalize_before=True / sa_first=True (the configuration run/train.py builds)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False,
+                 sa_first=True):
+        super().__init__()
+        self.sa_first = sa_first
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.dropout1, self.dropout2, self.dropout3 = nn.Dropout(dropout), nn.Dropout(dropout), nn.Dropout(dropout)
+        if activation != "relu":
+            raise NotImplementedError("TransformerDecoderLayer: relu only (reference default)")
+        self.activation = F.relu
+        self.normalize_before = normalize_before
+        self.nhead, self.p_attn = nhead, dropout
+        if d_model // nhead != 64:
+            raise NotImplementedError("TransformerDecoderLayer: libhh cross-attention is specialised for head_dim 64")
+
+    def with_pos_embed(self, tensor, pos: Optional[Tensor]):
+        return tensor if pos is None else tensor + pos
+
+    def _self_attention(self, x, qpos):
+        """nn.MultiheadAttention(q = k = x + qpos, v = x) on [B,Q,C] with stock ops (13 x 13 per clip)."""
+        m = self.self_attn
+        C, h = x.shape[-1], self.nhead
+        wq, wk, wv = m.in_proj_weight.chunk(3, dim=0)
+        bq, bk, bv = m.in_proj_bias.chunk(3, dim=0)
+        xq = x + qpos
+        B, Q = x.shape[:2]
+        q = F.linear(xq, wq, bq).view(B, Q, h, C // h).transpose(1, 2)
+        k = F.linear(xq, wk, bk).view(B, Q, h, C // h).transpose(1, 2)
+        v = F.linear(x, wv, bv).view(B, Q, h, C // h).transpose(1, 2)
+        p = torch.softmax((q * (C // h) ** -0.5) @ k.transpose(-1, -2), dim=-1)
+        p = F.dropout(p, self.p_attn, self.training)
+        o = (p @ v).transpose(1, 2).reshape(B, Q, C)
+        return F.linear(o, m.out_proj.weight, m.out_proj.bias)
+
+    def forward_tokens(self, tgt, qpos, token, holder, layer_idx):
+        """Batch-first forward_pre (tfm_decoder.py:430-461): tgt, qpos [B,Q,C] fp32."""
+        C, h = tgt.shape[-1], self.nhead
+        a = self.norm1(tgt)
+        tgt = tgt + self.dropout1(self._self_attention(a, qpos))
+        c = self.norm2(tgt)
+        m = self.multihead_attn
+        q = F.linear(c + qpos, m.in_proj_weight[:C], m.in_proj_bias[:C]) * ((C // h) ** -0.5)
+        p = self.p_attn if self.training else 0.0
+        ca = _XAttn.apply(q, token, holder, layer_idx, h, p, holder.seed + 7919 * layer_idx)
+        tgt = tgt + self.dropout2(F.linear(ca, m.out_proj.weight, m.out_proj.bias))
+        e = self.norm3(tgt)
+        tgt = tgt + self.dropout3(self.linear2(self.dropout(self.activation(self.linear1(e)))))
+        return tgt
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("TransformerDecoderLayer is driven through Cross_Attention / ObjDecoder "
+                                  "(memory K/V of all layers are projected in one batched GEMM)")
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+class TransformerDecoder(nn.Module):
+    """tfm_decoder.py:246-295."""
+
+    def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+
+    def forward_tokens(self, tgt, qpos, token, holder):
+        inter = []
+        for i, layer in enumerate(self.layers):
+            tgt = layer.forward_tokens(tgt, qpos, token, holder, i)
+            if self.return_intermediate:
+                inter.append(self.norm(tgt))
+        if self.return_intermediate:
+            return torch.stack(inter)                  # [L,B,Q,C]
+        return self.norm(tgt).unsqueeze(0)
+
+
+class Cross_Attention(nn.Module):
+    """tfm_decoder.py:50-93."""
+
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
+                 dropout=0.1, activation="relu", normalize_before=False, hidden_dim=768, return_intermediate_dec=False,
+                 sa_first=True):
+        super().__init__()
+        if not normalize_before or not sa_first:
+            raise NotImplementedError("Cross_Attention: only normalize_before=True, sa_first=True is usable in the "
+                                      "reference (forward_post returns 1 value where 3 are unpacked, SURVEY A7)")
+        self.pre_norm = nn.LayerNorm(d_model)
+        layer = TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout, activation, normalize_before, sa_first=sa_first)
+        self.decoder = TransformerDecoder(layer, num_decoder_layers, nn.LayerNorm(d_model), return_intermediate=return_intermediate_dec)
+        self._reset_parameters()
+        self.d_model, self.nhead = d_model, nhead
+        self.dec_layers, self.enc_layers = num_decoder_layers, num_encoder_layers
+        self._seed = 0
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward_tokens(self, feat_b, w_proj, pos, query_embed, B):
+        """feat_b bf16 [B*M, F] (no grad), w_proj [C,F], pos [M,C], query_embed [Q,C] -> hs [L,B,Q,C]."""
+        holder = _KVHolder()
+        self._seed = (self._seed * 1103515245 + 12345) & 0x7FFFFFFF
+        holder.seed = self._seed
+        layers = self.decoder.layers
+        in_w = [l.multihead_attn.in_proj_weight for l in layers]
+        in_b = [l.multihead_attn.in_proj_bias for l in layers]
+        token = _MemorySide.apply(feat_b, w_proj, self.pre_norm.weight, self.pre_norm.bias, pos, holder,
+                                  self.pre_norm.eps, *in_w, *in_b)
+        qpos = query_embed.unsqueeze(0).expand(B, -1, -1)
+        tgt = torch.zeros_like(qpos)
+        hs = self.decoder.forward_tokens(tgt, qpos, token, holder)
+        if not torch.is_grad_enabled():
+            holder.kv = None
+        return hs
+
+    def forward(self, src, mask, query_embed, pos_embed):
+        """Reference layout (tfm_decoder.py:76-93): src [B,C,T,n] (already projected), mask [B,T,n] (all False),
+        query_embed [Q,C], pos_embed [1,C,T,n] -> (hs [L,B,Q,C], memory [B,C,T,n], [], [])."""
+        _require_gpu(src, "Cross_Attention")
+        B, C, T, n = src.shape
+        mem0 = src.flatten(2).transpose(1, 2).reshape(B * T * n, C)
+        eye = torch.eye(C, device=src.device)
+        hs = self.forward_tokens(ops.to_bf16(mem0.float().contiguous()), eye, pos_embed.flatten(2)[0].t().contiguous(), query_embed, B)
+        memory = F.layer_norm(mem0.float(), (C,), self.pre_norm.weight, self.pre_norm.bias, self.pre_norm.eps)
+        return hs, memory.view(B, T, n, C).permute(0, 3, 1, 2), [], []
+
+
+class ObjDecoder(nn.Module):
+    """tfm_decoder.py:111-241.  forward(features [B,T,n,feature_dim]) -> (out dict, hs [L,B,Q,C], [], [])."""
+
+    def __init__(self, transformer, num_classes, num_queries, feature_dim=768, aux_loss=False, pred_traj=True, num_frames=4,
+                 patches_per_frame=256, backbone='LaviLa', self_attn=False):
+        super().__init__()
+        if self_attn or num_queries == 1:
+            raise NotImplementedError("ObjDecoder: self_attn=True / num_queries==1 branches are not on the hot path")
+        self.backbone = backbone
+        self.init_proj_layers()
+        self.num_queries = num_queries
+        self.transformer = transformer
+        hidden_dim = transformer.d_model
+        self.hidden_dim = hidden_dim
+        self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
+        self.bbox_embed = MLP(hidden_dim, hidden_dim, 4, 3)
+        self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        self.pred_traj = pred_traj
+        self.n_decode = 1
+        if self.pred_traj:
+            self.frame_index = nn.Embedding(num_frames, hidden_dim)
+            self.frame_proj = nn.Linear(hidden_dim * 2, hidden_dim)
+        self.aux_loss = aux_loss
+        self.pos_embed = nn.Parameter(torch.zeros(1, patches_per_frame + 1, hidden_dim))
+        self.temporal_embed = nn.Parameter(torch.zeros(1, num_frames, hidden_dim))
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        nn.init.trunc_normal_(self.temporal_embed, std=.02)
+        self.patches_per_frame = patches_per_frame
+        self.proj = nn.Linear(feature_dim, hidden_dim, bias=False)
+        self.num_frames = num_frames
+        self.init_obj_model()
+        # The reference materialises class logits for all 6 layers expanded over frames ([6, B*T, Q, 22048], a copy;
+        # tfm_decoder.py:208,216) although only argmax of the last layer feeds a no-grad metric (box_utils.py:151).
+        # materialize_logits=False returns 'pred_logits_argmax' [B*T,Q] instead and skips unused aux boxes.
+        self.materialize_logits = True
+
+    def construct_3d_pos_embed(self, T):
+        tile_pos_embed = self.pos_embed[:, 1:, :].repeat(1, T, 1)
+        tile_temporal_embed = self.temporal_embed[:, :T].repeat_interleave(self.patches_per_frame, 1)
+        return (tile_pos_embed + tile_temporal_embed).view(1, T, self.patches_per_frame, self.pos_embed.shape[-1])
+
+    def init_proj_layers(self):
+        self.txt_proj = nn.Sequential(nn.ReLU(), nn.Linear(768, 256))
+        self.vid_proj = nn.Sequential(nn.Linear(768, 256))
+
+    def init_obj_model(self):
+        self.obj_proj = nn.Sequential(nn.Linear(self.hidden_dim, self.hidden_dim), nn.ReLU(), nn.Linear(self.hidden_dim, 256))
+
+    def forward(self, features, use_checkpoint=False):
+        _require_gpu(features, "ObjDecoder")
+        B, T, n, Fd = features.shape
+        C = self.hidden_dim
+        feat_b = ops.to_bf16(features.detach().reshape(B * T * n, Fd).contiguous())
+        pos = self.construct_3d_pos_embed(T).view(T * n, C)
+        hs = self.transformer.forward_tokens(feat_b, self.proj.weight, pos, self.query_embed.weight, B)     # [L,B,Q,C]
+        L, _, Q, _ = hs.shape
+        full = self.materialize_logits
+        if self.pred_traj and T == self.num_frames:
+            w = self.frame_proj.weight
+            base = F.linear(hs if full else hs[-1:], w[:, :C])                                               # [l,B,Q,C]
+            fr = F.linear(self.frame_index.weight[:T], w[:, C:], self.frame_proj.bias)                      # [T,C]
+            cond = (base[:, :, None] + fr[None, None, :, None, :]).flatten(1, 2)                             # [l,B*T,Q,C]
+        else:
+            cond = hs if full else hs[-1:]
+        outputs_coord = self.bbox_embed(cond).sigmoid()
+        out = {'pred_boxes': outputs_coord[-1]}
+        expand_t = self.pred_traj and T == self.num_frames
+        if full:
+            outputs_class = self.class_embed(hs)
+            if expand_t:
+                outputs_class = outputs_class[:, :, None].expand(-1, -1, T, -1, -1).flatten(1, 2)
+            out['pred_logits'] = outputs_class[-1]
+            if self.aux_loss:
+                out['aux_outputs'] = self._set_aux_loss(outputs_class, outputs_coord)
+        else:
+            with torch.no_grad():
+                am = self.class_embed(hs[-1]).argmax(-1)                                                     # [B,Q]
+                out['pred_logits_argmax'] = am[:, None].expand(-1, T, -1).flatten(0, 1) if expand_t else am
+            out['pred_logits'] = None
+            out['num_classes'] = self.class_embed.out_features
+            if self.aux_loss:
+                out['aux_outputs'] = []
+        return out, hs, [], []
+
+    @torch.jit.unused
+    def _set_aux_loss(self, outputs_class, outputs_coord):
+        return [{'pred_logits': a, 'pred_boxes': b} for a, b in zip(outputs_class[:-1], outputs_coord[:-1])]
+
+
+def build_decoder(cfg, state_dict=None, device="cuda", feature_dim=None):
+    """ObjDecoder as run/train.py:447-457 builds it (num_queries = nq + 1, aux_loss, pred_traj, feature_dim)."""
+    tfm = Cross_Attention(d_model=cfg.dec_dim, nhead=cfg.dec_heads, num_decoder_layers=cfg.dec_layers,
+                          dim_feedforward=cfg.dec_ffn, normalize_before=True, return_intermediate_dec=True)
+    model = ObjDecoder(transformer=tfm, num_classes=cfg.num_classes, num_queries=cfg.dec_queries, aux_loss=True, pred_traj=True,
+                       feature_dim=feature_dim or cfg.embed_dim, num_frames=cfg.num_frames,
+                       patches_per_frame=cfg.patches_per_frame, self_attn=False)
+    if state_dict is not None:
+        model.load_state_dict(state_dict, strict=True)
+    return model.to(device)

@@ -71,19 +71,35 @@ def layernorm_bwd(x, gamma, mean, rstd, dy):
 
 
 def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, resid=None, colscale=1.0,
-         colscale_cols=0, remap=None, out_rows=None):
+         colscale_cols=0, remap=None, out_rows=None, splitk=1):
     """C = epilogue(A @ W^T).  a bf16 [M,K], w bf16 [N,K] (nn.Linear weight layout), bias fp32 [N].
 
     resid fp32 [rows,N] is added after the activation; `out` may alias `resid` (in-place residual update).
     remap=(group, skip, offset) scatters output row m to m + (m//group)*skip + offset (token-major scatter).
     """
-    _chk(a, w, bias, resid, out)
+    _chk(bias)
+    for t in (a, w, resid, out):                     # 2-D operands may be row-strided views (unit inner stride)
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("libhh ops need GPU tensors (got device %s); there is no CPU fallback" % t.device)
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError("gemm: operands must be 2-D with unit inner stride")
     if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
         raise TypeError("gemm: A and W must be bf16")
     M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K:
         raise ValueError("gemm: K mismatch %s vs %s" % (tuple(a.shape), tuple(w.shape)))
+    if splitk > 1:
+        if bias is not None or resid is not None or out is not None or act != ACT_NONE:
+            raise ValueError("gemm: split-K takes no bias / residual / activation / preallocated output")
+        part = torch.empty((splitk, M, N), dtype=torch.float32, device=a.device)
+        e = GemmEpilogue()
+        e.colscale, e.c_dtype, e.splitk, e.split_stride = 1.0, F32, int(splitk), M * N
+        _lib.check(_lib.lib().hh_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(part), N, M, N, K, ctypes.byref(e),
+                                           _stream()), "hh_gemm_bf16")
+        return part.sum(0)
     if out is None:
         out = torch.empty((out_rows if out_rows is not None else M, N), dtype=out_dtype, device=a.device)
     e = GemmEpilogue()
@@ -118,7 +134,8 @@ def to_f32(x):
 
 def transpose_bf16(x, pad_cols_to=1):
     """x [rows, cols] fp32/bf16 -> bf16 [cols, rows_padded] (rows padded with zeros to a multiple of pad_cols_to)."""
-    _chk(x)
+    if not x.is_cuda or x.dim() != 2 or x.stride(1) != 1:
+        raise RuntimeError("transpose_bf16: need a 2-D GPU tensor with unit inner stride (no CPU fallback)")
     rows, cols = x.shape
     rp = (rows + pad_cols_to - 1) // pad_cols_to * pad_cols_to
     y = (torch.zeros if rp != rows else torch.empty)((cols, rp), dtype=torch.bfloat16, device=x.device)
@@ -168,7 +185,7 @@ def divided_attention(qkv, B, T, n, heads, mode, out=None):
     return out
 
 
-def xattn_fwd(q, k, v, heads):
+def xattn_fwd(q, k, v, heads, dropout_p=0.0, seed=0):
     """q fp32 [B,Q,C] (pre-scaled); k, v bf16 [B,M,C] views with a common row stride -> (out fp32 [B,Q,C], lse [B,h,Q])."""
     for t in (q, k, v):
         if not t.is_cuda:
@@ -179,24 +196,27 @@ def xattn_fwd(q, k, v, heads):
         raise RuntimeError("xattn_fwd: k/v must be row-strided views [B,M,C] with dense batch stride")
     out = torch.empty_like(q)
     lse = torch.empty((B, heads, Q), dtype=torch.float32, device=q.device)
-    _lib.check(_lib.lib().hh_xattn_fwd(_p(q), _p(k), _p(v), k.stride(1), _p(out), _p(lse), B, Q, M, heads, _stream()), "hh_xattn_fwd")
+    _lib.check(_lib.lib().hh_xattn_fwd(_p(q), _p(k), _p(v), k.stride(1), _p(out), _p(lse), B, Q, M, heads,
+                                       float(dropout_p), int(seed) & 0xFFFFFFFF, _stream()), "hh_xattn_fwd")
     return out, lse
 
 
-def xattn_bwd(q, k, v, out, lse, dout, dk, dv, heads):
+def xattn_bwd(q, k, v, out, lse, dout, dk, dv, heads, dropout_p=0.0, seed=0):
     """Writes dk/dv (bf16 [B,M,C] row-strided views) in place; returns dq fp32 [B,Q,C]."""
     B, Q, C = q.shape
     M = k.shape[1]
     _chk(q, out, lse, dout)
     dq = torch.empty_like(q)
     _lib.check(_lib.lib().hh_xattn_bwd(_p(q), _p(k), _p(v), k.stride(1), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(dv),
-                                       dk.stride(1), B, Q, M, heads, _stream()), "hh_xattn_bwd")
+                                       dk.stride(1), B, Q, M, heads, float(dropout_p), int(seed) & 0xFFFFFFFF, _stream()),
+               "hh_xattn_bwd")
     return dq
 
 
-def match_boxes(pred, q0, q, raw_boxes, img=224.0, w_l1=5.0, w_giou=2.0):
-    """pred fp32 [F,Qtot,4]; raw_boxes fp32 [F,k,4] -> dict(tgt, count, pred_idx, tgt_idx, n) all on device."""
-    _chk(pred, raw_boxes)
+def match_boxes(pred, q0, q, raw_boxes, img=224.0, w_l1=5.0, w_giou=2.0, given_count=None):
+    """pred fp32 [F,Qtot,4]; raw_boxes fp32 [F,k,4] -> dict(tgt, count, pred_idx, tgt_idx, n) all on device.
+    given_count int32 [F]: raw_boxes are already-prepared cxcywh targets (list API of HungarianMatcher)."""
+    _chk(pred, raw_boxes, given_count)
     F_, Qtot, _ = pred.shape
     k = raw_boxes.shape[1]
     dev = pred.device
@@ -205,7 +225,7 @@ def match_boxes(pred, q0, q, raw_boxes, img=224.0, w_l1=5.0, w_giou=2.0):
     mp = torch.empty((F_, k), dtype=torch.int64, device=dev)
     mt = torch.empty((F_, k), dtype=torch.int64, device=dev)
     mn = torch.empty((F_,), dtype=torch.int32, device=dev)
-    _lib.check(_lib.lib().hh_match_boxes(_p(pred), Qtot, q0, q, _p(raw_boxes), k, float(img), float(w_l1), float(w_giou),
+    _lib.check(_lib.lib().hh_match_boxes(_p(pred), Qtot, q0, q, _p(raw_boxes), _p(given_count), k, float(img), float(w_l1), float(w_giou),
                                          _p(tgt), _p(cnt), _p(mp), _p(mt), _p(mn), F_, _stream()), "hh_match_boxes")
     return {"tgt": tgt, "count": cnt, "pred_idx": mp, "tgt_idx": mt, "n": mn}
 

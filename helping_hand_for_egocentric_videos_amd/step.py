@@ -1,0 +1,120 @@
+"""Training step and EgoMCQ forward harness: the build's counterpart of /root/reference/run/train.py:103-203
+and /root/reference/run/test_EgoMCQ.py:56-83 (those scripts need datasets / checkpoints / CUDA and hard-code
+4 frames -- SURVEY.md sections 0.6 and 8c -- so the composition is restated here, T-generic).
+
+Step = frozen TimeSformer forward (HIP) + text tower + object-query decoder forward/backward (HIP) + EgoNCE +
+hand/object box losses with on-device Hungarian matching (HIP) + word loss + gradient all-reduce (RCCL) +
+fused AdamW (HIP).  bf16 compute, fp32 accumulation / master weights, no GradScaler.
+No host synchronisation inside the step: every scalar in the returned dict is a device tensor.
+"""
+import torch
+
+from . import ops
+from .model import box_utils
+from .model.loss import EgoNCE, WordContrastiveLoss
+from .model.metric import compute_tv_accuracy, sim_matrix
+from .parallel import BucketedAllReduce, FlatArena, gather_contrastive, world
+
+ZEROED_NOUNS = [102, 504, 364, 321, 556]          # run/train.py:73
+WEIGHT_DICT = {"loss_bbox_hand_boxes": 5, "loss_bbox_obj_boxes": 5, "loss_giou_hand_boxes": 2, "loss_giou_obj_boxes": 2}
+
+
+def build_criterion():
+    """run/train.py:459-473."""
+    return box_utils.SetCriterion(22047, matcher=box_utils.build_matcher(None), weight_dict=dict(WEIGHT_DICT), eos_coef=0.1,
+                                  losses=["boxes", "cardinality"])
+
+
+class TrainStep:
+    def __init__(self, cfg, backbone, decoder, lr=3e-5, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8,
+                 bucket_bytes=16 << 20, fast_heads=True):
+        self.cfg, self.backbone, self.decoder = cfg, backbone, decoder
+        self.criterion = build_criterion().to(next(decoder.parameters()).device)
+        self.nce, self.word = EgoNCE(), WordContrastiveLoss()
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        decoder.materialize_logits = not fast_heads
+        self.arena = FlatArena(decoder, bucket_bytes)
+        self.m = torch.zeros_like(self.arena.params)
+        self.v = torch.zeros_like(self.arena.params)
+        self.comm = BucketedAllReduce(self.arena)
+        self.iteration = 0
+        backbone.eval()                               # run/train.py:89
+
+    # ------------------------------------------------------------------ forward
+    def encode(self, video, text):
+        """Frozen towers (run/train.py:108-116): returns video_grid bf16 [B,T,n,D] and text feature map fp32."""
+        B, T = video.shape[:2]
+        n = self.cfg.patches_per_frame
+        with torch.no_grad():
+            _, fmap = self.backbone.visual.forward_features(video, out_dtype=torch.bfloat16)
+            _, tmap = self.backbone.encode_text(text)
+        grid = fmap[:, 1:].reshape(B, T, n, fmap.shape[-1])
+        return grid, tmap
+
+    def losses(self, batch):
+        cfg = self.cfg
+        video, text = batch["video"], batch["text"]
+        B, T = video.shape[:2]
+        W, _ = world()
+        grid, tmap = self.encode(video, text)
+        det, hs, _, _ = self.decoder(grid)
+        eot = text.argmax(dim=-1)
+        text_embeds = self.decoder.txt_proj(tmap[torch.arange(text.shape[0], device=text.device), eot])
+        obj = self.decoder.obj_proj(hs[-1])                                        # [B,Q,256]
+        video_embeds = obj[:, -1]
+        noun_vec = batch["noun_vec"].clone()
+        noun_vec[:, ZEROED_NOUNS] = 0
+        pad_flag = ((text != 0).sum(-1) != 2).float()                               # run/train.py:144
+        ve, te, pf, vv, nv = gather_contrastive(video_embeds, text_embeds, pad_flag, batch["verb_vec"], noun_vec)
+        Bg = ve.shape[0]
+        sim = sim_matrix(te, ve)                                                    # [5Bg, Bg]
+        sim_v, sim_n = sim_matrix(vv, vv), sim_matrix(nv, nv)
+        nce, _ = self.nce(sim, sim_v, sim_n, multi_pad_mask=pf[:, None].repeat(1, Bg), strict_mask=True, return_mask=False)
+        R = te.shape[0] // Bg
+        with torch.no_grad():
+            acc_vt, acc_tv = compute_tv_accuracy(sim.view(Bg, R, Bg)[:, 0], te, sim_v, sim_n, Bg)
+        hand = batch["boxes"][:, :, :2].flatten(0, 1)
+        objb = batch["boxes"][:, :, 2:].flatten(0, 1)
+        nq = cfg.num_queries if cfg.num_queries != 0 else 10
+        lh, mh = box_utils.compute_box_loss("hand_boxes", self.criterion, det, hand, None, None, n_queries=nq)
+        lo, mo = box_utils.compute_box_loss("obj_boxes", self.criterion, det, objb, None, None, n_queries=nq)
+        noun_embeds = self.decoder.txt_proj(batch["all_nouns"])
+        word = self.word(noun_embeds, obj[:, :-1], batch["nouns"])
+        total = nce + lh + lo + 0.5 * word                                          # run/train.py:149,183,191
+        return {"total_loss": total, "nce_loss": nce.detach(), "box_loss_hand": lh.detach(), "box_loss_obj": lo.detach(),
+                "word_loss": word.detach(), "acc_vt": acc_vt, "acc_tv": acc_tv, "match_hand": mh, "match_obj": mo,
+                "pred_boxes": det["pred_boxes"], "hs": hs}
+
+    # ------------------------------------------------------------------ step
+    def step(self, batch):
+        self.decoder.train()
+        self.backbone.eval()
+        self.arena.zero_grad()
+        out = self.losses(batch)
+        out["total_loss"].backward()
+        self.comm.finish()
+        self.iteration += 1
+        a, nd = self.arena, self.arena.n_decay_padded
+        ops.adamw_step(a.params[:nd], a.grads[:nd], self.m[:nd], self.v[:nd], self.lr, *self.betas, self.eps, self.wd, self.iteration)
+        if a.total > nd:
+            ops.adamw_step(a.params[nd:], a.grads[nd:], self.m[nd:], self.v[nd:], self.lr, *self.betas, self.eps, 0.0, self.iteration)
+        out["total_loss"] = out["total_loss"].detach()
+        return out
+
+
+@torch.no_grad()
+def mcq_forward(backbone, decoder, video, text, cfg):
+    """Batched EgoMCQ scoring (run/test_EgoMCQ.py:56-83): video [q,5,T,3,H,W], text [q,77] -> scores [q,5]."""
+    q = video.shape[0]
+    T, n = video.shape[2], cfg.patches_per_frame
+    was = decoder.materialize_logits
+    decoder.materialize_logits = False
+    try:
+        _, fmap = backbone.visual.forward_features(video.flatten(0, 1), out_dtype=torch.bfloat16)
+        _, tmap = backbone.encode_text(text)
+        _, hs, _, _ = decoder(fmap[:, 1:].reshape(q * 5, T, n, fmap.shape[-1]))
+        te = decoder.txt_proj(tmap[torch.arange(q, device=text.device), text.argmax(-1)])
+        ve = decoder.obj_proj(hs[-1])[:, -1].view(q, 5, -1)
+        return sim_matrix(te[:, None], ve)[:, 0]
+    finally:
+        decoder.materialize_logits = was

@@ -59,6 +59,9 @@ typedef struct hh_gemm_epilogue {
     int act;                  /* hh_act */
     int c_dtype;              /* hh_dtype */
     int64_t remap_group, remap_skip, remap_offset;
+    int splitk;               /* <=1: off.  S>1: split s handles k-tiles [s*ceil(nk/S), ...) and writes its partial
+                                 (same epilogue, caller passes no bias/resid) at C + s*split_stride; caller sums */
+    int64_t split_stride;     /* elements between partial slabs */
 } hh_gemm_epilogue;
 
 int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
@@ -92,12 +95,14 @@ int hh_cls_attn_fwd(const void* qkv, void* out, int B, int N, int heads, hh_stre
 /* ---- decoder cross-attention core (nn.MultiheadAttention inside tfm_decoder.py:438-441; 13 x 4096, 8 heads)
  * q fp32 [B, Q, C] (already scaled by d^-0.5), k/v bf16 [B, M, ldkv] (head-major columns, C = heads*64 used),
  * out fp32 [B, Q, C], lse fp32 [B, heads, Q] (log-sum-exp for the backward).  Q <= 16. */
+/* dropout_p > 0 applies inverted dropout to the attention probabilities (nn.MultiheadAttention(dropout=0.1),
+ * tfm_decoder.py:365) with a counter-based mask keyed by (seed, clip, head, query, key); the backward regenerates it. */
 int hh_xattn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out, float* lse,
-                 int B, int Q, int M, int heads, hh_stream_t stream);
+                 int B, int Q, int M, int heads, float dropout_p, uint32_t seed, hh_stream_t stream);
 /* backward: dq fp32 [B,Q,C]; dk/dv bf16 [B, M, lddkv] */
 int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_t ldkv, const float* out, const float* lse,
                  const float* dout, float* dq, void* dk, void* dv, int64_t lddkv,
-                 int B, int Q, int M, int heads, hh_stream_t stream);
+                 int B, int Q, int M, int heads, float dropout_p, uint32_t seed, hh_stream_t stream);
 
 /* ---- Hungarian matching + box losses (model/box_utils.py:43-92,156-173,249-279; utils/box_ops.py:9-61)
  * pred fp32 [F, Qtot, 4] cxcywh; queries [q0, q0+q) are matched.  raw_boxes fp32 [F, k, 4] xyxy pixels
@@ -106,7 +111,9 @@ int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_t ldkv, con
  *   match_pred int64 [F,k], match_tgt int64 [F,k] (first min(q,count) entries valid, pred ascending), match_n int32 [F]
  * Exact shortest-augmenting-path LSAP (scipy.optimize.linear_sum_assignment semantics) in fp64 on the fp32 cost
  * C = w_l1*L1 - w_giou*GIoU, one thread per frame. q <= 16, k <= 16. */
-int hh_match_boxes(const float* pred, int Qtot, int q0, int q, const float* raw_boxes, int k, float img,
+/* If given_count != NULL, raw_boxes already holds prepared cxcywh targets (first given_count[f] rows valid) and the
+ * prepare_targets step is skipped (HungarianMatcher.forward list API). */
+int hh_match_boxes(const float* pred, int Qtot, int q0, int q, const float* raw_boxes, const int32_t* given_count, int k, float img,
                    float w_l1, float w_giou, float* tgt_cxcywh, int32_t* tgt_count,
                    int64_t* match_pred, int64_t* match_tgt, int32_t* match_n, int64_t F, hh_stream_t stream);
 /* generic batched LSAP on fp32 costs [P, nr, nc] (word loss, loss.py:83-93): the rows with row_valid != 0
