@@ -1,0 +1,187 @@
+"""Benchmark of the hot path: train clips/sec (16-frame 224p, nq=12) -- BASELINE.json's metric -- on N GPUs.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = frozen TimeSformer-L forward + text tower + object-query decoder forward/backward + EgoNCE / box /
+word losses (on-device Hungarian) + decoder-gradient all-reduce (RCCL) + fused AdamW over one synthetic batch
+that is resident in HBM.  Weak scaling: the per-GPU batch is fixed.  Prints ONE JSON line on rank 0.
+--workload mcq times the EgoMCQ forward-only path (BASELINE config 5) instead.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from helping_hand_for_egocentric_videos_amd import C2, ops, synth  # noqa: E402
+from helping_hand_for_egocentric_videos_amd.model import LaviLa, tfm_decoder  # noqa: E402
+from helping_hand_for_egocentric_videos_amd.step import TrainStep, mcq_forward  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+class KernelTimer:
+    """Live per-launch timing of selected libhh ops with events on the launch stream (torch's current stream)."""
+
+    def __init__(self):
+        self.rec = {}
+        self.on = False
+
+    def wrap(self, name, fn, work):
+        def inner(*a, **k):
+            if not self.on:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            self.rec.setdefault(name, []).append((e0, e1, work(*a, **k)))
+            return r
+        return inner
+
+    def summary(self, name):
+        ev = self.rec.get(name, [])
+        if not ev:
+            return 0, 0.0, 0.0
+        ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+        return len(ev), ms, float(sum(w for _, _, w in ev))
+
+
+def gemm_flops(a, w, *args, **kw):
+    sk = kw.get("splitk", 1)
+    return 2.0 * a.shape[0] * a.shape[1] * w.shape[0]
+
+
+def attn_bytes(qkv, B, T, n, heads, mode, out=None):
+    return 8.0 * qkv.shape[0] * heads * 64          # read q,k,v + write o, bf16 (8*N*D per call)
+
+
+def cpu_baseline(cfg, enc_sd, dec_sd, seed):
+    """Oracle (CPU restatement, fp32) timed on this host: one full training step on ONE clip of the same workload."""
+    from oracle import step as OS
+    cores = min(os.cpu_count() or 1, int(os.environ.get("HH_CPU_BASELINE_THREADS", 16)))   # >32 threads run slower here
+    torch.set_num_threads(cores)
+    batch = synth.make_batch(cfg, 1, seed=seed)
+    dsd = {k: v.clone() for k, v in dec_sd.items()}
+    t = time.time()
+    OS.train_step(enc_sd, dsd, batch, cfg)
+    dt = time.time() - t
+    return {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "1 clip (T=%d, %dpx, nq=%d): oracle fp32 full step fwd+bwd+AdamW, 1 iteration, %.1f s" % (
+                cfg.num_frames, cfg.img_size, cfg.num_queries, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--workload", default="train", choices=["train", "mcq"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    cfg = C2
+    torch.manual_seed(0)
+    enc_sd = synth.encoder_state(cfg, seed=0)
+    dec_sd = synth.decoder_state(cfg, seed=0)
+    backbone = LaviLa.build_backbone(cfg, enc_sd, device=dev)
+    decoder = tfm_decoder.build_decoder(cfg, dec_sd, device=dev)
+    B = args.batch
+
+    timer = KernelTimer()
+    if not args.no_kernel_timers:
+        ops.gemm = timer.wrap("gemm", ops.gemm, gemm_flops)
+        ops.divided_attention = timer.wrap("attn", ops.divided_attention, attn_bytes)
+
+    if args.workload == "train":
+        batch = {k: v.to(dev) for k, v in synth.make_batch(cfg, B, seed=1000 + rank).items()}
+        ts = TrainStep(cfg, backbone, decoder)
+        run = lambda: ts.step(batch)
+        clips_per_step = B
+        metric = "train clips/sec (16-frame 224p, nq=12)"
+    else:
+        items = max(1, B // 5)
+        mcq = synth.make_mcq_item(cfg, items, seed=1000 + rank)
+        video, text = mcq["video"].to(dev), mcq["text"].to(dev)
+        decoder.eval()
+        run = lambda: mcq_forward(backbone, decoder, video, text, cfg)
+        clips_per_step = items * 5
+        metric = "EgoMCQ fwd clips/sec (16-frame 224p)"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run()
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt)
+    value = clips_per_step * world * args.steps / dt
+
+    if rank == 0:
+        n_g, ms_g, fl_g = timer.summary("gemm")
+        n_a, ms_a, by_a = timer.summary("attn")
+        roof = None
+        if n_g:
+            ach = fl_g / (ms_g * 1e-3) / 1e12
+            roof = {"kernel": "gemm_bf16_kernel (hh_gemm_bf16)", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches": n_g, "avg_launch_us": round(ms_g * 1e3 / n_g, 1), "share_of_step": round(ms_g / (dt * 1e3), 3)}
+        line = {"metric": metric, "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "C2: 16-frame 224p, nq=12, frozen TimeSformer-L + object-query decoder %s" % (
+                    "train step" if args.workload == "train" else "EgoMCQ forward"), "clips_per_gpu": clips_per_step,
+                    "global_clips": clips_per_step * world, "parallelism": "dp%d" % world,
+                    "step_tflop_per_clip": 3.59 if args.workload == "train" else 3.45},
+                "end_to_end_mfma_frac": round(value * (3.59 if args.workload == "train" else 3.45) / (world * PEAK_BF16_TFLOPS), 4),
+                "roofline": roof}
+        if n_a:
+            gbs = by_a / (ms_a * 1e-3) / 1e9
+            line["attention_roofline"] = {"kernel": "space/time/cls attention (hh_*_attn_fwd)", "bound": "hbm", "achieved": round(gbs, 1),
+                                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                          "launches": n_a, "share_of_step": round(ms_a / (dt * 1e3), 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, enc_sd, dec_sd, seed=1000)
+        if args.workload == "train":
+            line["loss"] = round(float(out["total_loss"]), 4)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

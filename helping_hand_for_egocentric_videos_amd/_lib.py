@@ -3,6 +3,8 @@ missing or a call fails, a RuntimeError is raised (the product path never routes
 import ctypes
 import os
 
+import torch  # noqa: F401  -- must be imported BEFORE libhh.so so that both share torch's HIP runtime (libamdhip64)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libhh.so")
 

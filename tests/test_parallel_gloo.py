@@ -1,0 +1,133 @@
+"""Data-parallel layer on CPU with gloo, world_size 2 (the RCCL path is the same code on the GPU box).
+
+Asserts: (a) all ranks hold identical parameters after a step, (b) a 2-rank step equals
+a 1-rank step on the concatenated batch, (c) bucketed async all-reduce averages exactly, (d) the packed
+contrastive all-gather is differentiable with the W x local-slice backward.
+The kernels are not involved (no GPU here): a small torch model stands in for the decoder, with parameter names
+that exercise both AdamW groups, and the oracle's AdamW restatement plays the optimizer.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helping_hand_for_egocentric_videos_amd.parallel import (BucketedAllReduce, FlatArena, gather_contrastive, no_decay)
+from oracle import losses as OL, step as OS
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.proj = torch.nn.Linear(24, 16)
+        self.norm1 = torch.nn.LayerNorm(16)
+        self.obj_proj = torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 8))
+        self.txt_proj = torch.nn.Sequential(torch.nn.ReLU(), torch.nn.Linear(12, 8))
+        self.class_embed = torch.nn.Linear(16, 5)            # never gets a gradient -> must be skipped by the arena
+        self.box = torch.nn.Linear(16, 4)
+
+    def forward(self, feats, texts):
+        h = self.norm1(self.proj(feats))
+        return self.obj_proj(h), self.txt_proj(texts), self.box(h).sigmoid()
+
+
+def make_data(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"feats": torch.randn(B, 24, generator=g), "texts": torch.randn(B * 5, 12, generator=g),
+            "pad": (torch.rand(B * 5, generator=g) > 0.3).float().index_fill_(0, torch.arange(0, B * 5, 5), 1.0),
+            "verb": (torch.rand(B, 7, generator=g) < 0.3).float(), "noun": (torch.rand(B, 9, generator=g) < 0.3).float(),
+            "tgt": torch.rand(B, 4, generator=g)}
+
+
+def loss_fn(model, d, world):
+    ve, te, boxes = model(d["feats"], d["texts"])
+    gve, gte, pf, vv, nv = gather_contrastive(ve, te, d["pad"], d["verb"], d["noun"])
+    Bg = gve.shape[0]
+    sim = OL.sim_matrix(gte, gve)
+    nce, _ = OL.egonce(sim, OL.sim_matrix(vv, vv), OL.sim_matrix(nv, nv), pf[:, None].repeat(1, Bg))
+    # local term normalised by the GLOBAL count / world (like num_boxes, box_utils.py:218-222)
+    nb = torch.tensor([float(boxes.shape[0])])
+    if world > 1:
+        dist.all_reduce(nb)
+    box = (boxes - d["tgt"]).abs().sum() / (nb / world).clamp(min=1)[0]
+    return nce + box
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        model = Toy()
+        arena = FlatArena(model, bucket_bytes=512)
+        assert len(arena.buckets) > 2
+        assert all(not n.startswith("class_embed") for n, _ in arena.entries)
+        comm = BucketedAllReduce(arena)
+        full = make_data(4, 7)
+        b = 4 // world
+        local = {k: (v[rank * b:(rank + 1) * b] if v.shape[0] == 4 else v[rank * b * 5:(rank + 1) * b * 5]) for k, v in full.items()}
+        state = None
+        for it in range(2):
+            arena.zero_grad()
+            loss_fn(model, local, world).backward()
+            comm.finish()
+            grads = {n: p.grad.clone() for n, p in arena.entries}
+            params = {n: p.data for n, p in arena.entries}
+            state = OS.adamw_update(params, grads, state, lr=1e-2, wd=1e-2)
+        flat = arena.params.clone()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged"
+        if rank == 0:
+            ret["params"] = flat
+            ret["grads"] = arena.grads.clone()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_on_concatenated_batch():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    # single-process reference on the full batch
+    model = Toy()
+    arena = FlatArena(model, bucket_bytes=512)
+    full = make_data(4, 7)
+    state = None
+    for it in range(2):
+        arena.zero_grad()
+        loss_fn(model, full, 1).backward()
+        grads = {n: p.grad.clone() for n, p in arena.entries}
+        state = OS.adamw_update({n: p.data for n, p in arena.entries}, grads, state, lr=1e-2, wd=1e-2)
+    torch.testing.assert_close(ret["grads"], arena.grads, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(ret["params"], arena.params, rtol=1e-4, atol=1e-5)
+
+
+def test_arena_groups_follow_the_reference_optim_policy():
+    model = Toy()
+    arena = FlatArena(model)
+    for n, p in model.named_parameters():
+        if n.startswith("class_embed"):
+            assert n not in arena.offsets
+            continue
+        o, k = arena.offsets[n]
+        assert (o < arena.n_decay_padded) == (not no_decay(n))
+        assert p.data_ptr() == arena.params.data_ptr() + 4 * o and p.grad.data_ptr() == arena.grads.data_ptr() + 4 * o
+        assert o % 4 == 0
+    assert no_decay("transformer.pre_norm.bias") and not no_decay("transformer.pre_norm.weight")
+    # no process group: the comm layer is a no-op
+    comm = BucketedAllReduce(arena)
+    assert not comm.enabled
+    comm.finish()
