@@ -28,7 +28,7 @@ def _newer(a, b):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    hdr = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "hh.h")]
+    hdr = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "hh.h")]
     hdr_m = max(os.path.getmtime(h) for h in hdr)
     jobs = []
     for src in sources():

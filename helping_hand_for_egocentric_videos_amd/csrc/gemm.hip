@@ -10,26 +10,12 @@
 // per-lane SOURCE address, LDS destination stays lane-linear) -> ds_read_b128 fragment reads are conflict-free.
 // Block order is XCD-aware: blockIdx % 8 selects the XCD-local stream; each XCD walks groups of 8 m-tiles x all
 // n-tiles so an A tile is re-used from that XCD's L2 across its n-tiles.
-#include "common.h"
+#include "gemm_common.h"
 
 #define BM 128
 #define BN 128
 #define BK 64
 #define GROUP_M 8
-
-struct GemmParams {
-    const bf16_t* A; int64_t lda;
-    const bf16_t* W; int64_t ldw;
-    void* C; int64_t ldc;
-    int64_t M; int N; int K;
-    int Mt, Nt;
-    hh_gemm_epilogue e;
-};
-
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
 
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
@@ -46,7 +32,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     const int nt = r / GROUP_M, mi = r % GROUP_M;
     const int mt = xcd + 8 * (kg * GROUP_M + mi);
     if (mt >= p.Mt) return;
-    const int64_t m0 = (int64_t)mt * BM;
+    const int64_t m0 = p.m_start + (int64_t)mt * BM;
     const int n0 = nt * BN;
 
     // ---- staging: wave w issues 4 LDS-DMA pieces per operand per k-tile; piece i covers tile rows (w*4+i)*8..+8
@@ -130,29 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
             const int n = n0 + wn * 64 + tn * 16 + 4 * fq;
-            f32x4 v = acc[tn][tm];
-            if (e.bias) {
-                f32x4 bb = *(const f32x4*)(e.bias + n);
-                v += bb;
-            }
-            if (n < e.colscale_cols) v *= e.colscale;
-            if (e.act == HH_ACT_QUICKGELU) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = v[q] / (1.f + __expf(-1.702f * v[q]));
-            } else if (e.act == HH_ACT_RELU) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-            }
-            if (e.resid) {
-                f32x4 rr = *(const f32x4*)(e.resid + orow * e.ldr + n);
-                v += rr;
-            }
-            if constexpr (OUT_BF16) {
-                u32x2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-                *(u32x2*)((bf16_t*)Cbase + orow * p.ldc + n) = o;
-            } else {
-                *(f32x4*)((float*)Cbase + orow * p.ldc + n) = v;
-            }
+            gemm_store4<OUT_BF16>(e, Cbase, p.ldc, orow, n, acc[tn][tm]);
         }
     }
 }
@@ -172,7 +136,18 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     GemmParams p;
     p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.C = C; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K; p.e = *epi;
-    p.Mt = (int)((M + BM - 1) / BM);
+    p.m_start = 0;
+    p.skew_iters = 0;
+    if (hh_gemm256_eligible(p)) {
+        // full 256-row tiles on the 8-phase kernel; the (< 256)-row remainder on the 128x128 kernel so that it does not
+        // cost a whole extra round of 256x256 blocks (M = B*4097 is never a multiple of 256)
+        GemmParams pm = p;
+        pm.M = (M / 256) * 256;
+        int rc = hh_gemm256_launch(pm, (hipStream_t)stream);
+        if (rc != HH_OK || pm.M == M) return rc;
+        p.m_start = pm.M;
+    }
+    p.Mt = (int)((M - p.m_start + BM - 1) / BM);
     p.Nt = N / BN;
     const int per_xcd_mt = (p.Mt + 7) / 8;
     const int groups = (per_xcd_mt + GROUP_M - 1) / GROUP_M;

@@ -1,0 +1,297 @@
+// bf16 MFMA GEMM, 256x256 block tile, 8-phase software pipeline (the large-shape path of hh_gemm_bf16).
+//
+// Geometry: BM = BN = 256, BK = 64, 512 threads = 8 waves as 2 (M) x 4 (N).  LDS = 128 KiB ring of HALF-TILES
+// (128 rows x 64 k bf16 = 16 KiB): [2 K-tile buffers] x {B-lo, A-lo, B-hi, A-hi}.  A wave's 128 x 64 output is made of
+// 64 rows from A-lo + 64 rows from A-hi and 32 columns from B-lo + 32 from B-hi, so the four quadrant products of one
+// K-tile consume the half-tiles in the order (A-lo, B-lo) -> B-hi -> A-hi and free them one by one:
+//   phase 1: read B0 (B-lo, 4 ds_read_b128), A0 (A-lo, 8)   MFMA A0 x B0
+//   phase 2: read B1 (B-hi, 4)                              MFMA A0 x B1
+//   phase 3: read A1 (A-hi, 8; overwrites A0)               MFMA A1 x B1
+//   phase 4: -                                              MFMA A1 x B0
+// Each phase = {ds_reads ; ONE half-tile LDS-DMA prefetch (2 global_load_lds_dwordx4 per wave) ; s_barrier ;
+// 16 x mfma_f32_16x16x32_bf16 ; s_barrier}.  Prefetch stream (tile t computing from buffer t&1):
+//   phase 1 -> A-hi(t+1) into buffer (t+1)&1 ; phases 2,3,4 -> B-lo, A-lo, B-hi of tile t+2 into buffer t&1
+// (each slot is re-staged only after its reads retired: B-lo's 4 reads are retired by the lgkmcnt(8) ahead of phase 1's
+// first barrier, the others are >= 2 phases old).  ONE counted s_waitcnt vmcnt(6) per K-tile (phase 4) retires tile t+1
+// while 3 half-tiles stay in flight across the barriers; never vmcnt(0) in the steady state.
+// The wave rows (wr = 1) run one barrier behind (stagger): while one group issues MFMAs the other group on the same
+// SIMDs reads LDS / issues DMA, which keeps the matrix pipe fed.
+// LDS image of a half-tile: rows of 8 x 16-B chunks, chunk c of row r at position c ^ (r & 7) (swizzle on the DMA
+// source address; ds_read_b128 fragment reads conflict-free).  Operands swapped (A-operand = W) so a lane owns 4
+// consecutive n for one m: vector epilogue shared with gemm.hip.
+#include "gemm_common.h"
+#include <string.h>
+#include <stdlib.h>
+
+#define HT_BYTES 16384
+#define BUF_BYTES 65536
+// half-tile slots inside a K-tile buffer
+#define SLOT_BLO 0
+#define SLOT_ALO 1
+#define SLOT_BHI 2
+#define SLOT_AHI 3
+
+#define BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+template <bool OUT_BF16, bool STAGGER>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- XCD-aware tile assignment (same scheme as gemm.hip, 4 m-tiles x all n-tiles per XCD-local group)
+    const int GROUP = 4;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, j = b >> 3;
+    const int per = GROUP * p.Nt;
+    const int kg = j / per, r = j % per;
+    const int nt_i = r / GROUP, mi = r % GROUP;
+    const int mt = xcd + 8 * (kg * GROUP + mi);
+    if (mt >= p.Mt) return;
+    const int64_t m0 = (int64_t)mt * 256;
+    const int n0 = nt_i * 256;
+    // Start-time skew of the first round of blocks (one per CU): without it all CUs reach their epilogues together and the
+    // chip alternates between an HBM-idle main loop and an HBM-saturated store/residual burst.
+    if (p.skew_iters > 0 && b < 256) {
+        const int it = (int)(((int64_t)p.skew_iters * b) >> 8);
+        for (int i = 0; i < it; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+
+    // ---- staging sources: wave w stages pieces 2w, 2w+1 (8 rows each) of every half-tile
+    const bf16_t* src[4][2];       // [slot][piece]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + (lane >> 3);           // row inside the half-tile, 0..127
+        const int c = (lane & 7) ^ (row & 7);
+        int64_t ma = m0 + row, mb = m0 + 128 + row;
+        if (ma > p.M - 1) ma = p.M - 1;
+        if (mb > p.M - 1) mb = p.M - 1;
+        src[SLOT_ALO][i] = p.A + ma * p.lda + c * 8;
+        src[SLOT_AHI][i] = p.A + mb * p.lda + c * 8;
+        // W rows are permuted inside each 32-row group while staging: LDS row 16*tn + i holds n = 8*(i>>2) + 4*tn + (i&3),
+        // so that an output lane (which owns MFMA rows 4g..4g+3 of both tn tiles) ends up with 8 CONSECUTIVE n
+        // (one 16-byte store per tile pair instead of two 8-byte ones; the epilogue was store-issue bound).
+        const int rl = row & 31, nperm = (row & ~31) + 8 * ((rl & 15) >> 2) + 4 * (rl >> 4) + (rl & 3);
+        src[SLOT_BLO][i] = p.W + (int64_t)(n0 + nperm) * p.ldw + c * 8;
+        src[SLOT_BHI][i] = p.W + (int64_t)(n0 + 128 + nperm) * p.ldw + c * 8;
+    }
+    const int nk = p.K / 64;
+    auto stage = [&](int slot, int kt, int buf) {
+        char* dst = smem + buf * BUF_BYTES + slot * HT_BYTES + wave * 2048;
+        glds16(src[slot][0] + (int64_t)kt * 64, dst);
+        glds16(src[slot][1] + (int64_t)kt * 64, dst + 1024);
+    };
+
+    // ---- fragment read offsets inside a half-tile: row = base + (lane & 15), chunk = ks*4 + (lane >> 4)
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ks * 4 + fq;
+        a_off[ks] = (wr * 64 + frow) * 128 + ((c ^ (frow & 7)) << 4);     // + tm*2048
+        b_off[ks] = (wc * 32 + frow) * 128 + ((c ^ (frow & 7)) << 4);     // + tn*2048
+    }
+
+    f32x4 acc[2][4][2][2];      // [mh][tm][nh][tn]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) acc[a][c][d][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: tile 0 (4 half-tiles) + first three half-tiles of tile 1
+    stage(SLOT_BLO, 0, 0); stage(SLOT_ALO, 0, 0); stage(SLOT_BHI, 0, 0); stage(SLOT_AHI, 0, 0);
+    if (nk > 1) {
+        stage(SLOT_BLO, 1, 1); stage(SLOT_ALO, 1, 1); stage(SLOT_BHI, 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    BARRIER();
+    if (STAGGER && wr == 1) BARRIER();
+
+    bf16x8 af[4][2], bf0[2][2], bf1[2][2];      // A sub-tile [tm][ks]; B0 / B1 sub-tiles [tn][ks]
+
+#define MFMA_QUAD(MH, NH, BF)                                                                          \
+    __builtin_amdgcn_s_setprio(1);                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                   \
+        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                               \
+            _Pragma("unroll") for (int tm = 0; tm < 4; ++tm)                                           \
+                acc[MH][tm][NH][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[tn][ks], af[tm][ks], acc[MH][tm][NH][tn], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        const char* base = smem + cur * BUF_BYTES;
+        // ================= phase 1: A0 x B0
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bf0[tn][ks] = *(const bf16x8*)(base + SLOT_BLO * HT_BYTES + b_off[ks] + tn * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[tm][ks] = *(const bf16x8*)(base + SLOT_ALO * HT_BYTES + a_off[ks] + tm * 2048);
+        if (t + 1 < nk) stage(SLOT_AHI, t + 1, cur ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");          // the 4 B-lo reads (issued first) have retired
+        BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_QUAD(0, 0, bf0)
+        BARRIER();
+        // ================= phase 2: A0 x B1
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bf1[tn][ks] = *(const bf16x8*)(base + SLOT_BHI * HT_BYTES + b_off[ks] + tn * 2048);
+        if (t + 2 < nk) stage(SLOT_BLO, t + 2, cur);
+        BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_QUAD(0, 1, bf1)
+        BARRIER();
+        // ================= phase 3: A1 x B1
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[tm][ks] = *(const bf16x8*)(base + SLOT_AHI * HT_BYTES + a_off[ks] + tm * 2048);
+        if (t + 2 < nk) stage(SLOT_ALO, t + 2, cur);
+        BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_QUAD(1, 1, bf1)
+        BARRIER();
+        // ================= phase 4: A1 x B0 ; retire tile t+1
+        if (t + 2 < nk) {
+            stage(SLOT_BHI, t + 2, cur);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        BARRIER();
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_QUAD(1, 0, bf0)
+        BARRIER();
+    }
+    if (STAGGER && wr == 0) BARRIER();
+#undef MFMA_QUAD
+
+    // ---- epilogue: lane owns C[m][n .. n+7]; residual rows are fetched in batches of 16 vectors (one M half) BEFORE any
+    // use, so the read-modify-write is not serialised on memory latency
+    const hh_gemm_epilogue& e = p.e;
+    char* Cbase = (char*)p.C;
+    const int ncol = n0 + wc * 32 + 8 * fq;                  // + nh*128 ; lane owns n .. n+7 (tile tn at +4*tn)
+    constexpr int TN_OFF = 4;
+    f32x4 bias_v[2][2];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+        bias_v[nh][0] = e.bias ? *(const f32x4*)(e.bias + ncol + nh * 128) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        bias_v[nh][1] = e.bias ? *(const f32x4*)(e.bias + ncol + nh * 128 + TN_OFF) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+        int64_t orow[4];
+        bool live[4];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const int64_t m = m0 + mh * 128 + wr * 64 + tm * 16 + frow;
+            live[tm] = m < p.M;
+            orow[tm] = (e.remap_group > 0) ? m + (m / e.remap_group) * e.remap_skip + e.remap_offset : m;
+        }
+        f32x4 rv[4][2][2];
+        if (e.resid) {
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    const float* rp = e.resid + (live[tm] ? orow[tm] : 0) * e.ldr + ncol + nh * 128;
+                    rv[tm][nh][0] = *(const f32x4*)rp;
+                    rv[tm][nh][1] = *(const f32x4*)(rp + TN_OFF);
+                }
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                const int n = ncol + nh * 128;
+                f32x4 v0 = acc[mh][tm][nh][0] + bias_v[nh][0], v1 = acc[mh][tm][nh][1] + bias_v[nh][1];
+                if (n < e.colscale_cols) { v0 *= e.colscale; v1 *= e.colscale; }
+                if (e.act == HH_ACT_QUICKGELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v0[q] = quick_gelu(v0[q]); v1[q] = quick_gelu(v1[q]); }
+                } else if (e.act == HH_ACT_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+                }
+                if (e.resid) { v0 += rv[tm][nh][0]; v1 += rv[tm][nh][1]; }
+                if (!live[tm]) continue;
+                if constexpr (OUT_BF16) {
+                    u32x4 o = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+                    *(u32x4*)((bf16_t*)Cbase + orow[tm] * p.ldc + n) = o;
+                } else {
+                    *(f32x4*)((float*)Cbase + orow[tm] * p.ldc + n) = v0;
+                    *(f32x4*)((float*)Cbase + orow[tm] * p.ldc + n + TN_OFF) = v1;
+                }
+            }
+    }
+}
+
+static int g_skew = -1;            // start skew: -1 auto (on when the epilogue carries an fp32 residual), 0 off, 1 on
+static int g_mode = -1;            // gemm256 mode: 0 = off, 1 = on without stagger, 2 = on with stagger (default)
+static int gemm256_mode() {
+    if (g_mode < 0) {
+        const char* s = getenv("HH_GEMM256");
+        g_mode = s ? atoi(s) : 2;
+    }
+    return g_mode;
+}
+
+extern "C" int hh_set_tuning(const char* name, int value) {
+    if (name && !strcmp(name, "gemm256")) { g_mode = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm256_skew")) { g_skew = value; return HH_OK; }
+    hh_set_error("hh_set_tuning: unknown knob '%s'", name ? name : "(null)");
+    return HH_ERR_UNSUPPORTED;
+}
+
+bool hh_gemm256_eligible(const GemmParams& p) {
+    return gemm256_mode() > 0 && p.N % 256 == 0 && p.M >= 2048 && p.e.splitk <= 1;
+}
+
+int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)gemm256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipFuncSetAttribute((const void*)gemm256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipFuncSetAttribute((const void*)gemm256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipFuncSetAttribute((const void*)gemm256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        attr_done = true;
+    }
+    const int stagger = gemm256_mode() != 1;
+    GemmParams p = pin;
+    {
+        // one round ~ nk k-tiles x ~3300 cycles + epilogue; s_sleep(16) ~ 1024 cycles per iteration
+        const bool heavy = p.e.resid != nullptr || p.e.c_dtype == HH_F32;
+        const bool on = g_skew < 0 ? heavy : g_skew > 0;
+        p.skew_iters = on ? (int)(((int64_t)(p.K / 64) * 3300 + (heavy ? 30000 : 12000)) / 1024) : 0;
+    }
+    p.Mt = (int)((p.M + 255) / 256);
+    p.Nt = p.N / 256;
+    const int GROUP = 4;
+    const int per_xcd_mt = (p.Mt + 7) / 8;
+    const int groups = (per_xcd_mt + GROUP - 1) / GROUP;
+    const unsigned grid = 8u * (unsigned)groups * GROUP * (unsigned)p.Nt;
+    const bool bf = p.e.c_dtype == HH_BF16;
+    if (stagger) {
+        if (bf) hipLaunchKernelGGL((gemm256_kernel<true, true>), dim3(grid), dim3(512), 2 * BUF_BYTES, s, p);
+        else hipLaunchKernelGGL((gemm256_kernel<false, true>), dim3(grid), dim3(512), 2 * BUF_BYTES, s, p);
+    } else {
+        if (bf) hipLaunchKernelGGL((gemm256_kernel<true, false>), dim3(grid), dim3(512), 2 * BUF_BYTES, s, p);
+        else hipLaunchKernelGGL((gemm256_kernel<false, false>), dim3(grid), dim3(512), 2 * BUF_BYTES, s, p);
+    }
+    return hh_check_launch("hh_gemm_bf16(256x256)");
+}

@@ -1,0 +1,69 @@
+// Shared pieces of the bf16 GEMM kernels (gemm.hip: 128x128 tile, gemm256.hip: 256x256 8-phase).
+#pragma once
+#include "common.h"
+
+struct GemmParams {
+    const bf16_t* A; int64_t lda;
+    const bf16_t* W; int64_t ldw;
+    void* C; int64_t ldc;
+    int64_t M; int N; int K;
+    int Mt, Nt;
+    int skew_iters;           // 256x256 kernel: start-time skew quantum (0 = off)
+    int64_t m_start;          // first row handled by this launch (rows [m_start, M) are tiled)
+    hh_gemm_epilogue e;
+};
+
+__device__ __forceinline__ float quick_gelu(float v) {      // x * sigmoid(1.702 x), openai_model.py:177-179
+    return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v));
+}
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// Epilogue for one accumulator tile in the swapped (C^T) layout: lane owns C[orow][n .. n+3].
+template <bool OUT_BF16>
+__device__ __forceinline__ void gemm_store4(const hh_gemm_epilogue& e, char* Cbase, int64_t ldc, int64_t orow, int n, f32x4 v) {
+    if (e.bias) v += *(const f32x4*)(e.bias + n);
+    if (n < e.colscale_cols) v *= e.colscale;
+    if (e.act == HH_ACT_QUICKGELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = quick_gelu(v[q]);
+    } else if (e.act == HH_ACT_RELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+    }
+    if (e.resid) v += *(const f32x4*)(e.resid + orow * e.ldr + n);
+    if constexpr (OUT_BF16) {
+        u32x2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+        *(u32x2*)((bf16_t*)Cbase + orow * ldc + n) = o;
+    } else {
+        *(f32x4*)((float*)Cbase + orow * ldc + n) = v;
+    }
+}
+
+// 8 consecutive columns per lane (256x256 kernel): one 16-byte store for bf16, two for fp32.
+template <bool OUT_BF16>
+__device__ __forceinline__ void gemm_store8(const hh_gemm_epilogue& e, char* Cbase, int64_t ldc, int64_t orow, int n, f32x4 v0, f32x4 v1) {
+    if (e.bias) { v0 += *(const f32x4*)(e.bias + n); v1 += *(const f32x4*)(e.bias + n + 4); }
+    if (n < e.colscale_cols) { v0 *= e.colscale; v1 *= e.colscale; }
+    if (e.act == HH_ACT_QUICKGELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v0[q] = quick_gelu(v0[q]); v1[q] = quick_gelu(v1[q]); }
+    } else if (e.act == HH_ACT_RELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+    }
+    if (e.resid) { v0 += *(const f32x4*)(e.resid + orow * e.ldr + n); v1 += *(const f32x4*)(e.resid + orow * e.ldr + n + 4); }
+    if constexpr (OUT_BF16) {
+        u32x4 o = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+        *(u32x4*)((bf16_t*)Cbase + orow * ldc + n) = o;
+    } else {
+        *(f32x4*)((float*)Cbase + orow * ldc + n) = v0;
+        *(f32x4*)((float*)Cbase + orow * ldc + n + 4) = v1;
+    }
+}
+
+int hh_gemm256_launch(const GemmParams& p, hipStream_t s);   // gemm256.hip; returns HH_OK or an error
+bool hh_gemm256_eligible(const GemmParams& p);

@@ -41,6 +41,11 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def set_tuning(name, value):
+    """Performance knob for A/B measurements (include/hh.h: hh_set_tuning)."""
+    _lib.check(_lib.lib().hh_set_tuning(name.encode(), int(value)), "hh_set_tuning")
+
+
 def layernorm(x, gamma, beta, eps, out_dtype=torch.bfloat16, save_stats=False):
     """LayerNorm over the last dim; x fp32/bf16 [..., cols] -> out_dtype."""
     _chk(x, gamma, beta)

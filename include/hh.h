@@ -28,6 +28,10 @@ enum hh_dtype { HH_F32 = 0, HH_BF16 = 1 };
 enum hh_act { HH_ACT_NONE = 0, HH_ACT_QUICKGELU = 1, HH_ACT_RELU = 2 };
 
 int hh_version(void);
+/* Performance knobs for A/B measurements (never change results): "gemm256" = 0 (128x128 kernel only), 1 (256x256
+ * 8-phase, no stagger), 2 (256x256 with wave-group stagger, default); "gemm256_skew" = -1 auto / 0 off / 1 on
+ * (start-time skew of the first round of 256x256 blocks, spreads the epilogue HBM bursts). */
+int hh_set_tuning(const char* name, int value);
 const char* hh_last_error_string(void);
 
 /* ---- LayerNorm over the last dim (model/LaviLa.py:439,456 eps 1e-6 / 1e-5; tfm_decoder.py:57,375-377)
