@@ -69,6 +69,54 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
     }
 }
 
+// fused residual add + LayerNorm:  x (fp32, in place) += delta (bf16)  ;  y = LN(x)
+// Keeps the fp32 residual read-modify-write out of the GEMM epilogues (where it is limited by per-CU memory throughput and
+// cannot overlap the MFMA main loop) and does it here at streaming HBM rate; x is written back only when WRITE_X.
+template <int NV, typename TOUT, bool WRITE_X>
+__global__ __launch_bounds__(256) void add_ln_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     TOUT* __restrict__ y, int64_t rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NV][4], d[NV][4];
+    load_row<NV, float>(x + row * cols, cols, lane, v);
+    load_row<NV, bf16_t>(delta + row * cols, cols, lane, d);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] += d[i][j];
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        if (WRITE_X) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < cols) { f32x4 o = {v[i][0], v[i][1], v[i][2], v[i][3]}; *(f32x4*)(x + row * cols + c) = o; }
+        }
+    }
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float dd = v[i][j] - mean; q += dd * dd; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+            f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+            float o0 = (v[i][0] - mean) * rstd * g[0] + b[0], o1 = (v[i][1] - mean) * rstd * g[1] + b[1];
+            float o2 = (v[i][2] - mean) * rstd * g[2] + b[2], o3 = (v[i][3] - mean) * rstd * g[3] + b[3];
+            if constexpr (sizeof(TOUT) == 4) { f32x4 o = {o0, o1, o2, o3}; *(f32x4*)(y + row * cols + c) = o; }
+            else { u32x2 o = {pack_bf16(o0, o1), pack_bf16(o2, o3)}; *(u32x2*)(y + row * cols + c) = o; }
+        }
+    }
+}
+
 // backward: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma; dgamma += dy*xhat, dbeta += dy (atomics per block)
 template <int NV, typename TIN>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIN* __restrict__ x, const float* __restrict__ gamma,
@@ -184,4 +232,25 @@ extern "C" int hh_layernorm_bwd(const void* x, int x_dtype, const float* gamma, 
     else { if (nv <= 2) LAUNCH(2, bf16_t); else LAUNCH(4, bf16_t); }
 #undef LAUNCH
     return hh_check_launch("hh_layernorm_bwd");
+}
+
+extern "C" int hh_add_layernorm_fwd(float* x, const void* delta, int write_x, const float* gamma, const float* beta, void* y,
+                                    int y_dtype, int64_t rows, int cols, float eps, hh_stream_t stream) {
+    HH_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 2048, HH_ERR_SHAPE, "hh_add_layernorm_fwd: cols=%d must be a multiple of 8 and <= 2048", cols);
+    HH_REQUIRE(y_dtype == HH_F32 || y_dtype == HH_BF16, HH_ERR_DTYPE, "hh_add_layernorm_fwd: bad dtype");
+    HH_REQUIRE(delta != nullptr, HH_ERR_SHAPE, "hh_add_layernorm_fwd: delta is NULL (use hh_layernorm_fwd)");
+    HH_REQUIRE(HH_ALIGNED16(x) && HH_ALIGNED16(delta) && HH_ALIGNED16(y) && HH_ALIGNED16(gamma) && HH_ALIGNED16(beta), HH_ERR_ALIGN,
+               "hh_add_layernorm_fwd: pointers must be 16-byte aligned");
+    if (rows == 0) return HH_OK;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const bf16_t* d = (const bf16_t*)delta;
+    const int nv = (cols + 255) / 256;
+#define LA(NV, T, W) hipLaunchKernelGGL((add_ln_kernel<NV, T, W>), grid, block, 0, s, x, d, gamma, beta, (T*)y, rows, cols, eps)
+#define LB(NV) do { if (y_dtype == HH_BF16) { if (write_x) LA(NV, bf16_t, true); else LA(NV, bf16_t, false); } \
+                    else { if (write_x) LA(NV, float, true); else LA(NV, float, false); } } while (0)
+    if (nv <= 2) LB(2); else if (nv <= 4) LB(4); else LB(8);
+#undef LB
+#undef LA
+    return hh_check_launch("hh_add_layernorm_fwd");
 }

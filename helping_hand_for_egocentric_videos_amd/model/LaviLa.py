@@ -175,23 +175,28 @@ class SpaceTimeBlock(nn.Module):
                           "b2": self.mlp.fc2.bias.detach().float()}
         return self._pack
 
-    def fused(self, x, B, T, n):
-        """x fp32 [B*N, D] residual stream, updated IN PLACE; returns x."""
+    def fused(self, x, B, T, n, pending=None):
+        """x fp32 [B*N, D] residual stream (updated IN PLACE); `pending` = previous block's MLP output (bf16) that has
+        not been added to x yet.  Returns this block's MLP output (bf16), to be added by the next add+LayerNorm.
+
+        The GEMM epilogues only write bf16 branch outputs; every fp32 residual read-modify-write happens inside the
+        fused add+LayerNorm kernel (streaming HBM rate) instead of the GEMM epilogue (per-CU store-rate bound)."""
         pk = self.packed()
-        a = self.timeattn.core(ops.layernorm(x, *pk["n3"]), pk["time"], B, T, n, "time")
-        tr = ops.gemm(a, pk["time"]["wproj"], pk["time"]["bproj"], resid=x, out_dtype=torch.float32)          # x + time
-        a = self.attn.core(ops.layernorm(tr, *pk["n1"]), pk["space"], B, T, n, "space")
-        ops.gemm(a, pk["space"]["wproj"], pk["space"]["bproj"], resid=x, out=x)                                 # x + space (A1)
-        h = ops.gemm(ops.layernorm(x, *pk["n2"]), pk["w1"], pk["b1"], act=ops.ACT_QUICKGELU)
-        ops.gemm(h, pk["w2"], pk["b2"], resid=x, out=x)
-        return x
+        xn = ops.layernorm(x, *pk["n3"]) if pending is None else ops.add_layernorm(x, pending, *pk["n3"], write_x=True)
+        a = self.timeattn.core(xn, pk["time"], B, T, n, "time")
+        t = ops.gemm(a, pk["time"]["wproj"], pk["time"]["bproj"])                                             # time branch
+        a = self.attn.core(ops.add_layernorm(x, t, *pk["n1"], write_x=False), pk["space"], B, T, n, "space")   # LN1(x + t)
+        sp = ops.gemm(a, pk["space"]["wproj"], pk["space"]["bproj"])
+        h = ops.gemm(ops.add_layernorm(x, sp, *pk["n2"], write_x=True), pk["w1"], pk["b1"], act=ops.ACT_QUICKGELU)  # x += s (A1)
+        return ops.gemm(h, pk["w2"], pk["b2"])
 
     def forward(self, x, einops_from_space, einops_to_space, einops_from_time, einops_to_time, time_n, space_f,
                 use_checkpoint=False):
         _require_gpu(x, "SpaceTimeBlock")
         B, N, D = x.shape
         y = x.float().reshape(B * N, D).clone()
-        return self.fused(y, B, space_f, time_n).view(B, N, D)
+        m = self.fused(y, B, space_f, time_n)
+        return (y + m.float()).view(B, N, D)
 
 
 class SpaceTimeTransformer(nn.Module):
@@ -274,9 +279,14 @@ class SpaceTimeTransformer(nn.Module):
         xs = ops.embed_ln_pre(tok, pk["cls"], pk["pos"], pk["tmp"], *pk["ln_pre"][:2], B, T, n, pk["ln_pre"][2])
         del patches, tok
         xs = xs.view(B * (1 + T * n), D)
+        pending = None
         for blk in self.blocks:
-            blk.fused(xs, B, T, n)
-        out = ops.layernorm(xs, *pk["norm"], out_dtype=out_dtype).view(B, 1 + T * n, D)     # norm evaluated once (A5)
+            pending = blk.fused(xs, B, T, n, pending)
+        if pending is None:
+            out = ops.layernorm(xs, *pk["norm"], out_dtype=out_dtype)
+        else:
+            out = ops.add_layernorm(xs, pending, *pk["norm"], write_x=False, out_dtype=out_dtype)
+        out = out.view(B, 1 + T * n, D)                                                      # norm evaluated once (A5)
         return self.pre_logits(out[:, 0]), out
 
     def forward(self, x, use_checkpoint=False):

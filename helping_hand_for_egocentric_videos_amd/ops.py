@@ -62,6 +62,18 @@ def layernorm(x, gamma, beta, eps, out_dtype=torch.bfloat16, save_stats=False):
     return (y, mean, rstd) if save_stats else y
 
 
+def add_layernorm(x, delta, gamma, beta, eps, write_x=True, out_dtype=torch.bfloat16):
+    """x (fp32, in place if write_x) += delta (bf16); returns LN(x).  x, delta [rows, cols]."""
+    _chk(x, delta, gamma, beta)
+    if x.dtype != torch.float32 or delta.dtype != torch.bfloat16 or x.shape != delta.shape:
+        raise TypeError("add_layernorm: x fp32 and delta bf16 of the same shape")
+    cols = x.shape[-1]
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _lib.check(_lib.lib().hh_add_layernorm_fwd(_p(x), _p(delta), int(bool(write_x)), _p(gamma), _p(beta), _p(y), _dt(y),
+                                               x.numel() // cols, cols, float(eps), _stream()), "hh_add_layernorm_fwd")
+    return y
+
+
 def layernorm_bwd(x, gamma, mean, rstd, dy):
     _chk(x, gamma, mean, rstd, dy)
     cols = x.shape[-1]

@@ -41,6 +41,11 @@ const char* hh_last_error_string(void);
 int hh_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                      float* mean_out, float* rstd_out, int64_t rows, int cols, float eps, hh_stream_t stream);
 
+/* Fused residual add + LayerNorm: x (fp32 [rows, cols]) += delta (bf16) -- written back iff write_x -- and
+ * y = LN(x) (bf16 or fp32).  Used for x + attn / x + mlp of SpaceTimeBlock (model/LaviLa.py:364,384,388). */
+int hh_add_layernorm_fwd(float* x, const void* delta, int write_x, const float* gamma, const float* beta, void* y,
+                         int y_dtype, int64_t rows, int cols, float eps, hh_stream_t stream);
+
 /* LayerNorm backward: dx (same dtype as x_dtype... fp32) plus per-column partial sums for dgamma/dbeta.
  * dgamma_part/dbeta_part: [nparts, cols] fp32 workspace partials, reduced by hh_colsum_f32. */
 int hh_layernorm_bwd(const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd,

@@ -9,6 +9,8 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))      # the 256-thread GPU host is slower with >32 threads
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

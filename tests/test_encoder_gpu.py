@@ -61,9 +61,10 @@ def test_block_by_block_drift_is_bounded():
     tok = ops.gemm(patches, pk["wpatch"], out_dtype=torch.float32)
     xs = ops.embed_ln_pre(tok, pk["cls"], pk["pos"], pk["tmp"], *pk["ln_pre"][:2], B, T, n, pk["ln_pre"][2]).view(-1, D)
     assert rel_l2(xs.view(1, -1, D), inter[0]) < 5e-3
+    pending = None
     for i, blk in enumerate(vis.blocks):
-        blk.fused(xs, B, T, n)
-        assert rel_l2(xs.view(1, -1, D), inter[i + 1]) < 8e-3 * (i + 2), i
+        pending = blk.fused(xs, B, T, n, pending)
+        assert rel_l2((xs + pending.float()).view(1, -1, D), inter[i + 1]) < 8e-3 * (i + 2), i
 
 
 def test_module_api_shapes_and_standalone_forms():

@@ -44,6 +44,23 @@ def test_layernorm(cols, rows, xdt, ydt):
         assert_close_bf16(y, ref, 5e-3, "layernorm")
 
 
+@pytest.mark.parametrize("write_x", [True, False])
+@pytest.mark.parametrize("ydt", [torch.bfloat16, torch.float32])
+def test_add_layernorm(write_x, ydt):
+    rows, cols = 4097, 1024
+    x, d = rnd(rows, cols, seed=1, scale=2.0), bf(rnd(rows, cols, seed=2))
+    g, b = rnd(cols, seed=3) * 0.1 + 1, rnd(cols, seed=4) * 0.1
+    s = x + d.float()
+    ref = torch.nn.functional.layer_norm(s, (cols,), g, b, 1e-6)
+    X = x.to(DEV)
+    y = ops.add_layernorm(X, d.to(DEV), g.to(DEV), b.to(DEV), 1e-6, write_x=write_x, out_dtype=ydt)
+    assert torch.equal(X.cpu(), s if write_x else x)
+    if ydt == torch.float32:
+        torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-5)
+    else:
+        assert_close_bf16(y, ref, 5e-3, "add_layernorm")
+
+
 def test_layernorm_bwd():
     rows, cols = 1031, 512
     x = rnd(rows, cols, seed=4, scale=2.0)
