@@ -61,7 +61,7 @@ def gemm_flops(a, w, *args, **kw):
     return 2.0 * a.shape[0] * a.shape[1] * w.shape[0]
 
 
-def attn_bytes(qkv, B, T, n, heads, mode, out=None):
+def attn_bytes(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
     return 8.0 * qkv.shape[0] * heads * 64          # read q,k,v + write o, bf16 (8*N*D per call)
 
 

@@ -31,8 +31,9 @@ SIGNATURES = {
     "hh_transpose_to_bf16": [c_vp, c_int, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp],
     "hh_patch_im2col": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp],
     "hh_embed_ln_pre": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, c_vp],
-    "hh_space_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
-    "hh_time_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "hh_space_attn_fwd": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "hh_time_attn_fwd": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "hh_cls_combine": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp],
     "hh_cls_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "hh_xattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
     "hh_xattn_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_float,

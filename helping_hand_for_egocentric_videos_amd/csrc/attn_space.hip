@@ -27,7 +27,11 @@ __device__ __forceinline__ u32x2 pack_keys(unsigned a, unsigned b, unsigned c, u
     return r;
 }
 
+// layout of one CLS partial record: [m, l, 0, 0, o[64]] fp32
+#define CLS_REC 68
+
 __global__ __launch_bounds__(256, 2) void space_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                            float* __restrict__ cls_partial,
                                                             int B, int T, int n, int heads, int KP, int VS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                              // [KP][128 B]
@@ -166,15 +170,112 @@ __global__ __launch_bounds__(256, 2) void space_attn_kernel(const bf16_t* __rest
             *(u32x2*)(orow + 32 + 8 * g) = w1;
         }
     }
+    // ---- CLS query (model/LaviLa.py:255-258) folded in: partial softmax(q_cls . K_f^T) V_f over THIS frame's keys, which
+    // are already in LDS (the CLS key itself is counted by frame 0 only); hh_cls_combine merges the T partials.
+    if (cls_partial == nullptr) return;
+    __syncthreads();                                   // every wave is done with its reads; reuse the front of Ks as scratch
+    {
+        float* scratch = (float*)(smem + (size_t)KP * 128 + (size_t)64 * VS * 2);     // [4 waves][CLS_REC]
+        const int nkeys = n + (f == 0 ? 1 : 0);
+        float q[64];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            u32x4 u = *(const u32x4*)(base + c * 8);                                 // q row of token 0 (pre-scaled)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { q[c * 8 + 2 * w] = bf16_lo_to_f32(u[w]); q[c * 8 + 2 * w + 1] = bf16_hi_to_f32(u[w]); }
+        }
+        // wave w owns keys [w*KQ, (w+1)*KQ), one or more keys per lane
+        const int KQ = (nkeys + 3) / 4;
+        const int k_lo = wave * KQ, k_hi = min(nkeys, k_lo + KQ);
+        float mx = -INFINITY;
+        for (int j = k_lo + lane; j < k_hi; j += 64) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                u32x4 u = *(const u32x4*)(Ks + j * 128 + ((c ^ (j & 7)) << 4));
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    a0 = fmaf(q[c * 8 + 2 * w], bf16_lo_to_f32(u[w]), a0);
+                    a1 = fmaf(q[c * 8 + 2 * w + 1], bf16_hi_to_f32(u[w]), a1);
+                }
+            }
+            mx = fmaxf(mx, a0 + a1);
+        }
+        mx = wave_max(mx);
+        // second pass: p_j and the weighted V sum; lane d accumulates o[d] with p_j broadcast through readlane
+        float l = 0.f, o = 0.f;
+        for (int j0 = k_lo; j0 < k_hi; j0 += 64) {
+            const int j = j0 + lane;
+            float pj = 0.f;
+            if (j < k_hi) {
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    u32x4 u = *(const u32x4*)(Ks + j * 128 + ((c ^ (j & 7)) << 4));
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        a0 = fmaf(q[c * 8 + 2 * w], bf16_lo_to_f32(u[w]), a0);
+                        a1 = fmaf(q[c * 8 + 2 * w + 1], bf16_hi_to_f32(u[w]), a1);
+                    }
+                }
+                pj = __builtin_amdgcn_exp2f((a0 + a1 - mx) * LOG2E);
+            }
+            l += pj;
+            const int cnt = min(64, k_hi - j0);
+            const bf16_t* vrow = Vt + (size_t)lane * VS + j0;                      // V^T row d = lane
+            for (int jj = 0; jj < cnt; ++jj) o = fmaf(__shfl(pj, jj, 64), (float)vrow[jj], o);
+        }
+        l = wave_sum(l);
+        if (k_lo >= k_hi) { mx = -INFINITY; l = 0.f; o = 0.f; }
+        scratch[wave * CLS_REC + 4 + lane] = o;
+        if (lane == 0) { scratch[wave * CLS_REC] = mx; scratch[wave * CLS_REC + 1] = l; }
+        __syncthreads();
+        if (tid < 64) {
+            float m = fmaxf(fmaxf(scratch[0], scratch[CLS_REC]), fmaxf(scratch[2 * CLS_REC], scratch[3 * CLS_REC]));
+            float lt = 0.f, ot = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float e = __builtin_amdgcn_exp2f((scratch[w * CLS_REC] - m) * LOG2E);     // exp2(-inf) = 0 for empty waves
+                lt += scratch[w * CLS_REC + 1] * e;
+                ot += scratch[w * CLS_REC + 4 + tid] * e;
+            }
+            float* rec = cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC;
+            rec[4 + tid] = ot;
+            if (tid == 0) { rec[0] = m; rec[1] = lt; }
+        }
+    }
 }
 
-extern "C" int hh_space_attn_fwd(const void* qkv, void* out, int B, int T, int n, int heads, hh_stream_t stream) {
+// merge G partial records per (clip, head) into out row 0:  o = sum_g o_g e^{m_g - m} / sum_g l_g e^{m_g - m}
+__global__ __launch_bounds__(64) void cls_combine_kernel(const float* __restrict__ partial, int G, bf16_t* __restrict__ out,
+                                                         int N, int heads) {
+    const int head = blockIdx.x % heads, b = blockIdx.x / heads, d = threadIdx.x;
+    const float* rec = partial + ((int64_t)b * heads + head) * G * CLS_REC;
+    float m = -INFINITY;
+    for (int g = 0; g < G; ++g) m = fmaxf(m, rec[g * CLS_REC]);
+    float l = 0.f, o = 0.f;
+    for (int g = 0; g < G; ++g) {
+        const float e = __builtin_amdgcn_exp2f((rec[g * CLS_REC] - m) * 1.4426950408889634f);
+        l += rec[g * CLS_REC + 1] * e;
+        o += rec[g * CLS_REC + 4 + d] * e;
+    }
+    out[(int64_t)b * N * heads * 64 + head * 64 + d] = (bf16_t)(o / l);
+}
+
+extern "C" int hh_cls_combine(const float* partial, int G, void* out, int B, int N, int heads, hh_stream_t stream) {
+    HH_REQUIRE(B >= 0 && G > 0 && N > 0 && heads > 0 && partial != nullptr, HH_ERR_SHAPE, "hh_cls_combine: bad arguments");
+    if (B == 0) return HH_OK;
+    hipLaunchKernelGGL(cls_combine_kernel, dim3((unsigned)(B * heads)), dim3(64), 0, (hipStream_t)stream, partial, G, (bf16_t*)out, N, heads);
+    return hh_check_launch("hh_cls_combine");
+}
+
+extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream) {
     HH_REQUIRE(B >= 0 && T > 0 && heads > 0 && n > 0 && n % 32 == 0, HH_ERR_SHAPE, "hh_space_attn_fwd: n=%d must be a multiple of 32", n);
     HH_REQUIRE(HH_ALIGNED16(qkv) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_space_attn_fwd: pointers must be 16-byte aligned");
     if (B == 0) return HH_OK;
     const int KP = ((n + 1 + 31) / 32) * 32;
     const int VS = KP + 4;
-    const size_t lds = (size_t)KP * 128 + (size_t)64 * VS * 2;
+    const size_t lds = (size_t)KP * 128 + (size_t)64 * VS * 2 + 4 * CLS_REC * 4;
     HH_REQUIRE(lds <= 160 * 1024, HH_ERR_UNSUPPORTED, "hh_space_attn_fwd: n=%d needs %zu B of LDS (> 160 KiB)", n, lds);
     static size_t attr_set = 0;
     if (lds > attr_set) {
@@ -184,6 +285,6 @@ extern "C" int hh_space_attn_fwd(const void* qkv, void* out, int B, int T, int n
     }
     const int64_t blocks = (int64_t)B * T * heads;
     hipLaunchKernelGGL(space_attn_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream,
-                       (const bf16_t*)qkv, (bf16_t*)out, B, T, n, heads, KP, VS);
+                       (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP, VS);
     return hh_check_launch("hh_space_attn_fwd");
 }

@@ -10,8 +10,10 @@
 #include "common.h"
 
 template <int T>
+#define CLS_REC 68
+
 __global__ __launch_bounds__(256) void time_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                        int B, int n, int heads) {
+                                                        float* __restrict__ cls_partial, int B, int n, int heads) {
     // thread = (patch pi, query frame fq, half hf): each query row is split over two adjacent lanes (32 dims each)
     constexpr int P = 128 / T;
     __shared__ __attribute__((aligned(16))) unsigned int Ks[(T * P + 1) * 32];   // 128 B rows; last row = CLS
@@ -110,9 +112,53 @@ __global__ __launch_bounds__(256) void time_attn_kernel(const bf16_t* __restrict
             *(u32x4*)(op + c * 8) = w;
         }
     }
+    // ---- CLS query folded in: partial over this workgroup's T*P keys (already in LDS); group 0 also counts the CLS key
+    if (cls_partial == nullptr) return;
+    __shared__ float cp[T * P + 1];
+    __shared__ float cred[8];
+    {
+        const int nrows = T * P + (pg == 0 ? 1 : 0);                 // LDS row T*P is the CLS key/value
+        float sc = -INFINITY;
+        if (tid < nrows) {
+            const int fr = tid / P, pi2 = tid % P;
+            const bool valid = tid == T * P || (p0 + pi2) < n;
+            if (valid) {
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    u32x4 qv = *(const u32x4*)(base + c * 8);            // q row of token 0 (uniform address)
+                    u32x4 u = *(const u32x4*)(Ks + tid * 32 + c * 4);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        a0 = fmaf(bf16_lo_to_f32(qv[w]), bf16_lo_to_f32(u[w]), a0);
+                        a1 = fmaf(bf16_hi_to_f32(qv[w]), bf16_hi_to_f32(u[w]), a1);
+                    }
+                }
+                sc = a0 + a1;
+            }
+            (void)fr;
+        }
+        float mx = wave_max(sc);
+        if ((tid & 63) == 0) cred[tid >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(cred[0], cred[1]), fmaxf(cred[2], cred[3]));
+        const float pj = (sc == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((sc - mx) * 1.4426950408889634f);
+        if (tid <= T * P) cp[tid] = pj;
+        float l = wave_sum(pj);
+        if ((tid & 63) == 0) cred[4 + (tid >> 6)] = l;
+        __syncthreads();
+        if (tid < 64) {
+            float o = 0.f;
+            const unsigned short* vs16 = (const unsigned short*)Vs;
+            for (int j = 0; j < nrows; ++j) o = fmaf(cp[j], __uint_as_float((unsigned)vs16[j * 64 + tid] << 16), o);
+            float* rec = cls_partial + (((int64_t)b * heads + head) * groups + pg) * CLS_REC;
+            rec[4 + tid] = o;
+            if (tid == 0) { rec[0] = mx; rec[1] = (cred[4] + cred[5]) + (cred[6] + cred[7]); }
+        }
+    }
 }
 
-extern "C" int hh_time_attn_fwd(const void* qkv, void* out, int B, int T, int n, int heads, hh_stream_t stream) {
+extern "C" int hh_time_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream) {
     HH_REQUIRE(B >= 0 && n > 0 && heads > 0, HH_ERR_SHAPE, "hh_time_attn_fwd: bad shape");
     HH_REQUIRE(T == 1 || T == 2 || T == 4 || T == 8 || T == 16 || T == 32, HH_ERR_UNSUPPORTED,
                "hh_time_attn_fwd: num_frames=%d unsupported (1,2,4,8,16,32)", T);
@@ -123,7 +169,7 @@ extern "C" int hh_time_attn_fwd(const void* qkv, void* out, int B, int T, int n,
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* in = (const bf16_t*)qkv;
     bf16_t* o = (bf16_t*)out;
-#define LAUNCH(TT) hipLaunchKernelGGL(time_attn_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, s, in, o, B, n, heads)
+#define LAUNCH(TT) hipLaunchKernelGGL(time_attn_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, s, in, o, cls_partial, B, n, heads)
     switch (T) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;

@@ -182,23 +182,32 @@ def embed_ln_pre(tok, cls, pos, temporal, gamma, beta, B, T, n, eps=1e-5):
     return x
 
 
-def divided_attention(qkv, B, T, n, heads, mode, out=None):
-    """qkv bf16 [B*N, 3D] (q pre-scaled) -> bf16 [B*N, D]: CLS row via hh_cls_attn_fwd, the rest via space/time."""
+def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
+    """qkv bf16 [B*N, 3D] (q pre-scaled) -> bf16 [B*N, D].  Rows 1.. come from the space/time kernel; the CLS row
+    (query 0 attends all N keys) is folded into the same kernels as per-group partials + hh_cls_combine
+    (fold_cls=False runs the stand-alone hh_cls_attn_fwd pass instead)."""
     _chk(qkv, out)
     N = 1 + T * n
     D = heads * 64
     if qkv.dtype != torch.bfloat16 or qkv.shape != (B * N, 3 * D):
         raise ValueError("divided_attention: qkv must be bf16 [B*N, 3*heads*64], got %s" % (tuple(qkv.shape),))
+    if mode not in ("space", "time"):
+        raise ValueError(mode)
     if out is None:
         out = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device)
     L = _lib.lib()
-    _lib.check(L.hh_cls_attn_fwd(_p(qkv), _p(out), B, N, heads, _stream()), "hh_cls_attn_fwd")
-    if mode == "space":
-        _lib.check(L.hh_space_attn_fwd(_p(qkv), _p(out), B, T, n, heads, _stream()), "hh_space_attn_fwd")
-    elif mode == "time":
-        _lib.check(L.hh_time_attn_fwd(_p(qkv), _p(out), B, T, n, heads, _stream()), "hh_time_attn_fwd")
+    part, G = None, 0
+    if fold_cls:
+        G = T if mode == "space" else (n + (128 // T) - 1) // (128 // T)
+        part = torch.empty((B, heads, G, 68), dtype=torch.float32, device=qkv.device)
     else:
-        raise ValueError(mode)
+        _lib.check(L.hh_cls_attn_fwd(_p(qkv), _p(out), B, N, heads, _stream()), "hh_cls_attn_fwd")
+    if mode == "space":
+        _lib.check(L.hh_space_attn_fwd(_p(qkv), _p(out), _p(part), B, T, n, heads, _stream()), "hh_space_attn_fwd")
+    else:
+        _lib.check(L.hh_time_attn_fwd(_p(qkv), _p(out), _p(part), B, T, n, heads, _stream()), "hh_time_attn_fwd")
+    if fold_cls:
+        _lib.check(L.hh_cls_combine(_p(part), G, _p(out), B, N, heads, _stream()), "hh_cls_combine")
     return out
 
 

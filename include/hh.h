@@ -96,10 +96,14 @@ int hh_embed_ln_pre(const float* tok, const float* cls, const float* pos, const 
 /* ---- divided space-time attention cores (model/LaviLa.py:246-283, attn() :194-198)
  * qkv bf16 [B, N=1+T*n, 3*D] (q|k|v, head-major inside D, q pre-scaled), out bf16 [B, N, D]; head dim 64.
  * space: per (b, head, frame): n queries x (CLS + n) keys.  time: per (b, head, patch): T queries x (CLS + T) keys.
- * cls: the CLS query attends all N keys (row 0 of out).  Rows 1.. are written by space/time, row 0 by cls. */
-int hh_space_attn_fwd(const void* qkv, void* out, int B, int T, int n, int heads, hh_stream_t stream);
-int hh_time_attn_fwd(const void* qkv, void* out, int B, int T, int n, int heads, hh_stream_t stream);
+ * cls: the CLS query attends all N keys (row 0 of out).  Rows 1.. are written by space/time, row 0 by cls.
+ * cls_partial (optional, fp32 [B, heads, G, 68], G = T for space, ceil(n / (128/T)) for time): when non-NULL the kernel
+ * also emits the CLS query's partial softmax statistics over its own key group (record = m, l, 0, 0, o[64]);
+ * hh_cls_combine merges the G records into out row 0, which replaces the separate hh_cls_attn_fwd pass. */
+int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream);
+int hh_time_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream);
 int hh_cls_attn_fwd(const void* qkv, void* out, int B, int N, int heads, hh_stream_t stream);
+int hh_cls_combine(const float* partial, int G, void* out, int B, int N, int heads, hh_stream_t stream);
 
 /* ---- decoder cross-attention core (nn.MultiheadAttention inside tfm_decoder.py:438-441; 13 x 4096, 8 heads)
  * q fp32 [B, Q, C] (already scaled by d^-0.5), k/v bf16 [B, M, ldkv] (head-major columns, C = heads*64 used),

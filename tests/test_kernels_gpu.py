@@ -175,6 +175,10 @@ def test_divided_attention(mode, B, T, n, heads):
     qkv = bf(qkv)
     out = ops.divided_attention(qkv.to(DEV), B, T, n, heads, mode)
     ref = _ref_divided(qkv, B, T, n, heads, mode)
+    sep = ops.divided_attention(qkv.to(DEV), B, T, n, heads, mode, fold_cls=False)       # stand-alone CLS kernel
+    assert torch.equal(sep.view(B, -1, heads * 64)[:, 1:], out.view(B, -1, heads * 64)[:, 1:])
+    assert_close_bf16(sep.view(B, -1, heads * 64)[:, 0], ref.view(B, -1, heads * 64)[:, 0], 1.2e-2, "cls-separate")
+    assert_close_bf16(out.view(B, -1, heads * 64)[:, 0], ref.view(B, -1, heads * 64)[:, 0], 1.2e-2, "cls-folded")
     assert_close_bf16(out, ref, 1.2e-2, f"attn-{mode}")
     # row-wise check so a wrong small-magnitude row cannot hide behind the global scale
     err = (out.float().cpu() - ref).abs().amax(1)
