@@ -65,6 +65,19 @@ def attn_bytes(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
     return 8.0 * qkv.shape[0] * heads * 64          # read q,k,v + write o, bf16 (8*N*D per call)
 
 
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r1_pmc_summary.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction)."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        for k, v in json.load(f).items():
+            if kernel_substr in k:
+                return v["traffic_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(cfg, enc_sd, dec_sd, seed):
     """Oracle (CPU restatement, fp32) timed on this host: one full training step on ONE clip of the same workload."""
     from oracle import step as OS
@@ -157,8 +170,9 @@ def main():
         roof = None
         if n_g:
             ach = fl_g / (ms_g * 1e-3) / 1e12
-            roof = {"kernel": "gemm_bf16_kernel (hh_gemm_bf16)", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            roof = {"kernel": "gemm256_kernel / gemm_bf16_kernel (hh_gemm_bf16)", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic("gemm256_kernel<true"),
+                    "traffic_note": "bytes/launch from profiles/r1_pmc_summary.json (PMC passes at B=32); algorithmic avg ~0.99e9",
                     "launches": n_g, "avg_launch_us": round(ms_g * 1e3 / n_g, 1), "share_of_step": round(ms_g / (dt * 1e3), 3)}
         line = {"metric": metric, "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
