@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const int wr = wave >> 2, wc = wave & 3;
 
     // ---- XCD-aware tile assignment (same scheme as gemm.hip, 4 m-tiles x all n-tiles per XCD-local group)
-    const int GROUP = 4;
+    const int GROUP = p.group_m;
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
     const int per = GROUP * p.Nt;
@@ -241,6 +241,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     }
 }
 
+static int g_group = 8;            // m-tiles per XCD-local group (weight-panel reuse factor)
 static int g_skew = -1;            // start skew: -1 auto (on when the epilogue carries an fp32 residual), 0 off, 1 on
 static int g_mode = -1;            // gemm256 mode: 0 = off, 1 = on without stagger, 2 = on with stagger (default)
 static int gemm256_mode() {
@@ -254,6 +255,7 @@ static int gemm256_mode() {
 extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm256")) { g_mode = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_skew")) { g_skew = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm256_group") && value >= 1 && value <= 64) { g_group = value; return HH_OK; }
     hh_set_error("hh_set_tuning: unknown knob '%s'", name ? name : "(null)");
     return HH_ERR_UNSUPPORTED;
 }
@@ -281,7 +283,8 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
     }
     p.Mt = (int)((p.M + 255) / 256);
     p.Nt = p.N / 256;
-    const int GROUP = 4;
+    const int GROUP = g_group;
+    p.group_m = GROUP;
     const int per_xcd_mt = (p.Mt + 7) / 8;
     const int groups = (per_xcd_mt + GROUP - 1) / GROUP;
     const unsigned grid = 8u * (unsigned)groups * GROUP * (unsigned)p.Nt;

@@ -103,3 +103,19 @@ def test_full_width_t4_vs_oracle():
     gc, gx = vis.cuda()(video.cuda())
     assert rel_l2(gx, rx) < 1.5e-2, rel_l2(gx, rx)
     assert torch.nn.functional.cosine_similarity(gc.cpu(), rc, dim=-1).min() > 0.999
+
+
+def test_long_clip_high_res_shapes_c4():
+    """BASELINE config 4 shapes (T=32, 336^2 -> n=576, N=18433) at reduced width: exercises the multi-chunk online
+    softmax of the space kernel (n+1 = 577 keys), the T=32 time kernel and the CLS folding with 32 / 144 groups."""
+    cfg = TINY4.with_(num_frames=32, img_size=336)
+    sd = synth.encoder_state(cfg, seed=6, with_text=False)
+    video = synth.make_batch(cfg, 1, seed=6)["video"]
+    vis = LaviLa.build_backbone(cfg, None).visual
+    vis.load_state_dict({k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}, strict=True)
+    with torch.no_grad():
+        rc, rx = OE.vision_forward(video, sd, cfg)
+    gc, gx = vis.cuda()(video.cuda())
+    assert gx.shape == (1, 1 + 32 * 576, cfg.embed_dim)
+    assert rel_l2(gx, rx) < 1.5e-2, rel_l2(gx, rx)
+    assert rel_l2(gx[:, 0], rx[:, 0]) < 1.5e-2
