@@ -2,40 +2,44 @@
 // One workgroup per (clip, frame, head): n queries x (n frame keys + CLS key), head dim 64, no mask, no dropout.
 // HBM-bound in principle: algorithmic bytes per workgroup = (3*n + 2) * 128 B read + n * 128 B written.
 //
-// Structure: K tile [KP][64] (XOR-swizzled 16-B chunks) and V^T tile [64][KP+4] staged once in LDS (V is transposed
-// while staging: 4 keys x 8 d register blocks -> ds_write_b64), then each wave walks 32-query blocks:
+// Structure: K tile and V tile, both row-major [KP][64] with XOR-swizzled 16-B chunks, staged once in LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no VALU), then each wave walks 32-query blocks:
 //   S^T = K . Q^T      mfma_f32_32x32x16_bf16, A = K rows (LDS), B = Q rows (registers, straight from HBM)
 //   softmax over keys  in-lane over the 16 accumulator registers x tiles + one xor-32 shuffle (query = lane & 31)
 //   O^T = V^T . P^T    the S^T accumulator tile is re-used as the B operand with no lane movement
-//                      (k order inside a step: row 16s + 8(j>>2) + 4h + (j&3)); A = V^T rows (2 x ds_read_b64)
+//                      (k order inside a step: row 16s + 8(j>>2) + 4h + (j&3)); A = V^T fragments fetched from the
+//                      row-major V tile by the hardware-transposing ds_read_b64_tr_b16
 // Keys are processed in chunks of CH=5 tiles (160 keys) with an online-softmax merge between chunks, so n=576
 // (336^2) runs through the same code.  Frame keys sit at rows 0..n-1, the CLS key at row n, rows > n are zero/masked.
 #include "common.h"
 
 #define CH 5
+#define NW 4            // waves per workgroup
 
-__device__ __forceinline__ u32x2 pack_keys(unsigned a, unsigned b, unsigned c, unsigned d, bool hi) {
-    // pick the low or high bf16 of each of 4 dwords (4 keys, same d) -> 4 bf16 in key order
-    u32x2 r;
-    if (!hi) {
-        r[0] = (a & 0xffffu) | (b << 16);
-        r[1] = (c & 0xffffu) | (d << 16);
-    } else {
-        r[0] = (a >> 16) | (b & 0xffff0000u);
-        r[1] = (c >> 16) | (d & 0xffff0000u);
-    }
-    return r;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// 4 keys x 1 d (column-major delivery) of a row-major [key][64 d] bf16 tile: hardware-transposing LDS read.
+// Lane i = 4q + p of each 16-lane group supplies the address of row q, columns 4p..4p+3; it receives column i, rows 0..3.
+__device__ __forceinline__ bf16x4 lds_tr4(const char* addr) {
+    s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)addr);
+    return __builtin_bit_cast(bf16x4, r);
 }
 
 // layout of one CLS partial record: [m, l, 0, 0, o[64]] fp32
 #define CLS_REC 68
 
-__global__ __launch_bounds__(256, 2) void space_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(64 * NW, 2) void space_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ cls_partial,
-                                                            int B, int T, int n, int heads, int KP, int VS) {
+                                                            int B, int T, int n, int heads, int KP) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;                              // [KP][128 B]
-    bf16_t* Vt = (bf16_t*)(smem + (size_t)KP * 128);   // [64][VS]
+    char* Ks = smem;                                   // [KP][128 B], 16-B chunk c of row r at position c ^ (r & 7)
+    char* Vs = smem + (size_t)KP * 128;                // same layout, row-major V
+    float* scratch = (float*)(smem + (size_t)KP * 256);   // [KP] CLS scores + [4][CLS_REC] + 8
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = heads * 64;
@@ -45,45 +49,33 @@ __global__ __launch_bounds__(256, 2) void space_attn_kernel(const bf16_t* __rest
     const int head = bid % heads; bid /= heads;
     const int f = bid % T;
     const int b = bid / T;
-    const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;      // token 0 (CLS) of this clip / head
     const bf16_t* q_ptr = base + (int64_t)(1 + f * n) * ld;
-    const bf16_t* k_ptr = q_ptr + D;
-    const bf16_t* v_ptr = q_ptr + 2 * D;
-    const bf16_t* kc_ptr = base + D;       // CLS key / value (token 0)
-    const bf16_t* vc_ptr = base + 2 * D;
 
-    // ---- stage K (swizzled), rows >= n+1 zero
-    for (int idx = tid; idx < KP * 8; idx += 256) {
-        const int row = idx >> 3, pc = idx & 7, c = pc ^ (row & 7);
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < n) v = *(const u32x4*)(k_ptr + (int64_t)row * ld + c * 8);
-        else if (row == n) v = *(const u32x4*)(kc_ptr + c * 8);
-        *(u32x4*)(Ks + idx * 16) = v;
+    // ---- stage K and V by LDS-DMA (1 KiB = 8 rows per wave instruction); rows >= n take the CLS token's row (key n is the
+    // CLS key; rows > n are masked in S and multiplied by P = 0, they only have to be finite)
+    const int pieces = KP >> 3;
+    for (int pc = wave; pc < pieces; pc += NW) {
+        const int row = pc * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const bf16_t* src = (row < n) ? q_ptr + (int64_t)row * ld : base;
+        glds16(src + D + c * 8, Ks + pc * 1024);
     }
-    // ---- stage V transposed: 4 keys x 8 d per task
-    for (int idx = tid; idx < (n >> 2) * 8; idx += 256) {
-        const int kg = idx >> 3, c = idx & 7;
-        const bf16_t* src = v_ptr + (int64_t)(kg * 4) * ld + c * 8;
-        u32x4 r0 = *(const u32x4*)(src), r1 = *(const u32x4*)(src + ld), r2 = *(const u32x4*)(src + 2 * ld),
-              r3 = *(const u32x4*)(src + 3 * ld);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            *(u32x2*)(Vt + (size_t)(c * 8 + 2 * w) * VS + kg * 4) = pack_keys(r0[w], r1[w], r2[w], r3[w], false);
-            *(u32x2*)(Vt + (size_t)(c * 8 + 2 * w + 1) * VS + kg * 4) = pack_keys(r0[w], r1[w], r2[w], r3[w], true);
-        }
+    for (int pc = wave; pc < pieces; pc += NW) {
+        const int row = pc * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const bf16_t* src = (row < n) ? q_ptr + (int64_t)row * ld : base;
+        glds16(src + 2 * D + c * 8, Vs + pc * 1024);
     }
-    // CLS value at key n, zeros for keys n+1 .. VS-1
-    for (int idx = tid; idx < 64 * (VS - n); idx += 256) {
-        const int d = idx / (VS - n), kk = n + idx % (VS - n);
-        Vt[(size_t)d * VS + kk] = (kk == n) ? vc_ptr[d] : (bf16_t)0.f;
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int ql = lane & 31, h = lane >> 5;
     const int ntiles = KP >> 5;
     const float LOG2E = 1.4426950408889634f;
-    for (int qb = wave; qb < (n >> 5); qb += 4) {
-        // Q fragments: B operand, lane (col q = ql, half h) holds Q[q][16*ks + 8*h .. +8]
+    // transposing-read addressing: 16-lane group gi = lane>>4 covers d columns 16*(gi&1).. of the 32-wide d tile; lane i = 4q+p
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+    for (int qb = wave; qb < (n >> 5); qb += NW) {
         bf16x8 qf[4];
         const bf16_t* qrow = q_ptr + (int64_t)(qb * 32 + ql) * ld + 8 * h;
 #pragma unroll
@@ -108,20 +100,22 @@ __global__ __launch_bounds__(256, 2) void space_attn_kernel(const bf16_t* __rest
                     }
                 }
             }
-            // mask + running max   (key index of register r in tile ti: 32*(t0+ti) + (r&3) + 8*(r>>2) + 4*h)
             float mx = -INFINITY;
 #pragma unroll
             for (int ti = 0; ti < CH; ++ti) {
+                if (t0 + ti >= ntiles - 1) {            // only the last key tile (and unused tile slots) hold keys > n
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = (t0 + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key > n) s[ti][r] = -INFINITY;
-                    mx = fmaxf(mx, s[ti][r]);
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = (t0 + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (key > n) s[ti][r] = -INFINITY;
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[ti][r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);     // __builtin_amdgcn_exp2f(-inf) = 0 on the first chunk
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
             const float mb = m_new * LOG2E;
             float lsum = 0.f;
 #pragma unroll
@@ -137,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void space_attn_kernel(const bf16_t* __rest
             m_run = m_new;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-            // O^T += V^T . P^T
+            // O^T += V^T . P^T ; A operand element j of lane (d, h) = V[key0 + 8(j>>2) + (j&3)][d], key0 = 32 tile + 16 st + 4 h
 #pragma unroll
             for (int ti = 0; ti < CH; ++ti) {
                 if (t0 + ti < ntiles) {
@@ -146,20 +140,22 @@ __global__ __launch_bounds__(256, 2) void space_attn_kernel(const bf16_t* __rest
                         bf16x8 pf;
 #pragma unroll
                         for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)s[ti][8 * st + jj];
-                        const int key0 = (t0 + ti) * 32 + 16 * st + 4 * h;
-                        const bf16_t* v0 = Vt + (size_t)ql * VS + key0;
-                        const bf16_t* v1 = Vt + (size_t)(32 + ql) * VS + key0;
-                        bf16x4 a0 = *(const bf16x4*)(v0), a1 = *(const bf16x4*)(v0 + 8);
-                        bf16x4 c0 = *(const bf16x4*)(v1), c1 = *(const bf16x4*)(v1 + 8);
-                        bf16x8 vf0 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                        bf16x8 vf1 = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, pf, o0, 0, 0, 0);
-                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, pf, o1, 0, 0, 0);
+                        const int kb = (t0 + ti) * 32 + 16 * st + 4 * h + tq;            // this lane's address row (first 4-key group)
+                        bf16x8 vf[2];
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            const int col = 32 * dt + 16 * tg + 4 * tp;               // d column of this lane's address
+                            const int ch = col >> 3, sub = (col & 7) * 2;
+                            bf16x4 a0 = lds_tr4(Vs + kb * 128 + ((ch ^ (kb & 7)) << 4) + sub);
+                            bf16x4 a1 = lds_tr4(Vs + (kb + 8) * 128 + ((ch ^ ((kb + 8) & 7)) << 4) + sub);
+                            vf[dt] = (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                        }
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf, o0, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf, o1, 0, 0, 0);
                     }
                 }
             }
         }
-        // normalise and store: lane owns query ql; register r of o{0,1} is d = 32*dt + (r&3) + 8*(r>>2) + 4*h
         const float inv = 1.f / l_run;
         bf16_t* orow = out + ((int64_t)b * N + 1 + f * n + qb * 32 + ql) * D + head * 64 + 4 * h;
 #pragma unroll
@@ -170,78 +166,61 @@ __global__ __launch_bounds__(256, 2) void space_attn_kernel(const bf16_t* __rest
             *(u32x2*)(orow + 32 + 8 * g) = w1;
         }
     }
-    // ---- CLS query (model/LaviLa.py:255-258) folded in: partial softmax(q_cls . K_f^T) V_f over THIS frame's keys, which
-    // are already in LDS (the CLS key itself is counted by frame 0 only); hh_cls_combine merges the T partials.
+    // ---- CLS query (model/LaviLa.py:255-258) folded in: partial softmax(q_cls . K_f^T) V_f over THIS frame's keys (already
+    // in LDS; the CLS key itself is counted by frame 0 only); hh_cls_combine merges the T partials.
     if (cls_partial == nullptr) return;
-    __syncthreads();                                   // every wave is done with its reads; reuse the front of Ks as scratch
     {
-        float* scratch = (float*)(smem + (size_t)KP * 128 + (size_t)64 * VS * 2);     // [4 waves][CLS_REC]
+        float* cs = scratch;                      // [KP] scores / probabilities
+        float* wrec = scratch + KP;               // [NW][CLS_REC] per-wave partial o, + 2*NW reduction slots
+        float* red = wrec + NW * CLS_REC;
         const int nkeys = n + (f == 0 ? 1 : 0);
-        float q[64];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            u32x4 u = *(const u32x4*)(base + c * 8);                                 // q row of token 0 (pre-scaled)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { q[c * 8 + 2 * w] = bf16_lo_to_f32(u[w]); q[c * 8 + 2 * w + 1] = bf16_hi_to_f32(u[w]); }
-        }
-        // wave w owns keys [w*KQ, (w+1)*KQ), one or more keys per lane
-        const int KQ = (nkeys + 3) / 4;
-        const int k_lo = wave * KQ, k_hi = min(nkeys, k_lo + KQ);
         float mx = -INFINITY;
-        for (int j = k_lo + lane; j < k_hi; j += 64) {
+        for (int j = tid; j < nkeys; j += 64 * NW) {
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
+                u32x4 qv = *(const u32x4*)(base + c * 8);                               // q row of token 0 (uniform, pre-scaled)
                 u32x4 u = *(const u32x4*)(Ks + j * 128 + ((c ^ (j & 7)) << 4));
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    a0 = fmaf(q[c * 8 + 2 * w], bf16_lo_to_f32(u[w]), a0);
-                    a1 = fmaf(q[c * 8 + 2 * w + 1], bf16_hi_to_f32(u[w]), a1);
+                    a0 = fmaf(bf16_lo_to_f32(qv[w]), bf16_lo_to_f32(u[w]), a0);
+                    a1 = fmaf(bf16_hi_to_f32(qv[w]), bf16_hi_to_f32(u[w]), a1);
                 }
             }
+            cs[j] = a0 + a1;
             mx = fmaxf(mx, a0 + a1);
         }
         mx = wave_max(mx);
-        // second pass: p_j and the weighted V sum; lane d accumulates o[d] with p_j broadcast through readlane
-        float l = 0.f, o = 0.f;
-        for (int j0 = k_lo; j0 < k_hi; j0 += 64) {
-            const int j = j0 + lane;
-            float pj = 0.f;
-            if (j < k_hi) {
-                float a0 = 0.f, a1 = 0.f;
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        mx = red[0];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    u32x4 u = *(const u32x4*)(Ks + j * 128 + ((c ^ (j & 7)) << 4));
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        a0 = fmaf(q[c * 8 + 2 * w], bf16_lo_to_f32(u[w]), a0);
-                        a1 = fmaf(q[c * 8 + 2 * w + 1], bf16_hi_to_f32(u[w]), a1);
-                    }
-                }
-                pj = __builtin_amdgcn_exp2f((a0 + a1 - mx) * LOG2E);
-            }
+        for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
+        float l = 0.f;
+        for (int j = tid; j < nkeys; j += 64 * NW) {
+            const float pj = __builtin_amdgcn_exp2f((cs[j] - mx) * LOG2E);
+            cs[j] = pj;
             l += pj;
-            const int cnt = min(64, k_hi - j0);
-            const bf16_t* vrow = Vt + (size_t)lane * VS + j0;                      // V^T row d = lane
-            for (int jj = 0; jj < cnt; ++jj) o = fmaf(__shfl(pj, jj, 64), (float)vrow[jj], o);
         }
         l = wave_sum(l);
-        if (k_lo >= k_hi) { mx = -INFINITY; l = 0.f; o = 0.f; }
-        scratch[wave * CLS_REC + 4 + lane] = o;
-        if (lane == 0) { scratch[wave * CLS_REC] = mx; scratch[wave * CLS_REC + 1] = l; }
+        if (lane == 0) red[NW + wave] = l;
+        __syncthreads();
+        // o[d] partial per wave: wave w takes keys j = w, w+4, ... ; lane = d ; V row-major -> contiguous 128-B row reads
+        float o = 0.f;
+        const int dch = lane >> 3, dsub = (lane & 7) * 2;
+        for (int j = wave; j < nkeys; j += NW) {
+            const unsigned short vv = *(const unsigned short*)(Vs + j * 128 + ((dch ^ (j & 7)) << 4) + dsub);
+            o = fmaf(cs[j], __uint_as_float((unsigned)vv << 16), o);
+        }
+        wrec[wave * CLS_REC + lane] = o;
         __syncthreads();
         if (tid < 64) {
-            float m = fmaxf(fmaxf(scratch[0], scratch[CLS_REC]), fmaxf(scratch[2 * CLS_REC], scratch[3 * CLS_REC]));
-            float lt = 0.f, ot = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float e = __builtin_amdgcn_exp2f((scratch[w * CLS_REC] - m) * LOG2E);     // exp2(-inf) = 0 for empty waves
-                lt += scratch[w * CLS_REC + 1] * e;
-                ot += scratch[w * CLS_REC + 4 + tid] * e;
-            }
             float* rec = cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC;
+            float ot = 0.f, lt = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { ot += wrec[w * CLS_REC + tid]; lt += red[NW + w]; }
             rec[4 + tid] = ot;
-            if (tid == 0) { rec[0] = m; rec[1] = lt; }
+            if (tid == 0) { rec[0] = mx; rec[1] = lt; }
         }
     }
 }
@@ -274,8 +253,7 @@ extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial,
     HH_REQUIRE(HH_ALIGNED16(qkv) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_space_attn_fwd: pointers must be 16-byte aligned");
     if (B == 0) return HH_OK;
     const int KP = ((n + 1 + 31) / 32) * 32;
-    const int VS = KP + 4;
-    const size_t lds = (size_t)KP * 128 + (size_t)64 * VS * 2 + 4 * CLS_REC * 4;
+    const size_t lds = (size_t)KP * 256 + ((size_t)KP + NW * CLS_REC + 2 * NW) * 4;
     HH_REQUIRE(lds <= 160 * 1024, HH_ERR_UNSUPPORTED, "hh_space_attn_fwd: n=%d needs %zu B of LDS (> 160 KiB)", n, lds);
     static size_t attr_set = 0;
     if (lds > attr_set) {
@@ -284,7 +262,7 @@ extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial,
         attr_set = lds;
     }
     const int64_t blocks = (int64_t)B * T * heads;
-    hipLaunchKernelGGL(space_attn_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream,
-                       (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP, VS);
+    hipLaunchKernelGGL(space_attn_kernel, dim3((unsigned)blocks), dim3(64 * NW), lds, (hipStream_t)stream,
+                       (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP);
     return hh_check_launch("hh_space_attn_fwd");
 }

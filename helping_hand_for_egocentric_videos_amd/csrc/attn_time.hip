@@ -12,12 +12,13 @@
 template <int T>
 #define CLS_REC 68
 
-__global__ __launch_bounds__(256) void time_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 4) void time_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                         float* __restrict__ cls_partial, int B, int n, int heads) {
     // thread = (patch pi, query frame fq, half hf): each query row is split over two adjacent lanes (32 dims each)
     constexpr int P = 128 / T;
     __shared__ __attribute__((aligned(16))) unsigned int Ks[(T * P + 1) * 32];   // 128 B rows; last row = CLS
     __shared__ __attribute__((aligned(16))) unsigned int Vs[(T * P + 1) * 32];
+    __shared__ float Ss[(T + 1) * 128];                                             // scores [key][query]
     const int tid = threadIdx.x;
     const int D = heads * 64;
     const int64_t ld = 3 * (int64_t)D;
@@ -62,9 +63,11 @@ __global__ __launch_bounds__(256) void time_attn_kernel(const bf16_t* __restrict
         }
     }
     __syncthreads();
-    float s[T + 1];
+    // pass 1: scores -> LDS (one float per (key, query)), running max.  Rolled loops keep the register footprint at
+    // q[32] + o[32] + temporaries so that 3-4 waves per SIMD hide the LDS / HBM latency.
+    const int qi = tid >> 1;
     float mx = -INFINITY;
-#pragma unroll
+#pragma unroll 2
     for (int j = 0; j <= T; ++j) {
         const int row = (j == T) ? T * P : j * P + pi;
         float a0 = 0.f, a1 = 0.f;
@@ -79,20 +82,20 @@ __global__ __launch_bounds__(256) void time_attn_kernel(const bf16_t* __restrict
         }
         float sj = a0 + a1;
         sj += __shfl_xor(sj, 1, 64);
-        s[j] = sj;
+        if (hf == 0) Ss[j * 128 + qi] = sj;
         mx = fmaxf(mx, sj);
     }
+    // pass 2: p = exp(s - max), l, o += p * v   (the pair's partner lane wrote Ss: same wave, in-order LDS)
     float l = 0.f;
-#pragma unroll
-    for (int j = 0; j <= T; ++j) { s[j] = __builtin_amdgcn_exp2f((s[j] - mx) * 1.4426950408889634f); l += s[j]; }
-    const float inv = 1.f / l;
     float o[32];
 #pragma unroll
     for (int d = 0; d < 32; ++d) o[d] = 0.f;
-#pragma unroll
+    const float mb = mx * 1.4426950408889634f;
+#pragma unroll 2
     for (int j = 0; j <= T; ++j) {
         const int row = (j == T) ? T * P : j * P + pi;
-        const float pj = s[j] * inv;
+        const float pj = __builtin_amdgcn_exp2f(Ss[j * 128 + qi] * 1.4426950408889634f - mb);
+        l += pj;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             u32x4 u = *(const u32x4*)(Vs + row * 32 + hf * 16 + c * 4);
@@ -103,6 +106,9 @@ __global__ __launch_bounds__(256) void time_attn_kernel(const bf16_t* __restrict
             }
         }
     }
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] *= inv;
     if (active) {
         bf16_t* op = out + ((int64_t)b * N + qtok) * D + head * 64 + hf * 32;
 #pragma unroll
