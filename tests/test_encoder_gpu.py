@@ -97,7 +97,6 @@ def test_full_width_t4_vs_oracle():
     video = synth.make_batch(cfg, 1, seed=5)["video"]
     vis = LaviLa.build_backbone(cfg.with_(text_layers=1, vocab_size=512), None).visual
     vis.load_state_dict({k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}, strict=True)
-    torch.set_num_threads(os.cpu_count() or 8)
     with torch.no_grad():
         rc, rx = OE.vision_forward(video, sd, cfg)
     gc, gx = vis.cuda()(video.cuda())
