@@ -17,21 +17,32 @@
 #define BK 64
 #define GROUP_M 8
 
-template <bool OUT_BF16>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A 16 KB | W 16 KB]
+// STAGES = 2: double buffer, 2 blocks/CU (large grids).  STAGES = 4: 4-deep LDS-DMA ring with counted vmcnt, three k-tiles in
+// flight -- for small grids (row remainders, split-K slices, tiny shapes) whose k-loop is otherwise latency-bound.
+template <bool OUT_BF16, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void gemm_bf16_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [STAGES buffers][A 16 KB | W 16 KB]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- XCD-aware tile assignment
+    // ---- tile assignment: XCD-aware groups for tall problems, direct mapping (n-tiles spread over all XCDs) when there
+    // are fewer m-tiles than XCDs (row remainders, skinny / split-K GEMMs)
     const int b = blockIdx.x;
-    const int xcd = b & 7, j = b >> 3;
-    const int per = GROUP_M * p.Nt;
-    const int kg = j / per, r = j % per;
-    const int nt = r / GROUP_M, mi = r % GROUP_M;
-    const int mt = xcd + 8 * (kg * GROUP_M + mi);
-    if (mt >= p.Mt) return;
+    int mt, nt;
+    if (p.Mt < 8) {
+        mt = b % p.Mt;
+        nt = b / p.Mt;
+        if (nt >= p.Nt) return;
+    } else {
+        const int xcd = b & 7, j = b >> 3;
+        const int per = GROUP_M * p.Nt;
+        const int kg = j / per, r = j % per;
+        nt = r / GROUP_M;
+        const int mi = r % GROUP_M;
+        mt = xcd + 8 * (kg * GROUP_M + mi);
+        if (mt >= p.Mt) return;
+    }
     const int64_t m0 = p.m_start + (int64_t)mt * BM;
     const int n0 = nt * BN;
 
@@ -82,12 +93,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             glds16(w_src[i] + (int64_t)(kt0 + kt) * BK, base + 16384 + i * 1024);
         }
     };
-    if (nk > 0) stage(0, 0);
+    if constexpr (STAGES == 2) {
+        if (nk > 0) stage(0, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < STAGES - 1; ++i)
+            if (i < nk) stage(i, i);
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const char* As = smem + (kt & 1) * 32768;
+        if constexpr (STAGES == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            // tiles kt+1 .. min(kt+STAGES-2, nk-1) may stay in flight (8 LDS-DMA instructions per tile and wave)
+            const int ahead = (nk - 1 - kt) < (STAGES - 2) ? (nk - 1 - kt) : (STAGES - 2);
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (STAGES == 2) {
+            __syncthreads();
+            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        } else {
+            asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+            if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        }
+        const char* As = smem + (kt % STAGES) * 32768;
         const char* Ws = As + 16384;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -152,20 +182,27 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     p.Nt = N / BN;
     const int per_xcd_mt = (p.Mt + 7) / 8;
     const int groups = (per_xcd_mt + GROUP_M - 1) / GROUP_M;
-    const unsigned grid = 8u * (unsigned)groups * GROUP_M * (unsigned)p.Nt;
+    const unsigned grid = p.Mt < 8 ? (unsigned)(p.Mt * p.Nt) : 8u * (unsigned)groups * GROUP_M * (unsigned)p.Nt;
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         attr_done = true;
     }
     const unsigned splits = epi->splitk > 1 ? (unsigned)epi->splitk : 1u;
     HH_REQUIRE(splits <= 1024, HH_ERR_SHAPE, "hh_gemm_bf16: splitk too large");
     HH_REQUIRE(splits == 1 || (epi->resid == nullptr && epi->split_stride >= 0), HH_ERR_SHAPE, "hh_gemm_bf16: split-K partials take no residual");
-    if (epi->c_dtype == HH_BF16)
-        hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3(grid, splits), dim3(256), 65536, s, p);
-    else
-        hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3(grid, splits), dim3(256), 65536, s, p);
+    // deep ring when the launch cannot fill the chip twice anyway (real tiles, not the padded grid)
+    const bool deep = (int64_t)p.Mt * p.Nt * splits <= 512 && K >= 256;
+    if (deep) {
+        if (epi->c_dtype == HH_BF16) hipLaunchKernelGGL((gemm_bf16_kernel<true, 4>), dim3(grid, splits), dim3(256), 131072, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<false, 4>), dim3(grid, splits), dim3(256), 131072, s, p);
+    } else {
+        if (epi->c_dtype == HH_BF16) hipLaunchKernelGGL((gemm_bf16_kernel<true, 2>), dim3(grid, splits), dim3(256), 65536, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<false, 2>), dim3(grid, splits), dim3(256), 65536, s, p);
+    }
     return hh_check_launch("hh_gemm_bf16");
 }
