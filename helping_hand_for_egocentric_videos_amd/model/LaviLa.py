@@ -340,12 +340,21 @@ class CLIP(nn.Module):
         return x_cls @ self.image_projection, x
 
     def encode_text(self, text, use_checkpoint=False):
-        """LaviLa.py:660-670 on stock PyTorch-ROCm ops, bf16 autocast on the GPU."""
-        with torch.autocast("cuda", dtype=self.text_autocast, enabled=text.is_cuda and self.text_autocast is not None):
-            x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]
-            x = self.transformer(x.permute(1, 0, 2), use_checkpoint=use_checkpoint).permute(1, 0, 2)
-            x = self.ln_final(x)
-        x = x.float()
+        """LaviLa.py:660-670.  Frozen weights on the GPU (the training / MCQ path): Linears and LayerNorms of the 12 text
+        blocks on libhh kernels (`Transformer.forward_frozen`); otherwise stock PyTorch ops (bf16 autocast on the GPU)."""
+        frozen = text.is_cuda and not torch.is_grad_enabled() or (text.is_cuda and not any(p.requires_grad for p in self.transformer.parameters()))
+        if frozen and self.text_autocast is not None:
+            with torch.no_grad():
+                x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]
+                x = self.transformer.forward_frozen(x)
+                x = ops.layernorm(x, self.ln_final.weight.detach().float(), self.ln_final.bias.detach().float(), self.ln_final.eps,
+                                  out_dtype=torch.float32)
+        else:
+            with torch.autocast("cuda", dtype=self.text_autocast, enabled=text.is_cuda and self.text_autocast is not None):
+                x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]
+                x = self.transformer(x.permute(1, 0, 2), use_checkpoint=use_checkpoint).permute(1, 0, 2)
+                x = self.ln_final(x)
+            x = x.float()
         x_cls = x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)] @ self.text_projection
         return x_cls, x
 

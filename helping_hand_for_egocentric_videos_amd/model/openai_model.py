@@ -2,8 +2,10 @@
 
 QuickGELU (openai_model.py:177-179) is the TimeSformer MLP activation -- on the GPU it is fused into the
 fc1 GEMM epilogue (csrc/gemm.hip); the nn.Module here only carries the name for constructor compatibility.
-The CLIP text Transformer (openai_model.py:182-232) is on the call path of `CLIP.forward` but is not part of
-the north-star kernel set: it stays on stock PyTorch-ROCm ops.
+The CLIP text Transformer (openai_model.py:182-232) is on the call path of `CLIP.forward` (SURVEY.md section 8f
+rank 1).  With frozen weights on the GPU (`Transformer.forward_frozen`) its Linears / LayerNorms run on the libhh
+GEMM (bias / QuickGELU / residual epilogues) and LayerNorm kernels; the 77x77 causal attention core stays on
+torch's scaled_dot_product_attention.  The stock-module `forward` is kept for trainable / CPU use.
 """
 from collections import OrderedDict
 
@@ -40,8 +42,50 @@ class Transformer(nn.Module):
 
     def __init__(self, width: int, layers: int, heads: int, attn_mask: torch.Tensor = None):
         super().__init__()
-        self.width, self.layers = width, layers
+        self.width, self.layers, self.heads = width, layers, heads
         self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
+        self._pack = None
 
     def forward(self, x: torch.Tensor, use_checkpoint=False):
         return self.resblocks(x)
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._pack = None
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._pack = None
+        return r
+
+    def packed(self):
+        if self._pack is None:
+            from .. import ops
+            f = lambda t: t.detach().float().contiguous()
+            self._pack = [{"ln1": (f(b.ln_1.weight), f(b.ln_1.bias), b.ln_1.eps), "ln2": (f(b.ln_2.weight), f(b.ln_2.bias), b.ln_2.eps),
+                           "win": ops.to_bf16(f(b.attn.in_proj_weight)), "bin": f(b.attn.in_proj_bias),
+                           "wout": ops.to_bf16(f(b.attn.out_proj.weight)), "bout": f(b.attn.out_proj.bias),
+                           "wfc": ops.to_bf16(f(b.mlp.c_fc.weight)), "bfc": f(b.mlp.c_fc.bias),
+                           "wpr": ops.to_bf16(f(b.mlp.c_proj.weight)), "bpr": f(b.mlp.c_proj.bias)} for b in self.resblocks]
+        return self._pack
+
+    @torch.no_grad()
+    def forward_frozen(self, x: torch.Tensor):
+        """Inference path for frozen weights on the GPU: x fp32 [S, L, W] (batch-first) -> fp32 [S, L, W].
+        Same maths as forward() (pre-LN causal MHA + QuickGELU MLP), bf16 GEMM operands, fp32 residual stream."""
+        from .. import ops
+        import torch.nn.functional as F
+        S, L, W = x.shape
+        h, d = self.heads, W // self.heads
+        if W % 64 or (3 * W) % 128 or (4 * W) % 128:
+            raise NotImplementedError("Transformer.forward_frozen: width must be a multiple of 64 (GEMM tiling)")
+        xs = x.reshape(S * L, W).float().contiguous().clone()
+        for pk in self.packed():
+            qkv = ops.gemm(ops.layernorm(xs, *pk["ln1"]), pk["win"], pk["bin"])                           # bf16 [S*L, 3W]
+            q, k, v = qkv.view(S, L, 3, h, d).permute(2, 0, 3, 1, 4)
+            o = F.scaled_dot_product_attention(q, k, v, is_causal=True)                                    # [S,h,L,d]
+            o = o.permute(0, 2, 1, 3).reshape(S * L, W).contiguous()
+            ops.gemm(o, pk["wout"], pk["bout"], resid=xs, out=xs)
+            hid = ops.gemm(ops.layernorm(xs, *pk["ln2"]), pk["wfc"], pk["bfc"], act=ops.ACT_QUICKGELU)
+            ops.gemm(hid, pk["wpr"], pk["bpr"], resid=xs, out=xs)
+        return xs.view(S, L, W)

@@ -118,3 +118,18 @@ def test_long_clip_high_res_shapes_c4():
     assert gx.shape == (1, 1 + 32 * 576, cfg.embed_dim)
     assert rel_l2(gx, rx) < 1.5e-2, rel_l2(gx, rx)
     assert rel_l2(gx[:, 0], rx[:, 0]) < 1.5e-2
+
+
+def test_text_tower_on_libhh_matches_oracle_and_stock_path():
+    cfg = TINY16.with_(text_layers=3)
+    sd = synth.encoder_state(cfg, seed=8)
+    model = LaviLa.build_backbone(cfg, sd)
+    text = synth.make_batch(cfg, 4, seed=8)["text"]
+    with torch.no_grad():
+        rc, rx = OE.encode_text(text, sd, cfg)
+        gc, gx = model.encode_text(text.cuda())                  # libhh GEMM / LayerNorm path (frozen weights)
+        model.text_autocast = None
+        sc, sx = model.encode_text(text.cuda())                  # stock fp32 ops
+    assert rel_l2(sx, rx) < 1e-4
+    assert rel_l2(gx, rx) < 1.5e-2, rel_l2(gx, rx)
+    assert torch.nn.functional.cosine_similarity(gc.cpu(), rc, dim=-1).min() > 0.999

@@ -148,7 +148,6 @@ def test_full_step_vs_reference_golden(cfg, name):
     dsd = synth.decoder_state(cfg, seed=int(g["meta_seed_w"]))
     batch = synth.make_batch(cfg, B, seed=int(g["meta_seed_b"]))
     backbone = LaviLa.build_backbone(cfg, esd)
-    backbone.text_autocast = None                    # fp32 text tower for the parity run (stock ops either way)
     dec = tfm_decoder.build_decoder(cfg, dsd)
     ts = TrainStep(cfg, backbone, dec)
     dec.eval()
