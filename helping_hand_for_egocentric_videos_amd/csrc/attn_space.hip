@@ -12,6 +12,7 @@
 // Keys are processed in chunks of CH=5 tiles (160 keys) with an online-softmax merge between chunks, so n=576
 // (336^2) runs through the same code.  Frame keys sit at rows 0..n-1, the CLS key at row n, rows > n are zero/masked.
 #include "common.h"
+#include <stdlib.h>
 
 #define CH 5
 #define NW 4            // waves per workgroup
@@ -33,13 +34,183 @@ __device__ __forceinline__ bf16x4 lds_tr4(const char* addr) {
 // layout of one CLS partial record: [m, l, 0, 0, o[64]] fp32
 #define CLS_REC 68
 
+// One 32-query block of one (clip, frame, head) problem: S^T = K.Q^T, online softmax over CH-tile chunks, O^T = V^T.P^T.
+__device__ __forceinline__ void space_query_block(const char* Ks, const char* Vs, const bf16x8 (&qf)[4], bf16_t* orow, int n, int ntiles, int lane) {
+    const int ql = lane & 31, h = lane >> 5;
+    const float LOG2E = 1.4426950408889634f;
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int t0 = 0; t0 < ntiles; t0 += CH) {
+        f32x16 s[CH];
+#pragma unroll
+        for (int ti = 0; ti < CH; ++ti) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[ti][r] = 0.f;
+            if (t0 + ti < ntiles) {
+                const int krow = (t0 + ti) * 32 + ql;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int c = 2 * ks + h;
+                    bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + ((c ^ (krow & 7)) << 4));
+                    s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[ti], 0, 0, 0);
+                }
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int ti = 0; ti < CH; ++ti) {
+            if (t0 + ti >= ntiles - 1) {            // only the last key tile (and unused tile slots) hold keys > n
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = (t0 + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key > n) s[ti][r] = -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[ti][r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+        const float mb = m_new * LOG2E;
+        float lsum = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < CH; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[ti][r] * LOG2E - mb);
+                s[ti][r] = pv;
+                lsum += pv;
+            }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        // O^T += V^T . P^T ; A operand element j of lane (d, h) = V[key0 + 8(j>>2) + (j&3)][d], key0 = 32 tile + 16 st + 4 h
+#pragma unroll
+        for (int ti = 0; ti < CH; ++ti) {
+            if (t0 + ti < ntiles) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)s[ti][8 * st + jj];
+                    const int kb = (t0 + ti) * 32 + 16 * st + 4 * h + tq;            // this lane's address row (first 4-key group)
+                    bf16x8 vf[2];
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const int col = 32 * dt + 16 * tg + 4 * tp;               // d column of this lane's address
+                        const int ch = col >> 3, sub = (col & 7) * 2;
+                        bf16x4 a0 = lds_tr4(Vs + kb * 128 + ((ch ^ (kb & 7)) << 4) + sub);
+                        bf16x4 a1 = lds_tr4(Vs + (kb + 8) * 128 + ((ch ^ ((kb + 8) & 7)) << 4) + sub);
+                        vf[dt] = (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    }
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf, o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf, o1, 0, 0, 0);
+                }
+            }
+        }
+    }
+    const float inv = 1.f / l_run;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        u32x2 w0 = {pack_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
+        u32x2 w1 = {pack_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
+        *(u32x2*)(orow + 8 * g) = w0;
+        *(u32x2*)(orow + 32 + 8 * g) = w1;
+    }
+}
+
+// CLS query (model/LaviLa.py:255-258) folded in: partial softmax(q_cls . K_f^T) V_f over THIS frame's keys (already in LDS;
+// the CLS key itself is counted by frame 0 only); hh_cls_combine merges the T partials.  All NWV waves participate.
+template <int NWV>
+__device__ __forceinline__ void space_cls_partial(const char* Ks, const char* Vs, float* scratch, int KP, const bf16_t* base,
+                                                  float* rec, int n, bool first_frame, int tid, int lane, int wave) {
+    const float LOG2E = 1.4426950408889634f;
+    float* cs = scratch;                      // [KP] scores / probabilities
+    float* wrec = scratch + KP;               // [NWV][CLS_REC] per-wave partial o, + 2*NWV reduction slots
+    float* red = wrec + NWV * CLS_REC;
+    const int nkeys = n + (first_frame ? 1 : 0);
+    float mx = -INFINITY;
+    for (int j = tid; j < nkeys; j += 64 * NWV) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            u32x4 qv = *(const u32x4*)(base + c * 8);                               // q row of token 0 (uniform, pre-scaled)
+            u32x4 u = *(const u32x4*)(Ks + j * 128 + ((c ^ (j & 7)) << 4));
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                a0 = fmaf(bf16_lo_to_f32(qv[w]), bf16_lo_to_f32(u[w]), a0);
+                a1 = fmaf(bf16_hi_to_f32(qv[w]), bf16_hi_to_f32(u[w]), a1);
+            }
+        }
+        cs[j] = a0 + a1;
+        mx = fmaxf(mx, a0 + a1);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, red[w]);
+    float l = 0.f;
+    for (int j = tid; j < nkeys; j += 64 * NWV) {
+        const float pj = __builtin_amdgcn_exp2f((cs[j] - mx) * LOG2E);
+        cs[j] = pj;
+        l += pj;
+    }
+    l = wave_sum(l);
+    if (lane == 0) red[NWV + wave] = l;
+    __syncthreads();
+    float o = 0.f;
+    const int dch = lane >> 3, dsub = (lane & 7) * 2;
+    for (int j = wave; j < nkeys; j += NWV) {
+        const unsigned short vv = *(const unsigned short*)(Vs + j * 128 + ((dch ^ (j & 7)) << 4) + dsub);
+        o = fmaf(cs[j], __uint_as_float((unsigned)vv << 16), o);
+    }
+    wrec[wave * CLS_REC + lane] = o;
+    __syncthreads();
+    if (tid < 64) {
+        float ot = 0.f, lt = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { ot += wrec[w * CLS_REC + tid]; lt += red[NWV + w]; }
+        rec[4 + tid] = ot;
+        if (tid == 0) { rec[0] = mx; rec[1] = lt; }
+    }
+}
+
+// stage K and V of one (clip, frame, head) problem by LDS-DMA (1 KiB = 8 rows per wave instruction); rows >= n take the CLS
+// token's row (key n is the CLS key; rows > n are masked in S and multiplied by P = 0, they only have to be finite)
+template <int NWV>
+__device__ __forceinline__ void space_stage(char* Ks, char* Vs, const bf16_t* base, const bf16_t* q_ptr, int64_t ld, int D, int n,
+                                            int KP, int lane, int wave) {
+    const int pieces = KP >> 3;
+    for (int pc = wave; pc < pieces; pc += NWV) {
+        const int row = pc * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const bf16_t* src = (row < n) ? q_ptr + (int64_t)row * ld : base;
+        glds16(src + D + c * 8, Ks + pc * 1024);
+    }
+    for (int pc = wave; pc < pieces; pc += NWV) {
+        const int row = pc * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        const bf16_t* src = (row < n) ? q_ptr + (int64_t)row * ld : base;
+        glds16(src + 2 * D + c * 8, Vs + pc * 1024);
+    }
+}
+
+// ---- variant A: one workgroup per problem (any n with (n+1) keys fitting LDS once), 4 waves
 __global__ __launch_bounds__(64 * NW, 2) void space_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ cls_partial,
                                                             int B, int T, int n, int heads, int KP) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                                   // [KP][128 B], 16-B chunk c of row r at position c ^ (r & 7)
     char* Vs = smem + (size_t)KP * 128;                // same layout, row-major V
-    float* scratch = (float*)(smem + (size_t)KP * 256);   // [KP] CLS scores + [4][CLS_REC] + 8
+    float* scratch = (float*)(smem + (size_t)KP * 256);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = heads * 64;
@@ -51,177 +222,81 @@ __global__ __launch_bounds__(64 * NW, 2) void space_attn_kernel(const bf16_t* __
     const int b = bid / T;
     const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;      // token 0 (CLS) of this clip / head
     const bf16_t* q_ptr = base + (int64_t)(1 + f * n) * ld;
-
-    // ---- stage K and V by LDS-DMA (1 KiB = 8 rows per wave instruction); rows >= n take the CLS token's row (key n is the
-    // CLS key; rows > n are masked in S and multiplied by P = 0, they only have to be finite)
-    const int pieces = KP >> 3;
-    for (int pc = wave; pc < pieces; pc += NW) {
-        const int row = pc * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (row & 7);
-        const bf16_t* src = (row < n) ? q_ptr + (int64_t)row * ld : base;
-        glds16(src + D + c * 8, Ks + pc * 1024);
-    }
-    for (int pc = wave; pc < pieces; pc += NW) {
-        const int row = pc * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (row & 7);
-        const bf16_t* src = (row < n) ? q_ptr + (int64_t)row * ld : base;
-        glds16(src + 2 * D + c * 8, Vs + pc * 1024);
-    }
+    space_stage<NW>(Ks, Vs, base, q_ptr, ld, D, n, KP, lane, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-
     const int ql = lane & 31, h = lane >> 5;
-    const int ntiles = KP >> 5;
-    const float LOG2E = 1.4426950408889634f;
-    // transposing-read addressing: 16-lane group gi = lane>>4 covers d columns 16*(gi&1).. of the 32-wide d tile; lane i = 4q+p
-    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
     for (int qb = wave; qb < (n >> 5); qb += NW) {
         bf16x8 qf[4];
         const bf16_t* qrow = q_ptr + (int64_t)(qb * 32 + ql) * ld + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
-        f32x16 o0, o1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-        float m_run = -INFINITY, l_run = 0.f;
-        for (int t0 = 0; t0 < ntiles; t0 += CH) {
-            f32x16 s[CH];
-#pragma unroll
-            for (int ti = 0; ti < CH; ++ti) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[ti][r] = 0.f;
-                if (t0 + ti < ntiles) {
-                    const int krow = (t0 + ti) * 32 + ql;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const int c = 2 * ks + h;
-                        bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + ((c ^ (krow & 7)) << 4));
-                        s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[ti], 0, 0, 0);
-                    }
-                }
-            }
-            float mx = -INFINITY;
-#pragma unroll
-            for (int ti = 0; ti < CH; ++ti) {
-                if (t0 + ti >= ntiles - 1) {            // only the last key tile (and unused tile slots) hold keys > n
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = (t0 + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (key > n) s[ti][r] = -INFINITY;
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[ti][r]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-            const float mb = m_new * LOG2E;
-            float lsum = 0.f;
-#pragma unroll
-            for (int ti = 0; ti < CH; ++ti)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(s[ti][r] * LOG2E - mb);
-                    s[ti][r] = pv;
-                    lsum += pv;
-                }
-            lsum += __shfl_xor(lsum, 32, 64);
-            l_run = l_run * alpha + lsum;
-            m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-            // O^T += V^T . P^T ; A operand element j of lane (d, h) = V[key0 + 8(j>>2) + (j&3)][d], key0 = 32 tile + 16 st + 4 h
-#pragma unroll
-            for (int ti = 0; ti < CH; ++ti) {
-                if (t0 + ti < ntiles) {
-#pragma unroll
-                    for (int st = 0; st < 2; ++st) {
-                        bf16x8 pf;
-#pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)s[ti][8 * st + jj];
-                        const int kb = (t0 + ti) * 32 + 16 * st + 4 * h + tq;            // this lane's address row (first 4-key group)
-                        bf16x8 vf[2];
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            const int col = 32 * dt + 16 * tg + 4 * tp;               // d column of this lane's address
-                            const int ch = col >> 3, sub = (col & 7) * 2;
-                            bf16x4 a0 = lds_tr4(Vs + kb * 128 + ((ch ^ (kb & 7)) << 4) + sub);
-                            bf16x4 a1 = lds_tr4(Vs + (kb + 8) * 128 + ((ch ^ ((kb + 8) & 7)) << 4) + sub);
-                            vf[dt] = (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                        }
-                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf, o0, 0, 0, 0);
-                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf, o1, 0, 0, 0);
-                    }
-                }
-            }
-        }
-        const float inv = 1.f / l_run;
-        bf16_t* orow = out + ((int64_t)b * N + 1 + f * n + qb * 32 + ql) * D + head * 64 + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            u32x2 w0 = {pack_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
-            u32x2 w1 = {pack_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
-            *(u32x2*)(orow + 8 * g) = w0;
-            *(u32x2*)(orow + 32 + 8 * g) = w1;
-        }
+        space_query_block(Ks, Vs, qf, out + ((int64_t)b * N + 1 + f * n + qb * 32 + ql) * D + head * 64 + 4 * h, n, KP >> 5, lane);
     }
-    // ---- CLS query (model/LaviLa.py:255-258) folded in: partial softmax(q_cls . K_f^T) V_f over THIS frame's keys (already
-    // in LDS; the CLS key itself is counted by frame 0 only); hh_cls_combine merges the T partials.
     if (cls_partial == nullptr) return;
+    space_cls_partial<NW>(Ks, Vs, scratch, KP, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
+}
+
+// ---- variant B (n + 1 <= 288 keys): PERSISTENT, one 8-wave workgroup per CU walks the (clip, frame, head) problems with
+// a double-buffered K/V tile: while problem i is computed from buffer i&1, problem i+1 is prefetched by LDS-DMA into
+// the other buffer.  The per-CU memory phase (~136 KB per problem) then overlaps the MFMA/VALU phase instead of
+// alternating with it.
+#define NWP 8
+__global__ __launch_bounds__(64 * NWP, 2) void space_attn_persistent_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                          float* __restrict__ cls_partial,
+                                                                          int B, int T, int n, int heads, int KP) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const size_t tile = (size_t)KP * 256;              // K + V of one problem
+    float* scratch = (float*)(smem + 2 * tile);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = heads * 64;
+    const int64_t ld = 3 * (int64_t)D;
+    const int N = 1 + T * n;
+    const int total = B * T * heads;
+    const int ql = lane & 31, h = lane >> 5;
+    auto locate = [&](int prob, const bf16_t*& base, const bf16_t*& q_ptr, int& b, int& f, int& head) {
+        head = prob % heads;
+        f = (prob / heads) % T;
+        b = prob / (heads * T);
+        base = qkv + (int64_t)b * N * ld + head * 64;
+        q_ptr = base + (int64_t)(1 + f * n) * ld;
+    };
+    int prob = blockIdx.x;
+    if (prob >= total) return;
     {
-        float* cs = scratch;                      // [KP] scores / probabilities
-        float* wrec = scratch + KP;               // [NW][CLS_REC] per-wave partial o, + 2*NW reduction slots
-        float* red = wrec + NW * CLS_REC;
-        const int nkeys = n + (f == 0 ? 1 : 0);
-        float mx = -INFINITY;
-        for (int j = tid; j < nkeys; j += 64 * NW) {
-            float a0 = 0.f, a1 = 0.f;
+        const bf16_t *base, *q_ptr; int b, f, head;
+        locate(prob, base, q_ptr, b, f, head);
+        space_stage<NWP>(smem, smem + (size_t)KP * 128, base, q_ptr, ld, D, n, KP, lane, wave);
+    }
+    for (int it = 0; prob < total; prob += gridDim.x, ++it) {
+        char* Ks = smem + (it & 1) * tile;
+        char* Vs = Ks + (size_t)KP * 128;
+        const bf16_t *base, *q_ptr; int b, f, head;
+        locate(prob, base, q_ptr, b, f, head);
+        // this wave's query block (n <= 256 -> at most one per wave): fetched BEFORE the wait so that no ordinary load is
+        // pending while the next problem's LDS-DMA prefetch is in flight (hipcc would drain it with a vmcnt(0))
+        const bool has_q = wave < (n >> 5);
+        bf16x8 qf[4];
+        {
+            const bf16_t* qrow = q_ptr + (int64_t)((has_q ? wave : 0) * 32 + ql) * ld + 8 * h;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                u32x4 qv = *(const u32x4*)(base + c * 8);                               // q row of token 0 (uniform, pre-scaled)
-                u32x4 u = *(const u32x4*)(Ks + j * 128 + ((c ^ (j & 7)) << 4));
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    a0 = fmaf(bf16_lo_to_f32(qv[w]), bf16_lo_to_f32(u[w]), a0);
-                    a1 = fmaf(bf16_hi_to_f32(qv[w]), bf16_hi_to_f32(u[w]), a1);
-                }
-            }
-            cs[j] = a0 + a1;
-            mx = fmaxf(mx, a0 + a1);
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
         }
-        mx = wave_max(mx);
-        if (lane == 0) red[wave] = mx;
-        __syncthreads();
-        mx = red[0];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
-        float l = 0.f;
-        for (int j = tid; j < nkeys; j += 64 * NW) {
-            const float pj = __builtin_amdgcn_exp2f((cs[j] - mx) * LOG2E);
-            cs[j] = pj;
-            l += pj;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();          // this problem's tile has landed for every wave; every wave has left the other buffer
+        const int nxt = prob + gridDim.x;
+        if (nxt < total) {
+            const bf16_t *nb, *nq; int b2, f2, h2;
+            locate(nxt, nb, nq, b2, f2, h2);
+            char* Kn = smem + ((it + 1) & 1) * tile;
+            space_stage<NWP>(Kn, Kn + (size_t)KP * 128, nb, nq, ld, D, n, KP, lane, wave);
         }
-        l = wave_sum(l);
-        if (lane == 0) red[NW + wave] = l;
-        __syncthreads();
-        // o[d] partial per wave: wave w takes keys j = w, w+4, ... ; lane = d ; V row-major -> contiguous 128-B row reads
-        float o = 0.f;
-        const int dch = lane >> 3, dsub = (lane & 7) * 2;
-        for (int j = wave; j < nkeys; j += NW) {
-            const unsigned short vv = *(const unsigned short*)(Vs + j * 128 + ((dch ^ (j & 7)) << 4) + dsub);
-            o = fmaf(cs[j], __uint_as_float((unsigned)vv << 16), o);
-        }
-        wrec[wave * CLS_REC + lane] = o;
-        __syncthreads();
-        if (tid < 64) {
-            float* rec = cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC;
-            float ot = 0.f, lt = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) { ot += wrec[w * CLS_REC + tid]; lt += red[NW + w]; }
-            rec[4 + tid] = ot;
-            if (tid == 0) { rec[0] = mx; rec[1] = lt; }
-        }
+        if (has_q)
+            space_query_block(Ks, Vs, qf, out + ((int64_t)b * N + 1 + f * n + wave * 32 + ql) * D + head * 64 + 4 * h, n, KP >> 5, lane);
+        if (cls_partial != nullptr)
+            space_cls_partial<NWP>(Ks, Vs, scratch, KP, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0,
+                                   tid, lane, wave);
     }
 }
 
@@ -253,6 +328,26 @@ extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial,
     HH_REQUIRE(HH_ALIGNED16(qkv) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_space_attn_fwd: pointers must be 16-byte aligned");
     if (B == 0) return HH_OK;
     const int KP = ((n + 1 + 31) / 32) * 32;
+    // HH_SPACE_ATTN: 0 = one workgroup per problem (default; measured 453 us/call at B=32), 1 = persistent double-buffered
+    // variant (480 us: one workgroup per CU keeps fewer bytes in flight than two independent ones, which outweighs the overlap)
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("HH_SPACE_ATTN"); mode = e ? atoi(e) : 0; }
+    const size_t lds_p = 2 * (size_t)KP * 256 + ((size_t)KP + NWP * CLS_REC + 2 * NWP) * 4;
+    if (mode == 1 && lds_p <= 160 * 1024 && (n >> 5) <= NWP) {
+        static size_t attr_p = 0;
+        if (lds_p > attr_p) {
+            hipError_t e = hipFuncSetAttribute((const void*)space_attn_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+            HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds_p);
+            attr_p = lds_p;
+        }
+        static int ncu = 0;
+        if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+        const int64_t total = (int64_t)B * T * heads;
+        const unsigned grid = (unsigned)(total < ncu ? total : ncu);
+        hipLaunchKernelGGL(space_attn_persistent_kernel, dim3(grid), dim3(64 * NWP), lds_p, (hipStream_t)stream,
+                           (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP);
+        return hh_check_launch("hh_space_attn_fwd(persistent)");
+    }
     const size_t lds = (size_t)KP * 256 + ((size_t)KP + NW * CLS_REC + 2 * NW) * 4;
     HH_REQUIRE(lds <= 160 * 1024, HH_ERR_UNSUPPORTED, "hh_space_attn_fwd: n=%d needs %zu B of LDS (> 160 KiB)", n, lds);
     static size_t attr_set = 0;
