@@ -30,6 +30,7 @@ SIGNATURES = {
     "hh_cast_bf16_to_f32": [c_vp, c_vp, c_i64, c_vp],
     "hh_transpose_to_bf16": [c_vp, c_int, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp],
     "hh_patch_im2col": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp],
+    "hh_patch_im2col_u8": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_vp],
     "hh_embed_ln_pre": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, c_vp],
     "hh_space_attn_fwd": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "hh_time_attn_fwd": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],

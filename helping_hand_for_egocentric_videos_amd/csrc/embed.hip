@@ -28,6 +28,38 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ v
     }
 }
 
+// uint8 frames -> (u/255 - mean[c]) / std[c] -> bf16 patch rows (the host-side ToTensor + Normalize of
+// data_loader/transforms.py:38-75 / run/train.py:442-445 fused into the im2col).  channels_last: frames are [F,H,W,3]
+// (decoder output order), else [F,3,H,W].
+__global__ __launch_bounds__(256) void im2col_u8_kernel(const unsigned char* __restrict__ video, bf16_t* __restrict__ patches,
+                                                        int64_t frames, int H, int W, int P, int Kpad, int channels_last,
+                                                        float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int G = W / P, n = (H / P) * G, K = 3 * P * P;
+    const int chunks = Kpad / 8;
+    const int64_t total = frames * n * chunks;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(idx % chunks);
+        const int64_t row = idx / chunks;
+        const int64_t frame = row / n;
+        const int pr = (int)(row % n), py = pr / G, px = pr % G;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = ch * 8 + q;
+            if (k < K) {
+                const int c = k / (P * P), rem = k % (P * P), i = rem / P, jj = rem % P;
+                const int64_t y = py * P + i, x = px * P + jj;
+                const unsigned char u = channels_last ? video[((frame * H + y) * W + x) * 3 + c]
+                                                      : video[((frame * 3 + c) * H + y) * (int64_t)W + x];
+                v[q] = ((float)u / 255.f - mean[c]) / sd[c];
+            } else v[q] = 0.f;
+        }
+        u32x4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+        *(u32x4*)(patches + row * Kpad + ch * 8) = o;
+    }
+}
+
 // one wave per output token row; D <= NV*256 (guarded), D % 4 == 0
 template <int NV>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ tok, const float* __restrict__ cls,
@@ -88,6 +120,22 @@ extern "C" int hh_patch_im2col(const float* video, void* patches, int64_t frames
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, video, (bf16_t*)patches, frames, H, W, P, Kpad);
     return hh_check_launch("hh_patch_im2col");
+}
+
+extern "C" int hh_patch_im2col_u8(const uint8_t* video, void* patches, int64_t frames, int H, int W, int P, int Kpad,
+                                  int channels_last, const float* mean3, const float* std3, hh_stream_t stream) {
+    HH_REQUIRE(frames >= 0 && H > 0 && W > 0 && P > 0 && H % P == 0 && W % P == 0, HH_ERR_SHAPE, "hh_patch_im2col_u8: bad image/patch size");
+    HH_REQUIRE(Kpad % 8 == 0 && Kpad >= 3 * P * P, HH_ERR_SHAPE, "hh_patch_im2col_u8: Kpad=%d must be a multiple of 8 and >= 3*P*P", Kpad);
+    HH_REQUIRE(mean3 != nullptr && std3 != nullptr && std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, HH_ERR_SHAPE,
+               "hh_patch_im2col_u8: mean/std (3 host floats each) required, std != 0");
+    HH_REQUIRE(HH_ALIGNED16(patches), HH_ERR_ALIGN, "hh_patch_im2col_u8: output must be 16-byte aligned");
+    if (frames == 0) return HH_OK;
+    const int64_t total = frames * (H / P) * (W / P) * (Kpad / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(im2col_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, video, (bf16_t*)patches, frames, H, W, P,
+                       Kpad, channels_last, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    return hh_check_launch("hh_patch_im2col_u8");
 }
 
 extern "C" int hh_embed_ln_pre(const float* tok, const float* cls, const float* pos, const float* temporal,

@@ -234,6 +234,7 @@ class SpaceTimeTransformer(nn.Module):
         nn.init.trunc_normal_(self.pos_embed, std=.02)
         nn.init.trunc_normal_(self.cls_token, std=.02)
         self.einops_from_space, self.einops_to_space = 'b (f n) d', '(b f) n d'
+        self.input_mean, self.input_std = ops.NORM_MEAN, ops.NORM_STD     # used only for uint8 inputs (run/train.py:442-445)
         self.einops_from_time, self.einops_to_time = 'b (f n) d', '(b n) f d'
         self._pack = None
 
@@ -269,12 +270,16 @@ class SpaceTimeTransformer(nn.Module):
     def forward_features(self, x, use_checkpoint=False, cls_at_last=True, out_dtype=torch.float32):
         """LaviLa.py:537-573.  The tower is frozen in this path (run/train.py:89,109-110): no autograd graph."""
         _require_gpu(x, "SpaceTimeTransformer")
-        B, T, C, H, W = x.shape
+        B, T = x.shape[:2]
         if T > self.num_frames:
             raise ValueError(f"SpaceTimeTransformer: {T} frames > num_frames={self.num_frames}")
         n, D = self.patches_per_frame, self.embed_dim
         pk = self.packed()
-        patches = ops.patch_im2col(x.float().contiguous(), self.patch_embed.patch_size[0], self.patch_embed.kpad())
+        if x.dtype == torch.uint8:       # decoded frames: ToTensor + Normalize fused into the im2col kernel (SURVEY 8f rank 3)
+            patches = ops.patch_im2col_u8(x.contiguous(), self.patch_embed.patch_size[0], self.patch_embed.kpad(),
+                                          self.input_mean, self.input_std)
+        else:
+            patches = ops.patch_im2col(x.float().contiguous(), self.patch_embed.patch_size[0], self.patch_embed.kpad())
         tok = ops.gemm(patches, pk["wpatch"], out_dtype=torch.float32)
         xs = ops.embed_ln_pre(tok, pk["cls"], pk["pos"], pk["tmp"], *pk["ln_pre"][:2], B, T, n, pk["ln_pre"][2])
         del patches, tok

@@ -173,6 +173,27 @@ def patch_im2col(video, patch, kpad):
     return out
 
 
+# normalisation constants of the reference's training transform (run/train.py:442-445)
+NORM_MEAN = (108.3272985 / 255, 116.7460125 / 255, 104.09373615000001 / 255)
+NORM_STD = (68.5005327 / 255, 66.6321579 / 255, 70.32316305 / 255)
+
+
+def patch_im2col_u8(video, patch, kpad, mean=NORM_MEAN, std=NORM_STD):
+    """uint8 frames [B,T,3,H,W] or channels-last [B,T,H,W,3] -> normalised bf16 patch rows [B*T*n, kpad]."""
+    _chk(video)
+    if video.dtype != torch.uint8 or video.dim() != 5:
+        raise ValueError("patch_im2col_u8: expected uint8 [B,T,3,H,W] or [B,T,H,W,3]")
+    cl = video.shape[-1] == 3 and video.shape[2] != 3
+    B, T = video.shape[:2]
+    H, W = (video.shape[2], video.shape[3]) if cl else (video.shape[3], video.shape[4])
+    n = (H // patch) * (W // patch)
+    out = torch.empty((B * T * n, kpad), dtype=torch.bfloat16, device=video.device)
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    _lib.check(_lib.lib().hh_patch_im2col_u8(_p(video), _p(out), B * T, H, W, patch, kpad, int(cl), m3, s3, _stream()),
+               "hh_patch_im2col_u8")
+    return out
+
+
 def embed_ln_pre(tok, cls, pos, temporal, gamma, beta, B, T, n, eps=1e-5):
     _chk(tok, cls, pos, temporal, gamma, beta)
     D = tok.shape[-1]

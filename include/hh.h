@@ -87,6 +87,10 @@ int hh_transpose_to_bf16(const void* x, int x_dtype, int64_t ldx, void* y, int64
  * im2col: video [B*T,3,H,W] fp32 -> patches bf16 [B*T*n, Kpad] (k = c*P*P + i*P + j, zero padded to Kpad) */
 int hh_patch_im2col(const float* video, void* patches, int64_t frames, int H, int W, int P, int Kpad,
                     hh_stream_t stream);
+/* same, straight from decoded uint8 frames with ToTensor + Normalize fused in ((u/255 - mean[c]) / std[c]; mean3/std3 are
+ * HOST pointers to 3 floats; data_loader/transforms.py:38-75, run/train.py:442-445); channels_last: [F,H,W,3] else [F,3,H,W] */
+int hh_patch_im2col_u8(const uint8_t* video, void* patches, int64_t frames, int H, int W, int P, int Kpad,
+                       int channels_last, const float* mean3, const float* std3, hh_stream_t stream);
 /* x[b,0,:]   = LN(cls + pos[0]) ; x[b,1+f*n+p,:] = LN(tok[(b*T+f)*n+p,:] + pos[1+p] + temporal[f])  (eps, ln_pre)
  * tok fp32 [B*T*n, D]; x fp32 [B, 1+T*n, D] */
 int hh_embed_ln_pre(const float* tok, const float* cls, const float* pos, const float* temporal,

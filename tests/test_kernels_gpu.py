@@ -147,6 +147,19 @@ def test_patch_embed_front_end():
     torch.testing.assert_close(x.cpu(), ref, rtol=2e-2, atol=2e-2)      # bf16 patch GEMM operands
 
 
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_uint8_front_end_equals_float_path(channels_last):
+    g = torch.Generator().manual_seed(0)
+    u8 = torch.randint(0, 256, (2, 4, 3, 224, 224), generator=g, dtype=torch.uint8)
+    mean, std = torch.tensor(ops.NORM_MEAN), torch.tensor(ops.NORM_STD)
+    f32 = (u8.float() / 255 - mean.view(1, 1, 3, 1, 1)) / std.view(1, 1, 3, 1, 1)
+    ref = ops.patch_im2col(f32.to(DEV), 14, 640).float().cpu()
+    inp = u8.permute(0, 1, 3, 4, 2).contiguous() if channels_last else u8
+    got = ops.patch_im2col_u8(inp.to(DEV), 14, 640).float().cpu()
+    assert float((got - ref).abs().max()) <= 2 ** -6          # <= 1 bf16 ulp at |x| < 4 (division rounding)
+    assert float((got != ref).float().mean()) < 1e-3
+
+
 def _ref_divided(qkv, B, T, n, heads, mode):
     """fp32 reference of the attention core on the same bf16 qkv (q pre-scaled): oracle maths, LaviLa.py:255-279."""
     N, D = 1 + T * n, heads * 64
