@@ -38,16 +38,28 @@ class TrainStep:
         self.v = torch.zeros_like(self.arena.params)
         self.comm = BucketedAllReduce(self.arena)
         self.iteration = 0
+        self._text_stream = None
         backbone.eval()                               # run/train.py:89
 
     # ------------------------------------------------------------------ forward
     def encode(self, video, text):
-        """Frozen towers (run/train.py:108-116): returns video_grid bf16 [B,T,n,D] and text feature map fp32."""
+        """Frozen towers (run/train.py:108-116): returns video_grid bf16 [B,T,n,D] and text feature map fp32.
+
+        The text tower (12 k token rows) cannot fill the chip: it runs on a side HIP stream concurrently with the vision
+        tower and is joined before the decoder."""
         B, T = video.shape[:2]
         n = self.cfg.patches_per_frame
+        main = torch.cuda.current_stream()
+        if self._text_stream is None:
+            self._text_stream = torch.cuda.Stream()
+        side = self._text_stream
+        side.wait_stream(main)
         with torch.no_grad():
+            with torch.cuda.stream(side):
+                _, tmap = self.backbone.encode_text(text)
             _, fmap = self.backbone.visual.forward_features(video, out_dtype=torch.bfloat16)
-            _, tmap = self.backbone.encode_text(text)
+        main.wait_stream(side)
+        tmap.record_stream(main)
         grid = fmap[:, 1:].reshape(B, T, n, fmap.shape[-1])
         return grid, tmap
 
