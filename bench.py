@@ -35,10 +35,11 @@ class KernelTimer:
     def __init__(self):
         self.rec = {}
         self.on = False
+        self.stream = None          # only launches on this stream are timed (the text tower runs concurrently on a side stream)
 
     def wrap(self, name, fn, work):
         def inner(*a, **k):
-            if not self.on:
+            if not self.on or (self.stream is not None and torch.cuda.current_stream() != self.stream):
                 return fn(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -155,6 +156,7 @@ def main():
     for _ in range(args.warmup):
         run()
     barrier()
+    timer.stream = torch.cuda.current_stream()
     timer.on = True
     t0 = time.perf_counter()
     for _ in range(args.steps):

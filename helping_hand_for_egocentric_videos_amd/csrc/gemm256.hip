@@ -229,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                     for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
                 }
                 if (e.resid) { v0 += rv[tm][nh][0]; v1 += rv[tm][nh][1]; }
-                if (!live[tm]) continue;
+                if (!live[tm] || p.debug_nostore) continue;
                 if constexpr (OUT_BF16) {
                     u32x4 o = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
                     *(u32x4*)((bf16_t*)Cbase + orow[tm] * p.ldc + n) = o;
@@ -241,13 +241,235 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// PERSISTENT variant: one workgroup per CU walks its tiles (virtual block id v = blockIdx.x + i * gridDim.x, same XCD-aware
+// decode).  Per-block fixed costs measured on the one-tile-per-block kernel: ~5.5 us of epilogue store drain + 3.5-6 us of
+// prologue latency / launch on a ~23 us main loop at K = 1024.  Here the NEXT tile's first two k-tiles (16 LDS-DMA
+// instructions, both LDS buffers are free once the main loop ends) are issued BEFORE the current tile's epilogue stores; since
+// vmcnt retires in order and the stores are younger than that prologue, the waits of the next tile's first k-tile are
+// counted as vmcnt(N + STORES) and pass without waiting for the store drain.  Requires full tiles, no residual / row remap
+// (no other VMEM instruction may sit between prologue and stores) and K >= 128.
+template <bool OUT_BF16>
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmParams p) {
+    constexpr bool STAGGER = true;
+    constexpr int STORES = OUT_BF16 ? 16 : 32;        // global_store_dwordx4 per wave and tile in the epilogue (checked in the ISA)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int GROUP = p.group_m;
+    const int per = GROUP * p.Nt;
+    const int nk = p.K / 64;
+    const int vmax = 8 * ((((p.Mt + 7) / 8) + GROUP - 1) / GROUP) * GROUP * p.Nt;      // size of the virtual grid
+    auto decode = [&](int v, int64_t& m0, int& n0) -> bool {
+        const int xcd = v & 7, j = v >> 3;
+        const int kg = j / per, r = j % per;
+        const int nt_i = r / GROUP, mi = r % GROUP;
+        const int mt = xcd + 8 * (kg * GROUP + mi);
+        m0 = (int64_t)mt * 256;
+        n0 = nt_i * 256;
+        return mt < p.Mt;
+    };
+    auto next_valid = [&](int v, int64_t& m0, int& n0) -> int {       // first valid virtual id >= v on this block's stride, or -1
+        for (; v < vmax; v += gridDim.x)
+            if (decode(v, m0, n0)) return v;
+        return -1;
+    };
+    int64_t m0, nm0 = 0;
+    int n0, nn0 = 0;
+    int v = next_valid(blockIdx.x, m0, n0);
+    if (v < 0) return;
+    // ---- staging sources: wave w stages pieces 2w, 2w+1 (8 rows each) of every half-tile
+    const bf16_t* src[4][2];       // [slot][piece]
+    auto set_src = [&](int64_t tm0, int tn0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            src[SLOT_ALO][i] = p.A + (tm0 + row) * p.lda + c * 8;
+            src[SLOT_AHI][i] = p.A + (tm0 + 128 + row) * p.lda + c * 8;
+            const int rl = row & 31, nperm = (row & ~31) + 8 * ((rl & 15) >> 2) + 4 * (rl >> 4) + (rl & 3);
+            src[SLOT_BLO][i] = p.W + (int64_t)(tn0 + nperm) * p.ldw + c * 8;
+            src[SLOT_BHI][i] = p.W + (int64_t)(tn0 + 128 + nperm) * p.ldw + c * 8;
+        }
+    };
+    auto stage = [&](int slot, int kt, int buf) {
+        char* dst = smem + buf * BUF_BYTES + slot * HT_BYTES + wave * 2048;
+        glds16(src[slot][0] + (int64_t)kt * 64, dst);
+        glds16(src[slot][1] + (int64_t)kt * 64, dst + 1024);
+    };
+    auto prologue = [&]() {          // k-tiles 0 and 1 complete: 16 LDS-DMA instructions per wave
+        stage(SLOT_BLO, 0, 0); stage(SLOT_ALO, 0, 0); stage(SLOT_BHI, 0, 0); stage(SLOT_AHI, 0, 0);
+        stage(SLOT_BLO, 1, 1); stage(SLOT_ALO, 1, 1); stage(SLOT_BHI, 1, 1); stage(SLOT_AHI, 1, 1);
+    };
+    set_src(m0, n0);
+    prologue();
+    bool first = true;
+
+    // ---- fragment read offsets inside a half-tile: row = base + (lane & 15), chunk = ks*4 + (lane >> 4)
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ks * 4 + fq;
+        a_off[ks] = (wr * 64 + frow) * 128 + ((c ^ (frow & 7)) << 4);     // + tm*2048
+        b_off[ks] = (wc * 32 + frow) * 128 + ((c ^ (frow & 7)) << 4);     // + tn*2048
+    }
+
+    f32x4 acc[2][4][2][2];      // [mh][tm][nh][tn]
+    bf16x8 af[4][2], bf0[2][2], bf1[2][2];      // A sub-tile [tm][ks]; B0 / B1 sub-tiles [tn][ks]
+
+#define MFMA_QUAD(MH, NH, BF)                                                                          \
+    __builtin_amdgcn_s_setprio(1);                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                   \
+        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                               \
+            _Pragma("unroll") for (int tm = 0; tm < 4; ++tm)                                           \
+                acc[MH][tm][NH][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[tn][ks], af[tm][ks], acc[MH][tm][NH][tn], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+
+    for (;;) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) acc[a][c][d][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // k-tile 0 of this tile has landed (the previous tile's stores, if any, are younger than the whole prologue)
+        if (first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (OUT_BF16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");       // 8 + STORES
+        else asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+        BARRIER();
+        if (STAGGER && wr == 1) BARRIER();
+
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            const char* base = smem + cur * BUF_BYTES;
+            // ================= phase 1: A0 x B0
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) bf0[tn][ks] = *(const bf16x8*)(base + SLOT_BLO * HT_BYTES + b_off[ks] + tn * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af[tm][ks] = *(const bf16x8*)(base + SLOT_ALO * HT_BYTES + a_off[ks] + tm * 2048);
+            if (t >= 1 && t + 1 < nk) stage(SLOT_AHI, t + 1, cur ^ 1);       // A-hi(1) came with the prologue
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            BARRIER();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA_QUAD(0, 0, bf0)
+            BARRIER();
+            // ================= phase 2: A0 x B1
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) bf1[tn][ks] = *(const bf16x8*)(base + SLOT_BHI * HT_BYTES + b_off[ks] + tn * 2048);
+            if (t + 2 < nk) stage(SLOT_BLO, t + 2, cur);
+            BARRIER();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA_QUAD(0, 1, bf1)
+            BARRIER();
+            // ================= phase 3: A1 x B1
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) af[tm][ks] = *(const bf16x8*)(base + SLOT_AHI * HT_BYTES + a_off[ks] + tm * 2048);
+            if (t + 2 < nk) stage(SLOT_ALO, t + 2, cur);
+            BARRIER();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA_QUAD(1, 1, bf1)
+            BARRIER();
+            // ================= phase 4: A1 x B0 ; retire k-tile t+1
+            if (t + 2 < nk) {
+                stage(SLOT_BHI, t + 2, cur);
+                if (t == 0 && !first) {                    // in order: [prologue][STORES][B-lo, A-lo, B-hi of k-tile 2] -> keep stores + 6
+                    if (OUT_BF16) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                }
+            } else {
+                if (t == 0 && !first) {                    // nk == 2: only the stores are younger than the prologue
+                    if (OUT_BF16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA_QUAD(1, 0, bf0)
+            BARRIER();
+        }
+        if (STAGGER && wr == 0) BARRIER();
+
+        // ---- epilogue of tile (m0, n0).  Bias is fetched and waited for FIRST; then the next tile's prologue is issued;
+        // then exactly STORES store instructions per wave and nothing else.
+        const hh_gemm_epilogue& e = p.e;
+        const int ncol = n0 + wc * 32 + 8 * fq;
+        f32x4 bias_v[2][2];
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            bias_v[nh][0] = e.bias ? *(const f32x4*)(e.bias + ncol + nh * 128) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            bias_v[nh][1] = e.bias ? *(const f32x4*)(e.bias + ncol + nh * 128 + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // bias landed (and every older store / load retired)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) { asm volatile("" : "+v"(bias_v[nh][0]), "+v"(bias_v[nh][1])); }
+        const int nv = next_valid(v + gridDim.x, nm0, nn0);
+        if (nv >= 0) {
+            set_src(nm0, nn0);
+            prologue();
+        }
+        char* Cbase = (char*)p.C;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                const int64_t orow = m0 + mh * 128 + wr * 64 + tm * 16 + frow;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    const int n = ncol + nh * 128;
+                    f32x4 v0 = acc[mh][tm][nh][0] + bias_v[nh][0], v1 = acc[mh][tm][nh][1] + bias_v[nh][1];
+                    if (n < e.colscale_cols) { v0 *= e.colscale; v1 *= e.colscale; }
+                    if (e.act == HH_ACT_QUICKGELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v0[q] = quick_gelu(v0[q]); v1[q] = quick_gelu(v1[q]); }
+                    } else if (e.act == HH_ACT_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
+                    }
+                    if constexpr (OUT_BF16) {
+                        u32x4 o = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+                        *(u32x4*)((bf16_t*)Cbase + orow * p.ldc + n) = o;
+                    } else {
+                        *(f32x4*)((float*)Cbase + orow * p.ldc + n) = v0;
+                        *(f32x4*)((float*)Cbase + orow * p.ldc + n + 4) = v1;
+                    }
+                }
+            }
+        if (nv < 0) break;
+        v = nv; m0 = nm0; n0 = nn0;
+        first = false;
+    }
+#undef MFMA_QUAD
+}
+
+static int g_nostore = 0;          // debug: skip the epilogue stores (timing experiments only)
 static int g_group = 8;            // m-tiles per XCD-local group (weight-panel reuse factor)
 static int g_skew = -1;            // start skew: -1 auto (on when the epilogue carries an fp32 residual), 0 off, 1 on
-static int g_mode = -1;            // gemm256 mode: 0 = off, 1 = on without stagger, 2 = on with stagger (default)
+static int g_mode = -1;            // gemm256 mode: 0 = off, 1 = no stagger, 2 = stagger, 3 = persistent (stagger) where eligible
 static int gemm256_mode() {
     if (g_mode < 0) {
         const char* s = getenv("HH_GEMM256");
-        g_mode = s ? atoi(s) : 2;
+        g_mode = s ? atoi(s) : 3;
     }
     return g_mode;
 }
@@ -255,6 +477,7 @@ static int gemm256_mode() {
 extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm256")) { g_mode = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_skew")) { g_skew = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm256_debug_nostore")) { g_nostore = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_group") && value >= 1 && value <= 64) { g_group = value; return HH_OK; }
     hh_set_error("hh_set_tuning: unknown knob '%s'", name ? name : "(null)");
     return HH_ERR_UNSUPPORTED;
@@ -274,6 +497,12 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
         attr_done = true;
     }
     const int stagger = gemm256_mode() != 1;
+    static bool attr_p = false;
+    if (!attr_p) {
+        hipFuncSetAttribute((const void*)gemm256p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        attr_p = true;
+    }
     GemmParams p = pin;
     {
         // one round ~ nk k-tiles x ~3300 cycles + epilogue; s_sleep(16) ~ 1024 cycles per iteration
@@ -285,10 +514,20 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
     p.Nt = p.N / 256;
     const int GROUP = g_group;
     p.group_m = GROUP;
+    p.debug_nostore = g_nostore;
     const int per_xcd_mt = (p.Mt + 7) / 8;
     const int groups = (per_xcd_mt + GROUP - 1) / GROUP;
     const unsigned grid = 8u * (unsigned)groups * GROUP * (unsigned)p.Nt;
     const bool bf = p.e.c_dtype == HH_BF16;
+    if (gemm256_mode() == 3 && p.e.resid == nullptr && p.e.remap_group == 0 && p.K >= 128 && p.M % 256 == 0 && !g_nostore) {
+        static int ncu = 0;
+        if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+        const unsigned pg = grid < (unsigned)ncu ? grid : (unsigned)ncu;
+        p.skew_iters = 0;
+        if (bf) hipLaunchKernelGGL((gemm256p_kernel<true>), dim3(pg), dim3(512), 2 * BUF_BYTES, s, p);
+        else hipLaunchKernelGGL((gemm256p_kernel<false>), dim3(pg), dim3(512), 2 * BUF_BYTES, s, p);
+        return hh_check_launch("hh_gemm_bf16(256x256 persistent)");
+    }
     if (stagger) {
         if (bf) hipLaunchKernelGGL((gemm256_kernel<true, true>), dim3(grid), dim3(512), 2 * BUF_BYTES, s, p);
         else hipLaunchKernelGGL((gemm256_kernel<false, true>), dim3(grid), dim3(512), 2 * BUF_BYTES, s, p);
