@@ -39,6 +39,8 @@ class TrainStep:
         self.comm = BucketedAllReduce(self.arena)
         self.iteration = 0
         self._text_stream = None
+        self.enc_stream = None
+        self._pending = None
         backbone.eval()                               # run/train.py:89
 
     # ------------------------------------------------------------------ forward
@@ -46,29 +48,57 @@ class TrainStep:
         """Frozen towers (run/train.py:108-116): returns video_grid bf16 [B,T,n,D] and text feature map fp32.
 
         The text tower (12 k token rows) cannot fill the chip: it runs on a side HIP stream concurrently with the vision
-        tower and is joined before the decoder."""
+        tower and is joined before returning."""
         B, T = video.shape[:2]
         n = self.cfg.patches_per_frame
-        main = torch.cuda.current_stream()
+        cur = torch.cuda.current_stream()
         if self._text_stream is None:
             self._text_stream = torch.cuda.Stream()
         side = self._text_stream
-        side.wait_stream(main)
+        side.wait_stream(cur)
         with torch.no_grad():
             with torch.cuda.stream(side):
                 _, tmap = self.backbone.encode_text(text)
             _, fmap = self.backbone.visual.forward_features(video, out_dtype=torch.bfloat16)
-        main.wait_stream(side)
-        tmap.record_stream(main)
+        cur.wait_stream(side)
+        tmap.record_stream(cur)
         grid = fmap[:, 1:].reshape(B, T, n, fmap.shape[-1])
         return grid, tmap
 
-    def losses(self, batch):
+    def prefetch(self, batch):
+        """Start the frozen towers of `batch` on the encoder stream (software pipelining across steps: the frozen encoder
+        of step i+1 does not depend on step i's optimizer update, so it overlaps step i's decoder forward/backward, whose
+        13-row query-side kernels leave most CUs idle).  The result is picked up by the next step(batch)."""
+        if self.enc_stream is None:
+            self.enc_stream = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        self.enc_stream.wait_stream(main)
+        with torch.cuda.stream(self.enc_stream):
+            grid, tmap = self.encode(batch["video"], batch["text"])
+            ev = torch.cuda.Event()
+            ev.record(self.enc_stream)
+        self._pending = (batch, grid, tmap, ev)
+
+    def _encoded(self, batch):
+        if self._pending is not None and self._pending[0] is batch:
+            _, grid, tmap, ev = self._pending
+            self._pending = None
+            main = torch.cuda.current_stream()
+            main.wait_event(ev)
+            grid.record_stream(main)
+            tmap.record_stream(main)
+            return grid, tmap
+        self._pending = None
+        return self.encode(batch["video"], batch["text"])
+
+    def losses(self, batch, next_batch=None):
         cfg = self.cfg
         video, text = batch["video"], batch["text"]
         B, T = video.shape[:2]
         W, _ = world()
-        grid, tmap = self.encode(video, text)
+        grid, tmap = self._encoded(batch)
+        if next_batch is not None:
+            self.prefetch(next_batch)
         det, hs, _, _ = self.decoder(grid)
         eot = text.argmax(dim=-1)
         text_embeds = self.decoder.txt_proj(tmap[torch.arange(text.shape[0], device=text.device), eot])
@@ -98,11 +128,12 @@ class TrainStep:
                 "pred_boxes": det["pred_boxes"], "hs": hs}
 
     # ------------------------------------------------------------------ step
-    def step(self, batch):
+    def step(self, batch, next_batch=None):
+        """One optimisation step on `batch`; if `next_batch` is given its frozen-tower forward is launched concurrently."""
         self.decoder.train()
         self.backbone.eval()
         self.arena.zero_grad()
-        out = self.losses(batch)
+        out = self.losses(batch, next_batch)
         out["total_loss"].backward()
         self.comm.finish()
         self.iteration += 1
