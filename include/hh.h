@@ -37,7 +37,7 @@ const char* hh_last_error_string(void);
 
 /* ---- LayerNorm over the last dim (model/LaviLa.py:439,456 eps 1e-6 / 1e-5; tfm_decoder.py:57,375-377)
  * y[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta ; x dtype / y dtype in {HH_F32, HH_BF16}; gamma/beta fp32.
- * cols must be a multiple of 64*... see implementation: cols % 8 == 0 and cols <= 8192.
+ * cols % 8 == 0 and cols <= 2048.
  * If mean_out/rstd_out are non-NULL the per-row statistics (fp32) are stored for the backward. */
 int hh_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                      float* mean_out, float* rstd_out, int64_t rows, int cols, float eps, hh_stream_t stream);
@@ -47,8 +47,8 @@ int hh_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float
 int hh_add_layernorm_fwd(float* x, const void* delta, int write_x, const float* gamma, const float* beta, void* y,
                          int y_dtype, int64_t rows, int cols, float eps, hh_stream_t stream);
 
-/* LayerNorm backward: dx (same dtype as x_dtype... fp32) plus per-column partial sums for dgamma/dbeta.
- * dgamma_part/dbeta_part: [nparts, cols] fp32 workspace partials, reduced by hh_colsum_f32. */
+/* LayerNorm backward: dx fp32 [rows, cols]; dgamma / dbeta fp32 [cols] are ACCUMULATED with atomics (zero them first).
+ * x is the forward input (fp32 or bf16), mean / rstd the statistics saved by hh_layernorm_fwd.  cols <= 1024. */
 int hh_layernorm_bwd(const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd,
                      const float* dy, float* dx, float* dgamma, float* dbeta, int64_t rows, int cols,
                      hh_stream_t stream);

@@ -53,8 +53,8 @@ def test_load_4_frame_checkpoints_into_16_frame_models(tmp_path):
     # save / rolling window / reload
     fn = str(tmp_path / "runtime.pth.tar")
     for i in range(12):
-        p = ck.save_runtime_checkpoint(ck.make_save_dict(dec16, i, 0.0, i * 10, {"step": i}), fn.replace("runtime", f"runtime{i:02d}") if False else fn, keep=10)
-        os.rename(p, p.replace(".pth.tar", f"_{i:02d}.pth.tar"))
+        p = ck.save_runtime_checkpoint(ck.make_save_dict(dec16, i, 0.0, i * 10, {"step": i}), fn, keep=10)
+        os.rename(p, p.replace(".pth.tar", f"_{i:02d}.pth.tar"))        # distinct names even within one second
     assert len(list(tmp_path.glob("runtime_*.pth.tar"))) <= 11
     last = sorted(tmp_path.glob("runtime_*.pth.tar"))[-1]
     dec_b = tfm_decoder.build_decoder(TINY16.with_(num_queries=4), None, device="cpu")

@@ -48,7 +48,6 @@ def test_block_by_block_drift_is_bounded():
     cfg = TINY16
     sd = synth.encoder_state(cfg, seed=3, with_text=False)
     video = synth.make_batch(cfg, 1, seed=3)["video"]
-    model = LaviLa.build_backbone(cfg.with_(text_layers=1), {**sd}, device="cuda") if False else None
     vis = LaviLa.build_backbone(cfg, None).visual
     vis.load_state_dict({k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}, strict=True)
     vis = vis.cuda()
