@@ -257,3 +257,33 @@ def test_cross_attention_dropout_statistics():
     fd = float(((op - om) / (2 * eps) * dout).sum())
     an = float((dq * d).sum())
     assert abs(fd - an) <= 0.05 * abs(fd) + 1e-3, (fd, an)
+
+
+def test_headline_config_c2_losses_vs_oracle():
+    """BASELINE config 2 itself (full-width TimeSformer-L, T=16, 224p, nq=12), B=2: every loss term of the GPU step vs the
+    CPU oracle on identical synthetic weights/inputs; bit-exact matching on the GPU's own fp32 boxes."""
+    from helping_hand_for_egocentric_videos_amd import C2
+    cfg = C2
+    esd, dsd = synth.encoder_state(cfg, seed=0), synth.decoder_state(cfg, seed=0)
+    batch = synth.make_batch(cfg, 2, seed=1000)
+    backbone = LaviLa.build_backbone(cfg, esd)
+    dec = tfm_decoder.build_decoder(cfg, dsd)
+    ts = TrainStep(cfg, backbone, dec)
+    dec.eval()
+    ts.arena.zero_grad()
+    res = ts.losses(to_dev(batch))
+    with torch.no_grad():
+        ref = OS.step_losses(esd, dsd, batch, cfg)
+    rep = {}
+    for k, tol in (("total_loss", 1e-3), ("box_loss_hand", 1e-3), ("box_loss_obj", 1e-3), ("nce_loss", 3e-3), ("word_loss", 3e-3)):
+        got, want = float(res[k]), float(ref[k])
+        rep[k] = abs(got - want) / abs(want)
+        assert rep[k] <= tol, (k, got, want)
+    print("C2 rel loss errors vs oracle:", {k: f"{v:.2e}" for k, v in rep.items()})
+    pb = res["pred_boxes"].detach().cpu()
+    for key, sl, qs in (("match_hand", slice(0, 2), slice(0, 2)), ("match_obj", slice(2, 4), slice(2, cfg.num_queries))):
+        raw = batch["boxes"][:, :, sl].flatten(0, 1)
+        for (a, b), (c, d) in zip(res[key], OL.hungarian_match(pb[:, qs], OL.prepare_targets(raw))):
+            assert torch.equal(a, c) and torch.equal(b, d)
+    agree = [torch.equal(a, c) for (a, _), (c, _) in zip(res["match_obj"], ref["idx_obj"])]
+    print("C2 end-to-end object-index agreement with the fp32 oracle: %.3f" % (sum(agree) / len(agree)))
