@@ -123,6 +123,8 @@ def main():
 
     cfg = C2
     torch.manual_seed(0)
+    # host threads for the synthetic-weight generation: do not oversubscribe the node when N ranks build models at once
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // max(world, 1))))
     enc_sd = synth.encoder_state(cfg, seed=0)
     dec_sd = synth.decoder_state(cfg, seed=0)
     backbone = LaviLa.build_backbone(cfg, enc_sd, device=dev)

@@ -74,6 +74,16 @@ def _worker(rank, world, port, ret):
         dist.all_gather(gathered, flat)
         assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged"
         nce = float(ts.losses(local)["nce_loss"])            # collective: every rank must call it
+        # the exact call bench.py makes at N > 1: train mode (dropout on), next batch's frozen towers prefetched on the
+        # encoder stream while backward + bucketed all-reduce run -> ranks must still hold identical parameters
+        for _ in range(3):
+            out = ts.step(local, next_batch=local)
+        assert torch.isfinite(out["total_loss"]).item()
+        flat2 = ts.arena.params.detach().cpu()
+        gathered2 = [torch.empty_like(flat2) for _ in range(world)]
+        dist.all_gather(gathered2, flat2)
+        assert all(torch.equal(gathered2[0], g) for g in gathered2), "ranks diverged in pipelined train mode"
+        assert not torch.equal(flat2, flat)
         if rank == 0:
             ret["params"] = flat
             ret["nce"] = nce
