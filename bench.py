@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--workload", default="train", choices=["train", "mcq"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--enc-cus", type=int, default=None, help="CU budget of the persistent GEMMs on the pipelined encoder stream (multiple of 8; 0 = all)")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder forward with this step's decoder")
     args = ap.parse_args()
 
@@ -138,7 +139,7 @@ def main():
 
     if args.workload == "train":
         batch = {k: v.to(dev) for k, v in synth.make_batch(cfg, B, seed=1000 + rank).items()}
-        ts = TrainStep(cfg, backbone, decoder)
+        ts = TrainStep(cfg, backbone, decoder, enc_cus=args.enc_cus)
         run = lambda: ts.step(batch, next_batch=None if args.no_pipeline else batch)
         clips_per_step = B
         metric = "train clips/sec (16-frame 224p, nq=12)"

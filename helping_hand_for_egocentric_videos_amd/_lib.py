@@ -22,6 +22,8 @@ SIGNATURES = {
     "hh_version": [],
     "hh_last_error_string": [],
     "hh_set_tuning": [ctypes.c_char_p, c_int],
+    "hh_stream_set_cu_budget": [c_vp, c_int],
+    "hh_stream_get_cu_budget": [c_vp, ctypes.POINTER(c_int)],
     "hh_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_float, c_vp],
     "hh_add_layernorm_fwd": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_float, c_vp],
     "hh_layernorm_bwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],

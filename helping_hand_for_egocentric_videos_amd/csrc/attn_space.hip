@@ -34,6 +34,13 @@ __device__ __forceinline__ bf16x4 lds_tr4(const char* addr) {
 // layout of one CLS partial record: [m, l, 0, 0, o[64]] fp32
 #define CLS_REC 68
 
+// XOR-swizzle keys of the two LDS tiles (16-B chunk c of row r lives at position c ^ key(r)); chosen with the bank model of
+// MI355X_MICROARCH.md: K rows are read as ds_read_b128 fragments by 32 consecutive rows x 2 chunks -> (r ^ (r >> 3)) & 7 is
+// conflict-free (plain r & 7 is 2-way: rows 8/16/24 apart alias); V rows are read by ds_read_b64_tr_b16 as 4 rows x 64 B per
+// half-wave -> flipping the 64-B half with row bit 1 is conflict-free.
+__device__ __forceinline__ int kswz(int r) { return (r ^ (r >> 3)) & 7; }
+__device__ __forceinline__ int vswz(int r) { return ((r >> 1) & 1) << 2; }
+
 // One 32-query block of one (clip, frame, head) problem: S^T = K.Q^T, online softmax over CH-tile chunks, O^T = V^T.P^T.
 __device__ __forceinline__ void space_query_block(const char* Ks, const char* Vs, const bf16x8 (&qf)[4], bf16_t* orow, int n, int ntiles, int lane) {
     const int ql = lane & 31, h = lane >> 5;
@@ -54,7 +61,7 @@ __device__ __forceinline__ void space_query_block(const char* Ks, const char* Vs
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int c = 2 * ks + h;
-                    bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + ((c ^ (krow & 7)) << 4));
+                    bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + ((c ^ kswz(krow)) << 4));
                     s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[ti], 0, 0, 0);
                 }
             }
@@ -105,8 +112,8 @@ __device__ __forceinline__ void space_query_block(const char* Ks, const char* Vs
                     for (int dt = 0; dt < 2; ++dt) {
                         const int col = 32 * dt + 16 * tg + 4 * tp;               // d column of this lane's address
                         const int ch = col >> 3, sub = (col & 7) * 2;
-                        bf16x4 a0 = lds_tr4(Vs + kb * 128 + ((ch ^ (kb & 7)) << 4) + sub);
-                        bf16x4 a1 = lds_tr4(Vs + (kb + 8) * 128 + ((ch ^ ((kb + 8) & 7)) << 4) + sub);
+                        bf16x4 a0 = lds_tr4(Vs + kb * 128 + ((ch ^ vswz(kb)) << 4) + sub);
+                        bf16x4 a1 = lds_tr4(Vs + (kb + 8) * 128 + ((ch ^ vswz(kb + 8)) << 4) + sub);
                         vf[dt] = (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                     }
                     o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf, o0, 0, 0, 0);
@@ -141,7 +148,7 @@ __device__ __forceinline__ void space_cls_partial(const char* Ks, const char* Vs
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             u32x4 qv = *(const u32x4*)(base + c * 8);                               // q row of token 0 (uniform, pre-scaled)
-            u32x4 u = *(const u32x4*)(Ks + j * 128 + ((c ^ (j & 7)) << 4));
+            u32x4 u = *(const u32x4*)(Ks + j * 128 + ((c ^ kswz(j)) << 4));
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 a0 = fmaf(bf16_lo_to_f32(qv[w]), bf16_lo_to_f32(u[w]), a0);
@@ -169,7 +176,7 @@ __device__ __forceinline__ void space_cls_partial(const char* Ks, const char* Vs
     float o = 0.f;
     const int dch = lane >> 3, dsub = (lane & 7) * 2;
     for (int j = wave; j < nkeys; j += NWV) {
-        const unsigned short vv = *(const unsigned short*)(Vs + j * 128 + ((dch ^ (j & 7)) << 4) + dsub);
+        const unsigned short vv = *(const unsigned short*)(Vs + j * 128 + ((dch ^ vswz(j)) << 4) + dsub);
         o = fmaf(cs[j], __uint_as_float((unsigned)vv << 16), o);
     }
     wrec[wave * CLS_REC + lane] = o;
@@ -191,13 +198,13 @@ __device__ __forceinline__ void space_stage(char* Ks, char* Vs, const bf16_t* ba
     const int pieces = KP >> 3;
     for (int pc = wave; pc < pieces; pc += NWV) {
         const int row = pc * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (row & 7);
+        const int c = (lane & 7) ^ kswz(row);
         const bf16_t* src = (row < n) ? q_ptr + (int64_t)row * ld : base;
         glds16(src + D + c * 8, Ks + pc * 1024);
     }
     for (int pc = wave; pc < pieces; pc += NWV) {
         const int row = pc * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (row & 7);
+        const int c = (lane & 7) ^ vswz(row);
         const bf16_t* src = (row < n) ? q_ptr + (int64_t)row * ld : base;
         glds16(src + 2 * D + c * 8, Vs + pc * 1024);
     }

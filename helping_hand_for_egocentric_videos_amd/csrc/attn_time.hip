@@ -164,6 +164,191 @@ __global__ __launch_bounds__(256, 4) void time_attn_kernel(const bf16_t* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// MFMA variant (T <= 16, T a power of two): the VALU kernel above issues ~1200 vector instructions per (clip, head, patch)
+// problem (SQ_INSTS_VALU = 159 M per launch at B = 32: 260 us of pure VALU issue), which -- not HBM -- bounded it at ~400 us.
+// Here ONE WAVE owns 128 consecutive tokens of a (clip, head) = 128/T patch locations = 8 tiles of 16 rows (row r of a tile =
+// patch r / T, frame r % T) and runs every product on the matrix core with operands that come from HBM already in MFMA layout:
+//   S^T = K . Q^T          v_mfma_f32_16x16x32_bf16 x2, A = K rows, B = Q rows, both plain 16-B global loads (lane = row, 8 d)
+//   CLS key column         x2, A = K_cls replicated in rows 0/4/8/12 -> register 0 of every lane = q . k_cls
+//   softmax over keys      4 registers in-lane + xor-16 / xor-32 exchanges (lane = query); for T < 16 the tile is block-diagonal
+//   O^T = V^T . P^T        x4 (one per 16 d), B = normalised P^T straight from the S^T registers (k-slot 8g+jj: jj < 4 -> key
+//                          row 4g+jj, jj = 4 of g = 0 -> CLS key), A = V^T from the row-major V tile in LDS (staged by LDS-DMA,
+//                          2 KB per tile, double-buffered per wave) through the transposing ds_read_b64_tr_b16; row m of tile
+//                          dt is d = 16 (m >> 2) + 4 dt + (m & 3), so that a lane ends up with 16 CONSECUTIVE d of its query
+//                          (two 16-B stores)
+//   CLS query (folded)     the same MFMAs with B = q_cls in all 16 columns, online-softmax accumulated over the wave's 8 tiles
+//                          into one partial record per wave (same record grid as the VALU kernel: ceil(n / (128/T)) per head).
+// No workgroup barrier: the four waves of a workgroup are independent.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void tglds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ bf16x4 tlds_tr4(const char* addr) {
+    s16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)addr);
+    return __builtin_bit_cast(bf16x4, r);
+}
+
+template <int T>
+__global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                             float* __restrict__ cls_partial, int B, int n, int heads) {
+    constexpr int P = 128 / T;         // patch locations per wave (= per CLS partial record)
+    constexpr int PT = 16 / T;         // patch locations per 16-row tile
+    __shared__ __attribute__((aligned(16))) char Vsm[4 * 2 * 2048];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = heads * 64;
+    const int64_t ld = 3 * (int64_t)D;
+    const int N = 1 + T * n;
+    const int groups = (n + P - 1) / P;
+    int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    if (wid >= (int64_t)B * heads * groups) return;
+    const int pg = (int)(wid % groups); wid /= groups;
+    const int head = (int)(wid % heads);
+    const int b = (int)(wid / heads);
+    const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;
+    const int p0 = pg * P;
+    const int ntiles = min(8, (n - p0 + PT - 1) / PT);
+    const int c = lane & 15, g = lane >> 4;
+    const float LOG2E = 1.4426950408889634f;
+    char* vbuf = Vsm + wave * 4096;
+
+    // token row of tile t, tile row r; patches beyond n are clamped (their keys only meet their own, never stored, queries)
+    auto tokrow = [&](int t, int r) -> int64_t {
+        const int patch = min(p0 + t * PT + r / T, n - 1);
+        return 1 + (int64_t)(r % T) * n + patch;
+    };
+    auto issue = [&](int t, bf16x8 (&qq)[2], bf16x8 (&kk)[2]) {
+        char* dst = vbuf + (t & 1) * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            tglds16(base + tokrow(t, (lane >> 3) + 8 * i) * ld + 2 * D + (lane & 7) * 8, dst + i * 1024);
+        const bf16_t* rp = base + tokrow(t, c) * ld + 8 * g;
+        qq[0] = *(const bf16x8*)(rp);
+        qq[1] = *(const bf16x8*)(rp + 32);
+        kk[0] = *(const bf16x8*)(rp + D);
+        kk[1] = *(const bf16x8*)(rp + D + 32);
+    };
+
+    // per-(clip, head) constants: CLS key as an A tile (rows 0, 4, 8, 12), CLS query as a B tile (every column), CLS value slot
+    bf16x8 a2[2], qc[2];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kc = *(const bf16x8*)(base + D + 8 * g + 32 * ks);
+        a2[ks] = (c & 3) == 0 ? kc : zero8;
+        qc[ks] = *(const bf16x8*)(base + 8 * g + 32 * ks);
+    }
+    bf16_t vcls[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const bf16_t v = base[2 * D + 16 * (c >> 2) + 4 * dt + (c & 3)];
+        vcls[dt] = g == 0 ? v : (bf16_t)0.f;
+    }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    float mc = -INFINITY, lc = 0.f;
+    f32x4 accc[4] = {z4, z4, z4, z4};
+    const int trq = c >> 2, trp = c & 3;                 // ds_read_tr roles inside a 16-lane group: row, 4-column piece
+
+    auto compute = [&](int t, const bf16x8 (&q)[2], const bf16x8 (&k)[2]) {
+        f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0], q[0], z4, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1], q[1], s, 0, 0, 0);
+        f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], q[0], z4, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1], q[1], sc, 0, 0, 0);
+        float x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = (T == 16 || ((4 * g + j) / T) == (c / T)) ? s[j] : -INFINITY;
+        float m = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = fmaxf(m, sc[0]);
+        const float mb = m * LOG2E;
+        float p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = __builtin_amdgcn_exp2f(x[j] * LOG2E - mb);
+        const float pc = __builtin_amdgcn_exp2f(sc[0] * LOG2E - mb);
+        float l = (p[0] + p[1]) + (p[2] + p[3]);
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        l += pc;
+        const float inv = __builtin_amdgcn_rcpf(l);
+        const bf16x8 pf = {(bf16_t)(p[0] * inv), (bf16_t)(p[1] * inv), (bf16_t)(p[2] * inv), (bf16_t)(p[3] * inv),
+                           (bf16_t)(g == 0 ? pc * inv : 0.f), 0, 0, 0};
+        const char* vb = vbuf + (t & 1) * 2048 + (4 * g + trq) * 128 + 32 * trp;
+        bf16x8 af[4];
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x4 tr = tlds_tr4(vb + 8 * dt);
+            af[dt] = (bf16x8){tr[0], tr[1], tr[2], tr[3], vcls[dt], 0, 0, 0};
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], pf, z4, 0, 0, 0);
+        }
+        if (p0 + t * PT + c / T < n) {
+            bf16_t* op = out + ((int64_t)b * N + tokrow(t, c)) * D + head * 64 + 16 * g;
+            const u32x4 w0 = {pack_bf16(o[0][0], o[0][1]), pack_bf16(o[0][2], o[0][3]), pack_bf16(o[1][0], o[1][1]), pack_bf16(o[1][2], o[1][3])};
+            const u32x4 w1 = {pack_bf16(o[2][0], o[2][1]), pack_bf16(o[2][2], o[2][3]), pack_bf16(o[3][0], o[3][1]), pack_bf16(o[3][2], o[3][3])};
+            *(u32x4*)(op) = w0;
+            *(u32x4*)(op + 8) = w1;
+        }
+        if (cls_partial == nullptr) return;
+        // ---- CLS query over this tile's keys (lane (c, g) register j = key row 4g+j, identical for every c)
+        f32x4 s3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0], qc[0], z4, 0, 0, 0);
+        s3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1], qc[1], s3, 0, 0, 0);
+        float y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = (p0 + t * PT + (4 * g + j) / T < n) ? s3[j] : -INFINITY;
+        float gm = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
+        gm = fmaxf(gm, __shfl_xor(gm, 16, 64));
+        gm = fmaxf(gm, __shfl_xor(gm, 32, 64));
+        const bool first = pg == 0 && t == 0;            // the CLS key itself is counted once per (clip, head)
+        float yc = -INFINITY;
+        if (first) {
+            f32x4 s33 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], qc[0], z4, 0, 0, 0);
+            s33 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1], qc[1], s33, 0, 0, 0);
+            yc = s33[0];
+            gm = fmaxf(gm, yc);
+        }
+        const float m_new = fmaxf(mc, gm);
+        const float alpha = __builtin_amdgcn_exp2f((mc - m_new) * LOG2E);
+        const float mb3 = m_new * LOG2E;
+        float p3[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p3[j] = __builtin_amdgcn_exp2f(y[j] * LOG2E - mb3);
+        const float p3c = first ? __builtin_amdgcn_exp2f(yc * LOG2E - mb3) : 0.f;
+        float ls = (p3[0] + p3[1]) + (p3[2] + p3[3]);
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        lc = lc * alpha + ls + p3c;
+        mc = m_new;
+        const bf16x8 pf3 = {(bf16_t)p3[0], (bf16_t)p3[1], (bf16_t)p3[2], (bf16_t)p3[3], (bf16_t)(g == 0 ? p3c : 0.f), 0, 0, 0};
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) accc[dt][j] *= alpha;
+            accc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], pf3, accc[dt], 0, 0, 0);
+        }
+    };
+
+    bf16x8 qa[2], ka[2], qb[2], kb[2];
+    issue(0, qa, ka);
+    for (int t = 0; t < ntiles; t += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tile t: V rows in LDS, Q / K rows in registers
+        if (t + 1 < ntiles) issue(t + 1, qb, kb);
+        compute(t, qa, ka);
+        if (t + 1 >= ntiles) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + 2 < ntiles) issue(t + 2, qa, ka);
+        compute(t + 1, qb, kb);
+    }
+    if (cls_partial != nullptr && c == 0) {
+        float* rec = cls_partial + (((int64_t)b * heads + head) * groups + pg) * CLS_REC;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *(f32x4*)(rec + 4 + 16 * g + 4 * dt) = accc[dt];
+        if (g == 0) { rec[0] = mc; rec[1] = lc; }
+    }
+}
+
 extern "C" int hh_time_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream) {
     HH_REQUIRE(B >= 0 && n > 0 && heads > 0, HH_ERR_SHAPE, "hh_time_attn_fwd: bad shape");
     HH_REQUIRE(T == 1 || T == 2 || T == 4 || T == 8 || T == 16 || T == 32, HH_ERR_UNSUPPORTED,
@@ -175,6 +360,22 @@ extern "C" int hh_time_attn_fwd(const void* qkv, void* out, float* cls_partial, 
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* in = (const bf16_t*)qkv;
     bf16_t* o = (bf16_t*)out;
+    // HH_TIME_ATTN: 1 (default) = MFMA kernel for T <= 16, 0 = VALU kernel (the only one for T = 32)
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("HH_TIME_ATTN"); mode = e ? atoi(e) : 1; }
+    if (mode == 1 && T <= 16) {
+        const unsigned wg = (unsigned)((blocks + 3) / 4);           // one wave per record, four waves per workgroup
+#define LAUNCHM(TT) hipLaunchKernelGGL(time_attn_mfma_kernel<TT>, dim3(wg), dim3(256), 0, s, in, o, cls_partial, B, n, heads)
+        switch (T) {
+            case 1: LAUNCHM(1); break;
+            case 2: LAUNCHM(2); break;
+            case 4: LAUNCHM(4); break;
+            case 8: LAUNCHM(8); break;
+            default: LAUNCHM(16); break;
+        }
+#undef LAUNCHM
+        return hh_check_launch("hh_time_attn_fwd(mfma)");
+    }
 #define LAUNCH(TT) hipLaunchKernelGGL(time_attn_kernel<TT>, dim3((unsigned)blocks), dim3(256), 0, s, in, o, cls_partial, B, n, heads)
     switch (T) {
         case 1: LAUNCH(1); break;

@@ -18,6 +18,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 void hh_set_error(const char* fmt, ...);
 int hh_check_launch(const char* what);
+int hh_stream_cu_count(hipStream_t s);      // CUs the stream may use (runtime.cpp)
 
 #define HH_REQUIRE(cond, code, ...)                 \
     do {                                            \

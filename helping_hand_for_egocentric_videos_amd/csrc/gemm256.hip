@@ -520,8 +520,7 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
     const unsigned grid = 8u * (unsigned)groups * GROUP * (unsigned)p.Nt;
     const bool bf = p.e.c_dtype == HH_BF16;
     if (gemm256_mode() == 3 && p.e.resid == nullptr && p.e.remap_group == 0 && p.K >= 128 && p.M % 256 == 0 && !g_nostore) {
-        static int ncu = 0;
-        if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+        const int ncu = hh_stream_cu_count(s) & ~7;          // CU budget of this stream; the stride of the tile walk must keep blockIdx & 7 == XCD
         const unsigned pg = grid < (unsigned)ncu ? grid : (unsigned)ncu;
         p.skew_iters = 0;
         if (bf) hipLaunchKernelGGL((gemm256p_kernel<true>), dim3(pg), dim3(512), 2 * BUF_BYTES, s, p);

@@ -21,3 +21,53 @@ int hh_check_launch(const char* what) {
 
 extern "C" int hh_version(void) { return 100; }
 extern "C" const char* hh_last_error_string(void) { return g_err; }
+
+// ---- per-stream CU budget.  The pipelined training step runs the frozen towers of batch i+1 on one stream while the decoder
+// forward/backward of batch i runs on another.  The persistent 256x256 GEMM normally puts one workgroup on every CU (LDS and
+// VGPRs of a CU are then full), so kernels of the other stream only start in the gaps between encoder kernels.  A budget of
+// n < all CUs makes persistent kernels launched on that stream use n workgroups and leaves the other CUs to concurrent streams.
+// (Hardware CU masks -- hipExtStreamCreateWithCUMask -- were measured and rejected: mask bit i is CU (i / 8) of XCD (i % 8), but
+// the dispatcher keeps dealing workgroups evenly to the 4 shader engines of an XCD, so any mask that is not a multiple of 32
+// CUs runs at the speed of the emptiest shader engine: -15 % on LayerNorm, -35 % on the persistent GEMM at 248 of 256 CUs.)
+static hipStream_t g_budget_stream[16];
+static int g_budget_cus[16];
+static int g_budget_n = 0;
+
+static int device_cus() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (ncu <= 0) ncu = 256;
+    }
+    return ncu;
+}
+
+// Number of workgroups a one-per-CU persistent kernel launches on this stream.
+int hh_stream_cu_count(hipStream_t s) {
+    for (int i = 0; i < g_budget_n; ++i)
+        if (g_budget_stream[i] == s) return g_budget_cus[i];
+    return device_cus();
+}
+
+extern "C" int hh_stream_set_cu_budget(hh_stream_t stream, int n_cus) {
+    const int ncu = device_cus();
+    if (n_cus == 0) n_cus = ncu;
+    if (n_cus < 8 || n_cus > ncu || n_cus % 8) {
+        hh_set_error("hh_stream_set_cu_budget: n_cus = %d must be 0 or a multiple of 8 in [8, %d]", n_cus, ncu);
+        return HH_ERR_SHAPE;
+    }
+    for (int i = 0; i < g_budget_n; ++i)
+        if (g_budget_stream[i] == (hipStream_t)stream) { g_budget_cus[i] = n_cus; return HH_OK; }
+    if (g_budget_n == 16) { hh_set_error("hh_stream_set_cu_budget: more than 16 budgeted streams"); return HH_ERR_UNSUPPORTED; }
+    g_budget_stream[g_budget_n] = (hipStream_t)stream;
+    g_budget_cus[g_budget_n++] = n_cus;
+    return HH_OK;
+}
+
+extern "C" int hh_stream_get_cu_budget(hh_stream_t stream, int* out) {
+    if (!out) { hh_set_error("hh_stream_get_cu_budget: null out"); return HH_ERR_SHAPE; }
+    *out = hh_stream_cu_count((hipStream_t)stream);
+    return HH_OK;
+}

@@ -46,6 +46,19 @@ def set_tuning(name, value):
     _lib.check(_lib.lib().hh_set_tuning(name.encode(), int(value)), "hh_set_tuning")
 
 
+def set_stream_cu_budget(stream, n_cus):
+    """Persistent one-workgroup-per-CU kernels launched on `stream` use `n_cus` workgroups (0 = all CUs); include/hh.h:
+    hh_stream_set_cu_budget."""
+    _lib.check(_lib.lib().hh_stream_set_cu_budget(ctypes.c_void_p(stream.cuda_stream), int(n_cus)), "hh_stream_set_cu_budget")
+
+
+def stream_cu_budget(stream=None):
+    s = torch.cuda.current_stream() if stream is None else stream
+    n = ctypes.c_int()
+    _lib.check(_lib.lib().hh_stream_get_cu_budget(ctypes.c_void_p(s.cuda_stream), ctypes.byref(n)), "hh_stream_get_cu_budget")
+    return n.value
+
+
 def layernorm(x, gamma, beta, eps, out_dtype=torch.bfloat16, save_stats=False):
     """LayerNorm over the last dim; x fp32/bf16 [..., cols] -> out_dtype."""
     _chk(x, gamma, beta)

@@ -7,6 +7,8 @@ hand/object box losses with on-device Hungarian matching (HIP) + word loss + gra
 fused AdamW (HIP).  bf16 compute, fp32 accumulation / master weights, no GradScaler.
 No host synchronisation inside the step: every scalar in the returned dict is a device tensor.
 """
+import os
+
 import torch
 
 from . import ops
@@ -27,7 +29,7 @@ def build_criterion():
 
 class TrainStep:
     def __init__(self, cfg, backbone, decoder, lr=3e-5, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8,
-                 bucket_bytes=16 << 20, fast_heads=True):
+                 bucket_bytes=16 << 20, fast_heads=True, enc_cus=None):
         self.cfg, self.backbone, self.decoder = cfg, backbone, decoder
         self.criterion = build_criterion().to(next(decoder.parameters()).device)
         self.nce, self.word = EgoNCE(), WordContrastiveLoss()
@@ -40,6 +42,8 @@ class TrainStep:
         self.iteration = 0
         self._text_stream = None
         self.enc_stream = None
+        # CU budget of the persistent GEMMs on the pipelined encoder stream (0 = all CUs); see prefetch()
+        self.enc_cus = int(os.environ.get("HH_ENC_CUS", "0")) if enc_cus is None else int(enc_cus)
         self._pending = None
         backbone.eval()                               # run/train.py:89
 
@@ -71,6 +75,8 @@ class TrainStep:
         13-row query-side kernels leave most CUs idle).  The result is picked up by the next step(batch)."""
         if self.enc_stream is None:
             self.enc_stream = torch.cuda.Stream()
+            if self.enc_cus > 0:
+                ops.set_stream_cu_budget(self.enc_stream, self.enc_cus)
         main = torch.cuda.current_stream()
         self.enc_stream.wait_stream(main)
         with torch.cuda.stream(self.enc_stream):

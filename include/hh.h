@@ -35,6 +35,14 @@ int hh_version(void);
 int hh_set_tuning(const char* name, int value);
 const char* hh_last_error_string(void);
 
+/* Per-stream CU budget for the software-pipelined step (the reference's step, run/train.py:103-203, runs the frozen towers
+ * and the decoder back to back on one stream; here they overlap on two streams).  One-workgroup-per-CU persistent kernels
+ * (the 256x256 GEMM) launched on `stream` use n_cus workgroups instead of one per CU of the device, which leaves the other CUs
+ * to kernels of concurrent streams.  n_cus % 8 == 0 (one XCD-balanced slice); 0 restores the default (all CUs).  Never
+ * changes results. */
+int hh_stream_set_cu_budget(hh_stream_t stream, int n_cus);
+int hh_stream_get_cu_budget(hh_stream_t stream, int* out);
+
 /* ---- LayerNorm over the last dim (model/LaviLa.py:439,456 eps 1e-6 / 1e-5; tfm_decoder.py:57,375-377)
  * y[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta ; x dtype / y dtype in {HH_F32, HH_BF16}; gamma/beta fp32.
  * cols % 8 == 0 and cols <= 2048.

@@ -199,6 +199,22 @@ def test_divided_attention(mode, B, T, n, heads):
     assert (err / scale).max() < 5e-2
 
 
+@pytest.mark.parametrize("B,T,n,heads", [(2, 4, 50, 2), (1, 16, 37, 1), (2, 8, 96, 3), (1, 1, 70, 2), (1, 2, 5, 1), (3, 16, 256, 2)])
+def test_time_attention_ragged_patch_counts(B, T, n, heads):
+    """The MFMA time kernel packs 16/T patch locations per 16-row tile and 128/T per wave: patch counts that are not
+    multiples of either (partly empty tiles, clamped rows), block-diagonal masking for T < 16, several CLS records."""
+    N, D = 1 + T * n, heads * 64
+    qkv = rnd(B * N, 3 * D, seed=100 + T + n)
+    qkv[:, :D] *= 0.6
+    qkv[N - 1, :64] += 5.0
+    qkv = bf(qkv)
+    out = ops.divided_attention(qkv.to(DEV), B, T, n, heads, "time")
+    ref = _ref_divided(qkv, B, T, n, heads, "time")
+    assert_close_bf16(out, ref, 1.2e-2, "attn-time-ragged")
+    err = (out.float().cpu() - ref).abs().amax(1)
+    assert (err / (ref.abs().amax(1) + 1e-3)).max() < 5e-2
+
+
 @pytest.mark.parametrize("B,Q,M,heads", [(2, 13, 4096, 8), (3, 5, 1024, 8), (1, 16, 96, 2)])
 def test_xattn_fwd_bwd(B, Q, M, heads):
     C = heads * 64
