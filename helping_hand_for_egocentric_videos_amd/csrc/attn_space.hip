@@ -9,12 +9,15 @@
 //   O^T = V^T . P^T    the S^T accumulator tile is re-used as the B operand with no lane movement
 //                      (k order inside a step: row 16s + 8(j>>2) + 4h + (j&3)); A = V^T fragments fetched from the
 //                      row-major V tile by the hardware-transposing ds_read_b64_tr_b16
-// Keys are processed in chunks of CH=5 tiles (160 keys) with an online-softmax merge between chunks, so n=576
+// Keys are processed in chunks of CH=5 tiles (160 keys; CH = 4 / 6 / 8 measured slower: 433 / 441 / 487 us vs 418 us, 8 spills)
+// with an online-softmax merge between chunks, so n=576
 // (336^2) runs through the same code.  Frame keys sit at rows 0..n-1, the CLS key at row n, rows > n are zero/masked.
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef CH
 #define CH 5
+#endif
 #define NW 4            // waves per workgroup
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -41,86 +44,125 @@ __device__ __forceinline__ bf16x4 lds_tr4(const char* addr) {
 __device__ __forceinline__ int kswz(int r) { return (r ^ (r >> 3)) & 7; }
 __device__ __forceinline__ int vswz(int r) { return ((r >> 1) & 1) << 2; }
 
-// One 32-query block of one (clip, frame, head) problem: S^T = K.Q^T, online softmax over CH-tile chunks, O^T = V^T.P^T.
-__device__ __forceinline__ void space_query_block(const char* Ks, const char* Vs, const bf16x8 (&qf)[4], bf16_t* orow, int n, int ntiles, int lane) {
+// One chunk of key tiles for one 32-query block: NTC full 32-key tiles starting at tile t0 and, if CLS, the tile that holds
+// nothing but the CLS key (n % 32 == 0: key n is row 0 of tile n/32).  Everything is unrolled and unguarded: no zero-filled
+// accumulators (the first MFMA of a tile takes a constant-zero C), no per-register key masks (the CLS tile contributes ONE
+// score, register 0 of the h = 0 half-wave, and ONE k-slot of one PV step), no empty tile slots.  The guarded predecessor
+// spent 1420 VALU instructions per query block (SQ_INSTS_VALU), ~60 % of the SIMD issue time of the whole kernel.
+template <int NTC, bool CLS>
+__device__ __forceinline__ void space_chunk(const char* Ks, const char* Vs, const bf16x8 (&qf)[4], int t0, int lane,
+                                            f32x16& o0, f32x16& o1, float& m_run, float& l_run) {
     const int ql = lane & 31, h = lane >> 5;
     const float LOG2E = 1.4426950408889634f;
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+    f32x16 z16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z16[r] = 0.f;
+    f32x16 s[NTC > 0 ? NTC : 1];
+#pragma unroll
+    for (int ti = 0; ti < NTC; ++ti) {
+        const int krow = (t0 + ti) * 32 + ql;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + h;
+            bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + ((c ^ kswz(krow)) << 4));
+            s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? z16 : s[ti], 0, 0, 0);
+        }
+    }
+    float xc = -INFINITY;
+    if (CLS) {
+        const int krow = (t0 + NTC) * 32 + ql;
+        f32x16 sc = z16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + h;
+            bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + ((c ^ kswz(krow)) << 4));
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
+        }
+        xc = h == 0 ? sc[0] : -INFINITY;                  // key n = tile row 0 = register 0 of the lower half-wave
+    }
+    float mx = xc;
+#pragma unroll
+    for (int ti = 0; ti < NTC; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[ti][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+    const float mb = m_new * LOG2E;
+    float lsum = 0.f;
+#pragma unroll
+    for (int ti = 0; ti < NTC; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(s[ti][r] * LOG2E - mb);
+            s[ti][r] = pv;
+            lsum += pv;
+        }
+    float pc = 0.f;
+    if (CLS) {
+        pc = __builtin_amdgcn_exp2f(xc * LOG2E - mb);     // 0 in the upper half-wave
+        lsum += pc;
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    // O^T += V^T . P^T ; A operand element j of lane (d, h) = V[key0 + 8(j>>2) + (j&3)][d], key0 = 32 tile + 16 st + 4 h
+    auto vfrag = [&](int kb, int dt) -> bf16x8 {
+        const int col = 32 * dt + 16 * tg + 4 * tp;               // d column of this lane's address
+        const int ch = col >> 3, sub = (col & 7) * 2;
+        bf16x4 a0 = lds_tr4(Vs + kb * 128 + ((ch ^ vswz(kb)) << 4) + sub);
+        bf16x4 a1 = lds_tr4(Vs + (kb + 8) * 128 + ((ch ^ vswz(kb + 8)) << 4) + sub);
+        return (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    };
+#pragma unroll
+    for (int ti = 0; ti < NTC; ++ti) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 pf;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)s[ti][8 * st + jj];
+            const int kb = (t0 + ti) * 32 + 16 * st + 4 * h + tq;            // this lane's address row (first 4-key group)
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(kb, 0), pf, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(kb, 1), pf, o1, 0, 0, 0);
+        }
+    }
+    if (CLS) {
+        const bf16x8 pf = {(bf16_t)pc, 0, 0, 0, 0, 0, 0, 0};      // k-slot 0 of h = 0 is key 32 tile + 0 = n
+        const int kb = (t0 + NTC) * 32 + 4 * h + tq;
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(kb, 0), pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(kb, 1), pf, o1, 0, 0, 0);
+    }
+}
+
+// One 32-query block of one (clip, frame, head) problem: S^T = K.Q^T, online softmax over CH-tile chunks, O^T = V^T.P^T.
+// nf = n / 32 full key tiles, followed by the CLS tile (which rides on the last chunk).
+__device__ __forceinline__ void space_query_block(const char* Ks, const char* Vs, const bf16x8 (&qf)[4], bf16_t* orow, int nf, int lane) {
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
-    for (int t0 = 0; t0 < ntiles; t0 += CH) {
-        f32x16 s[CH];
-#pragma unroll
-        for (int ti = 0; ti < CH; ++ti) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[ti][r] = 0.f;
-            if (t0 + ti < ntiles) {
-                const int krow = (t0 + ti) * 32 + ql;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int c = 2 * ks + h;
-                    bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + ((c ^ kswz(krow)) << 4));
-                    s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[ti], 0, 0, 0);
-                }
-            }
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int ti = 0; ti < CH; ++ti) {
-            if (t0 + ti >= ntiles - 1) {            // only the last key tile (and unused tile slots) hold keys > n
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = (t0 + ti) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key > n) s[ti][r] = -INFINITY;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[ti][r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-        const float mb = m_new * LOG2E;
-        float lsum = 0.f;
-#pragma unroll
-        for (int ti = 0; ti < CH; ++ti)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(s[ti][r] * LOG2E - mb);
-                s[ti][r] = pv;
-                lsum += pv;
-            }
-        lsum += __shfl_xor(lsum, 32, 64);
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        // O^T += V^T . P^T ; A operand element j of lane (d, h) = V[key0 + 8(j>>2) + (j&3)][d], key0 = 32 tile + 16 st + 4 h
-#pragma unroll
-        for (int ti = 0; ti < CH; ++ti) {
-            if (t0 + ti < ntiles) {
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    bf16x8 pf;
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)s[ti][8 * st + jj];
-                    const int kb = (t0 + ti) * 32 + 16 * st + 4 * h + tq;            // this lane's address row (first 4-key group)
-                    bf16x8 vf[2];
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const int col = 32 * dt + 16 * tg + 4 * tp;               // d column of this lane's address
-                        const int ch = col >> 3, sub = (col & 7) * 2;
-                        bf16x4 a0 = lds_tr4(Vs + kb * 128 + ((ch ^ vswz(kb)) << 4) + sub);
-                        bf16x4 a1 = lds_tr4(Vs + (kb + 8) * 128 + ((ch ^ vswz(kb + 8)) << 4) + sub);
-                        vf[dt] = (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                    }
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pf, o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pf, o1, 0, 0, 0);
-                }
-            }
-        }
+    int t0 = 0;
+    for (; t0 + CH < nf; t0 += CH) space_chunk<CH, false>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run);
+    switch (nf - t0) {                                        // 1 .. CH tiles left (nf >= 1), plus the CLS tile
+        case 1: space_chunk<1, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
+        case 2: space_chunk<2, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
+        case 3: space_chunk<3, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
+#if CH >= 5
+        case 4: space_chunk<4, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
+#endif
+#if CH >= 6
+        case 5: space_chunk<5, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
+#endif
+#if CH >= 7
+        case 6: space_chunk<6, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
+#endif
+#if CH >= 8
+        case 7: space_chunk<7, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
+#endif
+        default: space_chunk<CH, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
     }
     const float inv = 1.f / l_run;
 #pragma unroll
@@ -238,7 +280,7 @@ __global__ __launch_bounds__(64 * NW, 2) void space_attn_kernel(const bf16_t* __
         const bf16_t* qrow = q_ptr + (int64_t)(qb * 32 + ql) * ld + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
-        space_query_block(Ks, Vs, qf, out + ((int64_t)b * N + 1 + f * n + qb * 32 + ql) * D + head * 64 + 4 * h, n, KP >> 5, lane);
+        space_query_block(Ks, Vs, qf, out + ((int64_t)b * N + 1 + f * n + qb * 32 + ql) * D + head * 64 + 4 * h, n >> 5, lane);
     }
     if (cls_partial == nullptr) return;
     space_cls_partial<NW>(Ks, Vs, scratch, KP, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
@@ -300,7 +342,7 @@ __global__ __launch_bounds__(64 * NWP, 2) void space_attn_persistent_kernel(cons
             space_stage<NWP>(Kn, Kn + (size_t)KP * 128, nb, nq, ld, D, n, KP, lane, wave);
         }
         if (has_q)
-            space_query_block(Ks, Vs, qf, out + ((int64_t)b * N + 1 + f * n + wave * 32 + ql) * D + head * 64 + 4 * h, n, KP >> 5, lane);
+            space_query_block(Ks, Vs, qf, out + ((int64_t)b * N + 1 + f * n + wave * 32 + ql) * D + head * 64 + 4 * h, n >> 5, lane);
         if (cls_partial != nullptr)
             space_cls_partial<NWP>(Ks, Vs, scratch, KP, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0,
                                    tid, lane, wave);
