@@ -6,7 +6,7 @@ import os
 import torch  # noqa: F401  -- must be imported BEFORE libhh.so so that both share torch's HIP runtime (libamdhip64)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhh.so")
+LIB_PATH = os.environ.get("HH_LIBHH_PATH") or os.path.join(HERE, "libhh.so")      # override: A/B runs of two builds in one session
 
 c_i64, c_int, c_float, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -22,6 +22,7 @@ SIGNATURES = {
     "hh_version": [],
     "hh_last_error_string": [],
     "hh_set_tuning": [ctypes.c_char_p, c_int],
+    "hh_debug_gemm_timeline": [c_vp, c_int],
     "hh_stream_set_cu_budget": [c_vp, c_int],
     "hh_stream_get_cu_budget": [c_vp, ctypes.POINTER(c_int)],
     "hh_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_float, c_vp],

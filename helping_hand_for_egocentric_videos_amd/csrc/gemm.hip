@@ -170,6 +170,7 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     p.skew_iters = 0;
     p.group_m = 4;
     p.debug_nostore = 0;
+    p.debug_ts = 0;
     if (hh_gemm256_eligible(p)) {
         // full 256-row tiles on the 8-phase kernel; the (< 256)-row remainder on the 128x128 kernel so that it does not
         // cost a whole extra round of 256x256 blocks (M = B*4097 is never a multiple of 256)

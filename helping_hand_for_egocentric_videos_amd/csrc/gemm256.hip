@@ -249,6 +249,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 // vmcnt retires in order and the stores are younger than that prologue, the waits of the next tile's first k-tile are
 // counted as vmcnt(N + STORES) and pass without waiting for the store drain.  Requires full tiles, no residual / row remap
 // (no other VMEM instruction may sit between prologue and stores) and K >= 128.
+// debug timeline (hh_set_tuning("gemm256_debug_ts", 1)): s_memrealtime (100 MHz) of wave 0 at 5 points of the first 8 tiles of
+// every workgroup; read back with hh_debug_gemm_timeline
+#define TS_TILES 8
+__device__ unsigned long long g_gemm_ts[512 * TS_TILES * 7];       // 5 x s_memrealtime + s_memtime at stamps 1, 2
+
 template <bool OUT_BF16>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmParams p) {
     constexpr bool STAGGER = true;
@@ -303,9 +308,25 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmParams p) {
         stage(SLOT_BLO, 0, 0); stage(SLOT_ALO, 0, 0); stage(SLOT_BHI, 0, 0); stage(SLOT_AHI, 0, 0);
         stage(SLOT_BLO, 1, 1); stage(SLOT_ALO, 1, 1); stage(SLOT_BHI, 1, 1); stage(SLOT_AHI, 1, 1);
     };
+    // the whole bias vector lives in the LDS left over by the two staging buffers (N <= 8192): the epilogue used to fetch its
+    // 16 bias values from global memory and stall on vmcnt(0) (~1.5 us per tile) before it could issue the next prologue
+    float* bias_s = (float*)(smem + 2 * BUF_BYTES);
+    for (int i = tid * 4; i < p.N; i += 512 * 4)
+        *(f32x4*)(bias_s + i) = p.e.bias ? *(const f32x4*)(p.e.bias + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    BARRIER();
     set_src(m0, n0);
     prologue();
     bool first = true;
+    int tile_i = 0;
+    auto stamp = [&](int k) {
+        if (p.debug_ts && tid == 0 && tile_i < TS_TILES && blockIdx.x < 512)
+        {
+            unsigned long long* r = g_gemm_ts + ((int)blockIdx.x * TS_TILES + tile_i) * 7;
+            r[k] = __builtin_amdgcn_s_memrealtime();
+            if (k == 1 || k == 2) r[4 + k] = __builtin_amdgcn_s_memtime();
+        }
+    };
 
     // ---- fragment read offsets inside a half-tile: row = base + (lane & 15), chunk = ks*4 + (lane >> 4)
     const int frow = lane & 15, fq = lane >> 4;
@@ -337,12 +358,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmParams p) {
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) acc[a][c][d][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        stamp(0);
         // k-tile 0 of this tile has landed (the previous tile's stores, if any, are younger than the whole prologue)
         if (first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (OUT_BF16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");       // 8 + STORES
         else asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
         BARRIER();
         if (STAGGER && wr == 1) BARRIER();
+        stamp(1);
 
         for (int t = 0; t < nk; ++t) {
             const int cur = t & 1;
@@ -409,25 +432,24 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmParams p) {
             BARRIER();
         }
         if (STAGGER && wr == 0) BARRIER();
+        stamp(2);
 
         // ---- epilogue of tile (m0, n0).  Bias is fetched and waited for FIRST; then the next tile's prologue is issued;
         // then exactly STORES store instructions per wave and nothing else.
         const hh_gemm_epilogue& e = p.e;
         const int ncol = n0 + wc * 32 + 8 * fq;
-        f32x4 bias_v[2][2];
+        f32x4 bias_v[2][2];                    // from the LDS copy: no VMEM instruction, no vmcnt stall in front of the prologue
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {
-            bias_v[nh][0] = e.bias ? *(const f32x4*)(e.bias + ncol + nh * 128) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            bias_v[nh][1] = e.bias ? *(const f32x4*)(e.bias + ncol + nh * 128 + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            bias_v[nh][0] = *(const f32x4*)(bias_s + ncol + nh * 128);
+            bias_v[nh][1] = *(const f32x4*)(bias_s + ncol + nh * 128 + 4);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // bias landed (and every older store / load retired)
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh) { asm volatile("" : "+v"(bias_v[nh][0]), "+v"(bias_v[nh][1])); }
         const int nv = next_valid(v + gridDim.x, nm0, nn0);
         if (nv >= 0) {
             set_src(nm0, nn0);
             prologue();
         }
+        stamp(3);
         char* Cbase = (char*)p.C;
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
@@ -455,6 +477,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmParams p) {
                     }
                 }
             }
+        stamp(4);
+        ++tile_i;
         if (nv < 0) break;
         v = nv; m0 = nm0; n0 = nn0;
         first = false;
@@ -462,6 +486,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmParams p) {
 #undef MFMA_QUAD
 }
 
+static int g_debug_ts = 0;         // debug: record the per-tile timeline of the persistent kernel
 static int g_nostore = 0;          // debug: skip the epilogue stores (timing experiments only)
 static int g_group = 8;            // m-tiles per XCD-local group (weight-panel reuse factor)
 static int g_skew = -1;            // start skew: -1 auto (on when the epilogue carries an fp32 residual), 0 off, 1 on
@@ -478,10 +503,13 @@ extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm256")) { g_mode = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_skew")) { g_skew = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_debug_nostore")) { g_nostore = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm256_debug_ts")) { g_debug_ts = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_group") && value >= 1 && value <= 64) { g_group = value; return HH_OK; }
     hh_set_error("hh_set_tuning: unknown knob '%s'", name ? name : "(null)");
     return HH_ERR_UNSUPPORTED;
 }
+
+#define P_LDS(N) (2 * BUF_BYTES + (size_t)(N) * 4)       // persistent kernel: two staging buffers + the bias vector
 
 bool hh_gemm256_eligible(const GemmParams& p) {
     return gemm256_mode() > 0 && p.N % 256 == 0 && p.M >= 2048 && p.e.splitk <= 1;
@@ -499,8 +527,8 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
     const int stagger = gemm256_mode() != 1;
     static bool attr_p = false;
     if (!attr_p) {
-        hipFuncSetAttribute((const void*)gemm256p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
-        hipFuncSetAttribute((const void*)gemm256p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192));
+        hipFuncSetAttribute((const void*)gemm256p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192));
         attr_p = true;
     }
     GemmParams p = pin;
@@ -515,16 +543,17 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
     const int GROUP = g_group;
     p.group_m = GROUP;
     p.debug_nostore = g_nostore;
+    p.debug_ts = g_debug_ts;
     const int per_xcd_mt = (p.Mt + 7) / 8;
     const int groups = (per_xcd_mt + GROUP - 1) / GROUP;
     const unsigned grid = 8u * (unsigned)groups * GROUP * (unsigned)p.Nt;
     const bool bf = p.e.c_dtype == HH_BF16;
-    if (gemm256_mode() == 3 && p.e.resid == nullptr && p.e.remap_group == 0 && p.K >= 128 && p.M % 256 == 0 && !g_nostore) {
+    if (gemm256_mode() == 3 && p.e.resid == nullptr && p.e.remap_group == 0 && p.K >= 128 && p.M % 256 == 0 && p.N <= 8192 && !g_nostore) {
         const int ncu = hh_stream_cu_count(s) & ~7;          // CU budget of this stream; the stride of the tile walk must keep blockIdx & 7 == XCD
         const unsigned pg = grid < (unsigned)ncu ? grid : (unsigned)ncu;
         p.skew_iters = 0;
-        if (bf) hipLaunchKernelGGL((gemm256p_kernel<true>), dim3(pg), dim3(512), 2 * BUF_BYTES, s, p);
-        else hipLaunchKernelGGL((gemm256p_kernel<false>), dim3(pg), dim3(512), 2 * BUF_BYTES, s, p);
+        if (bf) hipLaunchKernelGGL((gemm256p_kernel<true>), dim3(pg), dim3(512), P_LDS(p.N), s, p);
+        else hipLaunchKernelGGL((gemm256p_kernel<false>), dim3(pg), dim3(512), P_LDS(p.N), s, p);
         return hh_check_launch("hh_gemm_bf16(256x256 persistent)");
     }
     if (stagger) {
@@ -535,4 +564,12 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
         else hipLaunchKernelGGL((gemm256_kernel<false, false>), dim3(grid), dim3(512), 2 * BUF_BYTES, s, p);
     }
     return hh_check_launch("hh_gemm_bf16(256x256)");
+}
+
+// debug: copy the timeline of the last persistent launch (hh_set_tuning("gemm256_debug_ts", 1)); out[blocks][8 tiles][7]: 5 stamps + shader-clock counter at stamps 1 and 2
+extern "C" int hh_debug_gemm_timeline(unsigned long long* out, int blocks) {
+    HH_REQUIRE(out != nullptr && blocks > 0 && blocks <= 512, HH_ERR_SHAPE, "hh_debug_gemm_timeline: bad arguments");
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_ts), sizeof(unsigned long long) * (size_t)blocks * TS_TILES * 7);
+    HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_debug_gemm_timeline: %s", hipGetErrorString(e));
+    return HH_OK;
 }

@@ -9,6 +9,7 @@ struct GemmParams {
     int64_t M; int N; int K;
     int Mt, Nt;
     int debug_nostore;        // timing experiments only
+    int debug_ts;             // persistent 256x256 kernel: record the per-tile timeline (debug)
     int group_m;              // 256x256 kernel: m-tiles per XCD-local group
     int skew_iters;           // 256x256 kernel: start-time skew quantum (0 = off)
     int64_t m_start;          // first row handled by this launch (rows [m_start, M) are tiled)

@@ -34,6 +34,11 @@ int hh_version(void);
  * (start-time skew of the first round of 256x256 blocks, spreads the epilogue HBM bursts). */
 int hh_set_tuning(const char* name, int value);
 const char* hh_last_error_string(void);
+/* Debug only: after hh_set_tuning("gemm256_debug_ts", 1), every persistent 256x256 GEMM launch records, for the first 8 tiles of
+ * each workgroup, the 100 MHz timestamps {tile start, k-tile 0 landed, main loop done, next prologue issued, stores issued};
+ * this copies them to host memory: out[blocks][8][7] (entries 5, 6: s_memtime at stamps 1, 2 -> shader clock during the
+ * main loop). */
+int hh_debug_gemm_timeline(unsigned long long* out, int blocks);
 
 /* Per-stream CU budget for the software-pipelined step (the reference's step, run/train.py:103-203, runs the frozen towers
  * and the decoder back to back on one stream; here they overlap on two streams).  One-workgroup-per-CU persistent kernels

@@ -1,0 +1,66 @@
+#!/bin/bash
+# Regenerates the committed profile summaries on the GPU box (run through gpurun; copy gpurun_out/profiles_new/* to profiles/):
+#   1. rocprofv3 --kernel-trace --stats of the default pipelined bench      -> <tag>_bench_kernel_stats.csv, <tag>_summary.md
+#   2. same for the un-pipelined step (durations not inflated by overlap)   -> <tag>_unpipelined_kernel_stats.csv
+#   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)            -> <tag>_pmc_summary.{md,json}
+TAG=${1:-r1_final}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/profiles_new
+mkdir -p $OUT
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-kernel-timers"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_p -- $BENCH --steps 3 --warmup 2 > $OUT/${TAG}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_u -- $BENCH --steps 3 --warmup 2 --no-pipeline > $OUT/${TAG}_bench_unpipelined.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- $BENCH --steps 1 --warmup 1 --no-pipeline > $OUT/${TAG}_pmc_$c.log 2>&1
+done
+TAG=$TAG python3 - <<'PY'
+import csv, glob, json, os, collections
+R, TAG = os.environ["GRAFT_REPO_ROOT"], os.environ["TAG"]
+OUT = R + "/gpurun_out/profiles_new/"
+def stats(d, dst, title, cmd, note):
+    f = glob.glob(R + "/gpurun_out/%s/**/*kernel_stats.csv" % d, recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    open(OUT + dst + "_kernel_stats.csv", "w").write(open(f).read())
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    L = ["# %s -- rocprofv3 --kernel-trace --stats of `%s`" % (title, cmd), "", note % (tot / 1e6, tot / 5e6), "",
+         "| kernel | calls | total ms | avg us | % of kernel time |", "|---|---|---|---|---|"]
+    for r in rows[:24]:
+        L.append("| %s | %s | %.2f | %.1f | %.1f |" % (r["Name"][:96].replace("|", "/"), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                    float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+    return L
+L = stats("prof_p", TAG + "_bench", "Round 1, final build", "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timers",
+          "MI355X, B = 32 clips, config 2 (16-frame 224p, nq=12), software-pipelined step, 5 steps profiled (2 warm-up + 3 timed).\nSum of kernel durations %.1f ms over 5 steps = %.1f ms/step (kernels of the encoder stream and of the decoder stream overlap, so this sum exceeds the wall time per step).")
+L += [""] + stats("prof_u", TAG + "_unpipelined", "Same build, un-pipelined step", "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-pipeline",
+                  "Every kernel runs alone on the chip here, so the averages are the isolated kernel durations.\nSum of kernel durations %.1f ms over 5 steps = %.1f ms/step.")
+open(OUT + TAG + "_summary.md", "w").write("\n".join(L) + "\n")
+# ---- PMC
+val = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    agg, cnt = collections.defaultdict(float), collections.defaultdict(int)
+    for f in glob.glob(R + "/gpurun_out/pmc_%s/**/*counter_collection.csv" % c, recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == c:
+                agg[row["Kernel_Name"]] += float(row["Counter_Value"]); cnt[row["Kernel_Name"]] += 1
+    val[c] = (agg, cnt)
+names = [k for k in val["FETCH_SIZE"][0] if any(t in k for t in ("gemm", "attn", "ln_", "add_ln", "xattn", "transpose", "embed", "im2col"))]
+js, rows = {}, []
+for k in names:
+    n = val["FETCH_SIZE"][1][k]
+    fetch = 2.0 * val["FETCH_SIZE"][0][k] * 1024.0            # KiB, x2: gfx950 FETCH_SIZE correction (MI355X_MICROARCH.md)
+    write = val["WRITE_SIZE"][0].get(k, 0.0) * 1024.0
+    js[k] = {"launches": n, "fetch_bytes_corrected": int(fetch / n), "write_bytes": int(write / n), "traffic_bytes_per_launch": int((fetch + write) / n)}
+    rows.append((fetch + write, "| %s | %d | %.1f | %.1f | %.1f |" % (k[:80].replace("|", "/"), n, fetch / n / 2**20, write / n / 2**20, (fetch + write) / n / 2**20)))
+json.dump(js, open(OUT + TAG + "_pmc_summary.json", "w"), indent=1)
+M = ["# Round 1 (final build) -- HBM-side traffic from PMC counters (rocprofv3 --pmc, separate passes)", "",
+     "Commands (one counter per pass, as MI355X_MICROARCH.md prescribes):", "",
+     "    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_FETCH_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-pipeline",
+     "    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-pipeline", "",
+     "Units/corrections: counter values are KiB; on gfx950 FETCH_SIZE reports exactly 1/2 of wide coalesced streaming reads -> doubled below; WRITE_SIZE is exact.",
+     "The counters sit on the L2's fabric side, so Infinity-Cache hits are included.  Per-launch averages, B = 32 clips, config 2.", "",
+     "| kernel | launches | fetch (corrected) MiB | write MiB | traffic / launch MiB |", "|---|---|---|---|---|"]
+M += [r for _, r in sorted(rows, reverse=True)]
+open(OUT + TAG + "_pmc_summary.md", "w").write("\n".join(M) + "\n")
+print("\n".join(M[-len(rows):]))
+PY
+ls -la $OUT
