@@ -11,6 +11,7 @@
 // Block order is XCD-aware: blockIdx % 8 selects the XCD-local stream; each XCD walks groups of 8 m-tiles x all
 // n-tiles so an A tile is re-used from that XCD's L2 across its n-tiles.
 #include "gemm_common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -151,6 +152,91 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void gemm_bf16_kernel(Gem
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-tail kernel: the <= 64 rows that do not fill a 256-row tile of the persistent kernel (M = B*4097 always leaves B mod 256
+// CLS-ish rows; 168 such launches per step).  The 128x128 kernel walks K serially (16-64 barrier-separated k-tiles: 16-64 us of
+// a nearly idle chip per launch); here a workgroup owns 64 rows x 64 columns and its 4 waves SPLIT K four ways, each streaming
+// its operands from global memory directly in MFMA layout (v_mfma_f32_32x32x16_bf16: lane = row / column, 8 consecutive k per
+// lane = one 16-B load; no LDS staging, no barrier in the k loop), then the partial accumulators meet in LDS and wave w
+// finishes output tile w with the common epilogue.
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void gemm_tail_kernel(GemmParams p) {
+    __shared__ float red[4 * 4 * 16 * 64];                       // [wave][tile][reg][lane] = 64 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 64;
+    const int kslice = p.K / 4;                                   // K % 64 == 0 -> multiple of 16
+    const int k_begin = wave * kslice;
+    const bf16_t* ap[2];
+    const bf16_t* wp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int64_t gm = p.m_start + i * 32 + l31;
+        if (gm > p.M - 1) gm = p.M - 1;
+        ap[i] = p.A + gm * p.lda + k_begin + 8 * h;
+        wp[i] = p.W + (int64_t)(n0 + i * 32 + l31) * p.ldw + k_begin + 8 * h;
+    }
+    f32x16 acc[2][2];                                             // [nt][mt]: C^T tiles (rows = n, columns = m)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int k = 0; k < kslice; k += 64) {                        // 4 k-steps of 16 per iteration: 16 independent 16-B loads in flight
+        bf16x8 af[4][2], wf[4][2];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[s][i] = *(const bf16x8*)(ap[i] + k + 16 * s);
+                wf[s][i] = *(const bf16x8*)(wp[i] + k + 16 * s);
+            }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][nt], af[s][mt], acc[nt][mt], 0, 0, 0);
+    }
+    // ---- cross-wave reduction: wave w finishes tile w = (nt = w >> 1, mt = w & 1)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave * 4 + nt * 2 + mt) * 16 + r) * 64 + lane] = acc[nt][mt][r];
+    __syncthreads();
+    const int nt = wave >> 1, mt = wave & 1;
+    f32x16 t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += red[((w * 4 + nt * 2 + mt) * 16 + r) * 64 + lane];
+        t[r] = v;
+    }
+    const int64_t m = p.m_start + mt * 32 + l31;
+    if (m >= p.M) return;
+    int64_t orow = m;
+    const hh_gemm_epilogue& e = p.e;
+    if (e.remap_group > 0) orow = m + (m / e.remap_group) * e.remap_skip + e.remap_offset;
+    char* Cbase = (char*)p.C;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                                 // accumulator register r: n = 8 (r >> 2) + 4 h + (r & 3)
+        const f32x4 v = {t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
+        gemm_store4<OUT_BF16>(e, Cbase, p.ldc, orow, n0 + nt * 32 + 8 * g + 4 * h, v);
+    }
+}
+
+static int gemm_tail_enabled() {            // HH_GEMM_TAIL=0 routes row tails back to the 128x128 kernel (A/B measurements)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("HH_GEMM_TAIL"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                             int64_t M, int N, int K, const hh_gemm_epilogue* epi, hh_stream_t stream) {
     HH_REQUIRE(epi != nullptr, HH_ERR_SHAPE, "hh_gemm_bf16: epilogue descriptor is NULL");
@@ -179,6 +265,12 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         int rc = hh_gemm256_launch(pm, (hipStream_t)stream);
         if (rc != HH_OK || pm.M == M) return rc;
         p.m_start = pm.M;
+    }
+    if (M - p.m_start <= 64 && K % 256 == 0 && epi->splitk <= 1 && gemm_tail_enabled()) {
+        // (< 64)-row tail of a tall GEMM, or a GEMM that is this short altogether: split-K-in-workgroup kernel
+        if (epi->c_dtype == HH_BF16) hipLaunchKernelGGL((gemm_tail_kernel<true>), dim3((unsigned)(N / 64)), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((gemm_tail_kernel<false>), dim3((unsigned)(N / 64)), dim3(256), 0, (hipStream_t)stream, p);
+        return hh_check_launch("hh_gemm_bf16(tail)");
     }
     p.Mt = (int)((M - p.m_start + BM - 1) / BM);
     p.Nt = N / BN;

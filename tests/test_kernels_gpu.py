@@ -77,7 +77,10 @@ def test_layernorm_bwd():
     torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("M,N,K", [(4097, 3072, 1024), (300, 128, 64), (8194, 1024, 4096), (1, 256, 128), (129, 384, 128)])
+@pytest.mark.parametrize("M,N,K", [(4097, 3072, 1024), (300, 128, 64), (8194, 1024, 4096), (1, 256, 128), (129, 384, 128),
+                                   # row tails of the persistent kernel / short GEMMs -> split-K-in-workgroup tail kernel (K % 256 == 0)
+                                   (4096 + 32, 1024, 1024), (2048 + 64, 128, 4096), (2048 + 1, 384, 768), (33, 256, 512), (64, 128, 256),
+                                   (2048 + 65, 256, 256), (2048 + 37, 256, 640)])
 def test_gemm_plain_and_epilogues(M, N, K):
     a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
     bias = rnd(N, seed=3)
