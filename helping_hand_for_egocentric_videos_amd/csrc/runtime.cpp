@@ -1,5 +1,6 @@
 // Host-side runtime bits of libhh: version, thread-local error string, launch check.
 #include "common.h"
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -32,6 +33,7 @@ extern "C" const char* hh_last_error_string(void) { return g_err; }
 static hipStream_t g_budget_stream[16];
 static int g_budget_cus[16];
 static int g_budget_n = 0;
+static std::mutex g_budget_mu;               // the table is the library's only mutable global state besides tuning knobs
 
 static int device_cus() {
     static int ncu = 0;
@@ -46,6 +48,7 @@ static int device_cus() {
 
 // Number of workgroups a one-per-CU persistent kernel launches on this stream.
 int hh_stream_cu_count(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_budget_mu);
     for (int i = 0; i < g_budget_n; ++i)
         if (g_budget_stream[i] == s) return g_budget_cus[i];
     return device_cus();
@@ -58,6 +61,7 @@ extern "C" int hh_stream_set_cu_budget(hh_stream_t stream, int n_cus) {
         hh_set_error("hh_stream_set_cu_budget: n_cus = %d must be 0 or a multiple of 8 in [8, %d]", n_cus, ncu);
         return HH_ERR_SHAPE;
     }
+    std::lock_guard<std::mutex> lk(g_budget_mu);
     for (int i = 0; i < g_budget_n; ++i)
         if (g_budget_stream[i] == (hipStream_t)stream) { g_budget_cus[i] = n_cus; return HH_OK; }
     if (g_budget_n == 16) { hh_set_error("hh_stream_set_cu_budget: more than 16 budgeted streams"); return HH_ERR_UNSUPPORTED; }
