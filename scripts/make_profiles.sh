@@ -14,6 +14,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_u -- 
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- $BENCH --steps 1 --warmup 1 --no-pipeline > $OUT/${TAG}_pmc_$c.log 2>&1
 done
+#   4. SQ pass: matrix-core / VALU busy cycles per kernel                   -> <tag>_sq_summary.md
+rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $R/gpurun_out/pmc_SQ -- $BENCH --steps 1 --warmup 1 --no-pipeline > $OUT/${TAG}_pmc_SQ.log 2>&1
 TAG=$TAG python3 - <<'PY'
 import csv, glob, json, os, collections
 R, TAG = os.environ["GRAFT_REPO_ROOT"], os.environ["TAG"]
@@ -62,5 +64,26 @@ M = ["# Round 1 (final build) -- HBM-side traffic from PMC counters (rocprofv3 -
 M += [r for _, r in sorted(rows, reverse=True)]
 open(OUT + TAG + "_pmc_summary.md", "w").write("\n".join(M) + "\n")
 print("\n".join(M[-len(rows):]))
+# ---- SQ counters: MFMA / VALU busy share per kernel
+agg, cnt = collections.defaultdict(lambda: collections.defaultdict(float)), collections.defaultdict(int)
+for f in glob.glob(R + "/gpurun_out/pmc_SQ/**/*counter_collection.csv", recursive=True):
+    seen = set()
+    for row in csv.DictReader(open(f)):
+        agg[row["Kernel_Name"]][row["Counter_Name"]] += float(row["Counter_Value"])
+        if row["Counter_Name"] == "SQ_BUSY_CU_CYCLES": cnt[row["Kernel_Name"]] += 1
+S = ["# Round 1 (final build) -- matrix-core and VALU utilisation per kernel (rocprofv3 --pmc, SQ counters, one pass)", "",
+     "    rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-pipeline", "",
+     "MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) (the rocprof-compute definition); VALU busy % = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / (4 x SQ_BUSY_CU_CYCLES);",
+     "MFMA flop = 512 x SQ_INSTS_VALU_MFMA_MOPS_BF16.  Per-launch averages, B = 32 clips, config 2.", "",
+     "| kernel | launches | MFMA busy % | VALU busy % | MFMA GFLOP / launch |", "|---|---|---|---|---|"]
+rows = []
+for k, c in agg.items():
+    if not any(t in k for t in ("gemm", "attn", "ln_", "add_ln", "xattn")) or c["SQ_BUSY_CU_CYCLES"] <= 0: continue
+    busy = 4.0 * c["SQ_BUSY_CU_CYCLES"]
+    rows.append((c["SQ_VALU_MFMA_BUSY_CYCLES"], "| %s | %d | %.1f | %.1f | %.1f |" % (k[:80].replace("|", "/"), cnt[k], 100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / busy,
+                 100 * 4.0 * c["SQ_ACTIVE_INST_VALU"] / busy, 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_BF16"] / max(cnt[k], 1) / 1e9)))
+S += [r for _, r in sorted(rows, reverse=True)]
+open(OUT + TAG + "_sq_summary.md", "w").write("\n".join(S) + "\n")
+print("\n".join(S[-len(rows):]))
 PY
 ls -la $OUT
