@@ -349,6 +349,178 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
     }
 }
 
+// T = 32 (BASELINE config 4): a patch location spans TWO 16-row tiles (frames 0-15 and 16-31); one wave owns 4 patch locations
+// (= 128 tokens = one CLS record, as above).  Scores are four 16x16 blocks per patch (2 key tiles x 2 query tiles); the PV
+// product of a query tile contracts over all 32 frame keys in ONE 16x16x32 MFMA (k-slots jj < 4 -> key row 4g+jj of tile 0,
+// jj >= 4 -> key row 16+4g+jj-4 of tile 1) and takes the CLS key in a second MFMA whose only non-zero k-slot is slot 0 of g = 0.
+__global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                               float* __restrict__ cls_partial, int B, int n, int heads) {
+    constexpr int T = 32, P = 4;
+    __shared__ __attribute__((aligned(16))) char Vsm[4 * 2 * 4096];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = heads * 64;
+    const int64_t ld = 3 * (int64_t)D;
+    const int N = 1 + T * n;
+    const int groups = (n + P - 1) / P;
+    int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    if (wid >= (int64_t)B * heads * groups) return;
+    const int pg = (int)(wid % groups); wid /= groups;
+    const int head = (int)(wid % heads);
+    const int b = (int)(wid / heads);
+    const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;
+    const int p0 = pg * P;
+    const int npatch = min(P, n - p0);
+    const int c = lane & 15, g = lane >> 4;
+    const float LOG2E = 1.4426950408889634f;
+    char* vbuf = Vsm + wave * 8192;
+    auto tok = [&](int u, int fr) -> int64_t { return 1 + (int64_t)fr * n + p0 + u; };
+    auto issue = [&](int u, bf16x8 (&qq)[2][2], bf16x8 (&kk)[2][2]) {
+        char* dst = vbuf + (u & 1) * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            tglds16(base + tok(u, (lane >> 3) + 8 * i) * ld + 2 * D + (lane & 7) * 8, dst + i * 1024);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const bf16_t* rp = base + tok(u, 16 * kt + c) * ld + 8 * g;
+            qq[kt][0] = *(const bf16x8*)(rp);
+            qq[kt][1] = *(const bf16x8*)(rp + 32);
+            kk[kt][0] = *(const bf16x8*)(rp + D);
+            kk[kt][1] = *(const bf16x8*)(rp + D + 32);
+        }
+    };
+    bf16x8 a2[2], qc[2];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kc = *(const bf16x8*)(base + D + 8 * g + 32 * ks);
+        a2[ks] = (c & 3) == 0 ? kc : zero8;
+        qc[ks] = *(const bf16x8*)(base + 8 * g + 32 * ks);
+    }
+    bf16_t vcls[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const bf16_t v = base[2 * D + 16 * (c >> 2) + 4 * dt + (c & 3)];
+        vcls[dt] = g == 0 ? v : (bf16_t)0.f;
+    }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    float mc = -INFINITY, lc = 0.f;
+    f32x4 accc[4] = {z4, z4, z4, z4};
+    const int trq = c >> 2, trp = c & 3;
+
+    auto compute = [&](int u, const bf16x8 (&q)[2][2], const bf16x8 (&k)[2][2]) {
+        const char* vb = vbuf + (u & 1) * 4096 + (4 * g + trq) * 128 + 32 * trp;
+        bf16x8 afk[4], afc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x4 t0 = tlds_tr4(vb + 8 * dt), t1 = tlds_tr4(vb + 16 * 128 + 8 * dt);
+            afk[dt] = (bf16x8){t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+            afc[dt] = (bf16x8){vcls[dt], 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0][0], q[qt][0], z4, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0][1], q[qt][1], s0, 0, 0, 0);
+            f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1][0], q[qt][0], z4, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1][1], q[qt][1], s1, 0, 0, 0);
+            f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], q[qt][0], z4, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1], q[qt][1], sc, 0, 0, 0);
+            float m = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            m = fmaxf(m, sc[0]);
+            const float mb = m * LOG2E;
+            float p[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p[j] = __builtin_amdgcn_exp2f(s0[j] * LOG2E - mb);
+                p[4 + j] = __builtin_amdgcn_exp2f(s1[j] * LOG2E - mb);
+            }
+            const float pc = __builtin_amdgcn_exp2f(sc[0] * LOG2E - mb);
+            float l = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            l += pc;
+            const float inv = __builtin_amdgcn_rcpf(l);
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)(p[j] * inv);
+            const bf16x8 pfc = {(bf16_t)(g == 0 ? pc * inv : 0.f), 0, 0, 0, 0, 0, 0, 0};
+            f32x4 o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afk[dt], pf, z4, 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afc[dt], pfc, o[dt], 0, 0, 0);
+            }
+            bf16_t* op = out + ((int64_t)b * N + tok(u, 16 * qt + c)) * D + head * 64 + 16 * g;
+            const u32x4 w0 = {pack_bf16(o[0][0], o[0][1]), pack_bf16(o[0][2], o[0][3]), pack_bf16(o[1][0], o[1][1]), pack_bf16(o[1][2], o[1][3])};
+            const u32x4 w1 = {pack_bf16(o[2][0], o[2][1]), pack_bf16(o[2][2], o[2][3]), pack_bf16(o[3][0], o[3][1]), pack_bf16(o[3][2], o[3][3])};
+            *(u32x4*)(op) = w0;
+            *(u32x4*)(op + 8) = w1;
+        }
+        if (cls_partial == nullptr) return;
+        f32x4 y0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0][0], qc[0], z4, 0, 0, 0);
+        y0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0][1], qc[1], y0, 0, 0, 0);
+        f32x4 y1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1][0], qc[0], z4, 0, 0, 0);
+        y1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1][1], qc[1], y1, 0, 0, 0);
+        float gm = fmaxf(fmaxf(fmaxf(y0[0], y0[1]), fmaxf(y0[2], y0[3])), fmaxf(fmaxf(y1[0], y1[1]), fmaxf(y1[2], y1[3])));
+        gm = fmaxf(gm, __shfl_xor(gm, 16, 64));
+        gm = fmaxf(gm, __shfl_xor(gm, 32, 64));
+        const bool first = pg == 0 && u == 0;
+        float yc = -INFINITY;
+        if (first) {
+            f32x4 s33 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], qc[0], z4, 0, 0, 0);
+            s33 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1], qc[1], s33, 0, 0, 0);
+            yc = s33[0];
+            gm = fmaxf(gm, yc);
+        }
+        const float m_new = fmaxf(mc, gm);
+        const float alpha = __builtin_amdgcn_exp2f((mc - m_new) * LOG2E);
+        const float mb3 = m_new * LOG2E;
+        float p3[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p3[j] = __builtin_amdgcn_exp2f(y0[j] * LOG2E - mb3);
+            p3[4 + j] = __builtin_amdgcn_exp2f(y1[j] * LOG2E - mb3);
+        }
+        const float p3c = first ? __builtin_amdgcn_exp2f(yc * LOG2E - mb3) : 0.f;
+        float ls = ((p3[0] + p3[1]) + (p3[2] + p3[3])) + ((p3[4] + p3[5]) + (p3[6] + p3[7]));
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        lc = lc * alpha + ls + p3c;
+        mc = m_new;
+        bf16x8 pf3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf3[j] = (bf16_t)p3[j];
+        const bf16x8 pf3c = {(bf16_t)(g == 0 ? p3c : 0.f), 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) accc[dt][j] *= alpha;
+            accc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afk[dt], pf3, accc[dt], 0, 0, 0);
+            if (first) accc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afc[dt], pf3c, accc[dt], 0, 0, 0);
+        }
+    };
+
+    bf16x8 qa[2][2], ka[2][2], qb[2][2], kb[2][2];
+    issue(0, qa, ka);
+    for (int u = 0; u < npatch; u += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (u + 1 < npatch) issue(u + 1, qb, kb);
+        compute(u, qa, ka);
+        if (u + 1 >= npatch) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (u + 2 < npatch) issue(u + 2, qa, ka);
+        compute(u + 1, qb, kb);
+    }
+    if (cls_partial != nullptr && c == 0) {
+        float* rec = cls_partial + (((int64_t)b * heads + head) * groups + pg) * CLS_REC;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *(f32x4*)(rec + 4 + 16 * g + 4 * dt) = accc[dt];
+        if (g == 0) { rec[0] = mc; rec[1] = lc; }
+    }
+}
+
 extern "C" int hh_time_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream) {
     HH_REQUIRE(B >= 0 && n > 0 && heads > 0, HH_ERR_SHAPE, "hh_time_attn_fwd: bad shape");
     HH_REQUIRE(T == 1 || T == 2 || T == 4 || T == 8 || T == 16 || T == 32, HH_ERR_UNSUPPORTED,
@@ -360,9 +532,13 @@ extern "C" int hh_time_attn_fwd(const void* qkv, void* out, float* cls_partial, 
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* in = (const bf16_t*)qkv;
     bf16_t* o = (bf16_t*)out;
-    // HH_TIME_ATTN: 1 (default) = MFMA kernel for T <= 16, 0 = VALU kernel (the only one for T = 32)
+    // HH_TIME_ATTN: 1 (default) = MFMA kernels, 0 = VALU kernel
     static int mode = -1;
     if (mode < 0) { const char* e = getenv("HH_TIME_ATTN"); mode = e ? atoi(e) : 1; }
+    if (mode == 1 && T == 32) {
+        hipLaunchKernelGGL(time_attn_mfma32_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, s, in, o, cls_partial, B, n, heads);
+        return hh_check_launch("hh_time_attn_fwd(mfma, T=32)");
+    }
     if (mode == 1 && T <= 16) {
         const unsigned wg = (unsigned)((blocks + 3) / 4);           // one wave per record, four waves per workgroup
 #define LAUNCHM(TT) hipLaunchKernelGGL(time_attn_mfma_kernel<TT>, dim3(wg), dim3(256), 0, s, in, o, cls_partial, B, n, heads)

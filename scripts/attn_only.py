@@ -1,7 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from helping_hand_for_egocentric_videos_amd import ops
-B, T, n, heads = int(os.environ.get("B", 32)), 16, 256, 16
+B, T, n, heads = int(os.environ.get("B", 32)), int(os.environ.get("T", 16)), int(os.environ.get("NP", 256)), 16
 N, D = 1 + T * n, heads * 64
 g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(B * N, 3 * D, device="cuda", generator=g)

@@ -202,7 +202,8 @@ def test_divided_attention(mode, B, T, n, heads):
     assert (err / scale).max() < 5e-2
 
 
-@pytest.mark.parametrize("B,T,n,heads", [(2, 4, 50, 2), (1, 16, 37, 1), (2, 8, 96, 3), (1, 1, 70, 2), (1, 2, 5, 1), (3, 16, 256, 2)])
+@pytest.mark.parametrize("B,T,n,heads", [(2, 4, 50, 2), (1, 16, 37, 1), (2, 8, 96, 3), (1, 1, 70, 2), (1, 2, 5, 1), (3, 16, 256, 2),
+                                          (2, 32, 30, 2), (1, 32, 7, 1), (1, 32, 576, 2)])
 def test_time_attention_ragged_patch_counts(B, T, n, heads):
     """The MFMA time kernel packs 16/T patch locations per 16-row tile and 128/T per wave: patch counts that are not
     multiples of either (partly empty tiles, clamped rows), block-diagonal masking for T < 16, several CLS records."""
