@@ -4,6 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from helping_hand_for_egocentric_videos_amd import ops
 B = int(os.environ.get("B", 32)); M = B * 4097
+if os.environ.get("PSKEW"): ops.set_tuning("gemm256_pskew", int(os.environ["PSKEW"]))
 SCALE = float(os.environ.get("SCALE", 1.0))
 g = torch.Generator(device="cuda").manual_seed(0)
 def t(f, n=5):

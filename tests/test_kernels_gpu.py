@@ -106,6 +106,31 @@ def test_gemm_plain_and_epilogues(M, N, K):
     torch.testing.assert_close(R.cpu(), ref + bias + res, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
 
 
+@pytest.mark.parametrize("mode", [3, 4])
+@pytest.mark.parametrize("M,N,K", [(256 * 40, 2048, 256), (256 * 24, 3072, 192), (256 * 300, 256, 128), (256 * 20, 4096, 1024),
+                                   (256 * 33 + 17, 1024, 512)])
+def test_gemm_persistent_walks_many_tiles_per_workgroup(mode, M, N, K):
+    """More 256x256 tiles than CUs: every workgroup of the persistent kernels (3 = prologue per tile, 4 = continuous k-tile stream
+    across tile boundaries) walks several tiles, with even / odd k-tile counts (LDS buffer parity) and the 2-k-tile corner."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = (torch.randn(M, K, device=DEV, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    ref = a.float() @ w.float().t() + bias
+    ops.set_tuning("gemm256", mode)
+    try:
+        out_bf = ops.gemm(a, w, bias)
+        out_f32 = ops.gemm(a, w, bias, out_dtype=torch.float32)
+        out_act = ops.gemm(a, w, bias, act=ops.ACT_QUICKGELU)
+    finally:
+        ops.set_tuning("gemm256", 4)
+    scale = ref.abs().max().item()
+    assert (out_f32 - ref).abs().max().item() <= 2e-3 * scale
+    assert (out_bf.float() - ref).abs().max().item() <= 8e-3 * scale
+    r = ref * torch.sigmoid(1.702 * ref)
+    assert (out_act.float() - r).abs().max().item() <= 8e-3 * r.abs().max().item()
+
+
 def test_gemm_row_remap():
     B, T, n, K, N = 2, 4, 256, 640, 128
     a, w = bf(rnd(B * T * n, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
