@@ -131,6 +131,50 @@ def test_gemm_persistent_walks_many_tiles_per_workgroup(mode, M, N, K):
     assert (out_act.float() - r).abs().max().item() <= 8e-3 * r.abs().max().item()
 
 
+def test_stream_cu_budget_changes_the_grid_not_the_results():
+    """hh_stream_set_cu_budget: persistent GEMMs launched on a budgeted stream walk their tiles with fewer workgroups."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    a = torch.randn(256 * 20, 512, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(1024, 512, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    ref = ops.gemm(a, w)
+    s = torch.cuda.Stream()
+    assert ops.stream_cu_budget(s) == ops.stream_cu_budget()            # default: every CU
+    ops.set_stream_cu_budget(s, 64)
+    assert ops.stream_cu_budget(s) == 64
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        out = ops.gemm(a, w)
+    s.synchronize()
+    assert torch.equal(out, ref)
+    with pytest.raises(RuntimeError):
+        ops.set_stream_cu_budget(s, 12)                                  # not a multiple of 8
+    ops.set_stream_cu_budget(s, 0)
+    assert ops.stream_cu_budget(s) == ops.stream_cu_budget()
+
+
+def test_gemm_timeline_debug_records_monotonic_stamps_and_a_plausible_clock():
+    import ctypes
+    import numpy as np
+    from helping_hand_for_egocentric_videos_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(6)
+    a = torch.randn(256 * 512, 1024, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(1024, 1024, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    ops.gemm(a, w)
+    ops.set_tuning("gemm256_debug_ts", 1)
+    try:
+        ops.gemm(a, w)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning("gemm256_debug_ts", 0)
+    buf = np.zeros((256, 8, 7), dtype=np.uint64)
+    _lib.check(_lib.lib().hh_debug_gemm_timeline(buf.ctypes.data_as(ctypes.c_void_p), 256), "hh_debug_gemm_timeline")
+    t = buf.astype(np.int64)
+    assert (np.diff(t[:, :, :5], axis=2) >= 0).all()                     # stamps of a tile are ordered
+    assert (t[:, 1:, 0] >= t[:, :-1, 4]).all()                           # tiles of a workgroup follow each other
+    mhz = (t[:, :, 6] - t[:, :, 5]) / np.maximum((t[:, :, 2] - t[:, :, 1]) / 100.0, 1e-9)
+    assert 500 < mhz.mean() < 3000, mhz.mean()
+
+
 def test_gemm_row_remap():
     B, T, n, K, N = 2, 4, 256, 640, 128
     a, w = bf(rnd(B * T * n, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
