@@ -20,6 +20,7 @@
 // source address; ds_read_b128 fragment reads conflict-free).  Operands swapped (A-operand = W) so a lane owns 4
 // consecutive n for one m: vector epilogue shared with gemm.hip.
 #include "gemm_common.h"
+#include <type_traits>
 #include <string.h>
 #include <stdlib.h>
 
@@ -492,7 +493,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmParams p) {
 // starts right after the epilogue: no 16-instruction prologue (1.1 us) and no wait for its first k-tile (2-3 us) -- together
 // ~11 % of a K = 1024 tile in the timeline of the plain persistent kernel.  Source addresses are scalar tile bases + 4 per-lane
 // 32-bit offsets (the 8 x 64-bit per-lane pointers of the other kernels would not leave room for two tiles' worth).
-template <bool OUT_BF16>
+// EPI: the epilogue flavour is a template parameter (0 bias only, 1 bias + colscale on whole 128-column halves, 2 bias + QuickGELU,
+// 3 bias + ReLU).  The generic epilogue of the kernels above spends ~30 VALU instructions per 16-B store (a packed multiply and a
+// select for the column scale and register copies for the activation branches, taken or not): ~500 per tile and wave, 2.8 us of
+// matrix-core idle time per K = 1024 tile; bias-only needs 8.
+template <bool OUT_BF16, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256c_kernel(GemmParams p) {
     constexpr bool STAGGER = true;
     constexpr int STORES = OUT_BF16 ? 16 : 32;        // global_store_dwordx4 per wave and tile in the epilogue (checked in the ISA)
@@ -544,6 +549,7 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(GemmParams p) {
         char* dst = smem + buf * BUF_BYTES + slot * HT_BYTES + wave * 2048;
         const bool isA = slot == SLOT_ALO || slot == SLOT_AHI;
         const char* bp = (isA ? bA : bW) + ((slot == SLOT_AHI) ? hiA : (slot == SLOT_BHI) ? hiW : 0) + (int64_t)kt * 128;
+        asm volatile("" : "+s"(bp));            // keep the scalar base scalar: without this LLVM hoists 64-bit per-lane sums out of the k loop
         glds16(bp + (isA ? aoff[0] : woff[0]), dst);
         glds16(bp + (isA ? aoff[1] : woff[1]), dst + 1024);
     };
@@ -717,11 +723,12 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(GemmParams p) {
                 for (int nh = 0; nh < 2; ++nh) {
                     const int n = ncol + nh * 128;
                     f32x4 v0 = acc[mh][tm][nh][0] + bias_v[nh][0], v1 = acc[mh][tm][nh][1] + bias_v[nh][1];
-                    if (n < e.colscale_cols) { v0 *= e.colscale; v1 *= e.colscale; }
-                    if (e.act == HH_ACT_QUICKGELU) {
+                    if constexpr (EPI == 1) {
+                        if (n0 + nh * 128 < e.colscale_cols) { v0 *= e.colscale; v1 *= e.colscale; }      // uniform: colscale_cols % 128 == 0
+                    } else if constexpr (EPI == 2) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { v0[q] = quick_gelu(v0[q]); v1[q] = quick_gelu(v1[q]); }
-                    } else if (e.act == HH_ACT_RELU) {
+                    } else if constexpr (EPI == 3) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
                     }
@@ -744,6 +751,7 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(GemmParams p) {
     }
 #undef MFMA_QUAD
 }
+
 
 static int g_debug_ts = 0;         // debug: record the per-tile timeline of the persistent kernel
 static int g_nostore = 0;          // debug: skip the epilogue stores (timing experiments only)
@@ -790,8 +798,9 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
     if (!attr_p) {
         hipFuncSetAttribute((const void*)gemm256p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192));
         hipFuncSetAttribute((const void*)gemm256p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192));
-        hipFuncSetAttribute((const void*)gemm256c_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192));
-        hipFuncSetAttribute((const void*)gemm256c_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192));
+#define ATTRC(BF, E) hipFuncSetAttribute((const void*)gemm256c_kernel<BF, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192))
+        ATTRC(true, 0); ATTRC(false, 0); ATTRC(true, 1); ATTRC(false, 1); ATTRC(true, 2); ATTRC(false, 2); ATTRC(true, 3); ATTRC(false, 3);
+#undef ATTRC
         attr_p = true;
     }
     GemmParams p = pin;
@@ -815,11 +824,29 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
         const int ncu = hh_stream_cu_count(s) & ~7;          // CU budget of this stream; the stride of the tile walk must keep blockIdx & 7 == XCD
         const unsigned pg = grid < (unsigned)ncu ? grid : (unsigned)ncu;
         p.skew_iters = 0;
-        if (gemm256_mode() == 4) {
+        if (gemm256_mode() >= 4) {
             p.skew_iters = g_pskew;
-            if (bf) hipLaunchKernelGGL((gemm256c_kernel<true>), dim3(pg), dim3(512), P_LDS(p.N), s, p);
-            else hipLaunchKernelGGL((gemm256c_kernel<false>), dim3(pg), dim3(512), P_LDS(p.N), s, p);
-            return hh_check_launch("hh_gemm_bf16(256x256 continuous)");
+            // epilogue flavour; column scale together with an activation, or a scale boundary inside a 128-column half, take the
+            // generic persistent kernel below
+            const bool scaled = p.e.colscale_cols > 0;
+            int epi = -1;
+            if (p.e.act == HH_ACT_NONE) epi = scaled ? (p.e.colscale_cols % 128 == 0 ? 1 : -1) : 0;
+            else if (!scaled) epi = p.e.act == HH_ACT_QUICKGELU ? 2 : p.e.act == HH_ACT_RELU ? 3 : -1;
+            if (epi >= 0) {
+#define LAUNCHC(BF, E) hipLaunchKernelGGL((gemm256c_kernel<BF, E>), dim3(pg), dim3(512), P_LDS(p.N), s, p)
+                switch (epi * 2 + (bf ? 1 : 0)) {
+                    case 0: LAUNCHC(false, 0); break;
+                    case 1: LAUNCHC(true, 0); break;
+                    case 2: LAUNCHC(false, 1); break;
+                    case 3: LAUNCHC(true, 1); break;
+                    case 4: LAUNCHC(false, 2); break;
+                    case 5: LAUNCHC(true, 2); break;
+                    case 6: LAUNCHC(false, 3); break;
+                    default: LAUNCHC(true, 3); break;
+                }
+#undef LAUNCHC
+                return hh_check_launch("hh_gemm_bf16(256x256 continuous)");
+            }
         }
         if (bf) hipLaunchKernelGGL((gemm256p_kernel<true>), dim3(pg), dim3(512), P_LDS(p.N), s, p);
         else hipLaunchKernelGGL((gemm256p_kernel<false>), dim3(pg), dim3(512), P_LDS(p.N), s, p);
