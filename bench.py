@@ -76,15 +76,15 @@ def attn_bytes(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
 
 def pmc_traffic(kernel_substr):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r1_pmc_summary.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction)."""
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction); launch-weighted
+    mean over the template instantiations whose name contains `kernel_substr`."""
     path = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        for k, v in json.load(f).items():
-            if kernel_substr in k:
-                return v["traffic_bytes_per_launch"]
-    return None
+        rows = [v for k, v in json.load(f).items() if kernel_substr in k]
+    n = sum(v["launches"] for v in rows)
+    return int(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in rows) / n) if n else None
 
 
 def sustained_clock(dev):

@@ -2,11 +2,12 @@
 // One problem per (clip, head, patch location): T queries x (T frame keys + CLS key), head dim 64.
 // Pure HBM-bound op (~(T+1)/2 flop/B): algorithmic bytes = every q,k,v row read once + every o row written once.
 //
-// Structure: a workgroup owns P = 128/T neighbouring patch locations of one (clip, head); K and V of its P*T tokens
-// are staged once into LDS as [frame][patch][64] (each global read is a full 128-B row segment), thread (patch, frame)
-// (2 lanes per query, 32 dims each)
-// keeps its query row and fp32 output row in registers and walks the T+1 keys on the VALU; LDS reads of a key row are
-// broadcast across the T threads that share the patch.
+// Three kernels:
+//   time_attn_mfma_kernel<T>   T <= 16 (default): one wave per 128 tokens, everything on the matrix core (see its header below)
+//   time_attn_mfma32_kernel    T = 32 (BASELINE config 4): a patch location spans two 16-row tiles
+//   time_attn_kernel<T>        the first, VALU-only implementation, kept as an independent cross-check (HH_TIME_ATTN=0): a workgroup
+//                              owns 128/T neighbouring patch locations, K and V rows staged once into LDS, 2 lanes per query
+//                              (32 dims each) walk the T+1 keys with broadcast LDS reads
 #include "common.h"
 
 template <int T>
