@@ -781,7 +781,9 @@ extern "C" int hh_set_tuning(const char* name, int value) {
 #define P_LDS(N) (2 * BUF_BYTES + (size_t)(N) * 4)       // persistent kernel: two staging buffers + the bias vector
 
 bool hh_gemm256_eligible(const GemmParams& p) {
-    return gemm256_mode() > 0 && p.N % 256 == 0 && p.M >= 2048 && p.e.splitk <= 1;
+    // at least ~3/4 of the CUs must get a 256x256 tile: below that the 128x128 kernel (4x the tiles, two workgroups per CU) wins --
+    // measured on the text tower's N = 768 shapes at M = 12320 (147 tiles): 43 vs 65 us (K = 768), 97 vs 152 us (K = 3072)
+    return gemm256_mode() > 0 && p.N % 256 == 0 && p.M >= 2048 && p.e.splitk <= 1 && (p.M / 256) * (p.N / 256) >= 192;
 }
 
 int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {

@@ -1,0 +1,129 @@
+// Weight-gradient GEMM in its natural layout:  C[m, n] = sum_k At[k, m] * Bt[k, n]  with BOTH operands k-major (row = token).
+// dW = dY^T . X of an nn.Linear contracts over the tokens (K = B*M = 131 104 here), and dY [tokens, out] / X [tokens, in] are
+// exactly At / Bt as they sit in memory -- the NT kernel (gemm.hip) needed both transposed first: 6 transposes, 3.7 GB of HBM
+// traffic and 1.8 ms per training step (tfm_decoder.py K/V in-projection and memory projection of all 6 layers).
+//
+// 128 x 128 tile per workgroup (4 waves as 2 x 2, wave tile 64 x 64 = 4 x 4 v_mfma_f32_16x16x32_bf16), BK = 64 tokens.  Tiles are
+// staged k-major in LDS by LDS-DMA (row = 128 columns = 256 B = 16 lanes x 16 B); an MFMA operand wants 8 consecutive k per lane,
+// which the hardware-transposing ds_read_b64_tr_b16 delivers from the k-major tile (two reads of 4 k each).  16-B chunk c of row
+// r lives at position c ^ (2 (r & 3)) so that the 4 rows x 32 B a 16-lane group touches per read land in different banks.
+// Split-K over the token dimension: blockIdx.y owns a 64-aligned slice and writes its fp32 partial tile; rows beyond K read a
+// zero line.  Operands are swapped as in gemm.hip (accumulator = C^T tile) so that a lane owns 4 consecutive n of one m.
+#include "common.h"
+
+typedef short s16x4_tn __attribute__((ext_vector_type(4)));
+__device__ __attribute__((aligned(16))) char g_tn_zero[16];
+
+__device__ __forceinline__ void tn_glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ bf16x4 tn_tr4(const char* addr) {
+    s16x4_tn r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_tn*)addr);
+    return __builtin_bit_cast(bf16x4, r);
+}
+
+struct TnParams {
+    const bf16_t* At; int64_t lda;
+    const bf16_t* Bt; int64_t ldb;
+    float* C; int64_t split_stride;        // partials [splits][M][N]
+    int M, N; int64_t K;
+    int k_per_split;                       // multiple of 64
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 16384];       // [stage][A | B][64 rows x 256 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Nt = p.N / 128;
+    const int m0 = (blockIdx.x / Nt) * 128, n0 = (blockIdx.x % Nt) * 128;
+    const int64_t k_begin = (int64_t)blockIdx.y * p.k_per_split;
+    int64_t k_end = k_begin + p.k_per_split;
+    if (k_end > p.K) k_end = p.K;
+    float* Cp = p.C + (int64_t)blockIdx.y * p.split_stride;
+    const int nk = (int)((k_end - k_begin + 63) / 64);
+
+    // staging: wave w stages rows 16 w .. 16 w + 15 of both operands: 4 instructions x 4 rows each
+    const int srow = lane >> 4, schunk = lane & 15;
+    auto stage = [&](int kt, int buf) {
+        char* dA = smem + buf * 32768 + wave * 4096;
+        char* dB = dA + 16384;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wave * 16 + 4 * i + srow;                      // row inside the k-tile
+            const int c = schunk ^ (2 * (r & 3));                         // logical chunk that lives at this lane's position
+            const int64_t k = k_begin + (int64_t)kt * 64 + r;
+            const bool ok = k < k_end;
+            tn_glds16(ok ? (const void*)(p.At + k * p.lda + m0 + c * 8) : (const void*)g_tn_zero, dA + i * 1024);
+            tn_glds16(ok ? (const void*)(p.Bt + k * p.ldb + n0 + c * 8) : (const void*)g_tn_zero, dB + i * 1024);
+        }
+    };
+    // fragment reads: 16-lane group g of the wave reads k rows 8g .. 8g+7 (+ 32 per k-step); lane i = 4 q + pc inside the group
+    // supplies the address of row q, columns 4 pc .. 4 pc + 3 of the 16-column MFMA tile
+    const int g = lane >> 4, q = (lane & 15) >> 2, pc = lane & 3;
+    auto frag = [&](const char* tile, int col0, int ks) -> bf16x8 {     // col0: first column of the 16-wide MFMA tile
+        const int r0 = 32 * ks + 8 * g + q, r1 = r0 + 4;
+        const int ch = (col0 >> 3) + (pc >> 1);                           // 16-B chunk of this lane's 8-B piece
+        const bf16x4 a = tn_tr4(tile + r0 * 256 + ((ch ^ (2 * (r0 & 3))) << 4) + (pc & 1) * 8);
+        const bf16x4 b = tn_tr4(tile + r1 * 256 + ((ch ^ (2 * (r1 & 3))) << 4) + (pc & 1) * 8);
+        return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    };
+
+    f32x4 acc[4][4];                                                      // [tn][tm]: C^T tiles (rows n, columns m)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) stage(0, 0);
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                  // tile t landed everywhere; everyone left buffer cur ^ 1
+        if (t + 1 < nk) stage(t + 1, cur ^ 1);
+        const char* tA = smem + cur * 32768;
+        const char* tB = tA + 16384;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = frag(tA, wm * 64 + i * 16, ks);
+                bf[i] = frag(tB, wn * 64 + i * 16, ks);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+        }
+    }
+    // accumulator tile [tn][tm]: lane (c = lane & 15 -> m, g -> n rows 4g .. 4g+3)
+    const int mrow = lane & 15;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        const int m = m0 + wm * 64 + tm * 16 + mrow;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int n = n0 + wn * 64 + tn * 16 + 4 * g;
+            *(f32x4*)(Cp + (int64_t)m * p.N + n) = acc[tn][tm];
+        }
+    }
+}
+
+extern "C" int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int64_t ldb, float* partials, int M, int N, int64_t K,
+                               int splits, hh_stream_t stream) {
+    HH_REQUIRE(M > 0 && N > 0 && K > 0 && M % 128 == 0 && N % 128 == 0, HH_ERR_SHAPE,
+               "hh_gemm_tn_bf16: need M %% 128 == 0 and N %% 128 == 0 (M=%d N=%d K=%lld)", M, N, (long long)K);
+    HH_REQUIRE(lda >= M && ldb >= N && lda % 8 == 0 && ldb % 8 == 0, HH_ERR_SHAPE, "hh_gemm_tn_bf16: bad leading dimensions");
+    HH_REQUIRE(HH_ALIGNED16(At) && HH_ALIGNED16(Bt) && HH_ALIGNED16(partials), HH_ERR_ALIGN, "hh_gemm_tn_bf16: pointers must be 16-byte aligned");
+    HH_REQUIRE(splits >= 1 && splits <= 4096, HH_ERR_SHAPE, "hh_gemm_tn_bf16: splits out of range");
+    TnParams p;
+    p.At = (const bf16_t*)At; p.lda = lda; p.Bt = (const bf16_t*)Bt; p.ldb = ldb; p.C = partials; p.split_stride = (int64_t)M * N;
+    p.M = M; p.N = N; p.K = K;
+    const int64_t ktiles = (K + 63) / 64;
+    p.k_per_split = (int)(((ktiles + splits - 1) / splits) * 64);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((M / 128) * (N / 128)), (unsigned)splits), dim3(256), 0, (hipStream_t)stream, p);
+    return hh_check_launch("hh_gemm_tn_bf16");
+}

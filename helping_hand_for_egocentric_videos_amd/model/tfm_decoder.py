@@ -42,11 +42,6 @@ class _KVHolder:
         self.seed = 0
 
 
-def _splitk_for(tiles, k):
-    s = max(1, min(64, 512 // max(tiles, 1), k // 512))
-    return s
-
-
 class _MemorySide(torch.autograd.Function):
     """features -> proj -> pre_norm -> (+pos) -> K/V in-projection of every layer.  Returns a 1-element token that
     the cross-attention nodes consume, so that this node's backward runs after all of them have written holder.dkv."""
@@ -87,16 +82,15 @@ class _MemorySide(torch.autograd.Function):
         dmem_pos = ops.gemm(dk_all, ops.transpose_bf16(wk), out_dtype=torch.float32)                      # [BM, C]
         dmem = ops.gemm(dv_all, ops.transpose_bf16(wv), resid=dmem_pos, out_dtype=torch.float32)
         dpos = dmem_pos.view(h.B, h.M, C).sum(0)
-        # wgrad (contraction over B*M tokens): transposed bf16 operands + split-K
-        sk = _splitk_for((L * C // 128) * (C // 128), BM)
-        dwk = ops.gemm(ops.transpose_bf16(dk_all), ops.transpose_bf16(mem_pos), splitk=sk)               # [L*C, C]
-        dwv = ops.gemm(ops.transpose_bf16(dv_all), ops.transpose_bf16(memory), splitk=sk)
+        # wgrad (contraction over the B*M tokens): dY and X are token-major as they sit in memory = the k-major operands of the
+        # TN kernel (hh_gemm_tn_bf16, split-K over tokens) -- no transposed copies
+        dwk = ops.gemm_tn(dk_all, mem_pos)                                                                 # [L*C, C]
+        dwv = ops.gemm_tn(dv_all, memory)
         dbk = torch.sum(dk_all, dim=0, dtype=torch.float32)
         dbv = torch.sum(dv_all, dim=0, dtype=torch.float32)
         del dmem_pos
         dmem0, dg, db = ops.layernorm_bwd(mem0, g_pre.detach().float(), mean, rstd, dmem)
-        sk2 = _splitk_for((C // 128) * (feat_b.shape[1] // 128), BM)
-        dw_proj = ops.gemm(ops.transpose_bf16(dmem0), ops.transpose_bf16(feat_b), splitk=sk2)            # [C, F]
+        dw_proj = ops.gemm_tn(ops.to_bf16(dmem0), feat_b)                                                  # [C, F]
         h.kv = h.dkv = None
         gw, gb = [], []
         for l in range(L):

@@ -216,6 +216,25 @@ def embed_ln_pre(tok, cls, pos, temporal, gamma, beta, B, T, n, eps=1e-5):
     return x
 
 
+def gemm_tn(at, bt, splits=None):
+    """Weight-gradient GEMM: at bf16 [K, M], bt bf16 [K, N] (token-major, row-strided views allowed) -> fp32 [M, N] = at^T @ bt.
+    Split-K over the tokens; the partial tiles are summed here."""
+    for t_ in (at, bt):
+        if not t_.is_cuda:
+            raise RuntimeError("libhh ops need GPU tensors; there is no CPU fallback")
+    K, M = at.shape
+    N = bt.shape[1]
+    if at.dtype != torch.bfloat16 or bt.dtype != torch.bfloat16 or bt.shape[0] != K or at.stride(1) != 1 or bt.stride(1) != 1:
+        raise ValueError("gemm_tn: operands must be bf16 [K, M] / [K, N] with unit column stride")
+    if splits is None:
+        tiles = (M // 128) * (N // 128)
+        splits = max(1, min(256, 1024 // max(tiles, 1), (K + 511) // 512))
+    part = torch.empty((splits, M, N), dtype=torch.float32, device=at.device)
+    _lib.check(_lib.lib().hh_gemm_tn_bf16(_p(at), at.stride(0), _p(bt), bt.stride(0), _p(part), M, N, K, int(splits), _stream()),
+               "hh_gemm_tn_bf16")
+    return part[0] if splits == 1 else part.sum(0)
+
+
 def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
     """qkv bf16 [B*N, 3D] (q pre-scaled) -> bf16 [B*N, D].  Rows 1.. come from the space/time kernel; the CLS row
     (query 0 attends all N keys) is folded into the same kernels as per-group partials + hh_cls_combine

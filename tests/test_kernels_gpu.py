@@ -175,6 +175,20 @@ def test_gemm_timeline_debug_records_monotonic_stamps_and_a_plausible_clock():
     assert 500 < mhz.mean() < 3000, mhz.mean()
 
 
+@pytest.mark.parametrize("K,M,N,splits", [(4097, 128, 128, None), (1000, 256, 384, 1), (64 * 37 + 5, 3072, 512, None), (300, 128, 256, 7),
+                                          (131104 // 8, 512, 1024, None)])
+def test_gemm_tn_weight_gradient_layout(K, M, N, splits):
+    """C = At^T Bt with token-major operands (row-strided column slices of wider buffers), ragged K, explicit / automatic split-K."""
+    g = torch.Generator(device=DEV).manual_seed(K + M + N)
+    wide_a = torch.randn(K, M + 64, device=DEV, generator=g).to(torch.bfloat16)
+    wide_b = (torch.randn(K, N + 128, device=DEV, generator=g) * 0.3).to(torch.bfloat16)
+    at, bt = wide_a[:, 64:], wide_b[:, :N]
+    out = ops.gemm_tn(at, bt, splits=splits)
+    ref = at.float().t() @ bt.float()
+    assert out.shape == (M, N)
+    assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
 def test_gemm_row_remap():
     B, T, n, K, N = 2, 4, 256, 640, 128
     a, w = bf(rnd(B * T * n, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
