@@ -40,6 +40,7 @@ SIGNATURES = {
     "hh_time_attn_fwd": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "hh_cls_combine": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp],
     "hh_cls_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
+    "hh_text_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "hh_xattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
     "hh_xattn_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_float,
                      ctypes.c_uint32, c_vp],

@@ -81,10 +81,13 @@ class Transformer(nn.Module):
             raise NotImplementedError("Transformer.forward_frozen: width must be a multiple of 64 (GEMM tiling)")
         xs = x.reshape(S * L, W).float().contiguous().clone()
         for pk in self.packed():
-            qkv = ops.gemm(ops.layernorm(xs, *pk["ln1"]), pk["win"], pk["bin"])                           # bf16 [S*L, 3W]
-            q, k, v = qkv.view(S, L, 3, h, d).permute(2, 0, 3, 1, 4)
-            o = F.scaled_dot_product_attention(q, k, v, is_causal=True)                                    # [S,h,L,d]
-            o = o.permute(0, 2, 1, 3).reshape(S * L, W).contiguous()
+            qkv = ops.gemm(ops.layernorm(xs, *pk["ln1"]), pk["win"], pk["bin"], colscale=d ** -0.5, colscale_cols=W)   # bf16 [S*L, 3W], q scaled
+            if d == 64 and L <= 80:
+                o = ops.text_attention(qkv, S, L, h)                                                       # libhh causal attention
+            else:                                                                                          # other head sizes: stock SDPA
+                q, k, v = qkv.view(S, L, 3, h, d).permute(2, 0, 3, 1, 4)
+                o = F.scaled_dot_product_attention(q, k, v, is_causal=True, scale=1.0)                     # [S,h,L,d]
+                o = o.permute(0, 2, 1, 3).reshape(S * L, W).contiguous()
             ops.gemm(o, pk["wout"], pk["bout"], resid=xs, out=xs)
             hid = ops.gemm(ops.layernorm(xs, *pk["ln2"]), pk["wfc"], pk["bfc"], act=ops.ACT_QUICKGELU)
             ops.gemm(hid, pk["wpr"], pk["bpr"], resid=xs, out=xs)

@@ -264,6 +264,17 @@ def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
     return out
 
 
+def text_attention(qkv, S, L, heads):
+    """Causal self-attention of the text tower: qkv bf16 [S*L, 3*heads*64] (q pre-scaled) -> bf16 [S*L, heads*64]."""
+    _chk(qkv)
+    W = heads * 64
+    if qkv.dtype != torch.bfloat16 or qkv.shape != (S * L, 3 * W):
+        raise ValueError("text_attention: qkv must be bf16 [S*L, 3*heads*64], got %s" % (tuple(qkv.shape),))
+    out = torch.empty((S * L, W), dtype=torch.bfloat16, device=qkv.device)
+    _lib.check(_lib.lib().hh_text_attn_fwd(_p(qkv), _p(out), S, L, heads, _stream()), "hh_text_attn_fwd")
+    return out
+
+
 def xattn_fwd(q, k, v, heads, dropout_p=0.0, seed=0):
     """q fp32 [B,Q,C] (pre-scaled); k, v bf16 [B,M,C] views with a common row stride -> (out fp32 [B,Q,C], lse [B,h,Q])."""
     for t in (q, k, v):

@@ -132,6 +132,10 @@ int hh_time_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int 
 int hh_cls_attn_fwd(const void* qkv, void* out, int B, int N, int heads, hh_stream_t stream);
 int hh_cls_combine(const float* partial, int G, void* out, int B, int N, int heads, hh_stream_t stream);
 
+/* ---- causal self-attention of the CLIP text tower (model/openai_model.py:182-232; mask model/LaviLa.py:636-642)
+ * qkv bf16 [S, L, 3*W] (q|k|v, head-major inside W = heads*64, q pre-scaled by 64^-0.5), out bf16 [S, L, W]; L <= 80. */
+int hh_text_attn_fwd(const void* qkv, void* out, int S, int L, int heads, hh_stream_t stream);
+
 /* ---- decoder cross-attention core (nn.MultiheadAttention inside tfm_decoder.py:438-441; 13 x 4096, 8 heads)
  * q fp32 [B, Q, C] (already scaled by d^-0.5), k/v bf16 [B, M, ldkv] (head-major columns, C = heads*64 used),
  * out fp32 [B, Q, C], lse fp32 [B, heads, Q] (log-sum-exp for the backward).  Q <= 16. */

@@ -189,6 +189,24 @@ def test_gemm_tn_weight_gradient_layout(K, M, N, splits):
     assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("S,L,heads", [(7, 77, 12), (3, 16, 2), (2, 33, 1), (5, 80, 3), (1, 1, 2), (160, 77, 12)])
+def test_text_causal_attention(S, L, heads):
+    """hh_text_attn_fwd against fp32 softmax(QK^T + causal mask) V on the same bf16 qkv (q pre-scaled)."""
+    W = heads * 64
+    qkv = rnd(S * L, 3 * W, seed=S + L)
+    qkv[:, :W] *= 0.4
+    qkv[3 % (S * L), :64] += 4.0
+    qkv = bf(qkv)
+    out = ops.text_attention(qkv.to(DEV), S, L, heads)
+    q, k, v = qkv.float().view(S, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    sc = q @ k.transpose(-1, -2)
+    sc = sc.masked_fill(torch.ones(L, L, dtype=torch.bool).triu(1), float("-inf"))
+    ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(S * L, W)
+    assert_close_bf16(out, ref, 1.2e-2, "text-attn")
+    err = (out.float().cpu() - ref).abs().amax(1)
+    assert (err / (ref.abs().amax(1) + 1e-3)).max() < 5e-2
+
+
 def test_gemm_row_remap():
     B, T, n, K, N = 2, 4, 256, 640, 128
     a, w = bf(rnd(B * T * n, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
