@@ -80,15 +80,19 @@ class Transformer(nn.Module):
         if W % 64 or (3 * W) % 128 or (4 * W) % 128:
             raise NotImplementedError("Transformer.forward_frozen: width must be a multiple of 64 (GEMM tiling)")
         xs = x.reshape(S * L, W).float().contiguous().clone()
+        pending = None                        # bf16 branch output not yet added to the fp32 residual stream (as in SpaceTimeBlock.fused)
         for pk in self.packed():
-            qkv = ops.gemm(ops.layernorm(xs, *pk["ln1"]), pk["win"], pk["bin"], colscale=d ** -0.5, colscale_cols=W)   # bf16 [S*L, 3W], q scaled
+            xn = ops.layernorm(xs, *pk["ln1"]) if pending is None else ops.add_layernorm(xs, pending, *pk["ln1"], write_x=True)
+            qkv = ops.gemm(xn, pk["win"], pk["bin"], colscale=d ** -0.5, colscale_cols=W)                  # bf16 [S*L, 3W], q scaled
             if d == 64 and L <= 80:
                 o = ops.text_attention(qkv, S, L, h)                                                       # libhh causal attention
             else:                                                                                          # other head sizes: stock SDPA
                 q, k, v = qkv.view(S, L, 3, h, d).permute(2, 0, 3, 1, 4)
                 o = F.scaled_dot_product_attention(q, k, v, is_causal=True, scale=1.0)                     # [S,h,L,d]
                 o = o.permute(0, 2, 1, 3).reshape(S * L, W).contiguous()
-            ops.gemm(o, pk["wout"], pk["bout"], resid=xs, out=xs)
-            hid = ops.gemm(ops.layernorm(xs, *pk["ln2"]), pk["wfc"], pk["bfc"], act=ops.ACT_QUICKGELU)
-            ops.gemm(hid, pk["wpr"], pk["bpr"], resid=xs, out=xs)
+            a = ops.gemm(o, pk["wout"], pk["bout"])                                                        # bf16 branch
+            hid = ops.gemm(ops.add_layernorm(xs, a, *pk["ln2"], write_x=True), pk["wfc"], pk["bfc"], act=ops.ACT_QUICKGELU)
+            pending = ops.gemm(hid, pk["wpr"], pk["bpr"])
+        if pending is not None:
+            xs += pending.float()
         return xs.view(S, L, W)
