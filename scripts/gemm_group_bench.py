@@ -2,7 +2,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from helping_hand_for_egocentric_videos_amd import ops
 M = 32 * 4097
-GROUPS = [1, 2, 4, 8, 16]
+GROUPS = [2, 4, 8, 16, 32, 64]
 shapes = [("qkv", 3072, 1024, dict(colscale=0.125, colscale_cols=1024)), ("proj", 1024, 1024, {}), ("fc1", 4096, 1024, dict(act=ops.ACT_QUICKGELU)), ("fc2", 1024, 4096, {})]
 g = torch.Generator(device="cuda").manual_seed(0)
 for name, N, K, kw in shapes:
