@@ -26,7 +26,7 @@ SIGNATURES = {
     "hh_stream_set_cu_budget": [c_vp, c_int],
     "hh_stream_get_cu_budget": [c_vp, ctypes.POINTER(c_int)],
     "hh_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_float, c_vp],
-    "hh_add_layernorm_fwd": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_float, c_vp],
+    "hh_add_layernorm_fwd": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_float, c_vp],
     "hh_layernorm_bwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
     "hh_gemm_bf16": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, ctypes.POINTER(GemmEpilogue), c_vp],
     "hh_gemm_tn_bf16": [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_int, c_i64, c_int, c_vp],

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
 // cannot overlap the MFMA main loop) and does it here at streaming HBM rate; x is written back only when WRITE_X.
 template <int NV, typename TOUT, bool WRITE_X>
 __global__ __launch_bounds__(256) void add_ln_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                     const bf16_t* __restrict__ delta2,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      TOUT* __restrict__ y, int64_t rows, int cols, float eps) {
     const int lane = threadIdx.x & 63;
@@ -82,11 +83,20 @@ __global__ __launch_bounds__(256) void add_ln_kernel(float* __restrict__ x, cons
     float v[NV][4], d[NV][4];
     load_row<NV, float>(x + row * cols, cols, lane, v);
     load_row<NV, bf16_t>(delta + row * cols, cols, lane, d);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] += d[i][j];
+    if (delta2 != nullptr) {                      // second pending branch, added AFTER the first: (x + d1) + d2
+        load_row<NV, bf16_t>(delta2 + row * cols, cols, lane, d);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] += d[i][j];
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[i][j] += d[i][j];
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         if (WRITE_X) {
             const int c = (i * 64 + lane) * 4;
@@ -234,7 +244,7 @@ extern "C" int hh_layernorm_bwd(const void* x, int x_dtype, const float* gamma, 
     return hh_check_launch("hh_layernorm_bwd");
 }
 
-extern "C" int hh_add_layernorm_fwd(float* x, const void* delta, int write_x, const float* gamma, const float* beta, void* y,
+extern "C" int hh_add_layernorm_fwd(float* x, const void* delta, const void* delta2, int write_x, const float* gamma, const float* beta, void* y,
                                     int y_dtype, int64_t rows, int cols, float eps, hh_stream_t stream) {
     HH_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 2048, HH_ERR_SHAPE, "hh_add_layernorm_fwd: cols=%d must be a multiple of 8 and <= 2048", cols);
     HH_REQUIRE(y_dtype == HH_F32 || y_dtype == HH_BF16, HH_ERR_DTYPE, "hh_add_layernorm_fwd: bad dtype");
@@ -246,7 +256,7 @@ extern "C" int hh_add_layernorm_fwd(float* x, const void* delta, int write_x, co
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     const bf16_t* d = (const bf16_t*)delta;
     const int nv = (cols + 255) / 256;
-#define LA(NV, T, W) hipLaunchKernelGGL((add_ln_kernel<NV, T, W>), grid, block, 0, s, x, d, gamma, beta, (T*)y, rows, cols, eps)
+#define LA(NV, T, W) hipLaunchKernelGGL((add_ln_kernel<NV, T, W>), grid, block, 0, s, x, d, (const bf16_t*)delta2, gamma, beta, (T*)y, rows, cols, eps)
 #define LB(NV) do { if (y_dtype == HH_BF16) { if (write_x) LA(NV, bf16_t, true); else LA(NV, bf16_t, false); } \
                     else { if (write_x) LA(NV, float, true); else LA(NV, float, false); } } while (0)
     if (nv <= 2) LB(2); else if (nv <= 4) LB(4); else LB(8);

@@ -176,27 +176,31 @@ class SpaceTimeBlock(nn.Module):
         return self._pack
 
     def fused(self, x, B, T, n, pending=None):
-        """x fp32 [B*N, D] residual stream (updated IN PLACE); `pending` = previous block's MLP output (bf16) that has
-        not been added to x yet.  Returns this block's MLP output (bf16), to be added by the next add+LayerNorm.
+        """x fp32 [B*N, D] residual stream (updated IN PLACE); `pending` = the previous block's (space branch, MLP branch) bf16
+        outputs that have not been added to x yet.  Returns this block's (space branch, MLP branch), to be added by the next
+        add+LayerNorm: x = (x + space) + mlp is written once per block instead of twice.
 
         The GEMM epilogues only write bf16 branch outputs; every fp32 residual read-modify-write happens inside the
         fused add+LayerNorm kernel (streaming HBM rate) instead of the GEMM epilogue (per-CU store-rate bound)."""
         pk = self.packed()
-        xn = ops.layernorm(x, *pk["n3"]) if pending is None else ops.add_layernorm(x, pending, *pk["n3"], write_x=True)
+        if pending is None:
+            xn = ops.layernorm(x, *pk["n3"])
+        else:
+            xn = ops.add_layernorm(x, pending[0], *pk["n3"], write_x=True, delta2=pending[1])          # x = (x + s_prev) + m_prev
         a = self.timeattn.core(xn, pk["time"], B, T, n, "time")
         t = ops.gemm(a, pk["time"]["wproj"], pk["time"]["bproj"])                                             # time branch
         a = self.attn.core(ops.add_layernorm(x, t, *pk["n1"], write_x=False), pk["space"], B, T, n, "space")   # LN1(x + t)
         sp = ops.gemm(a, pk["space"]["wproj"], pk["space"]["bproj"])
-        h = ops.gemm(ops.add_layernorm(x, sp, *pk["n2"], write_x=True), pk["w1"], pk["b1"], act=ops.ACT_QUICKGELU)  # x += s (A1)
-        return ops.gemm(h, pk["w2"], pk["b2"])
+        h = ops.gemm(ops.add_layernorm(x, sp, *pk["n2"], write_x=False), pk["w1"], pk["b1"], act=ops.ACT_QUICKGELU)  # LN2(x + s)
+        return sp, ops.gemm(h, pk["w2"], pk["b2"])
 
     def forward(self, x, einops_from_space, einops_to_space, einops_from_time, einops_to_time, time_n, space_f,
                 use_checkpoint=False):
         _require_gpu(x, "SpaceTimeBlock")
         B, N, D = x.shape
         y = x.float().reshape(B * N, D).clone()
-        m = self.fused(y, B, space_f, time_n)
-        return (y + m.float()).view(B, N, D)
+        sp, m = self.fused(y, B, space_f, time_n)
+        return ((y + sp.float()) + m.float()).view(B, N, D)
 
 
 class SpaceTimeTransformer(nn.Module):
@@ -290,7 +294,7 @@ class SpaceTimeTransformer(nn.Module):
         if pending is None:
             out = ops.layernorm(xs, *pk["norm"], out_dtype=out_dtype)
         else:
-            out = ops.add_layernorm(xs, pending, *pk["norm"], write_x=False, out_dtype=out_dtype)
+            out = ops.add_layernorm(xs, pending[0], *pk["norm"], write_x=False, out_dtype=out_dtype, delta2=pending[1])
         out = out.view(B, 1 + T * n, D)                                                      # norm evaluated once (A5)
         return self.pre_logits(out[:, 0]), out
 

@@ -75,14 +75,16 @@ def layernorm(x, gamma, beta, eps, out_dtype=torch.bfloat16, save_stats=False):
     return (y, mean, rstd) if save_stats else y
 
 
-def add_layernorm(x, delta, gamma, beta, eps, write_x=True, out_dtype=torch.bfloat16):
-    """x (fp32, in place if write_x) += delta (bf16); returns LN(x).  x, delta [rows, cols]."""
-    _chk(x, delta, gamma, beta)
+def add_layernorm(x, delta, gamma, beta, eps, write_x=True, out_dtype=torch.bfloat16, delta2=None):
+    """x (fp32, in place if write_x) = (x + delta) + delta2 (bf16 branches, delta2 optional); returns LN(x).  [rows, cols]."""
+    _chk(x, delta, gamma, beta, delta2)
     if x.dtype != torch.float32 or delta.dtype != torch.bfloat16 or x.shape != delta.shape:
         raise TypeError("add_layernorm: x fp32 and delta bf16 of the same shape")
+    if delta2 is not None and (delta2.dtype != torch.bfloat16 or delta2.shape != x.shape):
+        raise TypeError("add_layernorm: delta2 must be bf16 of the shape of x")
     cols = x.shape[-1]
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    _lib.check(_lib.lib().hh_add_layernorm_fwd(_p(x), _p(delta), int(bool(write_x)), _p(gamma), _p(beta), _p(y), _dt(y),
+    _lib.check(_lib.lib().hh_add_layernorm_fwd(_p(x), _p(delta), _p(delta2), int(bool(write_x)), _p(gamma), _p(beta), _p(y), _dt(y),
                                                x.numel() // cols, cols, float(eps), _stream()), "hh_add_layernorm_fwd")
     return y
 

@@ -57,9 +57,10 @@ int hh_stream_get_cu_budget(hh_stream_t stream, int* out);
 int hh_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                      float* mean_out, float* rstd_out, int64_t rows, int cols, float eps, hh_stream_t stream);
 
-/* Fused residual add + LayerNorm: x (fp32 [rows, cols]) += delta (bf16) -- written back iff write_x -- and
- * y = LN(x) (bf16 or fp32).  Used for x + attn / x + mlp of SpaceTimeBlock (model/LaviLa.py:364,384,388). */
-int hh_add_layernorm_fwd(float* x, const void* delta, int write_x, const float* gamma, const float* beta, void* y,
+/* Fused residual add + LayerNorm: x (fp32 [rows, cols]) = (x + delta) + delta2 (bf16; delta2 may be NULL) -- written back iff
+ * write_x -- and y = LN(x) (bf16 or fp32).  Used for x + attn / x + mlp of SpaceTimeBlock (model/LaviLa.py:364,384,388); two
+ * deltas let the x += space-branch update ride on the next block's x += mlp-branch pass. */
+int hh_add_layernorm_fwd(float* x, const void* delta, const void* delta2, int write_x, const float* gamma, const float* beta, void* y,
                          int y_dtype, int64_t rows, int cols, float eps, hh_stream_t stream);
 
 /* LayerNorm backward: dx fp32 [rows, cols]; dgamma / dbeta fp32 [cols] are ACCUMULATED with atomics (zero them first).
