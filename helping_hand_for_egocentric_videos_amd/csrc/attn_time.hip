@@ -190,6 +190,22 @@ __device__ __forceinline__ bf16x4 tlds_tr4(const char* addr) {
     s16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)addr);
     return __builtin_bit_cast(bf16x4, r);
 }
+// The same read as opaque inline asm (callers follow a group of them with tlds_wait()).  hipcc puts s_waitcnt vmcnt(0) in front of
+// every LDS read that follows an LDS-DMA it cannot prove disjoint -- which also waits for the write acknowledgements of the
+// previous tile's output stores; with the read hidden, the counted wait the kernel issues itself is the only one.
+template <int OFF>
+__device__ __forceinline__ bf16x4 tlds_tr4_raw(unsigned lds_addr) {
+    s16x4_t r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
+    return __builtin_bit_cast(bf16x4, r);
+}
+__device__ __forceinline__ void tlds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_u32(const char* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+
+// s_waitcnt vmcnt(N) as the BUILTIN (not inline asm): hipcc's wait-count pass sees it and knows the older loads have landed.  With
+// an opaque asm wait it re-waits with vmcnt(0) at the first use of the loop-carried Q / K registers -- AFTER the next tile's
+// loads have been issued, i.e. it waits for the prefetch it is supposed to overlap with.
+#define HH_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))
 
 template <int T>
 __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
@@ -252,11 +268,26 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
     f32x4 accc[4] = {z4, z4, z4, z4};
     const int trq = c >> 2, trp = c & 3;                 // ds_read_tr roles inside a 16-lane group: row, 4-column piece
 
-    auto compute = [&](int t, const bf16x8 (&q)[2], const bf16x8 (&k)[2]) {
-        f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0], q[0], z4, 0, 0, 0);
+    // V^T fragments of tile t.  Read BEFORE the next tile's LDS-DMA is issued: hipcc drains every outstanding LDS-DMA (vmcnt(0)) in
+    // front of an LDS read it cannot prove disjoint, which would serialise the prefetch behind the PV step
+    auto vfrags = [&](int t, bf16x4 (&vf)[4]) {
+        const unsigned vb = lds_u32(vbuf + (t & 1) * 2048 + (4 * g + trq) * 128 + 32 * trp);
+        vf[0] = tlds_tr4_raw<0>(vb); vf[1] = tlds_tr4_raw<8>(vb); vf[2] = tlds_tr4_raw<16>(vb); vf[3] = tlds_tr4_raw<24>(vb);
+        tlds_wait();
+    };
+    // Every MFMA that reads the (loop-carried) Q / K registers is issued BEFORE the next tile's loads: hipcc waits for those
+    // registers with vmcnt(0) at their first use inside the loop, which must not include the prefetch.
+    auto scores = [&](const bf16x8 (&q)[2], const bf16x8 (&k)[2], f32x4& s, f32x4& sc, f32x4& s3) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0], q[0], z4, 0, 0, 0);
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1], q[1], s, 0, 0, 0);
-        f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], q[0], z4, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], q[0], z4, 0, 0, 0);
         sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1], q[1], sc, 0, 0, 0);
+        if (cls_partial != nullptr) {
+            s3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0], qc[0], z4, 0, 0, 0);
+            s3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1], qc[1], s3, 0, 0, 0);
+        }
+    };
+    auto compute = [&](int t, const f32x4& s, const f32x4& sc, const f32x4& s3, const bf16x4 (&vf)[4]) {
         float x[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) x[j] = (T == 16 || ((4 * g + j) / T) == (c / T)) ? s[j] : -INFINITY;
@@ -276,12 +307,11 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
         const float inv = __builtin_amdgcn_rcpf(l);
         const bf16x8 pf = {(bf16_t)(p[0] * inv), (bf16_t)(p[1] * inv), (bf16_t)(p[2] * inv), (bf16_t)(p[3] * inv),
                            (bf16_t)(g == 0 ? pc * inv : 0.f), 0, 0, 0};
-        const char* vb = vbuf + (t & 1) * 2048 + (4 * g + trq) * 128 + 32 * trp;
         bf16x8 af[4];
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            const bf16x4 tr = tlds_tr4(vb + 8 * dt);
+            const bf16x4 tr = vf[dt];
             af[dt] = (bf16x8){tr[0], tr[1], tr[2], tr[3], vcls[dt], 0, 0, 0};
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], pf, z4, 0, 0, 0);
         }
@@ -294,8 +324,6 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
         }
         if (cls_partial == nullptr) return;
         // ---- CLS query over this tile's keys (lane (c, g) register j = key row 4g+j, identical for every c)
-        f32x4 s3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0], qc[0], z4, 0, 0, 0);
-        s3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1], qc[1], s3, 0, 0, 0);
         float y[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = (p0 + t * PT + (4 * g + j) / T < n) ? s3[j] : -INFINITY;
@@ -334,13 +362,22 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
     bf16x8 qa[2], ka[2], qb[2], kb[2];
     issue(0, qa, ka);
     for (int t = 0; t < ntiles; t += 2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tile t: V rows in LDS, Q / K rows in registers
+        // tile t: V rows in LDS, Q / K rows in registers.  VMEM retires in order and the only younger instructions are the two
+        // output stores of tile t-1 (every processed tile has a stored query): do not wait for their write acknowledgements
+        bf16x4 vf[4];
+        f32x4 s, sc, s3 = z4;
+        if (t == 0) HH_WAIT_VMCNT(0);
+        else HH_WAIT_VMCNT(2);
+        vfrags(t, vf);
+        scores(qa, ka, s, sc, s3);
         if (t + 1 < ntiles) issue(t + 1, qb, kb);
-        compute(t, qa, ka);
+        compute(t, s, sc, s3, vf);
         if (t + 1 >= ntiles) break;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        HH_WAIT_VMCNT(2);
+        vfrags(t + 1, vf);
+        scores(qb, kb, s, sc, s3);
         if (t + 2 < ntiles) issue(t + 2, qa, ka);
-        compute(t + 1, qb, kb);
+        compute(t + 1, s, sc, s3, vf);
     }
     if (cls_partial != nullptr && c == 0) {
         float* rec = cls_partial + (((int64_t)b * heads + head) * groups + pg) * CLS_REC;
@@ -409,13 +446,21 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
     f32x4 accc[4] = {z4, z4, z4, z4};
     const int trq = c >> 2, trp = c & 3;
 
-    auto compute = [&](int u, const bf16x8 (&q)[2][2], const bf16x8 (&k)[2][2]) {
-        const char* vb = vbuf + (u & 1) * 4096 + (4 * g + trq) * 128 + 32 * trp;
+    auto vfrags = [&](int u, bf16x8 (&vf)[4]) {                      // before the next LDS-DMA issue (see time_attn_mfma_kernel)
+        const unsigned vb = lds_u32(vbuf + (u & 1) * 4096 + (4 * g + trq) * 128 + 32 * trp);
+        const bf16x4 a0 = tlds_tr4_raw<0>(vb), a1 = tlds_tr4_raw<8>(vb), a2_ = tlds_tr4_raw<16>(vb), a3 = tlds_tr4_raw<24>(vb);
+        const bf16x4 b0 = tlds_tr4_raw<2048>(vb), b1 = tlds_tr4_raw<2056>(vb), b2 = tlds_tr4_raw<2064>(vb), b3 = tlds_tr4_raw<2072>(vb);
+        tlds_wait();
+        vf[0] = (bf16x8){a0[0], a0[1], a0[2], a0[3], b0[0], b0[1], b0[2], b0[3]};
+        vf[1] = (bf16x8){a1[0], a1[1], a1[2], a1[3], b1[0], b1[1], b1[2], b1[3]};
+        vf[2] = (bf16x8){a2_[0], a2_[1], a2_[2], a2_[3], b2[0], b2[1], b2[2], b2[3]};
+        vf[3] = (bf16x8){a3[0], a3[1], a3[2], a3[3], b3[0], b3[1], b3[2], b3[3]};
+    };
+    auto compute = [&](int u, const bf16x8 (&q)[2][2], const bf16x8 (&k)[2][2], const bf16x8 (&vf)[4]) {
         bf16x8 afk[4], afc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            const bf16x4 t0 = tlds_tr4(vb + 8 * dt), t1 = tlds_tr4(vb + 16 * 128 + 8 * dt);
-            afk[dt] = (bf16x8){t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+            afk[dt] = vf[dt];
             afc[dt] = (bf16x8){vcls[dt], 0, 0, 0, 0, 0, 0, 0};
         }
 #pragma unroll
@@ -506,13 +551,17 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
     bf16x8 qa[2][2], ka[2][2], qb[2][2], kb[2][2];
     issue(0, qa, ka);
     for (int u = 0; u < npatch; u += 2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bf16x8 vf[4];
+        if (u == 0) HH_WAIT_VMCNT(0);
+        else HH_WAIT_VMCNT(4);           // the 4 output stores of the previous patch may stay in flight
+        vfrags(u, vf);
         if (u + 1 < npatch) issue(u + 1, qb, kb);
-        compute(u, qa, ka);
+        compute(u, qa, ka, vf);
         if (u + 1 >= npatch) break;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        HH_WAIT_VMCNT(4);
+        vfrags(u + 1, vf);
         if (u + 2 < npatch) issue(u + 2, qa, ka);
-        compute(u + 1, qb, kb);
+        compute(u + 1, qb, kb, vf);
     }
     if (cls_partial != nullptr && c == 0) {
         float* rec = cls_partial + (((int64_t)b * heads + head) * groups + pg) * CLS_REC;
