@@ -108,7 +108,7 @@ def test_gemm_plain_and_epilogues(M, N, K):
 
 @pytest.mark.parametrize("mode", [3, 4])
 @pytest.mark.parametrize("M,N,K", [(256 * 40, 2048, 256), (256 * 24, 3072, 192), (256 * 300, 256, 128), (256 * 20, 4096, 1024),
-                                   (256 * 33 + 17, 1024, 512)])
+                                   (256 * 33 + 17, 1024, 512), (256 * 300, 256, 64), (256 * 40, 8192 + 256, 128)])
 def test_gemm_persistent_walks_many_tiles_per_workgroup(mode, M, N, K):
     """More 256x256 tiles than CUs: every workgroup of the persistent kernels (3 = prologue per tile, 4 = continuous k-tile stream
     across tile boundaries) walks several tiles, with even / odd k-tile counts (LDS buffer parity) and the 2-k-tile corner."""
