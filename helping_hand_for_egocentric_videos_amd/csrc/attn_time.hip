@@ -456,7 +456,27 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
         vf[2] = (bf16x8){a2_[0], a2_[1], a2_[2], a2_[3], b2[0], b2[1], b2[2], b2[3]};
         vf[3] = (bf16x8){a3[0], a3[1], a3[2], a3[3], b3[0], b3[1], b3[2], b3[3]};
     };
-    auto compute = [&](int u, const bf16x8 (&q)[2][2], const bf16x8 (&k)[2][2], const bf16x8 (&vf)[4]) {
+    // all MFMAs that read the loop-carried Q / K registers, issued before the next patch's loads (see time_attn_mfma_kernel)
+    struct Scores { f32x4 s0[2], s1[2], sc[2], y0, y1; };
+    auto scores = [&](const bf16x8 (&q)[2][2], const bf16x8 (&k)[2][2], Scores& r) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            r.s0[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0][0], q[qt][0], z4, 0, 0, 0);
+            r.s0[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0][1], q[qt][1], r.s0[qt], 0, 0, 0);
+            r.s1[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1][0], q[qt][0], z4, 0, 0, 0);
+            r.s1[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1][1], q[qt][1], r.s1[qt], 0, 0, 0);
+            r.sc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], q[qt][0], z4, 0, 0, 0);
+            r.sc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1], q[qt][1], r.sc[qt], 0, 0, 0);
+        }
+        r.y0 = z4; r.y1 = z4;
+        if (cls_partial != nullptr) {
+            r.y0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0][0], qc[0], z4, 0, 0, 0);
+            r.y0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0][1], qc[1], r.y0, 0, 0, 0);
+            r.y1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1][0], qc[0], z4, 0, 0, 0);
+            r.y1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1][1], qc[1], r.y1, 0, 0, 0);
+        }
+    };
+    auto compute = [&](int u, const Scores& r, const bf16x8 (&vf)[4]) {
         bf16x8 afk[4], afc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -465,12 +485,7 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
         }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0][0], q[qt][0], z4, 0, 0, 0);
-            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0][1], q[qt][1], s0, 0, 0, 0);
-            f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1][0], q[qt][0], z4, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1][1], q[qt][1], s1, 0, 0, 0);
-            f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[0], q[qt][0], z4, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[1], q[qt][1], sc, 0, 0, 0);
+            const f32x4 s0 = r.s0[qt], s1 = r.s1[qt], sc = r.sc[qt];
             float m = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
             m = fmaxf(m, __shfl_xor(m, 16, 64));
             m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -505,10 +520,7 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
             *(u32x4*)(op + 8) = w1;
         }
         if (cls_partial == nullptr) return;
-        f32x4 y0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0][0], qc[0], z4, 0, 0, 0);
-        y0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[0][1], qc[1], y0, 0, 0, 0);
-        f32x4 y1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1][0], qc[0], z4, 0, 0, 0);
-        y1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k[1][1], qc[1], y1, 0, 0, 0);
+        const f32x4 y0 = r.y0, y1 = r.y1;
         float gm = fmaxf(fmaxf(fmaxf(y0[0], y0[1]), fmaxf(y0[2], y0[3])), fmaxf(fmaxf(y1[0], y1[1]), fmaxf(y1[2], y1[3])));
         gm = fmaxf(gm, __shfl_xor(gm, 16, 64));
         gm = fmaxf(gm, __shfl_xor(gm, 32, 64));
@@ -552,16 +564,19 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
     issue(0, qa, ka);
     for (int u = 0; u < npatch; u += 2) {
         bf16x8 vf[4];
+        Scores r;
         if (u == 0) HH_WAIT_VMCNT(0);
         else HH_WAIT_VMCNT(4);           // the 4 output stores of the previous patch may stay in flight
         vfrags(u, vf);
+        scores(qa, ka, r);
         if (u + 1 < npatch) issue(u + 1, qb, kb);
-        compute(u, qa, ka, vf);
+        compute(u, r, vf);
         if (u + 1 >= npatch) break;
         HH_WAIT_VMCNT(4);
         vfrags(u + 1, vf);
+        scores(qb, kb, r);
         if (u + 2 < npatch) issue(u + 2, qa, ka);
-        compute(u + 1, qb, kb, vf);
+        compute(u + 1, r, vf);
     }
     if (cls_partial != nullptr && c == 0) {
         float* rec = cls_partial + (((int64_t)b * heads + head) * groups + pg) * CLS_REC;
