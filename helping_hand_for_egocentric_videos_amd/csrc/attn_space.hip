@@ -286,67 +286,136 @@ __global__ __launch_bounds__(64 * NW, 2) void space_attn_kernel(const bf16_t* __
     space_cls_partial<NW>(Ks, Vs, scratch, KP, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
 }
 
-// ---- variant B (n + 1 <= 288 keys): PERSISTENT, one 8-wave workgroup per CU walks the (clip, frame, head) problems with
-// a double-buffered K/V tile: while problem i is computed from buffer i&1, problem i+1 is prefetched by LDS-DMA into
-// the other buffer.  The per-CU memory phase (~136 KB per problem) then overlaps the MFMA/VALU phase instead of
-// alternating with it.
-#define NWP 8
-__global__ __launch_bounds__(64 * NWP, 2) void space_attn_persistent_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                          float* __restrict__ cls_partial,
-                                                                          int B, int T, int n, int heads, int KP) {
+// ---- variant C: 16-query blocks on v_mfma_f32_16x16x32_bf16, 8 waves per workgroup (4 waves per SIMD with two workgroups per CU).
+// The 32-query kernel above is VALU-issue-bound at 2 waves per SIMD (SQ counters: VALU busy 49 %, MFMA 18 %).  Here a wave owns 16
+// queries: a 16-key score tile is 4 accumulator registers, a chunk of 9 tiles 36 registers, the whole kernel < 128 VGPRs; Q comes
+// from HBM directly in MFMA layout (lane = query, 8 d); PV contracts two 16-key tiles per MFMA (k-slots jj < 4 -> first tile row
+// 4g+jj, jj >= 4 -> second tile) with V^T fetched by the transposing LDS read, d permuted so that a lane ends with 16 consecutive d
+// of its query; the 1/l normalisation is applied to the 16 output registers instead of the probabilities.
+#define NW16 8
+#define CH16 9
+template <int NTC, bool CLS>
+__device__ __forceinline__ void space16_chunk(const char* Ks, const char* Vs, const bf16x8 (&q)[2], int t0, int lane,
+                                              f32x4 (&o)[4], float& m_run, float& l_run) {
+    const int c = lane & 15, g = lane >> 4;
+    const int trq = c >> 2, trp = c & 3;
+    const float LOG2E = 1.4426950408889634f;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s[NTC];
+#pragma unroll
+    for (int ti = 0; ti < NTC; ++ti) {
+        const int krow = (t0 + ti) * 16 + c;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((g + 4 * ks) ^ kswz(krow)) << 4));
+            s[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, q[ks], ks == 0 ? z4 : s[ti], 0, 0, 0);
+        }
+    }
+    if (CLS) {                                        // the chunk's last tile holds nothing but the CLS key (its row 0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (!(g == 0 && j == 0)) s[NTC - 1][j] = -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int ti = 0; ti < NTC; ++ti)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[ti][j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+    const float mb = m_new * LOG2E;
+    float lsum = 0.f;
+#pragma unroll
+    for (int ti = 0; ti < NTC; ++ti)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float pv = __builtin_amdgcn_exp2f(s[ti][j] * LOG2E - mb);
+            s[ti][j] = pv;
+            lsum += pv;
+        }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+    // O^T += V^T . P^T, two key tiles per MFMA
+#pragma unroll
+    for (int pr = 0; pr < (NTC + 1) / 2; ++pr) {
+        const bool has_b = 2 * pr + 1 < NTC;
+        const f32x4 pa = s[2 * pr], pb = s[has_b ? 2 * pr + 1 : 2 * pr];
+        const bf16x8 pf = {(bf16_t)pa[0], (bf16_t)pa[1], (bf16_t)pa[2], (bf16_t)pa[3],
+                           (bf16_t)(has_b ? pb[0] : 0.f), (bf16_t)(has_b ? pb[1] : 0.f), (bf16_t)(has_b ? pb[2] : 0.f), (bf16_t)(has_b ? pb[3] : 0.f)};
+        const int ra = (t0 + 2 * pr) * 16 + 4 * g + trq, rb = has_b ? ra + 16 : ra;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int ch = 2 * trp + (dt >> 1), sub = (dt & 1) * 8;
+            const bf16x4 a0 = lds_tr4(Vs + ra * 128 + ((ch ^ vswz(ra)) << 4) + sub);
+            const bf16x4 a1 = lds_tr4(Vs + rb * 128 + ((ch ^ vswz(rb)) << 4) + sub);
+            const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf, o[dt], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * NW16, 4) void space_attn16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                  float* __restrict__ cls_partial, int B, int T, int n, int heads, int KP) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const size_t tile = (size_t)KP * 256;              // K + V of one problem
-    float* scratch = (float*)(smem + 2 * tile);
+    char* Ks = smem;
+    char* Vs = smem + (size_t)KP * 128;
+    float* scratch = (float*)(smem + (size_t)KP * 256);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = heads * 64;
     const int64_t ld = 3 * (int64_t)D;
     const int N = 1 + T * n;
-    const int total = B * T * heads;
-    const int ql = lane & 31, h = lane >> 5;
-    auto locate = [&](int prob, const bf16_t*& base, const bf16_t*& q_ptr, int& b, int& f, int& head) {
-        head = prob % heads;
-        f = (prob / heads) % T;
-        b = prob / (heads * T);
-        base = qkv + (int64_t)b * N * ld + head * 64;
-        q_ptr = base + (int64_t)(1 + f * n) * ld;
-    };
-    int prob = blockIdx.x;
-    if (prob >= total) return;
-    {
-        const bf16_t *base, *q_ptr; int b, f, head;
-        locate(prob, base, q_ptr, b, f, head);
-        space_stage<NWP>(smem, smem + (size_t)KP * 128, base, q_ptr, ld, D, n, KP, lane, wave);
-    }
-    for (int it = 0; prob < total; prob += gridDim.x, ++it) {
-        char* Ks = smem + (it & 1) * tile;
-        char* Vs = Ks + (size_t)KP * 128;
-        const bf16_t *base, *q_ptr; int b, f, head;
-        locate(prob, base, q_ptr, b, f, head);
-        // this wave's query block (n <= 256 -> at most one per wave): fetched BEFORE the wait so that no ordinary load is
-        // pending while the next problem's LDS-DMA prefetch is in flight (hipcc would drain it with a vmcnt(0))
-        const bool has_q = wave < (n >> 5);
-        bf16x8 qf[4];
-        {
-            const bf16_t* qrow = q_ptr + (int64_t)((has_q ? wave : 0) * 32 + ql) * ld + 8 * h;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
+    int bid = blockIdx.x;
+    const int head = bid % heads; bid /= heads;
+    const int f = bid % T;
+    const int b = bid / T;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;
+    const bf16_t* q_ptr = base + (int64_t)(1 + f * n) * ld;
+    space_stage<NW16>(Ks, Vs, base, q_ptr, ld, D, n, KP, lane, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int c = lane & 15, g = lane >> 4;
+    const int nt = (n >> 4) + 1;                       // 16-key tiles incl. the CLS tile
+    for (int qb = wave; qb < (n >> 4); qb += NW16) {
+        bf16x8 q[2];
+        const bf16_t* qrow = q_ptr + (int64_t)(qb * 16 + c) * ld + 8 * g;
+        q[0] = *(const bf16x8*)(qrow);
+        q[1] = *(const bf16x8*)(qrow + 32);
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 o[4] = {z4, z4, z4, z4};
+        float m_run = -INFINITY, l_run = 0.f;
+        int t0 = 0;
+        for (; t0 + CH16 < nt; t0 += CH16) space16_chunk<CH16, false>(Ks, Vs, q, t0, lane, o, m_run, l_run);
+#define S16_TAIL(R) space16_chunk<R, true>(Ks, Vs, q, t0, lane, o, m_run, l_run)
+        switch (nt - t0) {                             // 1 .. CH16 tiles left, the last one is the CLS tile
+            case 1: S16_TAIL(1); break;
+            case 2: S16_TAIL(2); break;
+            case 3: S16_TAIL(3); break;
+            case 4: S16_TAIL(4); break;
+            case 5: S16_TAIL(5); break;
+            case 6: S16_TAIL(6); break;
+            case 7: S16_TAIL(7); break;
+            case 8: S16_TAIL(8); break;
+            default: S16_TAIL(9); break;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();          // this problem's tile has landed for every wave; every wave has left the other buffer
-        const int nxt = prob + gridDim.x;
-        if (nxt < total) {
-            const bf16_t *nb, *nq; int b2, f2, h2;
-            locate(nxt, nb, nq, b2, f2, h2);
-            char* Kn = smem + ((it + 1) & 1) * tile;
-            space_stage<NWP>(Kn, Kn + (size_t)KP * 128, nb, nq, ld, D, n, KP, lane, wave);
-        }
-        if (has_q)
-            space_query_block(Ks, Vs, qf, out + ((int64_t)b * N + 1 + f * n + wave * 32 + ql) * D + head * 64 + 4 * h, n >> 5, lane);
-        if (cls_partial != nullptr)
-            space_cls_partial<NWP>(Ks, Vs, scratch, KP, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0,
-                                   tid, lane, wave);
+#undef S16_TAIL
+        const float inv = 1.f / l_run;
+        bf16_t* op = out + ((int64_t)b * N + 1 + f * n + qb * 16 + c) * D + head * 64 + 16 * g;
+        const u32x4 w0 = {pack_bf16(o[0][0] * inv, o[0][1] * inv), pack_bf16(o[0][2] * inv, o[0][3] * inv),
+                          pack_bf16(o[1][0] * inv, o[1][1] * inv), pack_bf16(o[1][2] * inv, o[1][3] * inv)};
+        const u32x4 w1 = {pack_bf16(o[2][0] * inv, o[2][1] * inv), pack_bf16(o[2][2] * inv, o[2][3] * inv),
+                          pack_bf16(o[3][0] * inv, o[3][1] * inv), pack_bf16(o[3][2] * inv, o[3][3] * inv)};
+        *(u32x4*)(op) = w0;
+        *(u32x4*)(op + 8) = w1;
     }
+    if (cls_partial == nullptr) return;
+    space_cls_partial<NW16>(Ks, Vs, scratch, KP, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
 }
 
 // merge G partial records per (clip, head) into out row 0:  o = sum_g o_g e^{m_g - m} / sum_g l_g e^{m_g - m}
@@ -377,25 +446,22 @@ extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial,
     HH_REQUIRE(HH_ALIGNED16(qkv) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_space_attn_fwd: pointers must be 16-byte aligned");
     if (B == 0) return HH_OK;
     const int KP = ((n + 1 + 31) / 32) * 32;
-    // HH_SPACE_ATTN: 0 = one workgroup per problem (default; measured 453 us/call at B=32), 1 = persistent double-buffered
-    // variant (480 us: one workgroup per CU keeps fewer bytes in flight than two independent ones, which outweighs the overlap)
+    // HH_SPACE_ATTN: 2 (default) = 16-query blocks, 8 waves per workgroup (365 us/call at B = 32); 0 = 32-query blocks on
+    // 32x32x16 MFMAs, 4 waves per workgroup (420 us).  A persistent double-buffered variant of the latter was measured at 480 us
+    // and removed.
     static int mode = -1;
-    if (mode < 0) { const char* e = getenv("HH_SPACE_ATTN"); mode = e ? atoi(e) : 0; }
-    const size_t lds_p = 2 * (size_t)KP * 256 + ((size_t)KP + NWP * CLS_REC + 2 * NWP) * 4;
-    if (mode == 1 && lds_p <= 160 * 1024 && (n >> 5) <= NWP) {
-        static size_t attr_p = 0;
-        if (lds_p > attr_p) {
-            hipError_t e = hipFuncSetAttribute((const void*)space_attn_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
-            HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds_p);
-            attr_p = lds_p;
+    if (mode < 0) { const char* e = getenv("HH_SPACE_ATTN"); mode = e ? atoi(e) : 2; }
+    const size_t lds16 = (size_t)KP * 256 + ((size_t)KP + NW16 * CLS_REC + 2 * NW16) * 4;
+    if (mode == 2 && lds16 <= 160 * 1024) {
+        static size_t attr16 = 0;
+        if (lds16 > attr16) {
+            hipError_t e = hipFuncSetAttribute((const void*)space_attn16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+            HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds16);
+            attr16 = lds16;
         }
-        static int ncu = 0;
-        if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
-        const int64_t total = (int64_t)B * T * heads;
-        const unsigned grid = (unsigned)(total < ncu ? total : ncu);
-        hipLaunchKernelGGL(space_attn_persistent_kernel, dim3(grid), dim3(64 * NWP), lds_p, (hipStream_t)stream,
+        hipLaunchKernelGGL(space_attn16_kernel, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW16), lds16, (hipStream_t)stream,
                            (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP);
-        return hh_check_launch("hh_space_attn_fwd(persistent)");
+        return hh_check_launch("hh_space_attn_fwd(16-query blocks)");
     }
     const size_t lds = (size_t)KP * 256 + ((size_t)KP + NW * CLS_REC + 2 * NW) * 4;
     HH_REQUIRE(lds <= 160 * 1024, HH_ERR_UNSUPPORTED, "hh_space_attn_fwd: n=%d needs %zu B of LDS (> 160 KiB)", n, lds);
