@@ -360,6 +360,83 @@ __device__ __forceinline__ void space16_chunk(const char* Ks, const char* Vs, co
     }
 }
 
+// CLS query (model/LaviLa.py:255-258) over THIS frame's keys on the matrix core: wave w takes the 16-key tiles w, w + NW16, ...
+// (the CLS key's own tile is counted by frame 0 only) with B = q_cls replicated in all 16 columns, keeps an online-softmax partial
+// (m, l, o[64]) and the workgroup merges its NW16 partials through LDS.  The VALU version (space_cls_partial) issued ~350 vector
+// instructions per wave -- 36 % of this kernel's VALU work.
+__device__ __forceinline__ void space16_cls_partial(const char* Ks, const char* Vs, float* scratch, const bf16_t* base, float* rec,
+                                                    int n, bool first_frame, int tid, int lane, int wave) {
+    const int c = lane & 15, g = lane >> 4;
+    const int trq = c >> 2, trp = c & 3;
+    const float LOG2E = 1.4426950408889634f;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 qc[2];
+    qc[0] = *(const bf16x8*)(base + 8 * g);
+    qc[1] = *(const bf16x8*)(base + 8 * g + 32);
+    const int nfull = n >> 4, ntiles = nfull + (first_frame ? 1 : 0);
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[4] = {z4, z4, z4, z4};
+    for (int t = wave; t < ntiles; t += NW16) {
+        const int krow = t * 16 + c;
+        f32x4 s = z4;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((g + 4 * ks) ^ kswz(krow)) << 4));
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qc[ks], s, 0, 0, 0);
+        }
+        if (t == nfull) {                              // CLS tile: only its row 0 is a key
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!(g == 0 && j == 0)) s[j] = -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+        const float mb = m_new * LOG2E;
+        float p[4], ls = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { p[j] = __builtin_amdgcn_exp2f(s[j] * LOG2E - mb); ls += p[j]; }
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+        const bf16x8 pf = {(bf16_t)p[0], (bf16_t)p[1], (bf16_t)p[2], (bf16_t)p[3], 0, 0, 0, 0};
+        const int ra = t * 16 + 4 * g + trq;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int ch = 2 * trp + (dt >> 1), sub = (dt & 1) * 8;
+            const bf16x4 a0 = lds_tr4(Vs + ra * 128 + ((ch ^ vswz(ra)) << 4) + sub);
+            const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a0[0], a0[1], a0[2], a0[3]};      // second half meets zero probabilities
+            o[dt] *= alpha;
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf, o[dt], 0, 0, 0);
+        }
+    }
+    // per-wave partial -> LDS: [wave][m, l, -, -, o[64]]; accumulator lane (c, g) register (dt, j) = d 16 g + 4 dt + j, same for every c
+    float* wrec = scratch + wave * CLS_REC;
+    if (c == 0) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *(f32x4*)(wrec + 4 + 16 * g + 4 * dt) = o[dt];
+        if (g == 0) { wrec[0] = m_run; wrec[1] = l_run; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NW16; ++w) m = fmaxf(m, scratch[w * CLS_REC]);
+        float l = 0.f, ot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW16; ++w) {
+            const float e = __builtin_amdgcn_exp2f((scratch[w * CLS_REC] - m) * LOG2E);
+            l += scratch[w * CLS_REC + 1] * e;
+            ot += scratch[w * CLS_REC + 4 + tid] * e;
+        }
+        rec[4 + tid] = ot;
+        if (tid == 0) { rec[0] = m; rec[1] = l; }
+    }
+}
+
 __global__ __launch_bounds__(64 * NW16, 4) void space_attn16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                   float* __restrict__ cls_partial, int B, int T, int n, int heads, int KP) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -415,7 +492,7 @@ __global__ __launch_bounds__(64 * NW16, 4) void space_attn16_kernel(const bf16_t
         *(u32x4*)(op + 8) = w1;
     }
     if (cls_partial == nullptr) return;
-    space_cls_partial<NW16>(Ks, Vs, scratch, KP, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
+    space16_cls_partial(Ks, Vs, scratch, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
 }
 
 // merge G partial records per (clip, head) into out row 0:  o = sum_g o_g e^{m_g - m} / sum_g l_g e^{m_g - m}
