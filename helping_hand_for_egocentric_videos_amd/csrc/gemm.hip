@@ -155,67 +155,61 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 1) void gemm_bf16_kernel(Gem
 // ---------------------------------------------------------------------------------------------------------------------
 // Row-tail kernel: the <= 64 rows that do not fill a 256-row tile of the persistent kernel (M = B*4097 always leaves B mod 256
 // CLS-ish rows; 168 such launches per step).  The 128x128 kernel walks K serially (16-64 barrier-separated k-tiles: 16-64 us of
-// a nearly idle chip per launch); here a workgroup owns 64 rows x 64 columns and its 4 waves SPLIT K four ways, each streaming
+// a nearly idle chip per launch); here a workgroup owns 32 or 64 rows x 32 columns and its 4 or 8 waves SPLIT K, each streaming
 // its operands from global memory directly in MFMA layout (v_mfma_f32_32x32x16_bf16: lane = row / column, 8 consecutive k per
 // lane = one 16-B load; no LDS staging, no barrier in the k loop), then the partial accumulators meet in LDS and wave w
 // finishes output tile w with the common epilogue.
-template <bool OUT_BF16>
-__global__ __launch_bounds__(256) void gemm_tail_kernel(GemmParams p) {
-    __shared__ float red[4 * 4 * 16 * 64];                       // [wave][tile][reg][lane] = 64 KiB
+template <bool OUT_BF16, int NWT, int MT>
+__global__ __launch_bounds__(64 * NWT) void gemm_tail_kernel(GemmParams p) {
+    // workgroup = 32 MT rows x 32 columns; its NWT waves split K.  [wave][m-tile][reg][lane] partials meet in LDS (<= 64 KiB)
+    __shared__ float red[NWT * MT * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 64;
-    const int kslice = p.K / 4;                                   // K % 64 == 0 -> multiple of 16
+    const int n0 = blockIdx.x * 32;
+    const int kslice = p.K / NWT;                                 // multiple of 64 (checked by the launcher)
     const int k_begin = wave * kslice;
-    const bf16_t* ap[2];
-    const bf16_t* wp[2];
+    const bf16_t* ap[MT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MT; ++i) {
         int64_t gm = p.m_start + i * 32 + l31;
         if (gm > p.M - 1) gm = p.M - 1;
         ap[i] = p.A + gm * p.lda + k_begin + 8 * h;
-        wp[i] = p.W + (int64_t)(n0 + i * 32 + l31) * p.ldw + k_begin + 8 * h;
     }
-    f32x16 acc[2][2];                                             // [nt][mt]: C^T tiles (rows = n, columns = m)
+    const bf16_t* wp = p.W + (int64_t)(n0 + l31) * p.ldw + k_begin + 8 * h;
+    f32x16 acc[MT];                                               // C^T tiles (rows = n, columns = m)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    for (int k = 0; k < kslice; k += 64) {                        // 4 k-steps of 16 per iteration: 4 (MT + 1) independent 16-B loads in flight
+        bf16x8 af[4][MT], wf[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    for (int k = 0; k < kslice; k += 64) {                        // 4 k-steps of 16 per iteration: 16 independent 16-B loads in flight
-        bf16x8 af[4][2], wf[4][2];
+        for (int s = 0; s < 4; ++s) {
+            wf[s] = *(const bf16x8*)(wp + k + 16 * s);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[s][i] = *(const bf16x8*)(ap[i] + k + 16 * s);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[s][i] = *(const bf16x8*)(ap[i] + k + 16 * s);
-                wf[s][i] = *(const bf16x8*)(wp[i] + k + 16 * s);
-            }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][nt], af[s][mt], acc[nt][mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], af[s][mt], acc[mt], 0, 0, 0);
     }
-    // ---- cross-wave reduction: wave w finishes tile w = (nt = w >> 1, mt = w & 1)
+    // ---- cross-wave reduction: wave w < MT finishes m-tile w
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[((wave * 4 + nt * 2 + mt) * 16 + r) * 64 + lane] = acc[nt][mt][r];
+        for (int r = 0; r < 16; ++r) red[((wave * MT + mt) * 16 + r) * 64 + lane] = acc[mt][r];
     __syncthreads();
-    const int nt = wave >> 1, mt = wave & 1;
+    if (wave >= MT) return;
+    const int mt = wave;
     f32x16 t;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) v += red[((w * 4 + nt * 2 + mt) * 16 + r) * 64 + lane];
+        for (int w = 0; w < NWT; ++w) v += red[((w * MT + mt) * 16 + r) * 64 + lane];
         t[r] = v;
     }
     const int64_t m = p.m_start + mt * 32 + l31;
@@ -227,7 +221,7 @@ __global__ __launch_bounds__(256) void gemm_tail_kernel(GemmParams p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {                                 // accumulator register r: n = 8 (r >> 2) + 4 h + (r & 3)
         const f32x4 v = {t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
-        gemm_store4<OUT_BF16>(e, Cbase, p.ldc, orow, n0 + nt * 32 + 8 * g + 4 * h, v);
+        gemm_store4<OUT_BF16>(e, Cbase, p.ldc, orow, n0 + 8 * g + 4 * h, v);
     }
 }
 
@@ -267,9 +261,15 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         p.m_start = pm.M;
     }
     if (M - p.m_start <= 64 && K % 256 == 0 && epi->splitk <= 1 && gemm_tail_enabled()) {
-        // (< 64)-row tail of a tall GEMM, or a GEMM that is this short altogether: split-K-in-workgroup kernel
-        if (epi->c_dtype == HH_BF16) hipLaunchKernelGGL((gemm_tail_kernel<true>), dim3((unsigned)(N / 64)), dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((gemm_tail_kernel<false>), dim3((unsigned)(N / 64)), dim3(256), 0, (hipStream_t)stream, p);
+        // (< 64)-row tail of a tall GEMM, or a GEMM that is this short altogether: split-K-in-workgroup kernel, 32-column workgroups,
+        // 8 waves when K splits 8 ways into multiples of 64, one or two 32-row tiles
+        const bool bf = epi->c_dtype == HH_BF16, w8 = K % 512 == 0, two = M - p.m_start > 32;
+        const dim3 grid((unsigned)(N / 32));
+        hipStream_t ts = (hipStream_t)stream;
+#define TAIL(BF, NWT, MT) hipLaunchKernelGGL((gemm_tail_kernel<BF, NWT, MT>), grid, dim3(64 * NWT), 0, ts, p)
+        if (bf) { if (w8) { if (two) TAIL(true, 8, 2); else TAIL(true, 8, 1); } else { if (two) TAIL(true, 4, 2); else TAIL(true, 4, 1); } }
+        else    { if (w8) { if (two) TAIL(false, 8, 2); else TAIL(false, 8, 1); } else { if (two) TAIL(false, 4, 2); else TAIL(false, 4, 1); } }
+#undef TAIL
         return hh_check_launch("hh_gemm_bf16(tail)");
     }
     p.Mt = (int)((M - p.m_start + BM - 1) / BM);
