@@ -42,7 +42,7 @@ SIGNATURES = {
     "hh_cls_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "hh_text_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "hh_xattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
-    "hh_xattn_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_float,
+    "hh_xattn_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_float,
                      ctypes.c_uint32, c_vp],
     "hh_match_boxes": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_float, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "hh_lsap_rows": [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],

@@ -198,12 +198,16 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
     s16x4 qT[4], doT[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
+        // row m = ql of transposed tile dt is d = 16 (m >> 2) + 4 dt + (m & 3): the dV^T / dK^T accumulators of the four tiles then give a
+        // lane (key, g) the 16 CONSECUTIVE d 16 g .. 16 g + 15 -> two 16-B stores per key row and matrix (a full 128-B line per 4 lanes)
+        // instead of eight 8-B stores scattered 32 B apart
+        const int dperm = 16 * (ql >> 2) + 4 * dt + (ql & 3);
         bf16x4 a, c;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int qq = 4 * g + jj;
-            a[jj] = (bf16_t)((qq < Q) ? qrow[(int64_t)qq * C + dt * 16 + ql] : 0.f);
-            c[jj] = (bf16_t)((qq < Q) ? dorow[(int64_t)qq * C + dt * 16 + ql] : 0.f);
+            a[jj] = (bf16_t)((qq < Q) ? qrow[(int64_t)qq * C + dperm] : 0.f);
+            c[jj] = (bf16_t)((qq < Q) ? dorow[(int64_t)qq * C + dperm] : 0.f);
         }
         qT[dt] = __builtin_bit_cast(s16x4, a);
         doT[dt] = __builtin_bit_cast(s16x4, c);
@@ -223,7 +227,11 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dqa[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = wave * 32; k0 < M; k0 += 128) {
+    // blockIdx.y owns a contiguous slice of the keys (one workgroup per (clip, head) = 256 workgroups left three quarters of the
+    // memory pipeline idle: 2 MB per CU at ~20 GB/s per CU); dq partials of the slices are summed by the caller in a fixed order
+    const int m_per = ((M / 32 + gridDim.y - 1) / gridDim.y) * 32;
+    const int m_lo = blockIdx.y * m_per, m_hi = min(M, m_lo + m_per);
+    for (int k0 = m_lo + wave * 32; k0 < m_hi; k0 += 128) {
         stage_transposed(kb + (int64_t)k0 * ldkv, ldkv, tile, lane);
         bf16x8 dsT;
 #pragma unroll
@@ -257,15 +265,18 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
                 dsb[r] = (bf16_t)(p * (dpm - del_r[r]));
             }
             const s16x4 pbs = __builtin_bit_cast(s16x4, pb), dsbs = __builtin_bit_cast(s16x4, dsb);
+            unsigned wv[8], wk[8];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                f32x4 gv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(doT[dt], pbs, zero, 0, 0, 0);   // dV^T[d][key]
-                f32x4 gk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT[dt], dsbs, zero, 0, 0, 0);   // dK^T[d][key]
-                u32x2 wv = {pack_bf16(gv[0], gv[1]), pack_bf16(gv[2], gv[3])};
-                u32x2 wk = {pack_bf16(gk[0], gk[1]), pack_bf16(gk[2], gk[3])};
-                *(u32x2*)(dvb + key * lddkv + dt * 16 + 4 * g) = wv;
-                *(u32x2*)(dkb + key * lddkv + dt * 16 + 4 * g) = wk;
+                f32x4 gv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(doT[dt], pbs, zero, 0, 0, 0);   // dV^T[d = 16 g + 4 dt + j][key]
+                f32x4 gk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT[dt], dsbs, zero, 0, 0, 0);   // dK^T
+                wv[2 * dt] = pack_bf16(gv[0], gv[1]); wv[2 * dt + 1] = pack_bf16(gv[2], gv[3]);
+                wk[2 * dt] = pack_bf16(gk[0], gk[1]); wk[2 * dt + 1] = pack_bf16(gk[2], gk[3]);
             }
+            *(u32x4*)(dvb + key * lddkv + 16 * g) = (u32x4){wv[0], wv[1], wv[2], wv[3]};
+            *(u32x4*)(dvb + key * lddkv + 16 * g + 8) = (u32x4){wv[4], wv[5], wv[6], wv[7]};
+            *(u32x4*)(dkb + key * lddkv + 16 * g) = (u32x4){wk[0], wk[1], wk[2], wk[3]};
+            *(u32x4*)(dkb + key * lddkv + 16 * g + 8) = (u32x4){wk[4], wk[5], wk[6], wk[7]};
             // swapped: lane = q (ql), registers = key (4g + r)
             f32x4 st = zero, dpt = zero;
 #pragma unroll
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
     __syncthreads();
     for (int e = tid; e < Q * 64; e += 256) {
         const int qq = e >> 6, d = e & 63;
-        dq[((int64_t)b * Q + qq) * C + head * 64 + d] = (qbuf[0][qq][d] + qbuf[1][qq][d]) + (qbuf[2][qq][d] + qbuf[3][qq][d]);
+        dq[(((int64_t)blockIdx.y * B + b) * Q + qq) * C + head * 64 + d] = (qbuf[0][qq][d] + qbuf[1][qq][d]) + (qbuf[2][qq][d] + qbuf[3][qq][d]);
     }
 }
 
@@ -328,7 +339,7 @@ extern "C" int hh_xattn_fwd(const float* q, const void* k, const void* v, int64_
 }
 
 extern "C" int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_t ldkv, const float* out, const float* lse,
-                            const float* dout, float* dq, void* dk, void* dv, int64_t lddkv, int B, int Q, int M, int heads,
+                            const float* dout, float* dq, int dq_splits, void* dk, void* dv, int64_t lddkv, int B, int Q, int M, int heads,
                             float dropout_p, uint32_t seed, hh_stream_t stream) {
     int rc = xattn_check("hh_xattn_bwd", B, Q, M, heads, ldkv);
     if (rc) return rc;
@@ -339,7 +350,8 @@ extern "C" int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_
     if (B == 0) return HH_OK;
     unsigned thr; float sc;
     drop_params(dropout_p, &thr, &sc);
-    hipLaunchKernelGGL(xattn_bwd_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)k,
+    HH_REQUIRE(dq_splits >= 1 && dq_splits <= 64, HH_ERR_SHAPE, "hh_xattn_bwd: dq_splits must be in [1, 64]");
+    hipLaunchKernelGGL(xattn_bwd_kernel, dim3((unsigned)(B * heads), (unsigned)dq_splits), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)k,
                        (const bf16_t*)v, ldkv, out, lse, dout, dq, (bf16_t*)dk, (bf16_t*)dv, lddkv, B, Q, M, heads, thr, sc, seed);
     return hh_check_launch("hh_xattn_bwd");
 }

@@ -293,16 +293,19 @@ def xattn_fwd(q, k, v, heads, dropout_p=0.0, seed=0):
     return out, lse
 
 
-def xattn_bwd(q, k, v, out, lse, dout, dk, dv, heads, dropout_p=0.0, seed=0):
-    """Writes dk/dv (bf16 [B,M,C] row-strided views) in place; returns dq fp32 [B,Q,C]."""
+def xattn_bwd(q, k, v, out, lse, dout, dk, dv, heads, dropout_p=0.0, seed=0, splits=None):
+    """Writes dk/dv (bf16 [B,M,C] row-strided views) in place; returns dq fp32 [B,Q,C].  The keys are cut into `splits` slices
+    (one workgroup each per (clip, head)); the slices' dq partials are summed here in a fixed order."""
     B, Q, C = q.shape
     M = k.shape[1]
     _chk(q, out, lse, dout)
-    dq = torch.empty_like(q)
-    _lib.check(_lib.lib().hh_xattn_bwd(_p(q), _p(k), _p(v), k.stride(1), _p(out), _p(lse), _p(dout), _p(dq), _p(dk), _p(dv),
+    if splits is None:
+        splits = max(1, min(8, M // 1024))
+    dq = torch.empty((splits, B, Q, C), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().hh_xattn_bwd(_p(q), _p(k), _p(v), k.stride(1), _p(out), _p(lse), _p(dout), _p(dq), int(splits), _p(dk), _p(dv),
                                        dk.stride(1), B, Q, M, heads, float(dropout_p), int(seed) & 0xFFFFFFFF, _stream()),
                "hh_xattn_bwd")
-    return dq
+    return dq[0] if splits == 1 else dq.sum(0)
 
 
 def match_boxes(pred, q0, q, raw_boxes, img=224.0, w_l1=5.0, w_giou=2.0, given_count=None):

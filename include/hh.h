@@ -144,9 +144,10 @@ int hh_text_attn_fwd(const void* qkv, void* out, int S, int L, int heads, hh_str
  * tfm_decoder.py:365) with a counter-based mask keyed by (seed, clip, head, query, key); the backward regenerates it. */
 int hh_xattn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out, float* lse,
                  int B, int Q, int M, int heads, float dropout_p, uint32_t seed, hh_stream_t stream);
-/* backward: dq fp32 [B,Q,C]; dk/dv bf16 [B, M, lddkv] */
+/* backward: the keys are cut into dq_splits slices (one workgroup each per (clip, head)); dq fp32 [dq_splits, B, Q, C] holds the
+ * slices' partial dq (the caller sums them); dk/dv bf16 [B, M, lddkv] */
 int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_t ldkv, const float* out, const float* lse,
-                 const float* dout, float* dq, void* dk, void* dv, int64_t lddkv,
+                 const float* dout, float* dq, int dq_splits, void* dk, void* dv, int64_t lddkv,
                  int B, int Q, int M, int heads, float dropout_p, uint32_t seed, hh_stream_t stream);
 
 /* ---- Hungarian matching + box losses (model/box_utils.py:43-92,156-173,249-279; utils/box_ops.py:9-61)
