@@ -755,7 +755,7 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(GemmParams p) {
 
 static int g_debug_ts = 0;         // debug: record the per-tile timeline of the persistent kernel
 static int g_nostore = 0;          // debug: skip the epilogue stores (timing experiments only)
-static int g_group = 8;            // m-tiles per XCD-local group (weight-panel reuse factor)
+static int g_group = 0;            // m-tiles per XCD-local group (weight-panel reuse factor); 0 = per-shape default
 static int g_pskew = 0;            // continuous persistent kernel: start skew quantum (s_sleep(8) units per workgroup index in its XCD)
 static int g_skew = -1;            // start skew: -1 auto (on when the epilogue carries an fp32 residual), 0 off, 1 on
 static int g_mode = -1;            // gemm256 mode: 0 = off, 1 = no stagger, 2 = stagger, 3 = persistent, 4 = continuous persistent (default) where eligible
@@ -773,7 +773,7 @@ extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm256_pskew") && value >= 0 && value <= 64) { g_pskew = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_debug_nostore")) { g_nostore = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_debug_ts")) { g_debug_ts = value; return HH_OK; }
-    if (name && !strcmp(name, "gemm256_group") && value >= 1 && value <= 64) { g_group = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm256_group") && value >= 0 && value <= 64) { g_group = value; return HH_OK; }
     hh_set_error("hh_set_tuning: unknown knob '%s'", name ? name : "(null)");
     return HH_ERR_UNSUPPORTED;
 }
@@ -814,7 +814,9 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
     }
     p.Mt = (int)((p.M + 255) / 256);
     p.Nt = p.N / 256;
-    const int GROUP = g_group;
+    // m-tiles per XCD-local group: 8 everywhere except the narrow short-K projections (N <= 1024, K <= 1024: +2.8 % at 16 in the
+    // group sweep, scripts/gemm_group_bench.py); "gemm256_group" overrides
+    const int GROUP = g_group > 0 ? g_group : ((p.N / 256 <= 4 && p.K <= 1024) ? 16 : 8);
     p.group_m = GROUP;
     p.debug_nostore = g_nostore;
     p.debug_ts = g_debug_ts;
