@@ -30,8 +30,9 @@ enum hh_act { HH_ACT_NONE = 0, HH_ACT_QUICKGELU = 1, HH_ACT_RELU = 2 };
 int hh_version(void);
 /* Performance knobs for A/B measurements (never change results): "gemm256" = 0 (128x128 kernel only), 1 (256x256
  * 8-phase, no stagger), 2 (256x256 with wave-group stagger), 3 (persistent 256x256 -- one workgroup per CU walks its
- * tiles and prefetches the next tile's first two k-tiles before the epilogue stores -- where eligible, else mode 2), 4 (default:
- * continuous persistent -- the next tile's first two k-tiles are staged during the current tile's last two, no prologue at all);
+ * tiles and prefetches the next tile's first two k-tiles before the epilogue stores -- where eligible, else mode 2), 4 (continuous
+ * persistent -- the next tile's first two k-tiles are staged during the current tile's last two, no prologue at all), 5 (default:
+ * mode 4 with the A-lo and the A-hi phases merged: four barriers per k-tile instead of eight);
  * "gemm256_skew" = -1 auto / 0 off / 1 on (start-time skew of the first round of 256x256 blocks, spreads the epilogue HBM bursts);
  * "gemm256_pskew" = 0..64 (start skew quantum of the continuous kernel, default 0). */
 int hh_set_tuning(const char* name, int value);
