@@ -756,7 +756,9 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(GemmParams p) {
 // FOUR-BARRIER variant of the continuous kernel: the two A-lo phases and the two A-hi phases of a k-tile are merged (32 MFMAs per
 // wave between two barriers instead of 16; one counted vmcnt wait per k-tile as before).  The in-kernel timeline puts the main
 // loop at 2450-2680 cycles per k-tile against 2048 MFMA cycles: ~56 cycles are lost at each of the 8 barrier hand-overs between
-// the two waves of a SIMD; halving the hand-overs is the experiment.
+// the two waves of a SIMD; halving the hand-overs gives qkv 1170 -> 1225, fc1 1133 -> 1223, fc2 1305 -> 1350 TFLOP/s.  (One phase per
+// k-tile -- 64 MFMAs per hand-over, whole k-tiles staged into the buffer being computed from -- was tried: slower, 1040 TFLOP/s,
+// because the prefetch lead shrinks to one k-tile, and it raced in one test.)
 template <bool OUT_BF16, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256d_kernel(GemmParams p) {
     constexpr bool STAGGER = true;
