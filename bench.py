@@ -232,8 +232,8 @@ def main():
         roof = None
         if n_g:
             ach = fl_g / (ms_g * 1e-3) / 1e12
-            roof = {"kernel": "gemm256c_kernel (continuous persistent 256x256 8-phase; row tails on gemm_tail_kernel) via hh_gemm_bf16", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic("gemm256c_kernel<true") or pmc_traffic("gemm256p_kernel<true"),
+            roof = {"kernel": "gemm256d_kernel (continuous persistent 256x256, four barriers per k-tile; row tails on gemm_tail_kernel) via hh_gemm_bf16", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic("gemm256d_kernel<true") or pmc_traffic("gemm256c_kernel<true") or pmc_traffic("gemm256p_kernel<true"),
                     "traffic_note": "bytes/launch from profiles/r1_pmc_summary.json (PMC passes at B=32); algorithmic avg ~0.99e9",
                     "launches_timed": n_g, "sampling": "every %dth hh_gemm_bf16 launch of the timed region" % timer.stride,
                     "avg_launch_us": round(ms_g * 1e3 / n_g, 1), "share_of_step": round(ms_g * timer.stride / (dt * 1e3), 3)}
