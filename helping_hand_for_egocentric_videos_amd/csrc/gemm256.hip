@@ -1066,9 +1066,9 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
     }
     p.Mt = (int)((p.M + 255) / 256);
     p.Nt = p.N / 256;
-    // m-tiles per XCD-local group: 8 everywhere except the narrow short-K projections (N <= 1024, K <= 1024: +2.8 % at 16 in the
-    // group sweep, scripts/gemm_group_bench.py); "gemm256_group" overrides
-    const int GROUP = g_group > 0 ? g_group : ((p.N / 256 <= 4 && p.K <= 1024) ? 16 : 8);
+    // m-tiles per XCD-local group (scripts/gemm_group_bench.py with the four-barrier kernel): 16 for the short-K GEMMs up to 12 n-tiles
+    // (proj 1084 -> 1122, qkv 1181 -> 1201 TFLOP/s), 8 otherwise (fc1, fc2); "gemm256_group" overrides
+    const int GROUP = g_group > 0 ? g_group : ((p.N / 256 <= 12 && p.K <= 1024) ? 16 : 8);
     p.group_m = GROUP;
     p.debug_nostore = g_nostore;
     p.debug_ts = g_debug_ts;
