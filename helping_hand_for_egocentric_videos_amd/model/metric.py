@@ -18,7 +18,7 @@ def compute_tv_accuracy(similarity, text_embeds, sim_v, sim_n, num_samples, devi
     vt_argmax = similarity.argmax(dim=0)
     same = sim_matrix(text_embeds[::5], text_embeds[::5]) > 0.99
     ar = torch.arange(num_samples, device=similarity.device)
-    same[ar, ar] = False
+    same.fill_diagonal_(False)                       # (index_put_ with a Python scalar is an H2D copy + host sync)
     pos = (((sim_v * sim_n) + torch.eye(num_samples, device=similarity.device)) + same) > 0
     return pos[vt_argmax, ar].float().mean(), pos[ar, tv_argmax].float().mean()
 

@@ -45,6 +45,7 @@ class TrainStep:
         # CU budget of the persistent GEMMs on the pipelined encoder stream (0 = all CUs); see prefetch()
         self.enc_cus = int(os.environ.get("HH_ENC_CUS", "0")) if enc_cus is None else int(enc_cus)
         self._pending = None
+        self._zeroed_idx = None
         backbone.eval()                               # run/train.py:89
 
     # ------------------------------------------------------------------ forward
@@ -110,8 +111,9 @@ class TrainStep:
         text_embeds = self.decoder.txt_proj(tmap[torch.arange(text.shape[0], device=text.device), eot])
         obj = self.decoder.obj_proj(hs[-1])                                        # [B,Q,256]
         video_embeds = obj[:, -1]
-        noun_vec = batch["noun_vec"].clone()
-        noun_vec[:, ZEROED_NOUNS] = 0
+        if self._zeroed_idx is None or self._zeroed_idx.device != text.device:
+            self._zeroed_idx = torch.tensor(ZEROED_NOUNS, device=text.device)              # once: a Python-list index is an H2D copy + sync per step
+        noun_vec = batch["noun_vec"].clone().index_fill_(1, self._zeroed_idx, 0)
         pad_flag = ((text != 0).sum(-1) != 2).float()                               # run/train.py:144
         ve, te, pf, vv, nv = gather_contrastive(video_embeds, text_embeds, pad_flag, batch["verb_vec"], noun_vec)
         Bg = ve.shape[0]
