@@ -193,6 +193,26 @@ def test_full_step_vs_reference_golden(cfg, name):
     assert np.array_equal(scores.cpu().numpy().argmax(-1), g["mcq_scores"].argmax(-1))
 
 
+def test_step_issues_no_host_synchronisation():
+    """The step docstring's claim: after warm-up, a pipelined training step enqueues its work without a single synchronising call
+    (torch's sync debug mode raises on .item(), pageable H2D copies, boolean-mask indexing, ...)."""
+    cfg = TINY16
+    backbone = LaviLa.build_backbone(cfg, synth.encoder_state(cfg, seed=0), device="cuda")
+    decoder = tfm_decoder.build_decoder(cfg, synth.decoder_state(cfg, seed=0), device="cuda")
+    batch = {k: v.cuda() for k, v in synth.make_batch(cfg, 4, seed=1).items()}
+    ts = TrainStep(cfg, backbone, decoder)
+    for _ in range(2):
+        ts.step(batch, next_batch=batch)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = ts.step(batch, next_batch=batch)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["total_loss"]).item()
+
+
 def test_train_step_updates_like_oracle_adamw_and_learns():
     cfg = TINY4
     esd, dsd = synth.encoder_state(cfg, seed=4), synth.decoder_state(cfg, seed=4)
