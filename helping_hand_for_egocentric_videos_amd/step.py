@@ -153,6 +153,16 @@ class TrainStep:
         return out
 
 
+_MCQ_STREAMS = {}
+
+
+def _mcq_side_stream(device):
+    key = (device.type, device.index)
+    if key not in _MCQ_STREAMS:
+        _MCQ_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _MCQ_STREAMS[key]
+
+
 @torch.no_grad()
 def mcq_forward(backbone, decoder, video, text, cfg):
     """Batched EgoMCQ scoring (run/test_EgoMCQ.py:56-83): video [q,5,T,3,H,W], text [q,77] -> scores [q,5]."""
@@ -161,8 +171,15 @@ def mcq_forward(backbone, decoder, video, text, cfg):
     was = decoder.materialize_logits
     decoder.materialize_logits = False
     try:
+        # the text tower (77 x q tokens) cannot fill the chip: side stream beside the vision tower, as in TrainStep.encode
+        cur = torch.cuda.current_stream()
+        side = _mcq_side_stream(video.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            _, tmap = backbone.encode_text(text)
         _, fmap = backbone.visual.forward_features(video.flatten(0, 1), out_dtype=torch.bfloat16)
-        _, tmap = backbone.encode_text(text)
+        cur.wait_stream(side)
+        tmap.record_stream(cur)
         _, hs, _, _ = decoder(fmap[:, 1:].reshape(q * 5, T, n, fmap.shape[-1]))
         te = decoder.txt_proj(tmap[torch.arange(q, device=text.device), text.argmax(-1)])
         ve = decoder.obj_proj(hs[-1])[:, -1].view(q, 5, -1)
