@@ -25,6 +25,10 @@ SIGNATURES = {
     "hh_debug_gemm_timeline": [c_vp, c_int],
     "hh_stream_set_cu_budget": [c_vp, c_int],
     "hh_stream_get_cu_budget": [c_vp, ctypes.POINTER(c_int)],
+    "hh_workspace_bytes_gemm_splitk": [c_i64, c_int, c_int],
+    "hh_workspace_bytes_gemm_tn": [c_int, c_int, c_int],
+    "hh_workspace_bytes_xattn_bwd": [c_int, c_int, c_int, c_int],
+    "hh_workspace_bytes_attn_cls_partial": [c_int, c_int, c_int, c_int, c_int],
     "hh_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_float, c_vp],
     "hh_add_layernorm_fwd": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_float, c_vp],
     "hh_layernorm_bwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
@@ -44,13 +48,14 @@ SIGNATURES = {
     "hh_xattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
     "hh_xattn_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_float,
                      ctypes.c_uint32, c_vp],
-    "hh_match_boxes": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_float, c_float, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "hh_match_boxes": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_float, c_float, c_float, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "hh_lsap_rows": [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
     "hh_box_loss_fwd": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "hh_box_loss_bwd": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "hh_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_float, c_float, c_float, c_float, c_float, c_int, c_vp],
 }
-_RESTYPES = {"hh_last_error_string": ctypes.c_char_p}
+_RESTYPES = {"hh_last_error_string": ctypes.c_char_p, "hh_workspace_bytes_gemm_splitk": c_i64, "hh_workspace_bytes_gemm_tn": c_i64,
+             "hh_workspace_bytes_xattn_bwd": c_i64, "hh_workspace_bytes_attn_cls_partial": c_i64}
 
 _lib = None
 

@@ -3,22 +3,11 @@
 // HBM-bound in principle: algorithmic bytes per workgroup = (3*n + 2) * 128 B read + n * 128 B written.
 //
 // Structure: K tile and V tile, both row-major [KP][64] with XOR-swizzled 16-B chunks, staged once in LDS by LDS-DMA
-// (global_load_lds_dwordx4: no VGPR round trip, no VALU), then each wave walks 32-query blocks:
-//   S^T = K . Q^T      mfma_f32_32x32x16_bf16, A = K rows (LDS), B = Q rows (registers, straight from HBM)
-//   softmax over keys  in-lane over the 16 accumulator registers x tiles + one xor-32 shuffle (query = lane & 31)
-//   O^T = V^T . P^T    the S^T accumulator tile is re-used as the B operand with no lane movement
-//                      (k order inside a step: row 16s + 8(j>>2) + 4h + (j&3)); A = V^T fragments fetched from the
-//                      row-major V tile by the hardware-transposing ds_read_b64_tr_b16
-// Keys are processed in chunks of CH=5 tiles (160 keys; CH = 4 / 6 / 8 measured slower: 433 / 441 / 487 us vs 418 us, 8 spills)
-// with an online-softmax merge between chunks, so n=576
-// (336^2) runs through the same code.  Frame keys sit at rows 0..n-1, the CLS key at row n, rows > n are zero/masked.
+// (global_load_lds_dwordx4: no VGPR round trip, no VALU), then each wave walks 16-query blocks on v_mfma_f32_16x16x32_bf16
+// (see "16-query blocks" below).  Frame keys sit at rows 0..n-1, the CLS key at row n, rows > n are zero/masked.
+// The first generation (32-query blocks on 32x32x16 MFMAs, 4 waves per workgroup: 418 us per call at B = 32, VALU busy 49 %, MFMA
+// 18 %) was measured against this kernel in round 1 (365 -> 352 us) and removed in round 2.
 #include "common.h"
-#include <stdlib.h>
-
-#ifndef CH
-#define CH 5
-#endif
-#define NW 4            // waves per workgroup
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -44,194 +33,6 @@ __device__ __forceinline__ bf16x4 lds_tr4(const char* addr) {
 __device__ __forceinline__ int kswz(int r) { return (r ^ (r >> 3)) & 7; }
 __device__ __forceinline__ int vswz(int r) { return ((r >> 1) & 1) << 2; }
 
-// One chunk of key tiles for one 32-query block: NTC full 32-key tiles starting at tile t0 and, if CLS, the tile that holds
-// nothing but the CLS key (n % 32 == 0: key n is row 0 of tile n/32).  Everything is unrolled and unguarded: no zero-filled
-// accumulators (the first MFMA of a tile takes a constant-zero C), no per-register key masks (the CLS tile contributes ONE
-// score, register 0 of the h = 0 half-wave, and ONE k-slot of one PV step), no empty tile slots.  The guarded predecessor
-// spent 1420 VALU instructions per query block (SQ_INSTS_VALU), ~60 % of the SIMD issue time of the whole kernel.
-template <int NTC, bool CLS>
-__device__ __forceinline__ void space_chunk(const char* Ks, const char* Vs, const bf16x8 (&qf)[4], int t0, int lane,
-                                            f32x16& o0, f32x16& o1, float& m_run, float& l_run) {
-    const int ql = lane & 31, h = lane >> 5;
-    const float LOG2E = 1.4426950408889634f;
-    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
-    f32x16 z16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z16[r] = 0.f;
-    f32x16 s[NTC > 0 ? NTC : 1];
-#pragma unroll
-    for (int ti = 0; ti < NTC; ++ti) {
-        const int krow = (t0 + ti) * 32 + ql;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int c = 2 * ks + h;
-            bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + ((c ^ kswz(krow)) << 4));
-            s[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? z16 : s[ti], 0, 0, 0);
-        }
-    }
-    float xc = -INFINITY;
-    if (CLS) {
-        const int krow = (t0 + NTC) * 32 + ql;
-        f32x16 sc = z16;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int c = 2 * ks + h;
-            bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + ((c ^ kswz(krow)) << 4));
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
-        }
-        xc = h == 0 ? sc[0] : -INFINITY;                  // key n = tile row 0 = register 0 of the lower half-wave
-    }
-    float mx = xc;
-#pragma unroll
-    for (int ti = 0; ti < NTC; ++ti)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[ti][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-    const float mb = m_new * LOG2E;
-    float lsum = 0.f;
-#pragma unroll
-    for (int ti = 0; ti < NTC; ++ti)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(s[ti][r] * LOG2E - mb);
-            s[ti][r] = pv;
-            lsum += pv;
-        }
-    float pc = 0.f;
-    if (CLS) {
-        pc = __builtin_amdgcn_exp2f(xc * LOG2E - mb);     // 0 in the upper half-wave
-        lsum += pc;
-    }
-    lsum += __shfl_xor(lsum, 32, 64);
-    l_run = l_run * alpha + lsum;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-    // O^T += V^T . P^T ; A operand element j of lane (d, h) = V[key0 + 8(j>>2) + (j&3)][d], key0 = 32 tile + 16 st + 4 h
-    auto vfrag = [&](int kb, int dt) -> bf16x8 {
-        const int col = 32 * dt + 16 * tg + 4 * tp;               // d column of this lane's address
-        const int ch = col >> 3, sub = (col & 7) * 2;
-        bf16x4 a0 = lds_tr4(Vs + kb * 128 + ((ch ^ vswz(kb)) << 4) + sub);
-        bf16x4 a1 = lds_tr4(Vs + (kb + 8) * 128 + ((ch ^ vswz(kb + 8)) << 4) + sub);
-        return (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-    };
-#pragma unroll
-    for (int ti = 0; ti < NTC; ++ti) {
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            bf16x8 pf;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)s[ti][8 * st + jj];
-            const int kb = (t0 + ti) * 32 + 16 * st + 4 * h + tq;            // this lane's address row (first 4-key group)
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(kb, 0), pf, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(kb, 1), pf, o1, 0, 0, 0);
-        }
-    }
-    if (CLS) {
-        const bf16x8 pf = {(bf16_t)pc, 0, 0, 0, 0, 0, 0, 0};      // k-slot 0 of h = 0 is key 32 tile + 0 = n
-        const int kb = (t0 + NTC) * 32 + 4 * h + tq;
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(kb, 0), pf, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(kb, 1), pf, o1, 0, 0, 0);
-    }
-}
-
-// One 32-query block of one (clip, frame, head) problem: S^T = K.Q^T, online softmax over CH-tile chunks, O^T = V^T.P^T.
-// nf = n / 32 full key tiles, followed by the CLS tile (which rides on the last chunk).
-__device__ __forceinline__ void space_query_block(const char* Ks, const char* Vs, const bf16x8 (&qf)[4], bf16_t* orow, int nf, int lane) {
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-    int t0 = 0;
-    for (; t0 + CH < nf; t0 += CH) space_chunk<CH, false>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run);
-    switch (nf - t0) {                                        // 1 .. CH tiles left (nf >= 1), plus the CLS tile
-        case 1: space_chunk<1, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
-        case 2: space_chunk<2, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
-        case 3: space_chunk<3, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
-#if CH >= 5
-        case 4: space_chunk<4, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
-#endif
-#if CH >= 6
-        case 5: space_chunk<5, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
-#endif
-#if CH >= 7
-        case 6: space_chunk<6, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
-#endif
-#if CH >= 8
-        case 7: space_chunk<7, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
-#endif
-        default: space_chunk<CH, true>(Ks, Vs, qf, t0, lane, o0, o1, m_run, l_run); break;
-    }
-    const float inv = 1.f / l_run;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        u32x2 w0 = {pack_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
-        u32x2 w1 = {pack_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
-        *(u32x2*)(orow + 8 * g) = w0;
-        *(u32x2*)(orow + 32 + 8 * g) = w1;
-    }
-}
-
-// CLS query (model/LaviLa.py:255-258) folded in: partial softmax(q_cls . K_f^T) V_f over THIS frame's keys (already in LDS;
-// the CLS key itself is counted by frame 0 only); hh_cls_combine merges the T partials.  All NWV waves participate.
-template <int NWV>
-__device__ __forceinline__ void space_cls_partial(const char* Ks, const char* Vs, float* scratch, int KP, const bf16_t* base,
-                                                  float* rec, int n, bool first_frame, int tid, int lane, int wave) {
-    const float LOG2E = 1.4426950408889634f;
-    float* cs = scratch;                      // [KP] scores / probabilities
-    float* wrec = scratch + KP;               // [NWV][CLS_REC] per-wave partial o, + 2*NWV reduction slots
-    float* red = wrec + NWV * CLS_REC;
-    const int nkeys = n + (first_frame ? 1 : 0);
-    float mx = -INFINITY;
-    for (int j = tid; j < nkeys; j += 64 * NWV) {
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            u32x4 qv = *(const u32x4*)(base + c * 8);                               // q row of token 0 (uniform, pre-scaled)
-            u32x4 u = *(const u32x4*)(Ks + j * 128 + ((c ^ kswz(j)) << 4));
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                a0 = fmaf(bf16_lo_to_f32(qv[w]), bf16_lo_to_f32(u[w]), a0);
-                a1 = fmaf(bf16_hi_to_f32(qv[w]), bf16_hi_to_f32(u[w]), a1);
-            }
-        }
-        cs[j] = a0 + a1;
-        mx = fmaxf(mx, a0 + a1);
-    }
-    mx = wave_max(mx);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    mx = red[0];
-#pragma unroll
-    for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, red[w]);
-    float l = 0.f;
-    for (int j = tid; j < nkeys; j += 64 * NWV) {
-        const float pj = __builtin_amdgcn_exp2f((cs[j] - mx) * LOG2E);
-        cs[j] = pj;
-        l += pj;
-    }
-    l = wave_sum(l);
-    if (lane == 0) red[NWV + wave] = l;
-    __syncthreads();
-    float o = 0.f;
-    const int dch = lane >> 3, dsub = (lane & 7) * 2;
-    for (int j = wave; j < nkeys; j += NWV) {
-        const unsigned short vv = *(const unsigned short*)(Vs + j * 128 + ((dch ^ vswz(j)) << 4) + dsub);
-        o = fmaf(cs[j], __uint_as_float((unsigned)vv << 16), o);
-    }
-    wrec[wave * CLS_REC + lane] = o;
-    __syncthreads();
-    if (tid < 64) {
-        float ot = 0.f, lt = 0.f;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) { ot += wrec[w * CLS_REC + tid]; lt += red[NWV + w]; }
-        rec[4 + tid] = ot;
-        if (tid == 0) { rec[0] = mx; rec[1] = lt; }
-    }
-}
-
 // stage K and V of one (clip, frame, head) problem by LDS-DMA (1 KiB = 8 rows per wave instruction); rows >= n take the CLS
 // token's row (key n is the CLS key; rows > n are masked in S and multiplied by P = 0, they only have to be finite)
 template <int NWV>
@@ -252,42 +53,8 @@ __device__ __forceinline__ void space_stage(char* Ks, char* Vs, const bf16_t* ba
     }
 }
 
-// ---- variant A: one workgroup per problem (any n with (n+1) keys fitting LDS once), 4 waves
-__global__ __launch_bounds__(64 * NW, 2) void space_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                            float* __restrict__ cls_partial,
-                                                            int B, int T, int n, int heads, int KP) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;                                   // [KP][128 B], 16-B chunk c of row r at position c ^ (r & 7)
-    char* Vs = smem + (size_t)KP * 128;                // same layout, row-major V
-    float* scratch = (float*)(smem + (size_t)KP * 256);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int D = heads * 64;
-    const int64_t ld = 3 * (int64_t)D;
-    const int N = 1 + T * n;
-    int bid = blockIdx.x;
-    const int head = bid % heads; bid /= heads;
-    const int f = bid % T;
-    const int b = bid / T;
-    const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;      // token 0 (CLS) of this clip / head
-    const bf16_t* q_ptr = base + (int64_t)(1 + f * n) * ld;
-    space_stage<NW>(Ks, Vs, base, q_ptr, ld, D, n, KP, lane, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int ql = lane & 31, h = lane >> 5;
-    for (int qb = wave; qb < (n >> 5); qb += NW) {
-        bf16x8 qf[4];
-        const bf16_t* qrow = q_ptr + (int64_t)(qb * 32 + ql) * ld + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qrow + 16 * ks);
-        space_query_block(Ks, Vs, qf, out + ((int64_t)b * N + 1 + f * n + qb * 32 + ql) * D + head * 64 + 4 * h, n >> 5, lane);
-    }
-    if (cls_partial == nullptr) return;
-    space_cls_partial<NW>(Ks, Vs, scratch, KP, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
-}
-
-// ---- variant C: 16-query blocks on v_mfma_f32_16x16x32_bf16, 8 waves per workgroup (4 waves per SIMD with two workgroups per CU).
-// The 32-query kernel above is VALU-issue-bound at 2 waves per SIMD (SQ counters: VALU busy 49 %, MFMA 18 %).  Here a wave owns 16
+// ---- 16-query blocks on v_mfma_f32_16x16x32_bf16, 8 waves per workgroup (4 waves per SIMD with two workgroups per CU).
+// The 32-query predecessor was VALU-issue-bound at 2 waves per SIMD (SQ counters: VALU busy 49 %, MFMA 18 %).  Here a wave owns 16
 // queries: a 16-key score tile is 4 accumulator registers, a chunk of 9 tiles 36 registers, the whole kernel < 128 VGPRs; Q comes
 // from HBM directly in MFMA layout (lane = query, 8 d); PV contracts two 16-key tiles per MFMA (k-slots jj < 4 -> first tile row
 // 4g+jj, jj >= 4 -> second tile) with V^T fetched by the transposing LDS read, d permuted so that a lane ends with 16 consecutive d
@@ -528,33 +295,15 @@ extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial,
     HH_REQUIRE(HH_ALIGNED16(qkv) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_space_attn_fwd: pointers must be 16-byte aligned");
     if (B == 0) return HH_OK;
     const int KP = ((n + 1 + 31) / 32) * 32;
-    // HH_SPACE_ATTN: 2 (default) = 16-query blocks, 8 waves per workgroup (365 us/call at B = 32); 0 = 32-query blocks on
-    // 32x32x16 MFMAs, 4 waves per workgroup (420 us).  A persistent double-buffered variant of the latter was measured at 480 us
-    // and removed.
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("HH_SPACE_ATTN"); mode = e ? atoi(e) : 2; }
     const size_t lds16 = (size_t)KP * 256 + ((size_t)KP + NW16 * CLS_REC + 2 * NW16) * 4;
-    if (mode == 2 && lds16 <= 160 * 1024) {
-        static size_t attr16 = 0;
-        if (lds16 > attr16) {
-            hipError_t e = hipFuncSetAttribute((const void*)space_attn16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
-            HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds16);
-            attr16 = lds16;
-        }
-        hipLaunchKernelGGL(space_attn16_kernel, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW16), lds16, (hipStream_t)stream,
-                           (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP);
-        return hh_check_launch("hh_space_attn_fwd(16-query blocks)");
+    HH_REQUIRE(lds16 <= 160 * 1024, HH_ERR_UNSUPPORTED, "hh_space_attn_fwd: n=%d needs %zu B of LDS (> 160 KiB)", n, lds16);
+    static size_t attr16 = 0;
+    if (lds16 > attr16) {
+        hipError_t e = hipFuncSetAttribute((const void*)space_attn16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+        HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds16);
+        attr16 = lds16;
     }
-    const size_t lds = (size_t)KP * 256 + ((size_t)KP + NW * CLS_REC + 2 * NW) * 4;
-    HH_REQUIRE(lds <= 160 * 1024, HH_ERR_UNSUPPORTED, "hh_space_attn_fwd: n=%d needs %zu B of LDS (> 160 KiB)", n, lds);
-    static size_t attr_set = 0;
-    if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)space_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds);
-        attr_set = lds;
-    }
-    const int64_t blocks = (int64_t)B * T * heads;
-    hipLaunchKernelGGL(space_attn_kernel, dim3((unsigned)blocks), dim3(64 * NW), lds, (hipStream_t)stream,
+    hipLaunchKernelGGL(space_attn16_kernel, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW16), lds16, (hipStream_t)stream,
                        (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP);
     return hh_check_launch("hh_space_attn_fwd");
 }

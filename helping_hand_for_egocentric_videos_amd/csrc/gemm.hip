@@ -225,11 +225,7 @@ __global__ __launch_bounds__(64 * NWT) void gemm_tail_kernel(GemmParams p) {
     }
 }
 
-static int gemm_tail_enabled() {            // HH_GEMM_TAIL=0 routes row tails back to the 128x128 kernel (A/B measurements)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("HH_GEMM_TAIL"); v = e ? atoi(e) : 1; }
-    return v;
-}
+int hh_tuning_gemm_tail();                  // gemm256.hip: hh_set_tuning("gemm_tail", 0) routes row tails back to the 128x128 kernel (A/B measurements)
 
 extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                             int64_t M, int N, int K, const hh_gemm_epilogue* epi, hh_stream_t stream) {
@@ -260,7 +256,7 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         if (rc != HH_OK || pm.M == M) return rc;
         p.m_start = pm.M;
     }
-    if (M - p.m_start <= 64 && K % 256 == 0 && epi->splitk <= 1 && gemm_tail_enabled()) {
+    if (M - p.m_start <= 64 && K % 256 == 0 && epi->splitk <= 1 && hh_tuning_gemm_tail()) {
         // (< 64)-row tail of a tall GEMM, or a GEMM that is this short altogether: split-K-in-workgroup kernel, 32-column workgroups,
         // 8 waves when K splits 8 ways into multiples of 64, one or two 32-row tiles
         const bool bf = epi->c_dtype == HH_BF16, w8 = K % 512 == 0, two = M - p.m_start > 32;

@@ -243,522 +243,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// PERSISTENT variant: one workgroup per CU walks its tiles (virtual block id v = blockIdx.x + i * gridDim.x, same XCD-aware
-// decode).  Per-block fixed costs measured on the one-tile-per-block kernel: ~5.5 us of epilogue store drain + 3.5-6 us of
-// prologue latency / launch on a ~23 us main loop at K = 1024.  Here the NEXT tile's first two k-tiles (16 LDS-DMA
-// instructions, both LDS buffers are free once the main loop ends) are issued BEFORE the current tile's epilogue stores; since
-// vmcnt retires in order and the stores are younger than that prologue, the waits of the next tile's first k-tile are
-// counted as vmcnt(N + STORES) and pass without waiting for the store drain.  Requires full tiles, no residual / row remap
-// (no other VMEM instruction may sit between prologue and stores) and K >= 128.
+// PERSISTENT, CONTINUOUS, FOUR-BARRIER kernel (the default for full 256-row tiles without residual / row remap, K >= 128).
+//   * persistent: one workgroup per CU walks its tiles (virtual block id v = blockIdx.x + i * gridDim.x, same XCD-aware decode).
+//     Per-block fixed costs measured on the one-tile-per-block kernel above: ~5.5 us of epilogue store drain + 3.5-6 us of prologue
+//     latency / launch on a ~23 us main loop at K = 1024.
+//   * continuous: the k-tile stream does not stop at tile boundaries.  During the last two k-tiles of a tile the staging slots that
+//     have nothing left to fetch for it fetch k-tiles 0 and 1 of the workgroup's NEXT tile, so the next main loop starts right after
+//     the epilogue: no 16-instruction prologue (1.1 us) and no wait for its first k-tile (2-3 us).  Since vmcnt retires in order
+//     and the epilogue stores are younger than those loads, the waits of the next tile's first k-tile are counted as
+//     vmcnt(N + STORES) and pass without waiting for the store drain (no other VMEM instruction may sit between them: hence no
+//     residual / row remap, and the bias vector lives in LDS).  Source addresses are scalar tile bases + 4 per-lane 32-bit offsets.
+//   * four barriers per k-tile: the two A-lo phases and the two A-hi phases of a k-tile are merged (32 MFMAs per wave between two
+//     barriers instead of 16; one counted vmcnt wait per k-tile as before).  The in-kernel timeline put the eight-barrier main loop
+//     at 2450-2680 cycles per k-tile against 2048 MFMA cycles: ~56 cycles are lost at each barrier hand-over between the two waves
+//     of a SIMD; halving the hand-overs gave qkv 1170 -> 1225, fc1 1133 -> 1223, fc2 1305 -> 1350 TFLOP/s.  (One phase per k-tile --
+//     64 MFMAs per hand-over -- was tried: slower, 1040 TFLOP/s, the prefetch lead shrinks to one k-tile, and it raced in one test.)
+//   * EPI: the epilogue flavour is a template parameter (0 bias only, 1 bias + colscale on whole 128-column halves, 2 bias +
+//     QuickGELU, 3 bias + ReLU).  A generic epilogue spends ~30 VALU instructions per 16-B store (~500 per tile and wave, 2.8 us of
+//     matrix-core idle time per K = 1024 tile); bias-only needs 8.
+// Earlier generations (persistent with a per-tile prologue: 1127 TFLOP/s in-step; continuous with eight barriers: qkv 1162 / fc1 1200)
+// were measured against this kernel in round 1 ("GEMM kernel generations") and removed in round 2.
 // debug timeline (hh_set_tuning("gemm256_debug_ts", 1)): s_memrealtime (100 MHz) of wave 0 at 5 points of the first 8 tiles of
 // every workgroup; read back with hh_debug_gemm_timeline
 #define TS_TILES 8
 __device__ unsigned long long g_gemm_ts[512 * TS_TILES * 7];       // 5 x s_memrealtime + s_memtime at stamps 1, 2
 
-template <bool OUT_BF16>
-__global__ __launch_bounds__(512, 2) void gemm256p_kernel(GemmParams p) {
-    constexpr bool STAGGER = true;
-    constexpr int STORES = OUT_BF16 ? 16 : 32;        // global_store_dwordx4 per wave and tile in the epilogue (checked in the ISA)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-
-    const int GROUP = p.group_m;
-    const int per = GROUP * p.Nt;
-    const int nk = p.K / 64;
-    const int vmax = 8 * ((((p.Mt + 7) / 8) + GROUP - 1) / GROUP) * GROUP * p.Nt;      // size of the virtual grid
-    auto decode = [&](int v, int64_t& m0, int& n0) -> bool {
-        const int xcd = v & 7, j = v >> 3;
-        const int kg = j / per, r = j % per;
-        const int nt_i = r / GROUP, mi = r % GROUP;
-        const int mt = xcd + 8 * (kg * GROUP + mi);
-        m0 = (int64_t)mt * 256;
-        n0 = nt_i * 256;
-        return mt < p.Mt;
-    };
-    auto next_valid = [&](int v, int64_t& m0, int& n0) -> int {       // first valid virtual id >= v on this block's stride, or -1
-        for (; v < vmax; v += gridDim.x)
-            if (decode(v, m0, n0)) return v;
-        return -1;
-    };
-    int64_t m0, nm0 = 0;
-    int n0, nn0 = 0;
-    int v = next_valid(blockIdx.x, m0, n0);
-    if (v < 0) return;
-    // ---- staging sources: wave w stages pieces 2w, 2w+1 (8 rows each) of every half-tile
-    const bf16_t* src[4][2];       // [slot][piece]
-    auto set_src = [&](int64_t tm0, int tn0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (wave * 2 + i) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ (row & 7);
-            src[SLOT_ALO][i] = p.A + (tm0 + row) * p.lda + c * 8;
-            src[SLOT_AHI][i] = p.A + (tm0 + 128 + row) * p.lda + c * 8;
-            const int rl = row & 31, nperm = (row & ~31) + 8 * ((rl & 15) >> 2) + 4 * (rl >> 4) + (rl & 3);
-            src[SLOT_BLO][i] = p.W + (int64_t)(tn0 + nperm) * p.ldw + c * 8;
-            src[SLOT_BHI][i] = p.W + (int64_t)(tn0 + 128 + nperm) * p.ldw + c * 8;
-        }
-    };
-    auto stage = [&](int slot, int kt, int buf) {
-        char* dst = smem + buf * BUF_BYTES + slot * HT_BYTES + wave * 2048;
-        glds16(src[slot][0] + (int64_t)kt * 64, dst);
-        glds16(src[slot][1] + (int64_t)kt * 64, dst + 1024);
-    };
-    auto prologue = [&]() {          // k-tiles 0 and 1 complete: 16 LDS-DMA instructions per wave
-        stage(SLOT_BLO, 0, 0); stage(SLOT_ALO, 0, 0); stage(SLOT_BHI, 0, 0); stage(SLOT_AHI, 0, 0);
-        stage(SLOT_BLO, 1, 1); stage(SLOT_ALO, 1, 1); stage(SLOT_BHI, 1, 1); stage(SLOT_AHI, 1, 1);
-    };
-    // the whole bias vector lives in the LDS left over by the two staging buffers (N <= 8192): the epilogue used to fetch its
-    // 16 bias values from global memory and stall on vmcnt(0) (~1.5 us per tile) before it could issue the next prologue
-    float* bias_s = (float*)(smem + 2 * BUF_BYTES);
-    for (int i = tid * 4; i < p.N; i += 512 * 4)
-        *(f32x4*)(bias_s + i) = p.e.bias ? *(const f32x4*)(p.e.bias + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    BARRIER();
-    set_src(m0, n0);
-    prologue();
-    bool first = true;
-    int tile_i = 0;
-    auto stamp = [&](int k) {
-        if (p.debug_ts && tid == 0 && tile_i < TS_TILES && blockIdx.x < 512)
-        {
-            unsigned long long* r = g_gemm_ts + ((int)blockIdx.x * TS_TILES + tile_i) * 7;
-            r[k] = __builtin_amdgcn_s_memrealtime();
-            if (k == 1 || k == 2) r[4 + k] = __builtin_amdgcn_s_memtime();
-        }
-    };
-
-    // ---- fragment read offsets inside a half-tile: row = base + (lane & 15), chunk = ks*4 + (lane >> 4)
-    const int frow = lane & 15, fq = lane >> 4;
-    int a_off[2], b_off[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int c = ks * 4 + fq;
-        a_off[ks] = (wr * 64 + frow) * 128 + ((c ^ (frow & 7)) << 4);     // + tm*2048
-        b_off[ks] = (wc * 32 + frow) * 128 + ((c ^ (frow & 7)) << 4);     // + tn*2048
-    }
-
-    f32x4 acc[2][4][2][2];      // [mh][tm][nh][tn]
-    bf16x8 af[4][2], bf0[2][2], bf1[2][2];      // A sub-tile [tm][ks]; B0 / B1 sub-tiles [tn][ks]
-
-#define MFMA_QUAD(MH, NH, BF)                                                                          \
-    __builtin_amdgcn_s_setprio(1);                                                                     \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                   \
-        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                               \
-            _Pragma("unroll") for (int tm = 0; tm < 4; ++tm)                                           \
-                acc[MH][tm][NH][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[tn][ks], af[tm][ks], acc[MH][tm][NH][tn], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);
-
-    for (;;) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int d = 0; d < 2; ++d)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) acc[a][c][d][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        stamp(0);
-        // k-tile 0 of this tile has landed (the previous tile's stores, if any, are younger than the whole prologue)
-        if (first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (OUT_BF16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");       // 8 + STORES
-        else asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-        BARRIER();
-        if (STAGGER && wr == 1) BARRIER();
-        stamp(1);
-
-        for (int t = 0; t < nk; ++t) {
-            const int cur = t & 1;
-            const char* base = smem + cur * BUF_BYTES;
-            // ================= phase 1: A0 x B0
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) bf0[tn][ks] = *(const bf16x8*)(base + SLOT_BLO * HT_BYTES + b_off[ks] + tn * 2048);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) af[tm][ks] = *(const bf16x8*)(base + SLOT_ALO * HT_BYTES + a_off[ks] + tm * 2048);
-            if (t >= 1 && t + 1 < nk) stage(SLOT_AHI, t + 1, cur ^ 1);       // A-hi(1) came with the prologue
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-            BARRIER();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            MFMA_QUAD(0, 0, bf0)
-            BARRIER();
-            // ================= phase 2: A0 x B1
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) bf1[tn][ks] = *(const bf16x8*)(base + SLOT_BHI * HT_BYTES + b_off[ks] + tn * 2048);
-            if (t + 2 < nk) stage(SLOT_BLO, t + 2, cur);
-            BARRIER();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            MFMA_QUAD(0, 1, bf1)
-            BARRIER();
-            // ================= phase 3: A1 x B1
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) af[tm][ks] = *(const bf16x8*)(base + SLOT_AHI * HT_BYTES + a_off[ks] + tm * 2048);
-            if (t + 2 < nk) stage(SLOT_ALO, t + 2, cur);
-            BARRIER();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            MFMA_QUAD(1, 1, bf1)
-            BARRIER();
-            // ================= phase 4: A1 x B0 ; retire k-tile t+1
-            if (t + 2 < nk) {
-                stage(SLOT_BHI, t + 2, cur);
-                if (t == 0 && !first) {                    // in order: [prologue][STORES][B-lo, A-lo, B-hi of k-tile 2] -> keep stores + 6
-                    if (OUT_BF16) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                }
-            } else {
-                if (t == 0 && !first) {                    // nk == 2: only the stores are younger than the prologue
-                    if (OUT_BF16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-            }
-            BARRIER();
-            __builtin_amdgcn_sched_barrier(0);
-            MFMA_QUAD(1, 0, bf0)
-            BARRIER();
-        }
-        if (STAGGER && wr == 0) BARRIER();
-        stamp(2);
-
-        // ---- epilogue of tile (m0, n0).  Bias is fetched and waited for FIRST; then the next tile's prologue is issued;
-        // then exactly STORES store instructions per wave and nothing else.
-        const hh_gemm_epilogue& e = p.e;
-        const int ncol = n0 + wc * 32 + 8 * fq;
-        f32x4 bias_v[2][2];                    // from the LDS copy: no VMEM instruction, no vmcnt stall in front of the prologue
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
-            bias_v[nh][0] = *(const f32x4*)(bias_s + ncol + nh * 128);
-            bias_v[nh][1] = *(const f32x4*)(bias_s + ncol + nh * 128 + 4);
-        }
-        const int nv = next_valid(v + gridDim.x, nm0, nn0);
-        if (nv >= 0) {
-            set_src(nm0, nn0);
-            prologue();
-        }
-        stamp(3);
-        char* Cbase = (char*)p.C;
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm) {
-                const int64_t orow = m0 + mh * 128 + wr * 64 + tm * 16 + frow;
-#pragma unroll
-                for (int nh = 0; nh < 2; ++nh) {
-                    const int n = ncol + nh * 128;
-                    f32x4 v0 = acc[mh][tm][nh][0] + bias_v[nh][0], v1 = acc[mh][tm][nh][1] + bias_v[nh][1];
-                    if (n < e.colscale_cols) { v0 *= e.colscale; v1 *= e.colscale; }
-                    if (e.act == HH_ACT_QUICKGELU) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { v0[q] = quick_gelu(v0[q]); v1[q] = quick_gelu(v1[q]); }
-                    } else if (e.act == HH_ACT_RELU) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
-                    }
-                    if constexpr (OUT_BF16) {
-                        u32x4 o = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
-                        *(u32x4*)((bf16_t*)Cbase + orow * p.ldc + n) = o;
-                    } else {
-                        *(f32x4*)((float*)Cbase + orow * p.ldc + n) = v0;
-                        *(f32x4*)((float*)Cbase + orow * p.ldc + n + 4) = v1;
-                    }
-                }
-            }
-        stamp(4);
-        ++tile_i;
-        if (nv < 0) break;
-        v = nv; m0 = nm0; n0 = nn0;
-        first = false;
-    }
-#undef MFMA_QUAD
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// CONTINUOUS persistent variant: the k-tile stream does not stop at tile boundaries.  During the last two k-tiles of a tile the
-// staging slots that have nothing left to fetch for it fetch k-tiles 0 and 1 of the workgroup's NEXT tile, so the next main loop
-// starts right after the epilogue: no 16-instruction prologue (1.1 us) and no wait for its first k-tile (2-3 us) -- together
-// ~11 % of a K = 1024 tile in the timeline of the plain persistent kernel.  Source addresses are scalar tile bases + 4 per-lane
-// 32-bit offsets (the 8 x 64-bit per-lane pointers of the other kernels would not leave room for two tiles' worth).
-// EPI: the epilogue flavour is a template parameter (0 bias only, 1 bias + colscale on whole 128-column halves, 2 bias + QuickGELU,
-// 3 bias + ReLU).  The generic epilogue of the kernels above spends ~30 VALU instructions per 16-B store (a packed multiply and a
-// select for the column scale and register copies for the activation branches, taken or not): ~500 per tile and wave, 2.8 us of
-// matrix-core idle time per K = 1024 tile; bias-only needs 8.
-template <bool OUT_BF16, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256c_kernel(GemmParams p) {
-    constexpr bool STAGGER = true;
-    constexpr int STORES = OUT_BF16 ? 16 : 32;        // global_store_dwordx4 per wave and tile in the epilogue (checked in the ISA)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-
-    const int GROUP = p.group_m;
-    const int per = GROUP * p.Nt;
-    const int nk = p.K / 64;
-    const int vmax = 8 * ((((p.Mt + 7) / 8) + GROUP - 1) / GROUP) * GROUP * p.Nt;      // size of the virtual grid
-    auto decode = [&](int v, int64_t& m0, int& n0) -> bool {
-        const int xcd = v & 7, j = v >> 3;
-        const int kg = j / per, r = j % per;
-        const int nt_i = r / GROUP, mi = r % GROUP;
-        const int mt = xcd + 8 * (kg * GROUP + mi);
-        m0 = (int64_t)mt * 256;
-        n0 = nt_i * 256;
-        return mt < p.Mt;
-    };
-    auto next_valid = [&](int v, int64_t& m0, int& n0) -> int {       // first valid virtual id >= v on this block's stride, or -1
-        for (; v < vmax; v += gridDim.x)
-            if (decode(v, m0, n0)) return v;
-        return -1;
-    };
-    int64_t m0, nm0 = 0;
-    int n0, nn0 = 0;
-    int v = next_valid(blockIdx.x, m0, n0);
-    if (v < 0) return;
-    // ---- staging sources: wave w stages pieces 2w, 2w+1 (8 rows each) of every half-tile.  The per-lane part of a source address
-    // (row inside the half-tile, swizzled 16-B chunk) does not depend on the tile: 4 x 32-bit byte offsets; the tile part is a
-    // scalar base, kept for the CURRENT and for the NEXT tile of this workgroup's walk.
-    unsigned aoff[2], woff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (row & 7);
-        aoff[i] = (unsigned)((row * p.lda + c * 8) * 2);
-        const int rl = row & 31, nperm = (row & ~31) + 8 * ((rl & 15) >> 2) + 4 * (rl >> 4) + (rl & 3);
-        woff[i] = (unsigned)((nperm * p.ldw + c * 8) * 2);
-    }
-    const int64_t hiA = 128 * p.lda * 2, hiW = 128 * p.ldw * 2;          // bytes from the low to the high half-tile
-    const char* cA = (const char*)(p.A + m0 * p.lda);
-    const char* cW = (const char*)(p.W + (int64_t)n0 * p.ldw);
-    const char* nA = cA;
-    const char* nW = cW;
-    auto stage_from = [&](const char* bA, const char* bW, int slot, int kt, int buf) {
-        char* dst = smem + buf * BUF_BYTES + slot * HT_BYTES + wave * 2048;
-        const bool isA = slot == SLOT_ALO || slot == SLOT_AHI;
-        const char* bp = (isA ? bA : bW) + ((slot == SLOT_AHI) ? hiA : (slot == SLOT_BHI) ? hiW : 0) + (int64_t)kt * 128;
-        asm volatile("" : "+s"(bp));            // keep the scalar base scalar: without this LLVM hoists 64-bit per-lane sums out of the k loop
-        glds16(bp + (isA ? aoff[0] : woff[0]), dst);
-        glds16(bp + (isA ? aoff[1] : woff[1]), dst + 1024);
-    };
-    // the whole bias vector lives in the LDS left over by the two staging buffers (N <= 8192): the epilogue used to fetch its
-    // 16 bias values from global memory and stall on vmcnt(0) (~1.5 us per tile) before it could issue the next prologue
-    float* bias_s = (float*)(smem + 2 * BUF_BYTES);
-    for (int i = tid * 4; i < p.N; i += 512 * 4)
-        *(f32x4*)(bias_s + i) = p.e.bias ? *(const f32x4*)(p.e.bias + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    BARRIER();
-    // start-time skew: with equal tile times all 256 workgroups reach their epilogues together and 33 MB of stores hit the memory
-    // system at once (the ~5 us between two main loops are that drain); p.skew_iters spreads the workgroups of an XCD over one
-    // drain time, and the spread persists from tile to tile
-    if (p.skew_iters > 0) {
-        const int it = p.skew_iters * (int)((blockIdx.x >> 3) & 31);
-        for (int i = 0; i < it; ++i) __builtin_amdgcn_s_sleep(8);
-    }
-    {   // first tile only: k-tiles 0 and 1 complete (16 LDS-DMA instructions per wave)
-        stage_from(cA, cW, SLOT_BLO, 0, 0); stage_from(cA, cW, SLOT_ALO, 0, 0); stage_from(cA, cW, SLOT_BHI, 0, 0); stage_from(cA, cW, SLOT_AHI, 0, 0);
-        stage_from(cA, cW, SLOT_BLO, 1, 1); stage_from(cA, cW, SLOT_ALO, 1, 1); stage_from(cA, cW, SLOT_BHI, 1, 1); stage_from(cA, cW, SLOT_AHI, 1, 1);
-    }
-    bool first = true;
-    int kpar = 0;                   // LDS buffer of this tile's k-tile 0 (the k-tile stream runs on across tiles)
-    int tile_i = 0;
-    auto stamp = [&](int k) {
-        if (p.debug_ts && tid == 0 && tile_i < TS_TILES && blockIdx.x < 512)
-        {
-            unsigned long long* r = g_gemm_ts + ((int)blockIdx.x * TS_TILES + tile_i) * 7;
-            r[k] = __builtin_amdgcn_s_memrealtime();
-            if (k == 1 || k == 2) r[4 + k] = __builtin_amdgcn_s_memtime();
-        }
-    };
-
-    // ---- fragment read offsets inside a half-tile: row = base + (lane & 15), chunk = ks*4 + (lane >> 4)
-    const int frow = lane & 15, fq = lane >> 4;
-    int a_off[2], b_off[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int c = ks * 4 + fq;
-        a_off[ks] = (wr * 64 + frow) * 128 + ((c ^ (frow & 7)) << 4);     // + tm*2048
-        b_off[ks] = (wc * 32 + frow) * 128 + ((c ^ (frow & 7)) << 4);     // + tn*2048
-    }
-
-    f32x4 acc[2][4][2][2];      // [mh][tm][nh][tn]
-    bf16x8 af[4][2], bf0[2][2], bf1[2][2];      // A sub-tile [tm][ks]; B0 / B1 sub-tiles [tn][ks]
-
-#define MFMA_QUAD(MH, NH, BF)                                                                          \
-    __builtin_amdgcn_s_setprio(1);                                                                     \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                   \
-        _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                               \
-            _Pragma("unroll") for (int tm = 0; tm < 4; ++tm)                                           \
-                acc[MH][tm][NH][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[tn][ks], af[tm][ks], acc[MH][tm][NH][tn], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);
-
-    for (;;) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int d = 0; d < 2; ++d)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) acc[a][c][d][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        stamp(0);
-        // the walk's next tile, known up front: its k-tiles 0 and 1 are staged during THIS tile's last two k-tiles
-        const int nv = next_valid(v + gridDim.x, nm0, nn0);
-        const bool has_next = nv >= 0;
-        if (has_next) {
-            nA = (const char*)(p.A + nm0 * p.lda);
-            nW = (const char*)(p.W + (int64_t)nn0 * p.ldw);
-        }
-        // k-tile 0: first tile -> from the prologue; later tiles -> retired by the previous tile's last phase-4 wait
-        if (first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        BARRIER();
-        if (STAGGER && wr == 1) BARRIER();
-        stamp(1);
-
-        for (int t = 0; t < nk; ++t) {
-            const int cur = (t + kpar) & 1;
-            const char* base = smem + cur * BUF_BYTES;
-            // ================= phase 1: A0 x B0
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) bf0[tn][ks] = *(const bf16x8*)(base + SLOT_BLO * HT_BYTES + b_off[ks] + tn * 2048);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) af[tm][ks] = *(const bf16x8*)(base + SLOT_ALO * HT_BYTES + a_off[ks] + tm * 2048);
-            if (t >= 1) {                                                     // A-hi(1) came with the prologue / the previous epilogue
-                if (t + 1 < nk) stage_from(cA, cW, SLOT_AHI, t + 1, cur ^ 1);
-                else if (has_next) stage_from(nA, nW, SLOT_AHI, 0, cur ^ 1);
-            }
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-            BARRIER();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            MFMA_QUAD(0, 0, bf0)
-            BARRIER();
-            // ================= phase 2: A0 x B1
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) bf1[tn][ks] = *(const bf16x8*)(base + SLOT_BHI * HT_BYTES + b_off[ks] + tn * 2048);
-            if (t + 2 < nk) stage_from(cA, cW, SLOT_BLO, t + 2, cur);
-            else if (has_next) stage_from(nA, nW, SLOT_BLO, t + 2 - nk, cur);
-            BARRIER();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            MFMA_QUAD(0, 1, bf1)
-            BARRIER();
-            // ================= phase 3: A1 x B1
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) af[tm][ks] = *(const bf16x8*)(base + SLOT_AHI * HT_BYTES + a_off[ks] + tm * 2048);
-            if (t + 2 < nk) stage_from(cA, cW, SLOT_ALO, t + 2, cur);
-            else if (has_next) stage_from(nA, nW, SLOT_ALO, t + 2 - nk, cur);
-            BARRIER();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            MFMA_QUAD(1, 1, bf1)
-            BARRIER();
-            // ================= phase 4: A1 x B0 ; retire k-tile t+1 (of this tile, or k-tile 0 of the next one)
-            if (t + 2 < nk || has_next) {
-                if (t + 2 < nk) stage_from(cA, cW, SLOT_BHI, t + 2, cur);
-                else stage_from(nA, nW, SLOT_BHI, t + 2 - nk, cur);
-                if (t == 0 && !first) {                    // in order: [.. A-hi(1)][STORES][B-lo, A-lo, B-hi of k-tile 2] -> keep stores + 6
-                    if (OUT_BF16) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                }
-            } else {                                       // last tile of the walk, last two k-tiles: nothing staged
-                if (t == 0 && !first) {                    // nk == 2: only the stores are younger than A-hi(1)
-                    if (OUT_BF16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-            }
-            BARRIER();
-            __builtin_amdgcn_sched_barrier(0);
-            MFMA_QUAD(1, 0, bf0)
-            BARRIER();
-        }
-        if (STAGGER && wr == 0) BARRIER();
-        stamp(2);
-
-        // ---- epilogue of tile (m0, n0).  Bias is fetched and waited for FIRST; then the next tile's prologue is issued;
-        // then exactly STORES store instructions per wave and nothing else.
-        const hh_gemm_epilogue& e = p.e;
-        const int ncol = n0 + wc * 32 + 8 * fq;
-        f32x4 bias_v[2][2];                    // from the LDS copy: no VMEM instruction, no vmcnt stall in front of the prologue
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
-            bias_v[nh][0] = *(const f32x4*)(bias_s + ncol + nh * 128);
-            bias_v[nh][1] = *(const f32x4*)(bias_s + ncol + nh * 128 + 4);
-        }
-        // A-hi of the next tile's k-tile 1 goes out BEFORE the stores (it must not queue behind the store drain)
-        if (has_next) stage_from(nA, nW, SLOT_AHI, 1, (kpar + nk + 1) & 1);
-        stamp(3);
-        char* Cbase = (char*)p.C;
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm) {
-                const int64_t orow = m0 + mh * 128 + wr * 64 + tm * 16 + frow;
-#pragma unroll
-                for (int nh = 0; nh < 2; ++nh) {
-                    const int n = ncol + nh * 128;
-                    f32x4 v0 = acc[mh][tm][nh][0] + bias_v[nh][0], v1 = acc[mh][tm][nh][1] + bias_v[nh][1];
-                    if constexpr (EPI == 1) {
-                        if (n0 + nh * 128 < e.colscale_cols) { v0 *= e.colscale; v1 *= e.colscale; }      // uniform: colscale_cols % 128 == 0
-                    } else if constexpr (EPI == 2) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { v0[q] = quick_gelu(v0[q]); v1[q] = quick_gelu(v1[q]); }
-                    } else if constexpr (EPI == 3) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { v0[q] = fmaxf(v0[q], 0.f); v1[q] = fmaxf(v1[q], 0.f); }
-                    }
-                    if constexpr (OUT_BF16) {
-                        u32x4 o = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
-                        *(u32x4*)((bf16_t*)Cbase + orow * p.ldc + n) = o;
-                    } else {
-                        *(f32x4*)((float*)Cbase + orow * p.ldc + n) = v0;
-                        *(f32x4*)((float*)Cbase + orow * p.ldc + n + 4) = v1;
-                    }
-                }
-            }
-        stamp(4);
-        ++tile_i;
-        if (!has_next) break;
-        v = nv; m0 = nm0; n0 = nn0;
-        cA = nA; cW = nW;
-        kpar = (kpar + nk) & 1;
-        first = false;
-    }
-#undef MFMA_QUAD
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// FOUR-BARRIER variant of the continuous kernel: the two A-lo phases and the two A-hi phases of a k-tile are merged (32 MFMAs per
-// wave between two barriers instead of 16; one counted vmcnt wait per k-tile as before).  The in-kernel timeline puts the main
-// loop at 2450-2680 cycles per k-tile against 2048 MFMA cycles: ~56 cycles are lost at each of the 8 barrier hand-overs between
-// the two waves of a SIMD; halving the hand-overs gives qkv 1170 -> 1225, fc1 1133 -> 1223, fc2 1305 -> 1350 TFLOP/s.  (One phase per
-// k-tile -- 64 MFMAs per hand-over, whole k-tiles staged into the buffer being computed from -- was tried: slower, 1040 TFLOP/s,
-// because the prefetch lead shrinks to one k-tile, and it raced in one test.)
 template <bool OUT_BF16, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256d_kernel(GemmParams p) {
     constexpr bool STAGGER = true;
@@ -1004,28 +513,27 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(GemmParams p) {
 }
 
 
+// ---- tuning state.  hh_set_tuning() is the library's ONLY process-global mutable state besides the per-stream CU budget table
+// (runtime.cpp); no entry point reads the environment.  The knobs select between kernels that compute the same result.
 static int g_debug_ts = 0;         // debug: record the per-tile timeline of the persistent kernel
 static int g_nostore = 0;          // debug: skip the epilogue stores (timing experiments only)
 static int g_group = 0;            // m-tiles per XCD-local group (weight-panel reuse factor); 0 = per-shape default
-static int g_pskew = 0;            // continuous persistent kernel: start skew quantum (s_sleep(8) units per workgroup index in its XCD)
-static int g_skew = -1;            // start skew: -1 auto (on when the epilogue carries an fp32 residual), 0 off, 1 on
-static int g_mode = -1;            // gemm256 mode: 0 = off, 1 = no stagger, 2 = stagger, 3 = persistent, 4 = continuous persistent, 5 = continuous with four barriers per k-tile (default) where eligible
-static int gemm256_mode() {
-    if (g_mode < 0) {
-        const char* s = getenv("HH_GEMM256");
-        g_mode = s ? atoi(s) : 5;
-    }
-    return g_mode;
-}
+static int g_pskew = 0;            // persistent kernel: start skew quantum (s_sleep(8) units per workgroup index in its XCD)
+static int g_skew = -1;            // start skew of the one-tile-per-block kernel: -1 auto (on with an fp32 residual), 0 off, 1 on
+static int g_mode = 3;             // "gemm256": 0 = 128x128 kernel only, 1 = one tile per block, 2 = + wave-row stagger, 3 = persistent (default)
+static int g_tail = 1;             // "gemm_tail": 1 = row tails on the split-K-in-workgroup kernel (gemm.hip), 0 = on the 128x128 kernel
+
+int hh_tuning_gemm_tail() { return g_tail; }
 
 extern "C" int hh_set_tuning(const char* name, int value) {
-    if (name && !strcmp(name, "gemm256")) { g_mode = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm256") && value >= 0 && value <= 3) { g_mode = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm_tail") && (value == 0 || value == 1)) { g_tail = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_skew")) { g_skew = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_pskew") && value >= 0 && value <= 64) { g_pskew = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_debug_nostore")) { g_nostore = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_debug_ts")) { g_debug_ts = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_group") && value >= 0 && value <= 64) { g_group = value; return HH_OK; }
-    hh_set_error("hh_set_tuning: unknown knob '%s'", name ? name : "(null)");
+    hh_set_error("hh_set_tuning: unknown knob '%s' or value %d out of range", name ? name : "(null)", value);
     return HH_ERR_UNSUPPORTED;
 }
 
@@ -1034,7 +542,7 @@ extern "C" int hh_set_tuning(const char* name, int value) {
 bool hh_gemm256_eligible(const GemmParams& p) {
     // at least ~3/4 of the CUs must get a 256x256 tile: below that the 128x128 kernel (4x the tiles, two workgroups per CU) wins --
     // measured on the text tower's N = 768 shapes at M = 12320 (147 tiles): 43 vs 65 us (K = 768), 97 vs 152 us (K = 3072)
-    return gemm256_mode() > 0 && p.N % 256 == 0 && p.M >= 2048 && p.e.splitk <= 1 && (p.M / 256) * (p.N / 256) >= 192;
+    return g_mode > 0 && p.N % 256 == 0 && p.M >= 2048 && p.e.splitk <= 1 && (p.M / 256) * (p.N / 256) >= 192;
 }
 
 int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
@@ -1044,19 +552,12 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
         hipFuncSetAttribute((const void*)gemm256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
         hipFuncSetAttribute((const void*)gemm256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
         hipFuncSetAttribute((const void*)gemm256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+#define ATTRD(BF, E) hipFuncSetAttribute((const void*)gemm256d_kernel<BF, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192))
+        ATTRD(true, 0); ATTRD(false, 0); ATTRD(true, 1); ATTRD(false, 1); ATTRD(true, 2); ATTRD(false, 2); ATTRD(true, 3); ATTRD(false, 3);
+#undef ATTRD
         attr_done = true;
     }
-    const int stagger = gemm256_mode() != 1;
-    static bool attr_p = false;
-    if (!attr_p) {
-        hipFuncSetAttribute((const void*)gemm256p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192));
-        hipFuncSetAttribute((const void*)gemm256p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192));
-#define ATTRC(BF, E) do { hipFuncSetAttribute((const void*)gemm256c_kernel<BF, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192)); \
-                          hipFuncSetAttribute((const void*)gemm256d_kernel<BF, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192)); } while (0)
-        ATTRC(true, 0); ATTRC(false, 0); ATTRC(true, 1); ATTRC(false, 1); ATTRC(true, 2); ATTRC(false, 2); ATTRC(true, 3); ATTRC(false, 3);
-#undef ATTRC
-        attr_p = true;
-    }
+    const int stagger = g_mode != 1;
     GemmParams p = pin;
     {
         // one round ~ nk k-tiles x ~3300 cycles + epilogue; s_sleep(16) ~ 1024 cycles per iteration
@@ -1076,38 +577,31 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
     const int groups = (per_xcd_mt + GROUP - 1) / GROUP;
     const unsigned grid = 8u * (unsigned)groups * GROUP * (unsigned)p.Nt;
     const bool bf = p.e.c_dtype == HH_BF16;
-    if (gemm256_mode() >= 3 && p.e.resid == nullptr && p.e.remap_group == 0 && p.K >= 128 && p.M % 256 == 0 && p.N <= 8192 && !g_nostore) {
-        const int ncu = hh_stream_cu_count(s) & ~7;          // CU budget of this stream; the stride of the tile walk must keep blockIdx & 7 == XCD
-        const unsigned pg = grid < (unsigned)ncu ? grid : (unsigned)ncu;
-        p.skew_iters = 0;
-        if (gemm256_mode() >= 4) {
+    if (g_mode >= 3 && p.e.resid == nullptr && p.e.remap_group == 0 && p.K >= 128 && p.M % 256 == 0 && p.N <= 8192 && !g_nostore) {
+        // epilogue flavour; a column scale together with an activation, or a scale boundary inside a 128-column half, take the
+        // one-tile-per-block kernel below (generic epilogue)
+        const bool scaled = p.e.colscale_cols > 0;
+        int epi = -1;
+        if (p.e.act == HH_ACT_NONE) epi = scaled ? (p.e.colscale_cols % 128 == 0 ? 1 : -1) : 0;
+        else if (!scaled) epi = p.e.act == HH_ACT_QUICKGELU ? 2 : p.e.act == HH_ACT_RELU ? 3 : -1;
+        if (epi >= 0) {
+            const int ncu = hh_stream_cu_count(s) & ~7;      // CU budget of this stream; the stride of the tile walk must keep blockIdx & 7 == XCD
+            const unsigned pg = grid < (unsigned)ncu ? grid : (unsigned)ncu;
             p.skew_iters = g_pskew;
-            // epilogue flavour; column scale together with an activation, or a scale boundary inside a 128-column half, take the
-            // generic persistent kernel below
-            const bool scaled = p.e.colscale_cols > 0;
-            int epi = -1;
-            if (p.e.act == HH_ACT_NONE) epi = scaled ? (p.e.colscale_cols % 128 == 0 ? 1 : -1) : 0;
-            else if (!scaled) epi = p.e.act == HH_ACT_QUICKGELU ? 2 : p.e.act == HH_ACT_RELU ? 3 : -1;
-            if (epi >= 0) {
-#define LAUNCHC(BF, E) do { if (gemm256_mode() == 5) hipLaunchKernelGGL((gemm256d_kernel<BF, E>), dim3(pg), dim3(512), P_LDS(p.N), s, p); \
-                            else hipLaunchKernelGGL((gemm256c_kernel<BF, E>), dim3(pg), dim3(512), P_LDS(p.N), s, p); } while (0)
-                switch (epi * 2 + (bf ? 1 : 0)) {
-                    case 0: LAUNCHC(false, 0); break;
-                    case 1: LAUNCHC(true, 0); break;
-                    case 2: LAUNCHC(false, 1); break;
-                    case 3: LAUNCHC(true, 1); break;
-                    case 4: LAUNCHC(false, 2); break;
-                    case 5: LAUNCHC(true, 2); break;
-                    case 6: LAUNCHC(false, 3); break;
-                    default: LAUNCHC(true, 3); break;
-                }
-#undef LAUNCHC
-                return hh_check_launch("hh_gemm_bf16(256x256 continuous)");
+#define LAUNCHD(BF, E) hipLaunchKernelGGL((gemm256d_kernel<BF, E>), dim3(pg), dim3(512), P_LDS(p.N), s, p)
+            switch (epi * 2 + (bf ? 1 : 0)) {
+                case 0: LAUNCHD(false, 0); break;
+                case 1: LAUNCHD(true, 0); break;
+                case 2: LAUNCHD(false, 1); break;
+                case 3: LAUNCHD(true, 1); break;
+                case 4: LAUNCHD(false, 2); break;
+                case 5: LAUNCHD(true, 2); break;
+                case 6: LAUNCHD(false, 3); break;
+                default: LAUNCHD(true, 3); break;
             }
+#undef LAUNCHD
+            return hh_check_launch("hh_gemm_bf16(256x256 persistent)");
         }
-        if (bf) hipLaunchKernelGGL((gemm256p_kernel<true>), dim3(pg), dim3(512), P_LDS(p.N), s, p);
-        else hipLaunchKernelGGL((gemm256p_kernel<false>), dim3(pg), dim3(512), P_LDS(p.N), s, p);
-        return hh_check_launch("hh_gemm_bf16(256x256 persistent)");
     }
     if (stagger) {
         if (bf) hipLaunchKernelGGL((gemm256_kernel<true, true>), dim3(grid), dim3(512), 2 * BUF_BYTES, s, p);

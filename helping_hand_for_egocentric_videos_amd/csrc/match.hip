@@ -84,7 +84,8 @@ __device__ bool lsap_wide(int nr, int nc, const double* cost, int ldc, int* col4
 __global__ __launch_bounds__(64) void match_boxes_kernel(const float* __restrict__ pred, int Qtot, int q0, int q,
                                                          const float* __restrict__ raw, const int* __restrict__ given_count,
                                                          int k, float img, float w_l1,
-                                                         float w_giou, float* __restrict__ tgt, int* __restrict__ tgt_count,
+                                                         float w_giou, const float* __restrict__ class_cost, float w_class,
+                                                         float* __restrict__ tgt, int* __restrict__ tgt_count,
                                                          int64_t* __restrict__ mp, int64_t* __restrict__ mt,
                                                          int* __restrict__ mn, int64_t F) {
     const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -125,7 +126,10 @@ __global__ __launch_bounds__(64) void match_boxes_kernel(const float* __restrict
             for (int c = 0; c < 4; ++c) l1 = l1 + fabsf(p[c] - t[j][c]);
             const Box tb = to_xyxy(t[j]);
             const float g = giou_xyxy(pb, tb);
-            const float cst = w_l1 * l1 + w_giou * (-g);
+            float cst = w_l1 * l1 + w_giou * (-g);
+            // exclude_class=False (box_utils.py:83-85): C += cost_class * (-softmax(logits)[query, label of target j]); the
+            // caller passes that gathered term, indexed by the target's slot in the frame's kept-target list
+            if (class_cost) cst = cst + w_class * class_cost[((f * q) + i) * k + j];
             if (transpose) cost[j * q + i] = (double)cst; else cost[i * cnt + j] = (double)cst;
         }
     }
@@ -238,13 +242,13 @@ __global__ __launch_bounds__(64) void box_loss_bwd_kernel(const float* __restric
 }
 
 extern "C" int hh_match_boxes(const float* pred, int Qtot, int q0, int q, const float* raw_boxes, const int32_t* given_count, int k, float img,
-                              float w_l1, float w_giou, float* tgt_cxcywh, int32_t* tgt_count, int64_t* match_pred,
+                              float w_l1, float w_giou, const float* class_cost, float w_class, float* tgt_cxcywh, int32_t* tgt_count, int64_t* match_pred,
                               int64_t* match_tgt, int32_t* match_n, int64_t F, hh_stream_t stream) {
     HH_REQUIRE(F >= 0 && q > 0 && q <= MAXQ && k > 0 && k <= MAXK && q0 >= 0 && q0 + q <= Qtot, HH_ERR_SHAPE,
                "hh_match_boxes: need 0 < q <= %d, 0 < k <= %d, q0+q <= Qtot (q=%d k=%d q0=%d Qtot=%d)", MAXQ, MAXK, q, k, q0, Qtot);
     if (F == 0) return HH_OK;
     hipLaunchKernelGGL(match_boxes_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pred, Qtot, q0, q,
-                       raw_boxes, given_count, k, img, w_l1, w_giou, tgt_cxcywh, tgt_count, match_pred, match_tgt, match_n, F);
+                       raw_boxes, given_count, k, img, w_l1, w_giou, class_cost, w_class, tgt_cxcywh, tgt_count, match_pred, match_tgt, match_n, F);
     return hh_check_launch("hh_match_boxes");
 }
 

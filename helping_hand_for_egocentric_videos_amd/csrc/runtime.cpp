@@ -75,3 +75,20 @@ extern "C" int hh_stream_get_cu_budget(hh_stream_t stream, int* out) {
     *out = hh_stream_cu_count((hipStream_t)stream);
     return HH_OK;
 }
+
+// ---- caller-owned workspaces (kernels never allocate).  Sizes in bytes of the scratch buffers the entry
+// points below take as arguments, so that a host binding needs no knowledge of the kernels' internals.
+extern "C" int64_t hh_workspace_bytes_gemm_splitk(int64_t M, int N, int splitk) {
+    return (M < 0 || N <= 0 || splitk < 1) ? -1 : (int64_t)splitk * M * N * 4;                 // fp32 partial slabs [splitk, M, N]
+}
+extern "C" int64_t hh_workspace_bytes_gemm_tn(int M, int N, int splits) {
+    return (M <= 0 || N <= 0 || splits < 1) ? -1 : (int64_t)splits * M * N * 4;                // fp32 partial tiles [splits, M, N]
+}
+extern "C" int64_t hh_workspace_bytes_xattn_bwd(int B, int Q, int heads, int dq_splits) {
+    return (B < 0 || Q <= 0 || heads <= 0 || dq_splits < 1) ? -1 : (int64_t)dq_splits * B * Q * heads * 64 * 4;   // dq partials
+}
+extern "C" int64_t hh_workspace_bytes_attn_cls_partial(int B, int T, int n, int heads, int time_mode) {
+    if (B < 0 || T <= 0 || n <= 0 || heads <= 0 || (time_mode && T > 128)) return -1;
+    const int64_t G = time_mode ? (n + (128 / T) - 1) / (128 / T) : T;                         // key groups per (clip, head)
+    return (int64_t)B * heads * G * 68 * 4;                                                    // records {m, l, 0, 0, o[64]} fp32
+}

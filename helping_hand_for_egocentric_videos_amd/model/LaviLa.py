@@ -380,6 +380,31 @@ class CLIP(nn.Module):
         return out
 
 
+def CLIP_OPENAI_TIMESFORMER_LARGE(num_frames=4, timesformer_gated_xattn=False, drop_path_rate=0, timesformer_freeze_space=False,
+                                  temperature_init=0.07, project_embed_dim=256, use_adapter=False, **kwargs):
+    """The reference's factory name and arguments (LaviLa.py:114-172; called at run/train.py:425-431 and
+    run/test_EgoMCQ.py:206-212 with pretrained=None, text_use_cls_token=False, project_embed_dim=256, num_frames=4,
+    temperature_init=0.07), so those scripts import and call it unchanged.
+
+    It builds the same CLIP(SpaceTimeTransformer-L/14, 12x768 text tower) on the CPU.  The one thing it does NOT do is the
+    reference's download of OpenAI CLIP ViT-L/14 weights (LaviLa.py:130-133,163-171; there is no network here): parameters
+    keep their constructor initialisation, and both call sites overwrite every one of them right afterwards with
+    `backbone.load_state_dict(<LaViLa checkpoint>, strict=True)` (run/train.py:433-439).  Move the result to the GPU with
+    `.to(device)` as the scripts do; the libhh kernels are used from there on."""
+    if timesformer_freeze_space:
+        raise NotImplementedError("CLIP_OPENAI_TIMESFORMER_LARGE: timesformer_freeze_space needs the CLIP key remap of the "
+                                  "downloaded weights (LaviLa.py:134-146); the hot path freezes the whole backbone instead")
+    vision_model = SpaceTimeTransformer(img_size=224, patch_size=14, embed_dim=1024, depth=24, num_heads=16, num_frames=num_frames,
+                                        time_init='zeros', attention_style='frozen-in-time', ln_pre=True, act_layer=QuickGELU,
+                                        is_tanh_gating=timesformer_gated_xattn, drop_path_rate=drop_path_rate,
+                                        use_adapter=use_adapter)
+    vision_model.head = nn.Identity()
+    vision_model.pre_logits = nn.Identity()
+    vision_model.fc = nn.Identity()
+    return CLIP(embed_dim=project_embed_dim, vision_width=1024, vision_model=vision_model, context_length=77, vocab_size=49408,
+                transformer_width=768, transformer_heads=12, transformer_layers=12, tempearture_init=temperature_init, **kwargs)
+
+
 def build_backbone(cfg, state_dict=None, device="cuda"):
     """Construct CLIP(SpaceTimeTransformer) with the arguments of LaviLa.py:118-129,148-162, bypassing the
     network-bound factory; optionally load a reference-keyed state dict."""

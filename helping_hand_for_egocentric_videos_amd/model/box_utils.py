@@ -63,21 +63,42 @@ class HungarianMatcher(nn.Module):
                                self.cost_bbox, self.cost_giou)
 
     @torch.no_grad()
-    def forward(self, outputs, targets, exclude_class=False):
-        """Reference API (box_utils.py:43-92): targets = list of {'labels','boxes' cxcywh}; returns list of tuples."""
-        if not exclude_class:
-            raise NotImplementedError("HungarianMatcher: the hot path always matches with exclude_class=True "
-                                      "(box_utils.py:456); the class-probability cost is not built")
+    def match_list(self, outputs, targets, exclude_class=False):
+        """Device-side matching for the reference's list-of-dicts targets; returns (match dict, count int32 [F])."""
         pb = outputs["pred_boxes"].detach().float().contiguous()
         F_, q = pb.shape[:2]
-        k = max(1, max(len(t["boxes"]) for t in targets))
-        tg = torch.zeros((F_, k, 4), dtype=torch.float32, device=pb.device)
-        cnt = torch.tensor([len(t["boxes"]) for t in targets], dtype=torch.int32, device=pb.device)
-        for f, t in enumerate(targets):
-            if len(t["boxes"]):
-                tg[f, :len(t["boxes"])] = t["boxes"]
-        m = ops.match_boxes(pb, 0, q, tg, 224.0, self.cost_bbox, self.cost_giou, given_count=cnt)
+        tg, cnt, labels = _dense_targets(targets, pb.device)
+        cc, wc = None, 0.0
+        if not exclude_class:
+            # box_utils.py:62,83-85: cost_class = -softmax(pred_logits)[:, tgt_ids], C += self.cost_class * cost_class
+            prob = outputs["pred_logits"].detach().float().softmax(-1)                          # [F,q,classes]
+            cc = (-prob.gather(2, labels[:, None, :].expand(-1, q, -1))).contiguous()          # [F,q,k]
+            wc = self.cost_class
+        m = ops.match_boxes(pb, 0, q, tg, 224.0, self.cost_bbox, self.cost_giou, given_count=cnt, class_cost=cc, w_class=wc)
+        return m, cnt
+
+    @torch.no_grad()
+    def forward(self, outputs, targets, exclude_class=False):
+        """Reference API (box_utils.py:43-92): targets = list of {'labels','boxes' cxcywh}; returns list of tuples.
+        exclude_class=False adds the class-probability cost (never used by run/train.py, which passes True at :456)."""
+        m, _ = self.match_list(outputs, targets, exclude_class)
         return MatchResult(m).to_list()
+
+
+def _dense_targets(targets, device):
+    """list of {'labels' [k_f], 'boxes' [k_f,4]} -> (boxes fp32 [F,k,4] zero padded, count int32 [F], labels int64 [F,k])."""
+    F_ = len(targets)
+    k = max(1, max(len(t["boxes"]) for t in targets))
+    tg = torch.zeros((F_, k, 4), dtype=torch.float32, device=device)
+    labels = torch.zeros((F_, k), dtype=torch.int64, device=device)
+    cnt = torch.tensor([len(t["boxes"]) for t in targets], dtype=torch.int32, device=device)
+    for f, t in enumerate(targets):
+        n = len(t["boxes"])
+        if n:
+            tg[f, :n] = t["boxes"]
+            if "labels" in t and t["labels"] is not None:
+                labels[f, :n] = t["labels"].to(torch.int64)
+    return tg, cnt, labels
 
 
 def build_matcher(args):
@@ -147,27 +168,28 @@ class SetCriterion(nn.Module):
         return losses, MatchResult(m)
 
     def forward(self, outputs, targets, box_type, exclude_class=False):
-        """Reference API: targets = list of dicts (already prepared)."""
-        pred = outputs['pred_boxes']
-        F_, q = pred.shape[:2]
-        k = max(1, max(len(t["boxes"]) for t in targets))
-        tg = torch.zeros((F_, k, 4), dtype=torch.float32, device=pred.device)
-        cnt = torch.tensor([len(t["boxes"]) for t in targets], dtype=torch.int32, device=pred.device)
-        for f, t in enumerate(targets):
-            if len(t["boxes"]):
-                tg[f, :len(t["boxes"])] = t["boxes"]
-        if not exclude_class:
-            raise NotImplementedError("SetCriterion: exclude_class=True only (box_utils.py:456)")
-        m = ops.match_boxes(pred.detach().float().contiguous(), 0, q, tg, 224.0, self.matcher.cost_bbox, self.matcher.cost_giou,
-                            given_count=cnt)
+        """Reference API (box_utils.py:206-238): targets = list of dicts (already prepared); the aux_outputs loop is reproduced
+        (run/train.py never reaches it: split_detr_out empties the list)."""
+        m, cnt = self.matcher.match_list({k: v for k, v in outputs.items() if k != 'aux_outputs'}, targets, exclude_class)
         nb = self.num_boxes(m["count"])
-        s_l1, s_giou = _MatchedBoxLoss.apply(pred, 0, m)
-        losses = {f'loss_bbox_{box_type}': s_l1 / nb, f'loss_giou_{box_type}': s_giou / nb}
-        if outputs.get('pred_logits') is not None:
-            lg = outputs['pred_logits']
-            card = (lg.argmax(-1) != lg.shape[-1] - 1).sum(1)
-            losses[f'cardinality_error_{box_type}'] = (card.float() - cnt.float()).abs().mean()
+        losses = self._list_losses(outputs, m, cnt, nb, box_type)
+        for i, aux in enumerate(outputs.get('aux_outputs') or []):
+            ma, _ = self.matcher.match_list(aux, targets, exclude_class)
+            losses.update({k + f'_{i}': v for k, v in self._list_losses(aux, ma, cnt, nb, box_type).items()})
         return losses, MatchResult(m).to_list()
+
+    def _list_losses(self, outputs, m, cnt, nb, box_type):
+        losses = {}
+        if 'boxes' in self.losses:
+            s_l1, s_giou = _MatchedBoxLoss.apply(outputs['pred_boxes'], 0, m)
+            losses[f'loss_bbox_{box_type}'] = s_l1 / nb
+            losses[f'loss_giou_{box_type}'] = s_giou / nb
+        if 'cardinality' in self.losses and outputs.get('pred_logits') is not None:
+            with torch.no_grad():
+                lg = outputs['pred_logits']
+                card = (lg.argmax(-1) != lg.shape[-1] - 1).sum(1)
+                losses[f'cardinality_error_{box_type}'] = (card.float() - cnt.float()).abs().mean()
+        return losses
 
 
 @torch.no_grad()

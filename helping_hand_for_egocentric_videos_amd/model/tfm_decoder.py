@@ -133,6 +133,75 @@ class _XAttn(torch.autograd.Function):
         return dq, torch.zeros(1, dtype=torch.float32, device=q.device), None, None, None, None, None
 
 
+class _LinearBF16(torch.autograd.Function):
+    """y = x.W^T + b on hh_gemm_bf16 (bf16 operands, fp32 accumulation); backward = dgrad GEMM + TN weight-gradient GEMM.
+    x [rows,K] fp32/bf16, w [N,K], b [N] or None.  Used by the reference-signature layer forward, where every layer projects
+    its own K/V (the batched path projects all layers at once in _MemorySide)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, out_dtype):
+        xb = ops.to_bf16(x.detach().contiguous())
+        y = ops.gemm(xb, ops.to_bf16(w.detach().contiguous()), None if b is None else b.detach().float().contiguous(), out_dtype=out_dtype)
+        ctx.save_for_backward(xb, w)
+        ctx.has_bias, ctx.x_dtype = b is not None, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, w = ctx.saved_tensors
+        dyb = ops.to_bf16(dy.contiguous())
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dyb, ops.transpose_bf16(w.detach().contiguous()), out_dtype=torch.float32).to(ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            dw = ops.gemm_tn(dyb, xb)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.sum(dyb, dim=0, dtype=torch.float32)
+        return dx, dw, db, None
+
+
+class _LayerNormFn(torch.autograd.Function):
+    """LayerNorm over the last dim on hh_layernorm_fwd / hh_layernorm_bwd; x fp32 [rows, C] -> fp32."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        x = x.detach().float().contiguous()
+        y, mean, rstd = ops.layernorm(x, g.detach().float().contiguous(), b.detach().float().contiguous(), eps,
+                                      out_dtype=torch.float32, save_stats=True)
+        ctx.save_for_backward(x, g, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(x, g.detach().float().contiguous(), mean, rstd, dy.float().contiguous())
+        return dx, dg, db, None
+
+
+class _XAttnKV(torch.autograd.Function):
+    """softmax(q.K^T).V on explicit K/V tensors (bf16 [B,M,C], contiguous); q fp32 [B,Q,C] pre-scaled."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, dropout_p, seed):
+        q = q.detach().contiguous()
+        out, lse = ops.xattn_fwd(q, k.detach(), v.detach(), heads, dropout_p, seed)
+        ctx.heads, ctx.p, ctx.seed = heads, dropout_p, seed
+        ctx.save_for_backward(q, k, v, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dk, dv = torch.empty_like(k), torch.empty_like(v)
+        dq = ops.xattn_bwd(q, k.detach(), v.detach(), out, lse, dout.contiguous(), dk, dv, ctx.heads, ctx.p, ctx.seed)
+        return dq, dk, dv, None, None, None
+
+
+def _draw_seed():
+    """31-bit seed for the cross-attention dropout mask, drawn from torch's CPU generator (follows torch.manual_seed; no GPU sync)."""
+    return int(torch.randint(0, 0x7FFFFFFF, (1,)).item())
+
+
 class MLP(nn.Module):
     """Simple multi-layer perceptron (tfm_decoder.py:96-108)."""
 
@@ -190,23 +259,62 @@ class TransformerDecoderLayer(nn.Module):
         return F.linear(o, m.out_proj.weight, m.out_proj.bias)
 
     def forward_tokens(self, tgt, qpos, token, holder, layer_idx):
-        """Batch-first forward_pre (tfm_decoder.py:430-461): tgt, qpos [B,Q,C] fp32."""
+        """Batch-first forward_pre (tfm_decoder.py:430-461) on the holder's batched K/V: tgt, qpos [B,Q,C] fp32."""
+        p = self.p_attn if self.training else 0.0
+        return self._attend(tgt, qpos, lambda q: _XAttn.apply(q, token, holder, layer_idx, self.nhead, p, holder.seed + 7919 * layer_idx))
+
+    def _attend(self, tgt, qpos, xattn):
+        """forward_pre with sa_first (tfm_decoder.py:430-461) on batch-first fp32 [B,Q,C]; `xattn(q)` is the cross-attention core
+        of this layer (q already projected and scaled)."""
         C, h = tgt.shape[-1], self.nhead
         a = self.norm1(tgt)
         tgt = tgt + self.dropout1(self._self_attention(a, qpos))
         c = self.norm2(tgt)
         m = self.multihead_attn
         q = F.linear(c + qpos, m.in_proj_weight[:C], m.in_proj_bias[:C]) * ((C // h) ** -0.5)
-        p = self.p_attn if self.training else 0.0
-        ca = _XAttn.apply(q, token, holder, layer_idx, h, p, holder.seed + 7919 * layer_idx)
-        tgt = tgt + self.dropout2(F.linear(ca, m.out_proj.weight, m.out_proj.bias))
+        tgt = tgt + self.dropout2(F.linear(xattn(q), m.out_proj.weight, m.out_proj.bias))
         e = self.norm3(tgt)
-        tgt = tgt + self.dropout3(self.linear2(self.dropout(self.activation(self.linear1(e)))))
-        return tgt
+        return tgt + self.dropout3(self.linear2(self.dropout(self.activation(self.linear1(e)))))
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("TransformerDecoderLayer is driven through Cross_Attention / ObjDecoder "
-                                  "(memory K/V of all layers are projected in one batched GEMM)")
+    def forward_pre(self, tgt, memory, tgt_mask: Optional[Tensor] = None, memory_mask: Optional[Tensor] = None,
+                    tgt_key_padding_mask: Optional[Tensor] = None, memory_key_padding_mask: Optional[Tensor] = None,
+                    pos: Optional[Tensor] = None, query_pos: Optional[Tensor] = None, counter: Optional[Tensor] = None,
+                    num_frames: Optional[int] = 4, seq_len: Optional[int] = 196):
+        """Reference signature (tfm_decoder.py:420-461), sequence-first: tgt [Q,B,C], memory [M,B,C], pos [M,1|B,C],
+        query_pos [Q,B,C] -> (tgt [Q,B,C], attn, self_attn).  This layer projects its own K/V of `memory` (the batched path,
+        Cross_Attention.forward_tokens, projects all layers in one GEMM); the head-averaged attention maps the reference returns
+        and discards are None."""
+        _require_gpu(tgt, "TransformerDecoderLayer")
+        if not self.sa_first:
+            raise NotImplementedError("TransformerDecoderLayer: sa_first=True only (the reference default, tfm_decoder.py:54)")
+        if tgt_mask is not None or memory_mask is not None or tgt_key_padding_mask is not None:
+            raise NotImplementedError("TransformerDecoderLayer: attention masks are None on the hot path (tfm_decoder.py:270-276)")
+        if memory_key_padding_mask is not None and bool(memory_key_padding_mask.any()):
+            raise NotImplementedError("TransformerDecoderLayer: the key padding mask is all-False on the hot path (tfm_decoder.py:203)")
+        Q, B, C = tgt.shape
+        M = memory.shape[0]
+        x = tgt.transpose(0, 1).float()
+        qpos = torch.zeros_like(x) if query_pos is None else query_pos.transpose(0, 1).float()
+        mem_b = memory.transpose(0, 1).reshape(B * M, C)
+        kin = mem_b if pos is None else (memory + pos).transpose(0, 1).reshape(B * M, C)
+        m = self.multihead_attn
+        k = _LinearBF16.apply(kin, m.in_proj_weight[C:2 * C], m.in_proj_bias[C:2 * C], torch.bfloat16).view(B, M, C)
+        v = _LinearBF16.apply(mem_b, m.in_proj_weight[2 * C:], m.in_proj_bias[2 * C:], torch.bfloat16).view(B, M, C)
+        p = self.p_attn if self.training else 0.0
+        seed = _draw_seed() if p > 0 else 0
+        out = self._attend(x, qpos, lambda q: _XAttnKV.apply(q, k, v, self.nhead, p, seed))
+        return out.transpose(0, 1), None, None
+
+    def forward(self, tgt, memory, tgt_mask: Optional[Tensor] = None, memory_mask: Optional[Tensor] = None,
+                tgt_key_padding_mask: Optional[Tensor] = None, memory_key_padding_mask: Optional[Tensor] = None,
+                pos: Optional[Tensor] = None, query_pos: Optional[Tensor] = None, counter: Optional[Tensor] = None,
+                num_frames: Optional[int] = 4, seq_len: Optional[int] = 196):
+        """tfm_decoder.py:463-479."""
+        if not self.normalize_before:
+            raise NotImplementedError("TransformerDecoderLayer: forward_post is unusable in the reference (it returns one value "
+                                      "where TransformerDecoder.forward unpacks three, SURVEY A7)")
+        return self.forward_pre(tgt, memory, tgt_mask, memory_mask, tgt_key_padding_mask, memory_key_padding_mask, pos, query_pos,
+                                counter, num_frames, seq_len)
 
 
 def _get_clones(module, N):
@@ -222,6 +330,29 @@ class TransformerDecoder(nn.Module):
         self.num_layers = num_layers
         self.norm = norm
         self.return_intermediate = return_intermediate
+
+    def forward(self, tgt, memory, tgt_mask: Optional[Tensor] = None, memory_mask: Optional[Tensor] = None,
+                tgt_key_padding_mask: Optional[Tensor] = None, memory_key_padding_mask: Optional[Tensor] = None,
+                pos: Optional[Tensor] = None, query_pos: Optional[Tensor] = None, num_frames: Optional[int] = 4,
+                seq_len: Optional[int] = 196):
+        """Reference signature (tfm_decoder.py:255-295), sequence-first: -> (stack of normed intermediates [L,Q,B,C] or
+        norm(output)[None], [], []).  Each layer projects its own K/V; ObjDecoder.forward uses the batched forward_tokens."""
+        output = tgt
+        intermediate = []
+        for layer_i, layer in enumerate(self.layers):
+            output, _, _ = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                                 tgt_key_padding_mask=tgt_key_padding_mask, memory_key_padding_mask=memory_key_padding_mask,
+                                 pos=pos, query_pos=query_pos, counter=layer_i, num_frames=num_frames, seq_len=seq_len)
+            if self.return_intermediate:
+                intermediate.append(self.norm(output))
+        if self.norm is not None:
+            output = self.norm(output)
+            if self.return_intermediate:
+                intermediate.pop()
+                intermediate.append(output)
+        if self.return_intermediate:
+            return torch.stack(intermediate), [], []
+        return output.unsqueeze(0), [], []
 
     def forward_tokens(self, tgt, qpos, token, holder):
         inter = []
@@ -250,18 +381,28 @@ class Cross_Attention(nn.Module):
         self._reset_parameters()
         self.d_model, self.nhead = d_model, nhead
         self.dec_layers, self.enc_layers = num_decoder_layers, num_encoder_layers
-        self._seed = 0
+        self._seed = None            # dropout-mask stream of the cross-attention kernels; see next_dropout_seed()
 
     def _reset_parameters(self):
         for p in self.parameters():
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
+    def next_dropout_seed(self):
+        """Per-step seed of the attention-dropout masks (tfm_decoder.py:365, p = 0.1): an LCG stream that starts from
+        torch.initial_seed() mixed with the data-parallel rank (so torch.manual_seed controls it and ranks draw different masks);
+        TrainStep.state_dict() persists `_seed` so that a resumed run continues the stream."""
+        if self._seed is None:
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            self._seed = (torch.initial_seed() * 2654435761 + 40503 * rank + 1) & 0x7FFFFFFF
+        self._seed = (self._seed * 1103515245 + 12345) & 0x7FFFFFFF
+        return self._seed
+
     def forward_tokens(self, feat_b, w_proj, pos, query_embed, B):
         """feat_b bf16 [B*M, F] (no grad), w_proj [C,F], pos [M,C], query_embed [Q,C] -> hs [L,B,Q,C]."""
         holder = _KVHolder()
-        self._seed = (self._seed * 1103515245 + 12345) & 0x7FFFFFFF
-        holder.seed = self._seed
+        holder.seed = self.next_dropout_seed()
         layers = self.decoder.layers
         in_w = [l.multihead_attn.in_proj_weight for l in layers]
         in_b = [l.multihead_attn.in_proj_bias for l in layers]
@@ -276,14 +417,19 @@ class Cross_Attention(nn.Module):
 
     def forward(self, src, mask, query_embed, pos_embed):
         """Reference layout (tfm_decoder.py:76-93): src [B,C,T,n] (already projected), mask [B,T,n] (all False),
-        query_embed [Q,C], pos_embed [1,C,T,n] -> (hs [L,B,Q,C], memory [B,C,T,n], [], [])."""
+        query_embed [Q,C], pos_embed [1,C,T,n] -> (hs [L,B,Q,C], memory [B,C,T,n], [], []).  Differentiable in src, pos_embed,
+        query_embed and every parameter; ObjDecoder.forward takes the batched forward_tokens route instead."""
         _require_gpu(src, "Cross_Attention")
-        B, C, T, n = src.shape
-        mem0 = src.flatten(2).transpose(1, 2).reshape(B * T * n, C)
-        eye = torch.eye(C, device=src.device)
-        hs = self.forward_tokens(ops.to_bf16(mem0.float().contiguous()), eye, pos_embed.flatten(2)[0].t().contiguous(), query_embed, B)
-        memory = F.layer_norm(mem0.float(), (C,), self.pre_norm.weight, self.pre_norm.bias, self.pre_norm.eps)
-        return hs, memory.view(B, T, n, C).permute(0, 3, 1, 2), [], []
+        bs, c, h, w = src.shape
+        src = src.flatten(2).permute(2, 0, 1)                                  # [M,B,C]
+        pos_embed = pos_embed.flatten(2).permute(2, 0, 1)
+        query_embed = query_embed.unsqueeze(1).repeat(1, bs, 1)
+        mask = mask.flatten(1)
+        tgt = torch.zeros_like(query_embed)
+        memory = _LayerNormFn.apply(src.reshape(-1, c), self.pre_norm.weight, self.pre_norm.bias, self.pre_norm.eps).view(h * w, bs, c)
+        hs, attn_rollout, self_attn = self.decoder(tgt, memory, memory_key_padding_mask=mask, pos=pos_embed, query_pos=query_embed,
+                                                   num_frames=h, seq_len=w)
+        return hs.transpose(1, 2), memory.permute(1, 2, 0).reshape(bs, c, h, w), attn_rollout, self_attn
 
 
 class ObjDecoder(nn.Module):

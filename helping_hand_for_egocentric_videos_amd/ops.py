@@ -41,6 +41,14 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _workspace(fn_name, *dims, device):
+    """fp32 scratch buffer sized by the library (include/hh.h: hh_workspace_bytes_*)."""
+    nbytes = getattr(_lib.lib(), "hh_workspace_bytes_" + fn_name)(*dims)
+    if nbytes < 0:
+        raise ValueError("hh_workspace_bytes_%s%s: bad arguments" % (fn_name, dims))
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+
+
 def set_tuning(name, value):
     """Performance knob for A/B measurements (include/hh.h: hh_set_tuning)."""
     _lib.check(_lib.lib().hh_set_tuning(name.encode(), int(value)), "hh_set_tuning")
@@ -126,7 +134,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
     if splitk > 1:
         if bias is not None or resid is not None or out is not None or act != ACT_NONE:
             raise ValueError("gemm: split-K takes no bias / residual / activation / preallocated output")
-        part = torch.empty((splitk, M, N), dtype=torch.float32, device=a.device)
+        part = _workspace("gemm_splitk", M, N, int(splitk), device=a.device).view(splitk, M, N)
         e = GemmEpilogue()
         e.colscale, e.c_dtype, e.splitk, e.split_stride = 1.0, F32, int(splitk), M * N
         _lib.check(_lib.lib().hh_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(part), N, M, N, K, ctypes.byref(e),
@@ -231,7 +239,7 @@ def gemm_tn(at, bt, splits=None):
     if splits is None:
         tiles = (M // 128) * (N // 128)
         splits = max(1, min(256, 1024 // max(tiles, 1), (K + 511) // 512))
-    part = torch.empty((splits, M, N), dtype=torch.float32, device=at.device)
+    part = _workspace("gemm_tn", M, N, int(splits), device=at.device).view(splits, M, N)
     _lib.check(_lib.lib().hh_gemm_tn_bf16(_p(at), at.stride(0), _p(bt), bt.stride(0), _p(part), M, N, K, int(splits), _stream()),
                "hh_gemm_tn_bf16")
     return part[0] if splits == 1 else part.sum(0)
@@ -254,7 +262,7 @@ def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
     part, G = None, 0
     if fold_cls:
         G = T if mode == "space" else (n + (128 // T) - 1) // (128 // T)
-        part = torch.empty((B, heads, G, 68), dtype=torch.float32, device=qkv.device)
+        part = _workspace("attn_cls_partial", B, T, n, heads, int(mode == "time"), device=qkv.device).view(B, heads, G, 68)
     else:
         _lib.check(L.hh_cls_attn_fwd(_p(qkv), _p(out), B, N, heads, _stream()), "hh_cls_attn_fwd")
     if mode == "space":
@@ -301,17 +309,20 @@ def xattn_bwd(q, k, v, out, lse, dout, dk, dv, heads, dropout_p=0.0, seed=0, spl
     _chk(q, out, lse, dout)
     if splits is None:
         splits = max(1, min(8, M // 1024))
-    dq = torch.empty((splits, B, Q, C), dtype=torch.float32, device=q.device)
+    dq = _workspace("xattn_bwd", B, Q, heads, int(splits), device=q.device).view(splits, B, Q, C)
     _lib.check(_lib.lib().hh_xattn_bwd(_p(q), _p(k), _p(v), k.stride(1), _p(out), _p(lse), _p(dout), _p(dq), int(splits), _p(dk), _p(dv),
                                        dk.stride(1), B, Q, M, heads, float(dropout_p), int(seed) & 0xFFFFFFFF, _stream()),
                "hh_xattn_bwd")
     return dq[0] if splits == 1 else dq.sum(0)
 
 
-def match_boxes(pred, q0, q, raw_boxes, img=224.0, w_l1=5.0, w_giou=2.0, given_count=None):
+def match_boxes(pred, q0, q, raw_boxes, img=224.0, w_l1=5.0, w_giou=2.0, given_count=None, class_cost=None, w_class=0.0):
     """pred fp32 [F,Qtot,4]; raw_boxes fp32 [F,k,4] -> dict(tgt, count, pred_idx, tgt_idx, n) all on device.
-    given_count int32 [F]: raw_boxes are already-prepared cxcywh targets (list API of HungarianMatcher)."""
-    _chk(pred, raw_boxes, given_count)
+    given_count int32 [F]: raw_boxes are already-prepared cxcywh targets (list API of HungarianMatcher).
+    class_cost fp32 [F,q,k]: -softmax(logits)[query, label of target j] (exclude_class=False, box_utils.py:83-85)."""
+    _chk(pred, raw_boxes, given_count, class_cost)
+    if class_cost is not None and (class_cost.dtype != torch.float32 or tuple(class_cost.shape) != (pred.shape[0], q, raw_boxes.shape[1])):
+        raise ValueError("match_boxes: class_cost must be fp32 [F, q, k]")
     F_, Qtot, _ = pred.shape
     k = raw_boxes.shape[1]
     dev = pred.device
@@ -321,7 +332,7 @@ def match_boxes(pred, q0, q, raw_boxes, img=224.0, w_l1=5.0, w_giou=2.0, given_c
     mt = torch.empty((F_, k), dtype=torch.int64, device=dev)
     mn = torch.empty((F_,), dtype=torch.int32, device=dev)
     _lib.check(_lib.lib().hh_match_boxes(_p(pred), Qtot, q0, q, _p(raw_boxes), _p(given_count), k, float(img), float(w_l1), float(w_giou),
-                                         _p(tgt), _p(cnt), _p(mp), _p(mt), _p(mn), F_, _stream()), "hh_match_boxes")
+                                         _p(class_cost), float(w_class), _p(tgt), _p(cnt), _p(mp), _p(mt), _p(mn), F_, _stream()), "hh_match_boxes")
     return {"tgt": tgt, "count": cnt, "pred_idx": mp, "tgt_idx": mt, "n": mn}
 
 

@@ -28,13 +28,15 @@ enum hh_dtype { HH_F32 = 0, HH_BF16 = 1 };
 enum hh_act { HH_ACT_NONE = 0, HH_ACT_QUICKGELU = 1, HH_ACT_RELU = 2 };
 
 int hh_version(void);
-/* Performance knobs for A/B measurements (never change results): "gemm256" = 0 (128x128 kernel only), 1 (256x256
- * 8-phase, no stagger), 2 (256x256 with wave-group stagger), 3 (persistent 256x256 -- one workgroup per CU walks its
- * tiles and prefetches the next tile's first two k-tiles before the epilogue stores -- where eligible, else mode 2), 4 (continuous
- * persistent -- the next tile's first two k-tiles are staged during the current tile's last two, no prologue at all), 5 (default:
- * mode 4 with the A-lo and the A-hi phases merged: four barriers per k-tile instead of eight);
- * "gemm256_skew" = -1 auto / 0 off / 1 on (start-time skew of the first round of 256x256 blocks, spreads the epilogue HBM bursts);
- * "gemm256_pskew" = 0..64 (start skew quantum of the continuous kernel, default 0). */
+/* Performance knobs for A/B measurements (never change results).  Together with the per-stream CU budget below this is the
+ * library's ONLY process-global mutable state; no entry point reads the environment.
+ *   "gemm256"       0 = 128x128 kernel only, 1 = 256x256 one tile per block, 2 = + wave-row stagger, 3 (default) = persistent
+ *                   256x256: one workgroup per CU walks its tiles in one continuous k-tile stream, four barriers per k-tile
+ *   "gemm_tail"     1 (default) = (< 64)-row tails on the split-K-in-workgroup kernel, 0 = on the 128x128 kernel
+ *   "gemm256_group" m-tiles per XCD-local group of the tile walk (0 = per-shape default)
+ *   "gemm256_skew"  -1 auto / 0 off / 1 on: start-time skew of the one-tile-per-block kernel (spreads the epilogue HBM bursts)
+ *   "gemm256_pskew" 0..64: start skew quantum of the persistent kernel (default 0)
+ *   "gemm256_debug_ts", "gemm256_debug_nostore": diagnostics (timeline recording; skip the epilogue stores) */
 int hh_set_tuning(const char* name, int value);
 const char* hh_last_error_string(void);
 /* Debug only: after hh_set_tuning("gemm256_debug_ts", 1), every persistent 256x256 GEMM launch records, for the first 8 tiles of
@@ -50,6 +52,18 @@ int hh_debug_gemm_timeline(unsigned long long* out, int blocks);
  * changes results. */
 int hh_stream_set_cu_budget(hh_stream_t stream, int n_cus);
 int hh_stream_get_cu_budget(hh_stream_t stream, int* out);
+
+/* ---- caller-owned workspaces.  No entry point allocates; these return the size in BYTES of the scratch buffer an entry point
+ * takes (negative = bad arguments):
+ *   gemm_splitk      : C of hh_gemm_bf16 with epi->splitk = S  (fp32 [S, M, N], split_stride = M*N)
+ *   gemm_tn          : `partials` of hh_gemm_tn_bf16           (fp32 [splits, M, N])
+ *   xattn_bwd        : `dq` of hh_xattn_bwd                    (fp32 [dq_splits, B, Q, heads*64])
+ *   attn_cls_partial : `cls_partial` of hh_space_attn_fwd (time_mode 0) / hh_time_attn_fwd (1) and input of hh_cls_combine
+ *                      (fp32 [B, heads, G, 68]) */
+int64_t hh_workspace_bytes_gemm_splitk(int64_t M, int N, int splitk);
+int64_t hh_workspace_bytes_gemm_tn(int M, int N, int splits);
+int64_t hh_workspace_bytes_xattn_bwd(int B, int Q, int heads, int dq_splits);
+int64_t hh_workspace_bytes_attn_cls_partial(int B, int T, int n, int heads, int time_mode);
 
 /* ---- LayerNorm over the last dim (model/LaviLa.py:439,456 eps 1e-6 / 1e-5; tfm_decoder.py:57,375-377)
  * y[r,:] = (x[r,:]-mean)/sqrt(var+eps)*gamma+beta ; x dtype / y dtype in {HH_F32, HH_BF16}; gamma/beta fp32.
@@ -159,9 +173,11 @@ int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_t ldkv, con
  * Exact shortest-augmenting-path LSAP (scipy.optimize.linear_sum_assignment semantics) in fp64 on the fp32 cost
  * C = w_l1*L1 - w_giou*GIoU, one thread per frame. q <= 16, k <= 16. */
 /* If given_count != NULL, raw_boxes already holds prepared cxcywh targets (first given_count[f] rows valid) and the
- * prepare_targets step is skipped (HungarianMatcher.forward list API). */
+ * prepare_targets step is skipped (HungarianMatcher.forward list API).
+ * class_cost (optional, fp32 [F, q, k]): the exclude_class=False term of box_utils.py:83-85, i.e. -softmax(pred_logits)[query,
+ * label of the frame's j-th kept target], added as  C += w_class * class_cost  after the box terms (reference op order). */
 int hh_match_boxes(const float* pred, int Qtot, int q0, int q, const float* raw_boxes, const int32_t* given_count, int k, float img,
-                   float w_l1, float w_giou, float* tgt_cxcywh, int32_t* tgt_count,
+                   float w_l1, float w_giou, const float* class_cost, float w_class, float* tgt_cxcywh, int32_t* tgt_count,
                    int64_t* match_pred, int64_t* match_tgt, int32_t* match_n, int64_t F, hh_stream_t stream);
 /* generic batched LSAP on fp32 costs [P, nr, nc] (word loss, loss.py:83-93): the rows with row_valid != 0
  * (kept in order) x all nc columns; out col_of_row int64 [P, nr] (assigned column per row, -1 for invalid /

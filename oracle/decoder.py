@@ -47,6 +47,24 @@ def pos_embed_3d(sd, T, n):
     return (sd["pos_embed"][0, 1:].repeat(T, 1) + sd["temporal_embed"][0, :T].repeat_interleave(n, dim=0))
 
 
+def cross_attention_forward(src, mask, query_embed, pos_embed, sd, cfg, prefix="transformer."):
+    """Cross_Attention.forward in the reference's own layout -- tfm_decoder.py:76-93 (+ TransformerDecoder.forward
+    :255-295).  src [B,C,T,n] (already projected), mask [B,T,n] bool (all False on the hot path: a True entry would
+    exclude that key), query_embed [Q,C], pos_embed [1,C,T,n] -> (hs [L,B,Q,C], memory [B,C,T,n])."""
+    B, C, T, n = src.shape
+    assert not bool(mask.any()), "oracle: key padding is all-False on the hot path (tfm_decoder.py:203)"
+    mem = src.flatten(2).transpose(1, 2)                                       # [B,M,C] (batch-first view of [M,B,C])
+    pos = pos_embed.flatten(2).transpose(1, 2)                                 # [1,M,C]
+    memory = _ln(mem, sd, prefix + "pre_norm")
+    qpos = query_embed[None].expand(B, -1, -1)
+    tgt = torch.zeros_like(qpos)
+    inter = []
+    for l in range(cfg.dec_layers):
+        tgt = decoder_layer(tgt, memory, pos, qpos, sd, f"{prefix}decoder.layers.{l}.", cfg.dec_heads)
+        inter.append(_ln(tgt, sd, prefix + "decoder.norm"))
+    return torch.stack(inter), memory.transpose(1, 2).reshape(B, C, T, n)
+
+
 def objdecoder_forward(features, sd, cfg, compute_logits=True):
     """ObjDecoder.forward -- tfm_decoder.py:183-233 (+ Cross_Attention.forward :76-93,
     TransformerDecoder.forward :255-295).

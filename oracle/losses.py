@@ -116,12 +116,17 @@ def matcher_cost(pred, tgt, w_bbox=5.0, w_giou=2.0):
     return w_bbox * cb + w_giou * cg
 
 
-def hungarian_match(pred_boxes, targets, w_bbox=5.0, w_giou=2.0):
+def hungarian_match(pred_boxes, targets, w_bbox=5.0, w_giou=2.0, pred_logits=None, labels=None, w_class=1.0):
     """HungarianMatcher.forward -- box_utils.py:63-92; per-frame block-diagonal problems.
-    pred_boxes [F,q,4]; targets list of [k_f,4] -> list of (int64 rows, int64 cols)."""
+    pred_boxes [F,q,4]; targets list of [k_f,4] -> list of (int64 rows, int64 cols).
+    pred_logits [F,q,classes] + labels (list of int64 [k_f]) = the exclude_class=False branch (:62,83-85):
+    C += cost_class * (-softmax(logits)[:, tgt_ids])."""
     out = []
     for f, t in enumerate(targets):
-        C = matcher_cost(pred_boxes[f].detach(), t, w_bbox, w_giou).numpy() if len(t) else np.zeros((pred_boxes.shape[1], 0))
+        C = matcher_cost(pred_boxes[f].detach(), t, w_bbox, w_giou) if len(t) else torch.zeros((pred_boxes.shape[1], 0))
+        if pred_logits is not None and len(t):
+            C = C + w_class * (-pred_logits[f].detach().softmax(-1)[:, labels[f]])
+        C = C.numpy()
         r, c = linear_sum_assignment(C)
         out.append((torch.as_tensor(r, dtype=torch.int64), torch.as_tensor(c, dtype=torch.int64)))
     return out

@@ -106,12 +106,13 @@ def test_gemm_plain_and_epilogues(M, N, K):
     torch.testing.assert_close(R.cpu(), ref + bias + res, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
 
 
-@pytest.mark.parametrize("mode", [3, 4, 5])
+@pytest.mark.parametrize("mode", [2, 3])
 @pytest.mark.parametrize("M,N,K", [(256 * 40, 2048, 256), (256 * 24, 3072, 192), (256 * 300, 256, 128), (256 * 20, 4096, 1024),
                                    (256 * 33 + 17, 1024, 512), (256 * 300, 256, 64), (256 * 40, 8192 + 256, 128)])
 def test_gemm_persistent_walks_many_tiles_per_workgroup(mode, M, N, K):
-    """More 256x256 tiles than CUs: every workgroup of the persistent kernels (3 = prologue per tile, 4 = continuous k-tile stream
-    across tile boundaries) walks several tiles, with even / odd k-tile counts (LDS buffer parity) and the 2-k-tile corner."""
+    """More 256x256 tiles than CUs: every workgroup of the persistent kernel (mode 3: continuous k-tile stream across tile
+    boundaries) walks several tiles, with even / odd k-tile counts (LDS buffer parity) and the 2-k-tile corner; mode 2 = the
+    one-tile-per-block kernel on the same shapes."""
     g = torch.Generator(device=DEV).manual_seed(M + N + K)
     a = (torch.randn(M, K, device=DEV, generator=g)).to(torch.bfloat16)
     w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
@@ -123,7 +124,7 @@ def test_gemm_persistent_walks_many_tiles_per_workgroup(mode, M, N, K):
         out_f32 = ops.gemm(a, w, bias, out_dtype=torch.float32)
         out_act = ops.gemm(a, w, bias, act=ops.ACT_QUICKGELU)
     finally:
-        ops.set_tuning("gemm256", 5)
+        ops.set_tuning("gemm256", 3)
     scale = ref.abs().max().item()
     assert (out_f32 - ref).abs().max().item() <= 2e-3 * scale
     assert (out_bf.float() - ref).abs().max().item() <= 8e-3 * scale

@@ -132,6 +132,40 @@ def test_box_ops_matcher_and_losses(R):
             assert torch.equal(a, b)
 
 
+def test_matcher_with_class_cost(R):
+    """exclude_class=False branch of HungarianMatcher.forward (box_utils.py:62,83-85): class-probability cost added."""
+    g = torch.Generator().manual_seed(13)
+    for trial in range(10):
+        F_, q = 8, (2 if trial % 2 == 0 else 10)
+        pred = torch.rand(F_, q, 4, generator=g) * 0.5 + 0.2
+        logits = torch.randn(F_, q, 7, generator=g) * 2
+        boxes = synth.make_batch(TINY4, 2, seed=100 + trial)["boxes"][:, :, :2].flatten(0, 1)
+        with refglue.no_cuda_calls():
+            rt = R.box_utils.prepare_targets(boxes.clone(), None, None, center_crop=False)
+        for t in rt:                                  # give every target a class id (the reference's are all 0 = "object")
+            t["labels"] = torch.randint(0, 7, (len(t["boxes"]),), generator=g)
+        ridx = R.box_utils.build_matcher(None)({"pred_boxes": pred, "pred_logits": logits}, rt, exclude_class=False)
+        midx = OL.hungarian_match(pred, [t["boxes"] for t in rt], pred_logits=logits, labels=[t["labels"] for t in rt])
+        for (a, b), (c, d) in zip(midx, ridx):
+            assert torch.equal(a, c) and torch.equal(b, d)
+
+
+def test_cross_attention_reference_layout(R):
+    """Cross_Attention.forward(src, mask, query_embed, pos_embed) itself (tfm_decoder.py:76-93), not via ObjDecoder."""
+    cfg = TINY4
+    dsd = synth.decoder_state(cfg, seed=3)
+    dec = refglue.build_decoder(R, cfg, dsd).eval()
+    B, C, T, n = 2, cfg.dec_dim, cfg.num_frames, cfg.patches_per_frame
+    g = torch.Generator().manual_seed(2)
+    src = torch.randn(B, C, T, n, generator=g)
+    pos = torch.randn(1, C, T, n, generator=g) * 0.1
+    mask = torch.zeros(B, T, n, dtype=torch.bool)
+    rhs, rmem, _, _ = dec.transformer(src, mask, dec.query_embed.weight, pos)
+    mhs, mmem = OD.cross_attention_forward(src, mask, dsd["query_embed.weight"], pos, dsd, cfg)
+    _close(mhs, rhs)
+    _close(mmem, rmem)
+
+
 def test_egonce_word_and_accuracy(R):
     cfg = TINY4
     g = torch.Generator().manual_seed(3)
