@@ -7,7 +7,8 @@
 A step = frozen TimeSformer-L forward + text tower + object-query decoder forward/backward + EgoNCE / box /
 word losses (on-device Hungarian) + decoder-gradient all-reduce (RCCL) + fused AdamW over one synthetic batch
 that is resident in HBM.  Weak scaling: the per-GPU batch is fixed.  Prints ONE JSON line on rank 0.
---workload mcq times the EgoMCQ forward-only path (BASELINE config 5) instead.
+The same line carries an "mcq" sub-record: the EgoMCQ forward-only path (BASELINE config 5, q = 8 items) timed after the train
+region; --workload mcq times only that path.
 """
 import argparse
 import json
@@ -29,57 +30,35 @@ PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA peak, /opt/skills/guides/MI355
 PEAK_HBM_GBS = 8000.0
 
 
-class KernelTimer:
-    """Live per-launch timing of selected libhh ops with events on the launch stream (torch's current stream)."""
-
-    def __init__(self, stride=5):
-        self.rec = {}
-        self.on = False
-        self.streams = None         # only launches on these streams are timed (the text tower runs concurrently on a side stream)
-        # every stride-th eligible launch is bracketed by events (5 is co-prime with the 6 GEMMs / 2 attention calls per layer,
-        # so every shape is sampled equally); bracketing every launch costs ~3.5 % of the step in marker packets
-        self.stride = stride
-        self.count = {}
-
-    def wrap(self, name, fn, work):
-        def inner(*a, **k):
-            if not self.on or (self.streams is not None and torch.cuda.current_stream() not in self.streams):
-                return fn(*a, **k)
-            c = self.count.get(name, 0)
-            self.count[name] = c + 1
-            if c % self.stride:
-                return fn(*a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = fn(*a, **k)
-            e1.record()
-            self.rec.setdefault(name, []).append((e0, e1, work(*a, **k)))
-            return r
-        return inner
-
-    def summary(self, name):
-        ev = self.rec.get(name, [])
-        if not ev:
-            return 0, 0.0, 0.0
-        ms = sum(a.elapsed_time(b) for a, b, _ in ev)
-        return len(ev), ms, float(sum(w for _, _, w in ev))
+PROF = {"gemm256": 0, "gemm_other": 1, "space_attn": 2, "time_attn": 3, "add_ln": 4, "gemm_tn": 5, "xattn_fwd": 6, "xattn_bwd": 7}
 
 
-def gemm_flops(a, w, *args, **kw):
-    sk = kw.get("splitk", 1)
-    return 2.0 * a.shape[0] * a.shape[1] * w.shape[0]
+def prof_enable(stride):
+    """Library-side per-kernel timing (include/hh.h: hh_prof_enable): every stride-th launch of each instrumented kernel class is
+    bracketed by two HIP events on its launch stream with only that kernel between them.  stride 0 = off."""
+    from helping_hand_for_egocentric_videos_amd import _lib
+    _lib.check(_lib.lib().hh_prof_enable(int(stride)), "hh_prof_enable")
 
 
-def attn_bytes(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
-    return 8.0 * qkv.shape[0] * heads * 64          # read q,k,v + write o, bf16 (SURVEY 8d: 8*N*D per call)
+def prof_read(name):
+    """-> (launches timed, launches seen, total ms, total algorithmic work) of one kernel class; synchronises on its events."""
+    import ctypes
+    from helping_hand_for_egocentric_videos_amd import _lib
+    n, seen, ms, work = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+    _lib.check(_lib.lib().hh_prof_read(PROF[name], ctypes.byref(n), ctypes.byref(seen), ctypes.byref(ms), ctypes.byref(work)), "hh_prof_read")
+    return n.value, seen.value, ms.value, work.value
+
+
+def prof_snapshot():
+    return {k: prof_read(k) for k in PROF}
 
 
 def pmc_traffic(kernel_substr):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r1_pmc_summary.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction); launch-weighted
-    mean over the template instantiations whose name contains `kernel_substr`."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
-    if not os.path.exists(path):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r2_pmc_summary.json, else
+    round 1's: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction);
+    launch-weighted mean over the template instantiations whose name contains `kernel_substr`."""
+    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r2_pmc_summary.json", "r1_pmc_summary.json")) if os.path.exists(q)), None)
+    if path is None:
         return None
     with open(path) as f:
         rows = [v for k, v in json.load(f).items() if kernel_substr in k]
@@ -116,22 +95,29 @@ def sustained_clock(dev):
 
 
 def cpu_baseline(cfg, enc_sd, dec_sd, seed):
-    """Oracle (CPU restatement, fp32) timed on this host: one full training step on ONE clip of the same workload."""
+    """Oracle (CPU restatement, fp32) timed on this host: one full training step on ONE clip of the same workload, with the
+    thread count that is fastest on the 256-thread GPU host (16; more threads run slower) and with 8 threads (the dev container's
+    core count)."""
     from oracle import step as OS
-    cores = min(os.cpu_count() or 1, int(os.environ.get("HH_CPU_BASELINE_THREADS", 16)))   # >32 threads run slower here
-    torch.set_num_threads(cores)
     batch = synth.make_batch(cfg, 1, seed=seed)
-    dsd = {k: v.clone() for k, v in dec_sd.items()}
-    state = None
-    _, _, state = OS.train_step(enc_sd, dsd, batch, cfg, state)          # warm-up (allocator, thread pool)
-    iters = 4
-    t = time.time()
-    for _ in range(iters):
-        _, _, state = OS.train_step(enc_sd, dsd, batch, cfg, state)
-    dt = time.time() - t
-    return {"value": round(iters / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "1 clip/step (T=%d, %dpx, nq=%d): oracle fp32 full step fwd+bwd+AdamW, 1 warm-up + %d timed steps, %.1f s" % (
-                cfg.num_frames, cfg.img_size, cfg.num_queries, iters, dt)}
+
+    def timed(threads, iters):
+        torch.set_num_threads(threads)
+        dsd = {k: v.clone() for k, v in dec_sd.items()}
+        _, _, state = OS.train_step(enc_sd, dsd, batch, cfg, None)       # warm-up (allocator, thread pool)
+        t = time.time()
+        for _ in range(iters):
+            _, _, state = OS.train_step(enc_sd, dsd, batch, cfg, state)
+        return iters / (time.time() - t), time.time() - t
+
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, int(os.environ.get("HH_CPU_BASELINE_THREADS", 16)))
+    v16, dt16 = timed(cores, 3)
+    v8, dt8 = timed(min(8, ncpu), 2)
+    return {"value": round(v16, 4), "unit": "clips/s", "cores": cores, "kind": "port", "threads_8": round(v8, 4), "host_cpu_count": ncpu,
+            "sample": "1 clip/step (T=%d, %dpx, nq=%d): oracle fp32 full step fwd+bwd+AdamW; %d threads: 1 warm-up + 3 timed steps (%.1f s); "
+                      "8 threads: 1 warm-up + 2 timed steps (%.1f s); more than 16-32 threads run slower on this host" % (
+                          cfg.num_frames, cfg.img_size, cfg.num_queries, cores, dt16, dt8)}
 
 
 def main():
@@ -143,6 +129,7 @@ def main():
     ap.add_argument("--workload", default="train", choices=["train", "mcq"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--no-mcq", action="store_true", help="skip the EgoMCQ forward sub-record (second half of BASELINE.json's metric)")
     ap.add_argument("--enc-cus", type=int, default=None, help="CU budget of the persistent GEMMs on the pipelined encoder stream (multiple of 8; 0 = all)")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder forward with this step's decoder")
     args = ap.parse_args()
@@ -168,10 +155,8 @@ def main():
     decoder = tfm_decoder.build_decoder(cfg, dec_sd, device=dev)
     B = args.batch
 
-    timer = KernelTimer()
-    if not args.no_kernel_timers:
-        ops.gemm = timer.wrap("gemm", ops.gemm, gemm_flops)
-        ops.divided_attention = timer.wrap("attn", ops.divided_attention, attn_bytes)
+    STRIDE = 5      # every 5th launch of a class is timed (co-prime with the 6 GEMMs / 2 attention calls per block); bracketing every launch costs ~3 % in marker packets
+    timers = not args.no_kernel_timers
 
     if args.workload == "train":
         batch = {k: v.to(dev) for k, v in synth.make_batch(cfg, B, seed=1000 + rank).items()}
@@ -196,54 +181,85 @@ def main():
     for _ in range(args.warmup):
         run()
     barrier()
-    timer.streams = [torch.cuda.current_stream()]
-    if args.workload == "train" and ts.enc_stream is not None:
-        timer.streams.append(ts.enc_stream)
-    timer.on = True
+    if timers:
+        prof_enable(STRIDE)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = run()
     barrier()
     dt = time.perf_counter() - t0
-    timer.on = False
+    region = prof_snapshot() if timers else None
     iso = None
-    if args.workload == "train" and not args.no_kernel_timers and not args.no_pipeline:
-        # outside the timed region: two un-pipelined steps, so that the dominant kernel is also timed without decoder kernels
-        # of the previous step running beside it
-        t_iso = KernelTimer()
-        t_iso.rec, t_iso.on, t_iso.streams = {}, True, [torch.cuda.current_stream()]
-        keep = (timer.rec, timer.streams)
-        timer.rec, timer.streams, timer.on = t_iso.rec, t_iso.streams, True
+    if timers and args.workload == "train" and not args.no_pipeline:
+        # outside the timed region: two un-pipelined steps, so that every kernel is also timed alone on the chip (no decoder kernels
+        # of the previous step beside the encoder's)
+        prof_enable(STRIDE)
         for _ in range(2):
             ts.step(batch)
         barrier()
-        timer.on = False
-        iso = timer.summary("gemm")
-        timer.rec, timer.streams = keep
+        iso = prof_snapshot()
+    if timers:
+        prof_enable(0)
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt)
     value = clips_per_step * world * args.steps / dt
 
+    # second half of BASELINE.json's metric in the same line: EgoMCQ forward clips/s (config 5: q = 8 items = 40 clips + 8 queries)
+    mcq_rec = None
+    if args.workload == "train" and not args.no_mcq:
+        q = 8
+        item = synth.make_mcq_item(cfg, q, seed=2000 + rank)
+        mv, mt = item["video"].to(dev), item["text"].to(dev)
+        decoder.eval()
+        for _ in range(2):
+            mcq_forward(backbone, decoder, mv, mt, cfg)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            scores = mcq_forward(backbone, decoder, mv, mt, cfg)
+        barrier()
+        mt_ = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(mt_, op=dist.ReduceOp.MAX)
+        mcq_rec = {"metric": "EgoMCQ fwd clips/sec (16-frame 224p)", "value": round(q * 5 * world * 5 / float(mt_), 2), "unit": "clips/s",
+                   "ms_per_step": round(float(mt_) / 5 * 1e3, 2), "steps": 5, "warmup": 2,
+                   "config": {"workload": "C5: 16-frame EgoMCQ forward, q = %d items (%d clips + %d queries) per step per GPU, replicas only" % (q, 5 * q, q),
+                              "step_tflop_per_clip": 3.45}}
+        del mv, mt, scores
+
     if rank == 0:
-        n_g, ms_g, fl_g = timer.summary("gemm")
-        n_a, ms_a, by_a = timer.summary("attn")
+        def rate(rec, key, scale):
+            n, seen, ms, work = rec[key]
+            return (work / (ms * 1e-3) / scale, n, seen, ms) if n and ms > 0 else (None, n, seen, ms)
+
         roof = None
-        if n_g:
-            ach = fl_g / (ms_g * 1e-3) / 1e12
-            roof = {"kernel": "gemm256d_kernel (continuous persistent 256x256, four barriers per k-tile; row tails on gemm_tail_kernel) via hh_gemm_bf16", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic("gemm256d_kernel<true") or pmc_traffic("gemm256c_kernel<true") or pmc_traffic("gemm256p_kernel<true"),
-                    "traffic_note": "bytes/launch from profiles/r1_pmc_summary.json (PMC passes at B=32); algorithmic avg ~0.99e9",
-                    "launches_timed": n_g, "sampling": "every %dth hh_gemm_bf16 launch of the timed region" % timer.stride,
-                    "avg_launch_us": round(ms_g * 1e3 / n_g, 1), "share_of_step": round(ms_g * timer.stride / (dt * 1e3), 3)}
-            if iso is not None and iso[0]:
-                roof["isolated"] = {"achieved": round(iso[2] / (iso[1] * 1e-3) / 1e12, 1), "frac": round(iso[2] / (iso[1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                                    "note": "same kernel timed over 2 un-pipelined steps outside the timed region (no decoder kernels of the previous step running beside it)"}
-        if roof is not None and not args.no_kernel_timers:
-            sc = sustained_clock(dev)
-            sc["frac_of_clock_limited_peak"] = round(roof["achieved"] / sc["clock_limited_peak"], 4)
-            roof["sustained_clock"] = sc
+        if region is not None:
+            ach, n, seen, ms = rate(region, "gemm256", 1e12)
+            if ach is not None:
+                roof = {"kernel": "gemm256d_kernel (persistent 256x256x64 bf16 MFMA GEMM, continuous k-tile stream, four barriers per k-tile) -- every template instantiation, nothing else",
+                        "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                        "traffic": pmc_traffic("gemm256d_kernel<true"),
+                        "traffic_note": "HBM-side bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/*_pmc_summary.json, B=32); algorithmic bytes per launch average 0.99e9",
+                        "algorithmic_work": "2*M*N*K of the full 256-row tiles of each launch (DESIGN.md section 5)",
+                        "launches_timed": n, "launches_in_region": seen,
+                        "timing": "library-side HIP events around the kernel launch alone (hh_prof_enable), every %dth launch, on the launch stream" % STRIDE,
+                        "avg_launch_us": round(ms * 1e3 / n, 1), "share_of_step": round(ms * STRIDE / (dt * 1e3), 3),
+                        "region": "timed region (pipelined: decoder kernels of the previous step run beside it)" if not args.no_pipeline else "timed region (un-pipelined)"}
+                if iso is not None:
+                    a2, n2, _, ms2 = rate(iso, "gemm256", 1e12)
+                    if a2 is not None:
+                        roof["isolated"] = {"achieved": round(a2, 1), "frac": round(a2 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms2 * 1e3 / n2, 1),
+                                            "note": "same kernel over 2 un-pipelined steps outside the timed region (alone on the chip); compare with the un-pipelined rocprofv3 summary in profiles/"}
+                o, no, _, mso = rate(region, "gemm_other", 1e12)
+                if o is not None:
+                    roof["other_gemm_kernels"] = {"what": "row tails (gemm_tail_kernel), 128x128 kernel, one-tile-per-block 256x256 kernel -- NOT part of `achieved`",
+                                                  "achieved": round(o, 1), "unit": "TFLOP/s", "launches_timed": no, "avg_launch_us": round(mso * 1e3 / no, 1),
+                                                  "share_of_step": round(mso * STRIDE / (dt * 1e3), 3)}
+                sc = sustained_clock(dev)
+                sc["frac_of_clock_limited_peak"] = round(roof["achieved"] / sc["clock_limited_peak"], 4)
+                roof["sustained_clock"] = sc
         line = {"metric": metric, "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -254,11 +270,23 @@ def main():
                     "step_tflop_per_clip": 3.59 if args.workload == "train" else 3.45},
                 "end_to_end_mfma_frac": round(value * (3.59 if args.workload == "train" else 3.45) / (world * PEAK_BF16_TFLOPS), 4),
                 "roofline": roof}
-        if n_a:
-            gbs = by_a / (ms_a * 1e-3) / 1e9
-            line["attention_roofline"] = {"kernel": "space/time/cls attention (hh_*_attn_fwd)", "bound": "hbm", "achieved": round(gbs, 1),
-                                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                          "launches_timed": n_a, "share_of_step": round(ms_a * timer.stride / (dt * 1e3), 3)}
+        if region is not None:
+            att = {}
+            for key, kname in (("space_attn", "space_attn16_kernel"), ("time_attn", "time_attn_mfma_kernel<16>"), ("add_ln", "add_ln_kernel")):
+                r, n, _, ms = rate(region, key, 1e9)
+                if r is None:
+                    continue
+                att[key] = {"kernel": kname, "bound": "hbm", "achieved": round(r, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(r / PEAK_HBM_GBS, 4),
+                            "launches_timed": n, "avg_launch_us": round(ms * 1e3 / n, 1), "share_of_step": round(ms * STRIDE / (dt * 1e3), 3)}
+                if iso is not None:
+                    r2, n2, _, ms2 = rate(iso, key, 1e9)
+                    if r2 is not None:
+                        att[key]["isolated"] = {"achieved": round(r2, 1), "frac": round(r2 / PEAK_HBM_GBS, 4), "avg_launch_us": round(ms2 * 1e3 / n2, 1)}
+            if att:
+                att["note"] = "algorithmic bytes (8*N*D per attention call and clip; bytes read + written for add+LayerNorm) / event time of the kernel alone; `isolated` = un-pipelined steps"
+                line["attention_roofline"] = att
+        if mcq_rec is not None:
+            line["mcq"] = mcq_rec
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, enc_sd, dec_sd, seed=1000)
         if args.workload == "train":

@@ -25,6 +25,8 @@ SIGNATURES = {
     "hh_debug_gemm_timeline": [c_vp, c_int],
     "hh_stream_set_cu_budget": [c_vp, c_int],
     "hh_stream_get_cu_budget": [c_vp, ctypes.POINTER(c_int)],
+    "hh_prof_enable": [c_int],
+    "hh_prof_read": [c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
     "hh_workspace_bytes_gemm_splitk": [c_i64, c_int, c_int],
     "hh_workspace_bytes_gemm_tn": [c_int, c_int, c_int],
     "hh_workspace_bytes_xattn_bwd": [c_int, c_int, c_int, c_int],

@@ -303,6 +303,7 @@ extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial,
         HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds16);
         attr16 = lds16;
     }
+    HHProfScope prof(HH_PROF_SPACE_ATTN, 8.0 * B * (1.0 + (double)T * n) * heads * 64, (hipStream_t)stream);
     hipLaunchKernelGGL(space_attn16_kernel, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW16), lds16, (hipStream_t)stream,
                        (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP);
     return hh_check_launch("hh_space_attn_fwd");

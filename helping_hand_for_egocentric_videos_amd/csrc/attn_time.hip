@@ -443,6 +443,7 @@ extern "C" int hh_time_attn_fwd(const void* qkv, void* out, float* cls_partial, 
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* in = (const bf16_t*)qkv;
     bf16_t* o = (bf16_t*)out;
+    HHProfScope prof(HH_PROF_TIME_ATTN, 8.0 * B * (1.0 + (double)T * n) * heads * 64, s);
     if (T == 32) {
         hipLaunchKernelGGL(time_attn_mfma32_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, s, in, o, cls_partial, B, n, heads);
         return hh_check_launch("hh_time_attn_fwd(T=32)");

@@ -20,6 +20,14 @@ void hh_set_error(const char* fmt, ...);
 int hh_check_launch(const char* what);
 int hh_stream_cu_count(hipStream_t s);      // CUs the stream may use (runtime.cpp)
 
+// device timing of one kernel launch (runtime.cpp: hh_prof_enable / hh_prof_read); `work` = algorithmic flops or bytes of the launch
+struct HHProfScope {
+    HHProfScope(int klass, double work, hipStream_t s);
+    ~HHProfScope();
+    int rec_;
+    hipStream_t stream_;
+};
+
 #define HH_REQUIRE(cond, code, ...)                 \
     do {                                            \
         if (!(cond)) {                              \

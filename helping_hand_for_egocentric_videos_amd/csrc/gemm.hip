@@ -262,6 +262,7 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         const bool bf = epi->c_dtype == HH_BF16, w8 = K % 512 == 0, two = M - p.m_start > 32;
         const dim3 grid((unsigned)(N / 32));
         hipStream_t ts = (hipStream_t)stream;
+        HHProfScope prof(HH_PROF_GEMM_OTHER, 2.0 * (double)(M - p.m_start) * N * K, ts);
 #define TAIL(BF, NWT, MT) hipLaunchKernelGGL((gemm_tail_kernel<BF, NWT, MT>), grid, dim3(64 * NWT), 0, ts, p)
         if (bf) { if (w8) { if (two) TAIL(true, 8, 2); else TAIL(true, 8, 1); } else { if (two) TAIL(true, 4, 2); else TAIL(true, 4, 1); } }
         else    { if (w8) { if (two) TAIL(false, 8, 2); else TAIL(false, 8, 1); } else { if (two) TAIL(false, 4, 2); else TAIL(false, 4, 1); } }
@@ -287,6 +288,7 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     HH_REQUIRE(splits == 1 || (epi->resid == nullptr && epi->split_stride >= 0), HH_ERR_SHAPE, "hh_gemm_bf16: split-K partials take no residual");
     // deep ring when the launch cannot fill the chip twice anyway (real tiles, not the padded grid)
     const bool deep = (int64_t)p.Mt * p.Nt * splits <= 512 && K >= 256;
+    HHProfScope prof(HH_PROF_GEMM_OTHER, 2.0 * (double)(M - p.m_start) * N * K, s);
     if (deep) {
         if (epi->c_dtype == HH_BF16) hipLaunchKernelGGL((gemm_bf16_kernel<true, 4>), dim3(grid, splits), dim3(256), 131072, s, p);
         else hipLaunchKernelGGL((gemm_bf16_kernel<false, 4>), dim3(grid, splits), dim3(256), 131072, s, p);

@@ -588,6 +588,7 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
             const int ncu = hh_stream_cu_count(s) & ~7;      // CU budget of this stream; the stride of the tile walk must keep blockIdx & 7 == XCD
             const unsigned pg = grid < (unsigned)ncu ? grid : (unsigned)ncu;
             p.skew_iters = g_pskew;
+            HHProfScope prof(HH_PROF_GEMM256, 2.0 * (double)p.M * p.N * p.K, s);
 #define LAUNCHD(BF, E) hipLaunchKernelGGL((gemm256d_kernel<BF, E>), dim3(pg), dim3(512), P_LDS(p.N), s, p)
             switch (epi * 2 + (bf ? 1 : 0)) {
                 case 0: LAUNCHD(false, 0); break;
@@ -603,6 +604,7 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
             return hh_check_launch("hh_gemm_bf16(256x256 persistent)");
         }
     }
+    HHProfScope prof(HH_PROF_GEMM_OTHER, 2.0 * (double)p.M * p.N * p.K, s);
     if (stagger) {
         if (bf) hipLaunchKernelGGL((gemm256_kernel<true, true>), dim3(grid), dim3(512), 2 * BUF_BYTES, s, p);
         else hipLaunchKernelGGL((gemm256_kernel<false, true>), dim3(grid), dim3(512), 2 * BUF_BYTES, s, p);

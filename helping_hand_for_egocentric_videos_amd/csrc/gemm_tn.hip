@@ -124,6 +124,7 @@ extern "C" int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int6
     p.M = M; p.N = N; p.K = K;
     const int64_t ktiles = (K + 63) / 64;
     p.k_per_split = (int)(((ktiles + splits - 1) / splits) * 64);
+    HHProfScope prof(HH_PROF_GEMM_TN, 2.0 * (double)M * N * (double)K, (hipStream_t)stream);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((M / 128) * (N / 128)), (unsigned)splits), dim3(256), 0, (hipStream_t)stream, p);
     return hh_check_launch("hh_gemm_tn_bf16");
 }

@@ -1,6 +1,8 @@
 // Host-side runtime bits of libhh: version, thread-local error string, launch check.
 #include "common.h"
+#include <atomic>
 #include <mutex>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -91,4 +93,67 @@ extern "C" int64_t hh_workspace_bytes_attn_cls_partial(int B, int T, int n, int 
     if (B < 0 || T <= 0 || n <= 0 || heads <= 0 || (time_mode && T > 128)) return -1;
     const int64_t G = time_mode ? (n + (128 / T) - 1) / (128 / T) : T;                         // key groups per (clip, head)
     return (int64_t)B * heads * G * 68 * 4;                                                    // records {m, l, 0, 0, o[64]} fp32
+}
+
+// ---- per-kernel device timing recorded by the library itself (bench.py's `roofline`).  When enabled, every stride-th launch of
+// an instrumented kernel class is bracketed by two hipEvents recorded on ITS launch stream, with nothing but that kernel between
+// them -- so the sum of the elapsed times is comparable with rocprofv3's per-kernel durations (a torch-side bracket around
+// hh_gemm_bf16 also contains the row-tail launch and the host gaps).  Off by default: the launch sites then pay one relaxed load.
+struct ProfRec { int klass; hipEvent_t e0, e1; double work; };
+static std::atomic<int> g_prof_stride{0};
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+static long long g_prof_seen[HH_PROF_CLASSES];
+
+static hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+HHProfScope::HHProfScope(int klass, double work, hipStream_t s) : rec_(-1), stream_(s) {
+    const int stride = g_prof_stride.load(std::memory_order_relaxed);
+    if (stride <= 0 || klass < 0 || klass >= HH_PROF_CLASSES) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if ((g_prof_seen[klass]++ % stride) != 0) return;
+    ProfRec r{klass, prof_event(), prof_event(), work};
+    hipEventRecord(r.e0, s);
+    g_prof_recs.push_back(r);
+    rec_ = (int)g_prof_recs.size() - 1;
+}
+
+HHProfScope::~HHProfScope() {
+    if (rec_ < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (rec_ < (int)g_prof_recs.size()) hipEventRecord(g_prof_recs[rec_].e1, stream_);
+}
+
+extern "C" int hh_prof_enable(int stride) {
+    HH_REQUIRE(stride >= 0, HH_ERR_SHAPE, "hh_prof_enable: stride must be >= 0");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+    g_prof_recs.clear();
+    for (int i = 0; i < HH_PROF_CLASSES; ++i) g_prof_seen[i] = 0;
+    g_prof_stride.store(stride, std::memory_order_relaxed);
+    return HH_OK;
+}
+
+extern "C" int hh_prof_read(int klass, int64_t* launches_timed, int64_t* launches_seen, double* total_ms, double* total_work) {
+    HH_REQUIRE(klass >= 0 && klass < HH_PROF_CLASSES && launches_timed && launches_seen && total_ms && total_work, HH_ERR_SHAPE,
+               "hh_prof_read: bad arguments");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int64_t n = 0;
+    double ms = 0.0, work = 0.0;
+    for (auto& r : g_prof_recs) {
+        if (r.klass != klass) continue;
+        hipError_t e = hipEventSynchronize(r.e1);
+        float t = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, r.e0, r.e1);
+        HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_prof_read: %s", hipGetErrorString(e));
+        ms += t; work += r.work; ++n;
+    }
+    *launches_timed = n; *launches_seen = g_prof_seen[klass]; *total_ms = ms; *total_work = work;
+    return HH_OK;
 }

@@ -333,6 +333,7 @@ extern "C" int hh_xattn_fwd(const float* q, const void* k, const void* v, int64_
     if (B == 0) return HH_OK;
     unsigned thr; float sc;
     drop_params(dropout_p, &thr, &sc);
+    HHProfScope prof(HH_PROF_XATTN_FWD, 4.0 * (double)B * M * heads * 64, (hipStream_t)stream);         // K and V rows, bf16
     hipLaunchKernelGGL(xattn_fwd_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)k,
                        (const bf16_t*)v, ldkv, out, lse, B, Q, M, heads, thr, sc, seed);
     return hh_check_launch("hh_xattn_fwd");
@@ -351,6 +352,7 @@ extern "C" int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_
     unsigned thr; float sc;
     drop_params(dropout_p, &thr, &sc);
     HH_REQUIRE(dq_splits >= 1 && dq_splits <= 64, HH_ERR_SHAPE, "hh_xattn_bwd: dq_splits must be in [1, 64]");
+    HHProfScope prof(HH_PROF_XATTN_BWD, 8.0 * (double)B * M * heads * 64, (hipStream_t)stream);         // K, V read + dK, dV written
     hipLaunchKernelGGL(xattn_bwd_kernel, dim3((unsigned)(B * heads), (unsigned)dq_splits), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)k,
                        (const bf16_t*)v, ldkv, out, lse, dout, dq, (bf16_t*)dk, (bf16_t*)dv, lddkv, B, Q, M, heads, thr, sc, seed);
     return hh_check_launch("hh_xattn_bwd");

@@ -5,9 +5,11 @@ WordContrastiveLoss :72-106) without the reference's host round trips.
     here dropped rows are masked in place (identical value and gradient), so the step never syncs.
   * WordContrastiveLoss: scipy.optimize.linear_sum_assignment on `.cpu()` costs (loss.py:87-93) is replaced by the
     on-device exact LSAP kernel hh_lsap_rows (bit-identical assignment, csrc/match.hip).
+  * Under data parallelism the word loss divides by the all-reduced valid-word count / W (the reference has no DP semantics).
 Small fp32 reductions (log-softmax over a [5B,B] matrix, CE over 582 nouns) stay on stock PyTorch-ROCm ops.
 """
 import torch
+import torch.distributed as dist
 import torch.nn.functional as F
 from torch import nn
 
@@ -86,5 +88,12 @@ class WordContrastiveLoss(nn.Module):
         noun_mask = noun_sim.index_select(0, noun_gt_inds.flatten()) > self.noun_threshold
         ce = F.cross_entropy(sim_all.masked_fill(noun_mask, -1) / self.temperature, noun_gt_inds.flatten(), reduction='none')
         v = valid.flatten()
-        loss = torch.where(v, ce, torch.zeros((), device=ce.device)).sum() / v.sum()
+        count = v.sum().float()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # data parallel: normalise by the mean word count over ranks (as SetCriterion.num_boxes does, box_utils.py:218-222), so
+            # that mean-reduced parameter gradients equal those of one process on the concatenated batch
+            count = count.reshape(1).clone()
+            dist.all_reduce(count)
+            count = count[0] / dist.get_world_size()
+        loss = torch.where(v, ce, torch.zeros((), device=ce.device)).sum() / count
         return (loss, cols) if return_assignment else loss

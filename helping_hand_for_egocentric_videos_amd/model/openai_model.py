@@ -4,8 +4,9 @@ QuickGELU (openai_model.py:177-179) is the TimeSformer MLP activation -- on the 
 fc1 GEMM epilogue (csrc/gemm.hip); the nn.Module here only carries the name for constructor compatibility.
 The CLIP text Transformer (openai_model.py:182-232) is on the call path of `CLIP.forward` (SURVEY.md section 8f
 rank 1).  With frozen weights on the GPU (`Transformer.forward_frozen`) its Linears / LayerNorms run on the libhh
-GEMM (bias / QuickGELU / residual epilogues) and LayerNorm kernels; the 77x77 causal attention core stays on
-torch's scaled_dot_product_attention.  The stock-module `forward` is kept for trainable / CPU use.
+GEMM (bias / QuickGELU / residual epilogues) and LayerNorm kernels and the 77x77 causal attention core on
+hh_text_attn_fwd (csrc/attn_text.hip; head dim 64, L <= 80 -- other shapes fall back to torch SDPA).  The stock-module
+`forward` is kept for trainable / CPU use.
 """
 from collections import OrderedDict
 

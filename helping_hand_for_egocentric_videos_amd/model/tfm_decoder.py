@@ -40,6 +40,7 @@ class _KVHolder:
         self.dkv = None
         self.B = self.M = self.C = self.L = 0
         self.seed = 0
+        self.keep, self.kept = False, None
 
 
 class _MemorySide(torch.autograd.Function):
@@ -91,6 +92,8 @@ class _MemorySide(torch.autograd.Function):
         del dmem_pos
         dmem0, dg, db = ops.layernorm_bwd(mem0, g_pre.detach().float(), mean, rstd, dmem)
         dw_proj = ops.gemm_tn(ops.to_bf16(dmem0), feat_b)                                                  # [C, F]
+        if h.keep:
+            h.kept = (h.kv, h.dkv)                 # test hook (Cross_Attention.debug_keep_kv): K/V and dK/dV outlive the backward
         h.kv = h.dkv = None
         gw, gb = [], []
         for l in range(L):
@@ -381,6 +384,7 @@ class Cross_Attention(nn.Module):
         self._reset_parameters()
         self.d_model, self.nhead = d_model, nhead
         self.dec_layers, self.enc_layers = num_decoder_layers, num_encoder_layers
+        self.debug_keep_kv, self.last_holder = False, None        # tests: keep the batched K/V and their gradients after backward
         self._seed = None            # dropout-mask stream of the cross-attention kernels; see next_dropout_seed()
 
     def _reset_parameters(self):
@@ -403,6 +407,8 @@ class Cross_Attention(nn.Module):
         """feat_b bf16 [B*M, F] (no grad), w_proj [C,F], pos [M,C], query_embed [Q,C] -> hs [L,B,Q,C]."""
         holder = _KVHolder()
         holder.seed = self.next_dropout_seed()
+        holder.keep = self.debug_keep_kv
+        self.last_holder = holder if self.debug_keep_kv else None
         layers = self.decoder.layers
         in_w = [l.multihead_attn.in_proj_weight for l in layers]
         in_b = [l.multihead_attn.in_proj_bias for l in layers]

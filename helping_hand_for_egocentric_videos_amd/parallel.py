@@ -72,8 +72,52 @@ class FlatArena:
                 cur_start, cur_names, cur_bytes = off, [], 0
         if cur_names:
             self.buckets.append((cur_start, off, cur_names))
+        # parameters whose gradient was written in the current step (torch.optim.AdamW skips grad-less parameters entirely, no
+        # weight decay either: e.g. frame_index / frame_proj when a clip length != num_frames skips the trajectory branch)
+        self.touched = set()
+        self.steps = {n: 0 for n, _ in self.entries}            # per-parameter AdamW step count (bias correction)
+        self._sizes = dict(zip((n for n, _ in self.entries), sizes))
+        self._plan_cache = {}
+        self._touch_hooks = [p.register_post_accumulate_grad_hook(self._make_touch_hook(n)) for n, p in self.entries]
+
+    def _make_touch_hook(self, name):
+        def hook(param):
+            self.touched.add(name)
+        return hook
+
+    def update_plan(self):
+        """AdamW launch plan for the parameters touched in this step: list of (start, end, weight_decayed, step) over contiguous
+        arena ranges.  Adjacent entries of the same decay group and the same step count share a range -- when every parameter has a
+        gradient every step (the normal case) that is two ranges.  Advances the per-parameter step counts."""
+        key = frozenset(self.touched)
+        ranges = self._plan_cache.get(key)
+        if ranges is None:                                      # [start, end, decayed, names] ignoring step counts
+            ranges, off = [], 0
+            for n, _ in self.entries:
+                sz = self._sizes[n]
+                if n in key:
+                    dec = not no_decay(n)
+                    if ranges and ranges[-1][1] == off and ranges[-1][2] == dec:
+                        ranges[-1][1] = off + sz
+                        ranges[-1][3].append(n)
+                    else:
+                        ranges.append([off, off + sz, dec, [n]])
+                off += sz
+            self._plan_cache[key] = ranges
+        plan = []
+        for a, b, dec, names in ranges:
+            if len({self.steps[n] for n in names}) == 1:
+                plan.append((a, b, dec, self.steps[names[0]] + 1))
+            else:                                               # parameters that skipped earlier steps: one launch per parameter
+                for n in names:
+                    o, _ = self.offsets[n]
+                    plan.append((o, o + self._sizes[n], dec, self.steps[n] + 1))
+        for n in key:
+            self.steps[n] += 1
+        return plan
 
     def zero_grad(self):
+        self.touched.clear()
         self.grads.zero_()
         for n, p in self.entries:                    # autograd may have replaced .grad; re-point it at the arena
             o, k = self.offsets[n]
@@ -82,14 +126,20 @@ class FlatArena:
 
 
 class BucketedAllReduce:
-    """Asynchronous mean all-reduce of arena buckets, launched from post-accumulate-grad hooks."""
+    """Asynchronous mean all-reduce of arena buckets, launched from post-accumulate-grad hooks on a communication stream.
 
-    def __init__(self, arena: FlatArena, group=None):
+    The mean is taken by the collective itself (ReduceOp.AVG) on RCCL; gloo (CPU tests) has no AVG, there each bucket is summed
+    and scaled by 1/W when it has landed.  `force=True` runs the collectives even in a 1-rank group (used to exercise the real
+    RCCL code path -- comm stream, hooks, bucket order -- on a single GPU)."""
+
+    def __init__(self, arena: FlatArena, group=None, force=False):
         self.arena, self.group = arena, group
         self.W, _ = world()
-        self.enabled = self.W > 1
+        self.enabled = self.W > 1 or (force and dist.is_available() and dist.is_initialized())
         self.pending = []
         self.comm_stream = torch.cuda.Stream() if (self.enabled and arena.params.is_cuda) else None
+        self.avg = self.enabled and dist.get_backend(group) == "nccl"
+        self.launched = 0                                        # collectives issued so far (tests / diagnostics)
         self._remaining = []
         self._bucket_of = {}
         for bi, (_, _, names) in enumerate(arena.buckets):
@@ -120,27 +170,31 @@ class BucketedAllReduce:
     def _launch(self, bi):
         s, e, _ = self.arena.buckets[bi]
         buf = self.arena.grads[s:e]
+        op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                work = dist.all_reduce(buf, group=self.group, async_op=True)
+                work = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
         else:
-            work = dist.all_reduce(buf, group=self.group, async_op=True)
-        self.pending.append(work)
+            work = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
+        self.launched += 1
+        self.pending.append((work, buf))
 
     def finish(self):
-        """Wait for every bucket (launching the ones whose hooks never fired, e.g. unused parameters) and average."""
+        """Wait for every bucket (launching the ones whose hooks never fired, e.g. unused parameters); gradients are then the
+        mean over ranks."""
         if not self.enabled:
             return
         for bi, rem in enumerate(self._remaining):
             if rem > 0:
                 self._remaining[bi] = 0
                 self._launch(bi)
-        for w in self.pending:
+        for w, buf in self.pending:
             w.wait()
+            if not self.avg and self.W > 1:
+                buf.mul_(1.0 / self.W)
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
-        self.arena.grads.mul_(1.0 / self.W)
         self.reset()
 
 
@@ -164,13 +218,13 @@ class _AllGatherScaled(torch.autograd.Function):
         return g[ctx.b * ctx.r: ctx.b * (ctx.r + 1)] * ctx.W, None
 
 
-def gather_contrastive(video_embeds, text_embeds, pad_flag, verb_vec, noun_vec, group=None):
+def gather_contrastive(video_embeds, text_embeds, pad_flag, verb_vec, noun_vec, group=None, force=False):
     """ONE packed all-gather of everything EgoNCE needs across ranks (run/train.py:126-140 uses 5-6 collectives).
 
     video_embeds [b,E], text_embeds [R*b,E] (differentiable), pad_flag [R*b], verb_vec [b,V], noun_vec [b,Nn].
-    Returns the global tensors in rank-major order."""
+    Returns the global tensors in rank-major order.  force=True runs the collective in a 1-rank group too (RCCL smoke test)."""
     W, _ = world()
-    if W == 1:
+    if W == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return video_embeds, text_embeds, pad_flag, verb_vec, noun_vec
     b, E = video_embeds.shape
     Rb = text_embeds.shape[0]

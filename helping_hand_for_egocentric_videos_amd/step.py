@@ -7,17 +7,16 @@ hand/object box losses with on-device Hungarian matching (HIP) + word loss + gra
 fused AdamW (HIP).  bf16 compute, fp32 accumulation / master weights, no GradScaler.
 No host synchronisation inside the step: every scalar in the returned dict is a device tensor.
 """
-import os
-
 import torch
 
 from . import ops
 from .model import box_utils
 from .model.loss import EgoNCE, WordContrastiveLoss
 from .model.metric import compute_tv_accuracy, sim_matrix
-from .parallel import BucketedAllReduce, FlatArena, gather_contrastive, world
+from .parallel import BucketedAllReduce, FlatArena, gather_contrastive, no_decay, world
 
 ZEROED_NOUNS = [102, 504, 364, 321, 556]          # run/train.py:73
+DP_ENC_CUS = 248                                  # encoder-stream CU budget under data parallelism (31 of 32 CUs per XCD)
 WEIGHT_DICT = {"loss_bbox_hand_boxes": 5, "loss_bbox_obj_boxes": 5, "loss_giou_hand_boxes": 2, "loss_giou_obj_boxes": 2}
 
 
@@ -29,7 +28,7 @@ def build_criterion():
 
 class TrainStep:
     def __init__(self, cfg, backbone, decoder, lr=3e-5, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8,
-                 bucket_bytes=16 << 20, fast_heads=True, enc_cus=None):
+                 bucket_bytes=16 << 20, fast_heads=True, enc_cus=None, force_comm=False):
         self.cfg, self.backbone, self.decoder = cfg, backbone, decoder
         self.criterion = build_criterion().to(next(decoder.parameters()).device)
         self.nce, self.word = EgoNCE(), WordContrastiveLoss()
@@ -38,12 +37,15 @@ class TrainStep:
         self.arena = FlatArena(decoder, bucket_bytes)
         self.m = torch.zeros_like(self.arena.params)
         self.v = torch.zeros_like(self.arena.params)
-        self.comm = BucketedAllReduce(self.arena)
+        self.force_comm = bool(force_comm)
+        self.comm = BucketedAllReduce(self.arena, force=force_comm)
         self.iteration = 0
         self._text_stream = None
         self.enc_stream = None
-        # CU budget of the persistent GEMMs on the pipelined encoder stream (0 = all CUs); see prefetch()
-        self.enc_cus = int(os.environ.get("HH_ENC_CUS", "0")) if enc_cus is None else int(enc_cus)
+        # CU budget of the persistent GEMMs on the pipelined encoder stream (0 = all CUs); see prefetch().  With gradient
+        # collectives in flight (W > 1) the default leaves one CU per XCD (8 of 256) to the RCCL kernels of the comm stream:
+        # a persistent grid that owns every CU would make each all-reduce bucket wait for a whole GEMM to drain.
+        self.enc_cus = (DP_ENC_CUS if self.comm.enabled else 0) if enc_cus is None else int(enc_cus)
         self._pending = None
         self._zeroed_idx = None
         backbone.eval()                               # run/train.py:89
@@ -115,7 +117,7 @@ class TrainStep:
             self._zeroed_idx = torch.tensor(ZEROED_NOUNS, device=text.device)              # once: a Python-list index is an H2D copy + sync per step
         noun_vec = batch["noun_vec"].clone().index_fill_(1, self._zeroed_idx, 0)
         pad_flag = ((text != 0).sum(-1) != 2).float()                               # run/train.py:144
-        ve, te, pf, vv, nv = gather_contrastive(video_embeds, text_embeds, pad_flag, batch["verb_vec"], noun_vec)
+        ve, te, pf, vv, nv = gather_contrastive(video_embeds, text_embeds, pad_flag, batch["verb_vec"], noun_vec, force=self.force_comm)
         Bg = ve.shape[0]
         sim = sim_matrix(te, ve)                                                    # [5Bg, Bg]
         sim_v, sim_n = sim_matrix(vv, vv), sim_matrix(nv, nv)
@@ -145,12 +147,75 @@ class TrainStep:
         out["total_loss"].backward()
         self.comm.finish()
         self.iteration += 1
-        a, nd = self.arena, self.arena.n_decay_padded
-        ops.adamw_step(a.params[:nd], a.grads[:nd], self.m[:nd], self.v[:nd], self.lr, *self.betas, self.eps, self.wd, self.iteration)
-        if a.total > nd:
-            ops.adamw_step(a.params[nd:], a.grads[nd:], self.m[nd:], self.v[nd:], self.lr, *self.betas, self.eps, 0.0, self.iteration)
+        a = self.arena
+        for start, end, decayed, t in a.update_plan():          # two launches when every parameter has a gradient (the normal case)
+            ops.adamw_step(a.params[start:end], a.grads[start:end], self.m[start:end], self.v[start:end], self.lr, *self.betas, self.eps,
+                           self.wd if decayed else 0.0, t)
         out["total_loss"] = out["total_loss"].detach()
         return out
+
+
+    # ------------------------------------------------------------------ optimizer state (checkpoint exchange with the reference)
+    def _reference_param_order(self):
+        """Parameter numbering of the reference's optimizer: torch.optim.AdamW over optim_policy's two groups
+        (utils/train_utils.py:28-48; run/train.py:519-520): group 0 = no-decay names, group 1 = the rest, each in
+        named_parameters() order, requires_grad only.  Returns (names of group 0, names of group 1)."""
+        named = [n for n, p in self.decoder.named_parameters() if p.requires_grad]
+        return [n for n in named if no_decay(n)], [n for n in named if not no_decay(n)]
+
+    def state_dict(self):
+        """`optimizer.state_dict()` in torch.optim.AdamW's own format, so the 'optimizer' entry of a runtime checkpoint
+        (run/train.py:232-237) can be exchanged with the reference in both directions: per-parameter {'step', 'exp_avg',
+        'exp_avg_sq'} for every parameter that has been updated (class_embed / vid_proj never are), two param_groups.  The extra
+        top-level key 'hh' (ignored by torch's loader) carries the attention-dropout seed stream and the step counter."""
+        g0, g1 = self._reference_param_order()
+        state = {}
+        for idx, n in enumerate(g0 + g1):
+            if n in self.arena.offsets and self.arena.steps[n] > 0:
+                o, k = self.arena.offsets[n]
+                state[idx] = {"step": torch.tensor(float(self.arena.steps[n])),
+                              "exp_avg": self.m[o:o + k].detach().clone(), "exp_avg_sq": self.v[o:o + k].detach().clone()}
+        shapes = {n: p.shape for n, p in self.decoder.named_parameters()}
+        for idx, n in enumerate(g0 + g1):
+            if idx in state:
+                state[idx]["exp_avg"] = state[idx]["exp_avg"].view(shapes[n])
+                state[idx]["exp_avg_sq"] = state[idx]["exp_avg_sq"].view(shapes[n])
+        common = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "amsgrad": False, "maximize": False, "foreach": None,
+                  "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": True}
+        groups = [dict(common, weight_decay=0.0, params=list(range(len(g0)))),
+                  dict(common, weight_decay=self.wd, params=list(range(len(g0), len(g0) + len(g1))))]
+        return {"state": state, "param_groups": groups,
+                "hh": {"iteration": self.iteration, "xattn_seed": self.decoder.transformer._seed}}
+
+    def load_state_dict(self, sd):
+        """Inverse of state_dict(); also accepts the reference's own `optimizer.state_dict()` (no 'hh' entry: the dropout seed
+        stream restarts, the step counter is taken from the per-parameter 'step')."""
+        g0, g1 = self._reference_param_order()
+        names = g0 + g1
+        groups = sd["param_groups"]
+        if len(groups) != 2 or len(groups[0]["params"]) != len(g0) or len(groups[1]["params"]) != len(g1):
+            raise ValueError("TrainStep.load_state_dict: param_groups do not match optim_policy's (no-decay, decay) split "
+                             "(%s vs %d/%d parameters)" % ([len(g["params"]) for g in groups], len(g0), len(g1)))
+        ids = list(groups[0]["params"]) + list(groups[1]["params"])
+        self.lr, self.betas, self.eps = groups[1]["lr"], tuple(groups[1]["betas"]), groups[1]["eps"]
+        self.wd = groups[1]["weight_decay"]
+        self.m.zero_()
+        self.v.zero_()
+        for n in self.arena.steps:
+            self.arena.steps[n] = 0
+        for pid, n in zip(ids, names):
+            st = sd["state"].get(pid)
+            if st is None:
+                continue
+            if n not in self.arena.offsets:
+                raise ValueError(f"TrainStep.load_state_dict: optimizer state for '{n}', which never receives a gradient here")
+            o, k = self.arena.offsets[n]
+            self.m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+            self.v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+            self.arena.steps[n] = int(float(st["step"]))
+        extra = sd.get("hh") or {}
+        self.iteration = int(extra.get("iteration", max(self.arena.steps.values(), default=0)))
+        self.decoder.transformer._seed = extra.get("xattn_seed", None)
 
 
 _MCQ_STREAMS = {}

@@ -80,7 +80,7 @@ def load_decoder_checkpoint(decoder, checkpoint, optimizer_state=None, num_frame
 def save_runtime_checkpoint(state, filename, rm_history=True, keep=10):
     """utils/train_utils.py:192-205: timestamped file next to `filename`, keep the newest `keep`."""
     assert filename.endswith('.pth.tar')
-    stamp = datetime.now().strftime("%Y_%m_%d_%H_%M_%S")
+    stamp = datetime.now().strftime("%Y_%m_%d_%H_%M")           # the reference's stamp format (minute resolution)
     path = filename.replace('.pth.tar', f'_{stamp}.pth.tar')
     torch.save(state, path)
     if rm_history:
@@ -94,6 +94,22 @@ def save_runtime_checkpoint(state, filename, rm_history=True, keep=10):
 
 
 def make_save_dict(decoder, epoch, best_acc, iteration, optimizer_state):
-    """The dict run/train.py:232-237 saves (decoder weights only -- the frozen backbone is never checkpointed)."""
+    """The dict run/train.py:232-237 saves (decoder weights only -- the frozen backbone is never checkpointed).
+    `optimizer_state` = TrainStep.state_dict() (torch.optim.AdamW format) or a TrainStep, whose state is taken."""
+    if hasattr(optimizer_state, "state_dict") and not isinstance(optimizer_state, dict):
+        optimizer_state = optimizer_state.state_dict()
     return {'epoch': epoch, 'state_dict': decoder.state_dict(), 'best_acc': best_acc, 'optimizer': optimizer_state,
             'iteration': iteration}
+
+
+def resume_train_step(train_step, checkpoint, num_frames=None):
+    """run/train.py:523-545: load decoder weights AND optimizer state (AdamW moments, per-parameter step counts, dropout seed
+    stream) of a runtime checkpoint into a step.TrainStep.  Returns the bookkeeping fields (epoch, best_acc, iteration)."""
+    if isinstance(checkpoint, (str, os.PathLike)):
+        checkpoint = torch.load(checkpoint, map_location='cpu', weights_only=False)
+    info = load_decoder_checkpoint(train_step.decoder, checkpoint, num_frames=num_frames)
+    if info.get('optimizer') is not None:
+        train_step.load_state_dict(info['optimizer'])
+    if info.get('iteration') is not None:
+        train_step.iteration = int(info['iteration'])
+    return {k: info[k] for k in ('epoch', 'best_acc', 'iteration')}

@@ -53,6 +53,25 @@ int hh_debug_gemm_timeline(unsigned long long* out, int blocks);
 int hh_stream_set_cu_budget(hh_stream_t stream, int n_cus);
 int hh_stream_get_cu_budget(hh_stream_t stream, int* out);
 
+/* ---- built-in per-kernel timing (bench.py `roofline`).  hh_prof_enable(stride > 0): from now on every stride-th launch of each
+ * instrumented kernel class is bracketed by two events recorded on its launch stream with ONLY that kernel between them (stride 0
+ * = off, the default; every call clears the records).  hh_prof_read sums them for one class: launches timed / seen, elapsed ms,
+ * and the launches' algorithmic work (flops for the GEMM classes, bytes for the others; formulas in DESIGN.md section 5).  It
+ * synchronises on the recorded events. */
+enum hh_prof_class {
+    HH_PROF_GEMM256 = 0,      /* persistent 256x256 GEMM kernel (gemm256d_kernel): 2*M*N*K of the full-tile rows */
+    HH_PROF_GEMM_OTHER = 1,   /* row tails, 128x128 kernel, one-tile-per-block 256x256 kernel: 2*M*N*K of their rows */
+    HH_PROF_SPACE_ATTN = 2,   /* space_attn16_kernel: 8*B*N*D bytes (q,k,v read + o written, bf16) */
+    HH_PROF_TIME_ATTN = 3,    /* time_attn_mfma*_kernel: 8*B*N*D bytes */
+    HH_PROF_ADD_LN = 4,       /* fused residual add + LayerNorm: bytes read + written */
+    HH_PROF_GEMM_TN = 5,      /* weight-gradient GEMM: 2*M*N*K */
+    HH_PROF_XATTN_FWD = 6,    /* decoder cross-attention forward: K,V bytes read */
+    HH_PROF_XATTN_BWD = 7,    /* decoder cross-attention backward: K,V read + dK,dV written */
+    HH_PROF_CLASSES = 8
+};
+int hh_prof_enable(int stride);
+int hh_prof_read(int klass, int64_t* launches_timed, int64_t* launches_seen, double* total_ms, double* total_work);
+
 /* ---- caller-owned workspaces.  No entry point allocates; these return the size in BYTES of the scratch buffer an entry point
  * takes (negative = bad arguments):
  *   gemm_splitk      : C of hh_gemm_bf16 with epi->splitk = S  (fp32 [S, M, N], split_stride = M*N)

@@ -30,12 +30,45 @@ def mha(q_in, k_in, v_in, sd, prefix, heads):
     return F.linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
 
 
-def decoder_layer(tgt, memory, pos, qpos, sd, b, heads):
-    """TransformerDecoderLayer.forward_pre, sa_first -- tfm_decoder.py:430-461 (all LN eps 1e-5)."""
+def mha_given_kv(q_in, K, V, sd, prefix, heads):
+    """Cross-attention of `mha` with the key/value projections ALREADY applied: K, V [B,M,C] = k_in.Wk^T+bk, v_in.Wv^T+bv.
+    Lets a test feed the oracle's query side the very K/V tensors another implementation produced."""
+    C = q_in.shape[-1]
+    d = C // heads
+    Wq, bq = sd[prefix + ".in_proj_weight"][:C], sd[prefix + ".in_proj_bias"][:C]
+    B, Lq, Lk = q_in.shape[0], q_in.shape[1], K.shape[1]
+    q = F.linear(q_in, Wq, bq).view(B, Lq, heads, d).transpose(1, 2) * (d ** -0.5)
+    k = K.view(B, Lk, heads, d).transpose(1, 2)
+    v = V.view(B, Lk, heads, d).transpose(1, 2)
+    o = (torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v).transpose(1, 2).reshape(B, Lq, C)
+    return F.linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
+
+
+def memory_kv(features, sd, cfg):
+    """Memory side of ObjDecoder/Cross_Attention (tfm_decoder.py:200-205,86-88,438-441): features [B,T,n,F] ->
+    (K, V) [L,B,M,C] with K_l = (pre_norm(proj(x)) + pos).Wk_l^T + bk_l and V_l = pre_norm(proj(x)).Wv_l^T + bv_l."""
+    B, T, n, _ = features.shape
+    C, L = cfg.dec_dim, cfg.dec_layers
+    memory = _ln(F.linear(features, sd["proj.weight"]).reshape(B, T * n, C), sd, "transformer.pre_norm")
+    pos = pos_embed_3d(sd, T, n)[None]
+    Ks, Vs = [], []
+    for l in range(L):
+        w, b = sd[f"transformer.decoder.layers.{l}.multihead_attn.in_proj_weight"], sd[f"transformer.decoder.layers.{l}.multihead_attn.in_proj_bias"]
+        Ks.append(F.linear(memory + pos, w[C:2 * C], b[C:2 * C]))
+        Vs.append(F.linear(memory, w[2 * C:], b[2 * C:]))
+    return torch.stack(Ks), torch.stack(Vs)
+
+
+def decoder_layer(tgt, memory, pos, qpos, sd, b, heads, kv=None):
+    """TransformerDecoderLayer.forward_pre, sa_first -- tfm_decoder.py:430-461 (all LN eps 1e-5).  kv = (K, V) of this layer
+    replaces the in-layer key/value projection of (memory + pos, memory)."""
     a = _ln(tgt, sd, b + "norm1")
     tgt = tgt + mha(a + qpos, a + qpos, a, sd, b + "self_attn", heads)
     c = _ln(tgt, sd, b + "norm2")
-    tgt = tgt + mha(c + qpos, memory + pos, memory, sd, b + "multihead_attn", heads)
+    if kv is not None:
+        tgt = tgt + mha_given_kv(c + qpos, kv[0], kv[1], sd, b + "multihead_attn", heads)
+    else:
+        tgt = tgt + mha(c + qpos, memory + pos, memory, sd, b + "multihead_attn", heads)
     e = _ln(tgt, sd, b + "norm3")
     ff = F.linear(F.relu(F.linear(e, sd[b + "linear1.weight"], sd[b + "linear1.bias"])),
                   sd[b + "linear2.weight"], sd[b + "linear2.bias"])
@@ -65,12 +98,13 @@ def cross_attention_forward(src, mask, query_embed, pos_embed, sd, cfg, prefix="
     return torch.stack(inter), memory.transpose(1, 2).reshape(B, C, T, n)
 
 
-def objdecoder_forward(features, sd, cfg, compute_logits=True):
+def objdecoder_forward(features, sd, cfg, compute_logits=True, kv=None):
     """ObjDecoder.forward -- tfm_decoder.py:183-233 (+ Cross_Attention.forward :76-93,
     TransformerDecoder.forward :255-295).
 
     features [B,T,n,F] -> (out dict, hs [L,B,Q,C]).  out['pred_boxes'] [B*T,Q,4] (cx,cy,w,h),
     out['pred_logits'] [B*T,Q,classes+1], out['aux_outputs'] for layers 0..L-2.
+    kv = (K, V) [L,B,M,C]: run the query side on these key/value projections (see mha_given_kv) instead of the memory side's.
     """
     B, T, n, _ = features.shape
     C, heads, L = cfg.dec_dim, cfg.dec_heads, cfg.dec_layers
@@ -81,7 +115,8 @@ def objdecoder_forward(features, sd, cfg, compute_logits=True):
     tgt = torch.zeros_like(qpos)
     inter = []
     for l in range(L):
-        tgt = decoder_layer(tgt, memory, pos, qpos, sd, f"transformer.decoder.layers.{l}.", heads)
+        tgt = decoder_layer(tgt, memory, pos, qpos, sd, f"transformer.decoder.layers.{l}.", heads,
+                            None if kv is None else (kv[0][l], kv[1][l]))
         inter.append(_ln(tgt, sd, "transformer.decoder.norm"))
     hs = torch.stack(inter)                                                   # [L,B,Q,C]
     Q = hs.shape[2]

@@ -8,14 +8,14 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-kernel-timers"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-kernel-timers --no-mcq"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_p -- $BENCH --steps 3 --warmup 2 > $OUT/${TAG}_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_u -- $BENCH --steps 3 --warmup 2 --no-pipeline > $OUT/${TAG}_bench_unpipelined.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- $BENCH --steps 1 --warmup 1 --no-pipeline > $OUT/${TAG}_pmc_$c.log 2>&1
 done
 #   4. SQ pass: matrix-core / VALU busy cycles per kernel                   -> <tag>_sq_summary.md
-rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $R/gpurun_out/pmc_SQ -- $BENCH --steps 1 --warmup 1 --no-pipeline > $OUT/${TAG}_pmc_SQ.log 2>&1
+rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU --kernel-trace --output-format csv -d $R/gpurun_out/pmc_SQ -- $BENCH --steps 1 --warmup 1 --no-pipeline > $OUT/${TAG}_pmc_SQ.log 2>&1
 TAG=$TAG python3 - <<'PY'
 import csv, glob, json, os, collections
 R, TAG = os.environ["GRAFT_REPO_ROOT"], os.environ["TAG"]
@@ -31,9 +31,9 @@ def stats(d, dst, title, cmd, note):
         L.append("| %s | %s | %.2f | %.1f | %.1f |" % (r["Name"][:96].replace("|", "/"), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                     float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
     return L
-L = stats("prof_p", TAG + "_bench", "Round 1, final build", "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timers",
+L = stats("prof_p", TAG + "_bench", TAG + " build", "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-mcq",
           "MI355X, B = 32 clips, config 2 (16-frame 224p, nq=12), software-pipelined step, 5 steps profiled (2 warm-up + 3 timed).\nSum of kernel durations %.1f ms over 5 steps = %.1f ms/step (kernels of the encoder stream and of the decoder stream overlap, so this sum exceeds the wall time per step).")
-L += [""] + stats("prof_u", TAG + "_unpipelined", "Same build, un-pipelined step", "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-pipeline",
+L += [""] + stats("prof_u", TAG + "_unpipelined", "Same build, un-pipelined step", "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-mcq --no-pipeline",
                   "Every kernel runs alone on the chip here, so the averages are the isolated kernel durations.\nSum of kernel durations %.1f ms over 5 steps = %.1f ms/step.")
 open(OUT + TAG + "_summary.md", "w").write("\n".join(L) + "\n")
 # ---- PMC
@@ -54,10 +54,10 @@ for k in names:
     js[k] = {"launches": n, "fetch_bytes_corrected": int(fetch / n), "write_bytes": int(write / n), "traffic_bytes_per_launch": int((fetch + write) / n)}
     rows.append((fetch + write, "| %s | %d | %.1f | %.1f | %.1f |" % (k[:80].replace("|", "/"), n, fetch / n / 2**20, write / n / 2**20, (fetch + write) / n / 2**20)))
 json.dump(js, open(OUT + TAG + "_pmc_summary.json", "w"), indent=1)
-M = ["# Round 1 (final build) -- HBM-side traffic from PMC counters (rocprofv3 --pmc, separate passes)", "",
+M = ["# " + TAG + " -- HBM-side traffic from PMC counters (rocprofv3 --pmc, separate passes)", "",
      "Commands (one counter per pass, as MI355X_MICROARCH.md prescribes):", "",
-     "    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_FETCH_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-pipeline",
-     "    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-pipeline", "",
+     "    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_FETCH_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-mcq --no-pipeline",
+     "    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-mcq --no-pipeline", "",
      "Units/corrections: counter values are KiB; on gfx950 FETCH_SIZE reports exactly 1/2 of wide coalesced streaming reads -> doubled below; WRITE_SIZE is exact.",
      "The counters sit on the L2's fabric side, so Infinity-Cache hits are included.  Per-launch averages, B = 32 clips, config 2.", "",
      "| kernel | launches | fetch (corrected) MiB | write MiB | traffic / launch MiB |", "|---|---|---|---|---|"]
@@ -71,17 +71,17 @@ for f in glob.glob(R + "/gpurun_out/pmc_SQ/**/*counter_collection.csv", recursiv
     for row in csv.DictReader(open(f)):
         agg[row["Kernel_Name"]][row["Counter_Name"]] += float(row["Counter_Value"])
         if row["Counter_Name"] == "SQ_BUSY_CU_CYCLES": cnt[row["Kernel_Name"]] += 1
-S = ["# Round 1 (final build) -- matrix-core and VALU utilisation per kernel (rocprofv3 --pmc, SQ counters, one pass)", "",
-     "    rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-pipeline", "",
+S = ["# " + TAG + " -- matrix-core and VALU utilisation per kernel (rocprofv3 --pmc, SQ counters, one pass)", "",
+     "    rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-mcq --no-pipeline", "",
      "MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) (the rocprof-compute definition); VALU busy % = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / (4 x SQ_BUSY_CU_CYCLES);",
      "MFMA flop = 512 x SQ_INSTS_VALU_MFMA_MOPS_BF16.  Per-launch averages, B = 32 clips, config 2.", "",
-     "| kernel | launches | MFMA busy % | VALU busy % | MFMA GFLOP / launch |", "|---|---|---|---|---|"]
+     "| kernel | launches | MFMA busy % | VALU busy % | MFMA GFLOP / launch | SQ_INSTS_VALU / launch (M) |", "|---|---|---|---|---|---|"]
 rows = []
 for k, c in agg.items():
     if not any(t in k for t in ("gemm", "attn", "ln_", "add_ln", "xattn")) or c["SQ_BUSY_CU_CYCLES"] <= 0: continue
     busy = 4.0 * c["SQ_BUSY_CU_CYCLES"]
-    rows.append((c["SQ_VALU_MFMA_BUSY_CYCLES"], "| %s | %d | %.1f | %.1f | %.1f |" % (k[:80].replace("|", "/"), cnt[k], 100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / busy,
-                 100 * 4.0 * c["SQ_ACTIVE_INST_VALU"] / busy, 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_BF16"] / max(cnt[k], 1) / 1e9)))
+    rows.append((c["SQ_VALU_MFMA_BUSY_CYCLES"], "| %s | %d | %.1f | %.1f | %.1f | %.1f |" % (k[:80].replace("|", "/"), cnt[k], 100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / busy,
+                 100 * 4.0 * c["SQ_ACTIVE_INST_VALU"] / busy, 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_BF16"] / max(cnt[k], 1) / 1e9, c["SQ_INSTS_VALU"] / max(cnt[k], 1) / 1e6)))
 S += [r for _, r in sorted(rows, reverse=True)]
 open(OUT + TAG + "_sq_summary.md", "w").write("\n".join(S) + "\n")
 print("\n".join(S[-len(rows):]))

@@ -41,9 +41,9 @@ def _one_step(ts, dec, batch):
     out["total_loss"].backward()
     ts.comm.finish()
     ts.iteration += 1
-    a, nd = ts.arena, ts.arena.n_decay_padded
-    ops.adamw_step(a.params[:nd], a.grads[:nd], ts.m[:nd], ts.v[:nd], ts.lr, *ts.betas, ts.eps, ts.wd, ts.iteration)
-    ops.adamw_step(a.params[nd:], a.grads[nd:], ts.m[nd:], ts.v[nd:], ts.lr, *ts.betas, ts.eps, 0.0, ts.iteration)
+    a = ts.arena
+    for s, e, decayed, t in a.update_plan():
+        ops.adamw_step(a.params[s:e], a.grads[s:e], ts.m[s:e], ts.v[s:e], ts.lr, *ts.betas, ts.eps, ts.wd if decayed else 0.0, t)
     return out
 
 
@@ -102,10 +102,62 @@ def test_two_ranks_on_one_gpu_equal_one_rank_on_concatenated_batch():
         _one_step(ts, dec, full)
     ref = ts.arena.params.detach().cpu()
     got = ret["params"]
-    # NOTE: the word loss is a per-rank mean over a varying word count, so it is only approximately batch-equivalent
-    # under DP; Adam's sign-like early steps amplify tiny gradient differences -> compare with lr-scale atol.
+    # every loss term is normalised by its all-reduced count / W (num_boxes, valid words), so W ranks are one process on the
+    # concatenated batch up to bf16 K/V rounding; Adam's sign-like early steps amplify tiny gradient differences of near-zero
+    # gradients -> the max is compared at lr scale, the mean tightly.
     diff = (got - ref).abs()
+    print("DP 2 ranks vs 1 rank: max |dp| %.3e, mean %.3e (lr 1e-4, 2 steps)" % (float(diff.max()), float(diff.mean())))
     assert float(diff.max()) <= 2.5 * 1e-4 * 2, float(diff.max())          # <= ~2 steps x lr
-    assert float(diff.mean()) < 2e-5, float(diff.mean())
+    assert float(diff.mean()) < 1e-5, float(diff.mean())
     nce_ref = float(ts.losses(full)["nce_loss"])
     assert abs(ret["nce"] - nce_ref) < 5e-3 * abs(nce_ref)                  # identical global contrastive loss on every rank
+
+
+def _rccl_worker(rank, world, port, ret):
+    """One rank, backend "nccl" (= RCCL): the real collectives -- bucketed gradient all-reduce (ReduceOp.AVG) on the comm stream,
+    packed contrastive all-gather, num_boxes all-reduce -- run beside the pipelined encoder stream's persistent GEMMs."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from helping_hand_for_egocentric_videos_amd import synth, TINY16, ops
+        from helping_hand_for_egocentric_videos_amd.model import LaviLa, tfm_decoder
+        from helping_hand_for_egocentric_videos_amd.step import TrainStep, DP_ENC_CUS
+        cfg = TINY16
+        batch = {k: v.cuda() for k, v in synth.make_batch(cfg, 4, seed=21).items()}
+
+        def build(force):
+            backbone = LaviLa.build_backbone(cfg, synth.encoder_state(cfg, seed=4))
+            dec = tfm_decoder.build_decoder(cfg, synth.decoder_state(cfg, seed=4))
+            return TrainStep(cfg, backbone, dec, lr=1e-4, bucket_bytes=1 << 20, force_comm=force), dec
+
+        ts, dec = build(True)
+        assert ts.comm.enabled and ts.comm.avg and ts.comm.comm_stream is not None and len(ts.arena.buckets) >= 4
+        assert ts.enc_cus == DP_ENC_CUS
+        ref, rdec = build(False)
+        assert not ref.comm.enabled
+        # (a) one eval-mode backward: gradients through the RCCL path == gradients without it (AVG over one rank is the identity)
+        for t, d in ((ts, dec), (ref, rdec)):
+            d.eval()
+            t.arena.zero_grad()
+            t.losses(batch)["total_loss"].backward()
+            t.comm.finish()
+        assert ts.comm.launched == len(ts.arena.buckets)
+        torch.testing.assert_close(ts.arena.grads, ref.arena.grads, rtol=1e-4, atol=1e-7)
+        # (b) the call bench.py makes at N > 1: pipelined train-mode steps, collectives overlapping the next batch's encoder
+        for _ in range(3):
+            out = ts.step(batch, next_batch=batch)
+        torch.cuda.synchronize()
+        assert ops.stream_cu_budget(ts.enc_stream) == DP_ENC_CUS
+        assert ts.comm.launched == 4 * len(ts.arena.buckets)
+        ret["loss"] = float(out["total_loss"])
+        ret["finite"] = bool(torch.isfinite(ts.arena.params).all())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_run_on_the_comm_stream_beside_the_pipelined_encoder():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert ret["finite"] and ret["loss"] == ret["loss"]

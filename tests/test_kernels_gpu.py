@@ -321,7 +321,7 @@ def test_time_attention_ragged_patch_counts(B, T, n, heads):
     assert (err / (ref.abs().amax(1) + 1e-3)).max() < 5e-2
 
 
-@pytest.mark.parametrize("B,Q,M,heads", [(2, 13, 4096, 8), (3, 5, 1024, 8), (1, 16, 96, 2)])
+@pytest.mark.parametrize("B,Q,M,heads", [(2, 13, 4096, 8), (3, 5, 1024, 8), (1, 16, 96, 2), (1, 13, 18432, 8)])   # last: config 4 (32 x 576 keys)
 def test_xattn_fwd_bwd(B, Q, M, heads):
     C = heads * 64
     q = rnd(B, Q, C, seed=1, scale=0.3)

@@ -79,3 +79,17 @@ def test_step_against_reference_golden(cfg, name):
     mcq = synth.make_mcq_item(cfg, 2, seed=int(g["meta_seed_b"]))
     scores = OS.mcq_forward(esd, dsd, mcq["video"], mcq["text"], cfg)
     np.testing.assert_allclose(scores.numpy(), g["mcq_scores"], rtol=1e-4, atol=1e-5)
+
+
+def test_query_side_on_given_kv_equals_the_plain_decoder():
+    """oracle.decoder.memory_kv + mha_given_kv (used by the GPU gradient test to share K/V with the HIP path) restate the same
+    maths as the in-layer projection of objdecoder_forward."""
+    from oracle import decoder as OD
+    cfg = TINY4
+    dsd = synth.decoder_state(cfg, seed=3)
+    feats = torch.randn(2, cfg.num_frames, cfg.patches_per_frame, cfg.embed_dim, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        a, hs_a = OD.objdecoder_forward(feats, dsd, cfg, compute_logits=False)
+        b, hs_b = OD.objdecoder_forward(feats, dsd, cfg, compute_logits=False, kv=OD.memory_kv(feats, dsd, cfg))
+    torch.testing.assert_close(hs_a, hs_b, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a["pred_boxes"], b["pred_boxes"], rtol=1e-5, atol=1e-6)

@@ -2,11 +2,13 @@
 golden fixtures emitted from the imported reference.
 
 Stated tolerances (north_star: "decoder loss within 1e-3 rel of CPU reference, bit-exact Hungarian indices"):
-  * losses: |gpu - ref| <= 1e-3 * |ref| for the box losses and the total; EgoNCE / word loss 2e-3 (they sit on
-    cosine similarities /0.07, which amplify bf16 noise of the frozen towers ~14x);
+  * losses: |gpu - ref| <= 1e-3 * |ref| for EVERY term (total, hand / object box loss, EgoNCE, word loss) -- the north-star bound;
   * activations (hs, pred_boxes): scale-relative 2e-2 / absolute 5e-3 (bf16 operands, fp32 accumulation);
-  * gradients: relative L2 per tensor <= 1.5e-1 (ReLU kinks flip single hidden units under bf16 noise when only
-    B*Q ~ 10 rows feed a weight row), median over tensors <= 5e-2 (each kernel is checked tightly on identical inputs in test_kernels_gpu.py);
+  * gradients: (1) with the oracle fed the GPU path's OWN bf16 K/V (query side) and the GPU's own dK/dV (memory side), so that
+    both sides differentiate the same function at the same point: relative L2 per tensor <= 2e-2
+    (test_decoder_gradients_on_shared_kv); (2) end to end against the fp32 oracle / the reference golden, where bf16 noise of
+    K/V flips single ReLU units of the FFN (B*Q ~ 10 rows feed a weight row): per tensor <= 1.5e-1, median <= 5e-2, and the
+    fixture's gradient samples <= 1e-1 relative L2;
   * matching indices: bit-exact vs the oracle run on the SAME fp32 pred_boxes (index stability across precisions
     is not defined for untrained queries -- SURVEY.md section 8a R12 -- and is reported as a statistic only).
 Parity is defined in eval mode (dropout p=0).
@@ -153,7 +155,7 @@ def test_full_step_vs_reference_golden(cfg, name):
     dec.eval()
     ts.arena.zero_grad()
     res = ts.losses(to_dev(batch))
-    tol = {"total_loss": 1e-3, "box_loss_hand": 1e-3, "box_loss_obj": 1e-3, "nce_loss": 2e-3, "word_loss": 2e-3}
+    tol = {"total_loss": 1e-3, "box_loss_hand": 1e-3, "box_loss_obj": 1e-3, "nce_loss": 1e-3, "word_loss": 1e-3}
     report = {}
     for k, t in tol.items():
         ref = float(g["loss_" + k])
@@ -161,6 +163,9 @@ def test_full_step_vs_reference_golden(cfg, name):
         report[k] = abs(got - ref) / abs(ref)
         assert report[k] <= t, (k, got, ref, report[k])
     print("rel loss errors vs reference golden:", {k: f"{v:.2e}" for k, v in report.items()})
+    # R17: compute_tv_accuracy of the product (model/metric.py:378-392) vs the reference's values on the same step
+    assert abs(float(res["acc_vt"]) - float(g["loss_acc_vt"])) < 1e-6 and abs(float(res["acc_tv"]) - float(g["loss_acc_tv"])) < 1e-6, \
+        (float(res["acc_vt"]), float(g["loss_acc_vt"]), float(res["acc_tv"]), float(g["loss_acc_tv"]))
     np.testing.assert_allclose(res["hs"].detach().cpu().numpy(), g["hs"], rtol=0, atol=2e-2 * np.abs(g["hs"]).max())
     assert np.abs(res["pred_boxes"].detach().cpu().numpy() - g["pred_boxes"]).max() < 5e-3
     # bit-exact matching on identical fp32 boxes: oracle LSAP on the GPU's own pred_boxes
@@ -186,6 +191,23 @@ def test_full_step_vs_reference_golden(cfg, name):
         else:
             assert n_.startswith(("class_embed", "vid_proj")), n_
     assert not bad, bad[:5]
+    # the fixture's gradient SAMPLES (64 evenly spaced elements per tensor, make_golden.sample): catches sign / slice errors that
+    # a norm comparison cannot
+    params = dict(dec.named_parameters())
+    rels = {}
+    for key in g.files:
+        if not key.startswith("grad_sample__"):
+            continue
+        n_ = key[len("grad_sample__"):]
+        f = params[n_].grad.detach().flatten().cpu()
+        idx = torch.linspace(0, f.numel() - 1, min(64, f.numel())).long()
+        got, want = f[idx].numpy(), g[key]
+        if "multihead_attn.in_proj_weight" in n_ and np.abs(want).max() == 0:
+            continue
+        rels[n_] = float(np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-12))
+    assert len(rels) >= 15
+    print("grad samples vs reference golden: worst", sorted(rels.items(), key=lambda kv: -kv[1])[:3])
+    assert max(rels.values()) < 1e-1, sorted(rels.items(), key=lambda kv: -kv[1])[:5]
     # EgoMCQ forward
     mcq = synth.make_mcq_item(cfg, 2, seed=int(g["meta_seed_b"]))
     scores = mcq_forward(backbone, dec, mcq["video"].cuda(), mcq["text"].cuda(), cfg)
@@ -295,7 +317,7 @@ def test_headline_config_c2_losses_vs_oracle():
     with torch.no_grad():
         ref = OS.step_losses(esd, dsd, batch, cfg)
     rep = {}
-    for k, tol in (("total_loss", 1e-3), ("box_loss_hand", 1e-3), ("box_loss_obj", 1e-3), ("nce_loss", 3e-3), ("word_loss", 3e-3)):
+    for k, tol in (("total_loss", 1e-3), ("box_loss_hand", 1e-3), ("box_loss_obj", 1e-3), ("nce_loss", 1e-3), ("word_loss", 1e-3)):
         got, want = float(res[k]), float(ref[k])
         rep[k] = abs(got - want) / abs(want)
         assert rep[k] <= tol, (k, got, want)
@@ -307,3 +329,292 @@ def test_headline_config_c2_losses_vs_oracle():
             assert torch.equal(a, c) and torch.equal(b, d)
     agree = [torch.equal(a, c) for (a, _), (c, _) in zip(res["match_obj"], ref["idx_obj"])]
     print("C2 end-to-end object-index agreement with the fp32 oracle: %.3f" % (sum(agree) / len(agree)))
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+@pytest.mark.parametrize("cfg", [TINY4, TINY16], ids=["T4", "T16"])
+def test_decoder_gradients_on_shared_kv(cfg):
+    """Gradient parity without ReLU-kink noise: both sides differentiate the same function at the same point.
+
+    Stage 1 (query side): the oracle's 13-row side runs on the GPU path's OWN bf16 K/V of all six layers (holder.kv) -> every
+    query-side parameter gradient and dK/dV within 2e-2 relative L2 per tensor.
+    Stage 2 (memory side): the oracle's proj -> pre_norm -> (+pos) -> K/V chain is back-propagated from the GPU's own dK/dV ->
+    proj / pre_norm / key-value in-projection / positional-embedding gradients within 2e-2."""
+    C, L = cfg.dec_dim, cfg.dec_layers
+    dsd = synth.decoder_state(cfg, seed=3)
+    dec = tfm_decoder.build_decoder(cfg, dsd).eval()
+    dec.transformer.debug_keep_kv = True
+    B, T, n = 2, cfg.num_frames, cfg.patches_per_frame
+    feats = torch.randn(B, T, n, cfg.embed_dim, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).float()
+    out, hs, _, _ = dec(feats.cuda())
+    g = torch.Generator().manual_seed(1)
+    w, wb = torch.randn(hs.shape, generator=g), torch.randn(out["pred_boxes"].shape, generator=g)
+    ((hs * w.cuda()).sum() + (out["pred_boxes"] * wb.cuda()).sum()).backward()
+    kv, dkv = dec.transformer.last_holder.kept
+    M = T * n
+    K = kv[:, :L * C].float().cpu().view(B, M, L, C).permute(2, 0, 1, 3).contiguous().requires_grad_(True)       # [L,B,M,C]
+    V = kv[:, L * C:].float().cpu().view(B, M, L, C).permute(2, 0, 1, 3).contiguous().requires_grad_(True)
+    # ---- stage 1
+    params = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    ro, rhs = OD.objdecoder_forward(feats, params, cfg, compute_logits=False, kv=(K, V))
+    assert scaled_err(hs, rhs) < 5e-3                                    # same K/V -> hs agrees to the kernel's own rounding
+    ((rhs * w).sum() + (ro["pred_boxes"] * wb).sum()).backward()
+    memory_side = ("proj.weight", "transformer.pre_norm.", "pos_embed", "temporal_embed")
+    rel = {}
+    for name, p in dec.named_parameters():
+        rg = params[name].grad
+        if rg is None or name.startswith(memory_side):
+            continue
+        gg = p.grad.detach().cpu()
+        if "multihead_attn.in_proj" in name:                            # query rows only; key/value rows belong to stage 2
+            gg, rg = gg[:C], rg[:C]
+        rel[name] = _rel(gg, rg)
+    dK = dkv[:, :L * C].float().cpu().view(B, M, L, C).permute(2, 0, 1, 3)
+    dV = dkv[:, L * C:].float().cpu().view(B, M, L, C).permute(2, 0, 1, 3)
+    for l in range(L):
+        rel[f"dK[{l}]"], rel[f"dV[{l}]"] = _rel(dK[l], K.grad[l]), _rel(dV[l], V.grad[l])
+    worst = sorted(rel.items(), key=lambda kv_: -kv_[1])[:4]
+    print("query side on shared K/V: %d tensors, median %.2e, worst %s" % (len(rel), float(np.median(list(rel.values()))), worst))
+    assert len(rel) > 100 and max(rel.values()) < 2e-2, worst
+    # ---- stage 2
+    params2 = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    K2, V2 = OD.memory_kv(feats, params2, cfg)
+    torch.autograd.backward([K2, V2], [dK.contiguous(), dV.contiguous()])
+    assert _rel(K.detach(), K2) < 1e-2 and _rel(V.detach(), V2) < 1e-2       # the GPU's bf16 K/V are the oracle's, rounded
+    rel2 = {}
+    gp = dict(dec.named_parameters())
+    for name in ("proj.weight", "transformer.pre_norm.weight", "transformer.pre_norm.bias", "pos_embed", "temporal_embed"):
+        gg, rg = gp[name].grad.detach().cpu(), params2[name].grad
+        if name == "pos_embed":                                          # row 0 (CLS slot) is unused by construct_3d_pos_embed
+            gg, rg = gg[:, 1:], rg[:, 1:]
+        rel2[name] = _rel(gg, rg)
+    for l in range(L):
+        for suffix in ("in_proj_weight", "in_proj_bias"):
+            name = f"transformer.decoder.layers.{l}.multihead_attn.{suffix}"
+            gg, rg = gp[name].grad.detach().cpu(), params2[name].grad
+            rel2[name + "[v]"] = _rel(gg[2 * C:], rg[2 * C:])
+            if suffix == "in_proj_weight":                               # the key BIAS gradient is 0 in exact arithmetic (softmax shift invariance)
+                rel2[name + "[k]"] = _rel(gg[C:2 * C], rg[C:2 * C])
+    worst2 = sorted(rel2.items(), key=lambda kv_: -kv_[1])[:4]
+    print("memory side from shared dK/dV: median %.2e, worst %s" % (float(np.median(list(rel2.values()))), worst2))
+    assert max(rel2.values()) < 2e-2, worst2
+
+
+def test_long_clip_decoder_and_step_c4_shapes():
+    """BASELINE config 4's decoder / step half at its real sequence shape (T = 32 frames, 336 px -> n = 576, M = 18 432 memory
+    tokens, nq = 12) on the reduced-width tower: T-dependent positional embedding and frame conditioning
+    (tfm_decoder.py:161-166,212-215), the M-dependent key-slice split of the cross-attention backward, matcher / box head with 32
+    frames.  Losses within 1e-3 of the oracle, bit-exact indices on the GPU's own boxes, decoder gradients finite and close."""
+    cfg = TINY4.with_(num_frames=32, img_size=336, num_queries=12)
+    assert cfg.patches_per_frame == 576 and cfg.num_frames * cfg.patches_per_frame == 18432
+    esd, dsd = synth.encoder_state(cfg, seed=2), synth.decoder_state(cfg, seed=2)
+    batch = synth.make_batch(cfg, 2, seed=33)
+    backbone = LaviLa.build_backbone(cfg, esd)
+    dec = tfm_decoder.build_decoder(cfg, dsd)
+    ts = TrainStep(cfg, backbone, dec)
+    dec.eval()
+    ts.arena.zero_grad()
+    res = ts.losses(to_dev(batch))
+    params = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    ref = OS.step_losses(esd, params, batch, cfg)
+    rep = {}
+    for k in ("total_loss", "box_loss_hand", "box_loss_obj", "nce_loss", "word_loss"):
+        got, want = float(res[k]), float(ref[k])
+        rep[k] = abs(got - want) / abs(want)
+        assert rep[k] <= 1e-3, (k, got, want)
+    print("C4-shape rel loss errors vs oracle:", {k: f"{v:.2e}" for k, v in rep.items()})
+    assert res["pred_boxes"].shape == (2 * 32, 13, 4) and res["hs"].shape == (6, 2, 13, 512)
+    assert scaled_err(res["hs"], ref["hs"]) < 2e-2
+    pb = res["pred_boxes"].detach().cpu()
+    for key, sl, qs in (("match_hand", slice(0, 2), slice(0, 2)), ("match_obj", slice(2, 4), slice(2, cfg.num_queries))):
+        raw = batch["boxes"][:, :, sl].flatten(0, 1)
+        idx = OL.hungarian_match(pb[:, qs], OL.prepare_targets(raw))
+        assert len(idx) == 64
+        for (a, b), (c, d) in zip(res[key], idx):
+            assert torch.equal(a, c) and torch.equal(b, d)
+    res["total_loss"].backward()
+    ref["total_loss"].backward()
+    rel = {}
+    for name, p in dec.named_parameters():
+        if params[name].grad is None:
+            continue
+        assert torch.isfinite(p.grad).all(), name
+        gg, rg = p.grad.detach().cpu(), params[name].grad
+        if "multihead_attn.in_proj_bias" in name:
+            sel = torch.cat([torch.arange(0, cfg.dec_dim), torch.arange(2 * cfg.dec_dim, 3 * cfg.dec_dim)])
+            gg, rg = gg[sel], rg[sel]
+        rel[name] = _rel(gg, rg)
+    worst = sorted(rel.items(), key=lambda kv_: -kv_[1])[:4]
+    print("C4-shape decoder grads vs fp32 oracle: median %.2e, worst %s" % (float(np.median(list(rel.values()))), worst))
+    assert max(rel.values()) < 1.5e-1 and float(np.median(list(rel.values()))) < 5e-2, worst
+    # frame conditioning really is T-dependent: all 32 frame_index rows receive gradient
+    assert int((dec.frame_index.weight.grad.abs().sum(1) > 0).sum()) == 32
+
+
+def test_metrics_vs_oracle_r17():
+    """compute_tv_accuracy / egomcq_accuracy_metrics (model/metric.py:378-392,209-225) on the GPU vs the oracle's restatement on
+    identical inputs, including verb/noun-sharing and duplicate-caption positives."""
+    from helping_hand_for_egocentric_videos_amd.model.metric import compute_tv_accuracy, egomcq_accuracy_metrics
+    g = torch.Generator().manual_seed(7)
+    for Bn in (4, 9):
+        te = torch.randn(5 * Bn, 256, generator=g)
+        te[5] = te[0]                                                     # clips 0 and 1 share their first caption
+        ve = torch.randn(Bn, 256, generator=g)
+        vv, nv = (torch.rand(Bn, 11, generator=g) < 0.3).float(), (torch.rand(Bn, 13, generator=g) < 0.3).float()
+        vv[2], nv[2] = vv[3], nv[3]
+        sv, sn = OL.sim_matrix(vv, vv), OL.sim_matrix(nv, nv)
+        sim = OL.sim_matrix(te, ve).view(Bn, 5, Bn)[:, 0]
+        want = OL.compute_tv_accuracy(sim, te, sv, sn, Bn)
+        got = compute_tv_accuracy(sim.cuda(), te.cuda(), sv.cuda(), sn.cuda(), Bn)
+        assert abs(float(got[0]) - float(want[0])) < 1e-6 and abs(float(got[1]) - float(want[1])) < 1e-6
+    preds = torch.randn(40, 5, generator=g)
+    labels = torch.randint(0, 5, (40,), generator=g)
+    types = torch.randint(1, 3, (40,), generator=g)
+    got = egomcq_accuracy_metrics(preds.cuda(), labels.cuda(), types.cuda())
+    want = OL.egomcq_accuracy(preds, labels, types)
+    assert set(got) == set(want) == {"Intra-video", "Inter-video"}
+    for k in want:
+        assert abs(got[k] - want[k]) < 1e-4, (k, got[k], want[k])
+
+
+def test_cross_attention_reference_signature_r8():
+    """Cross_Attention.forward(src, mask, query_embed, pos_embed) in the reference's own layout (tfm_decoder.py:76-93), which runs
+    TransformerDecoder.forward / TransformerDecoderLayer.forward_pre with their reference signatures (every layer projects its own
+    K/V): forward vs the oracle, agreement with the batched ObjDecoder route, and gradients through the per-layer path."""
+    cfg = TINY4
+    dsd = synth.decoder_state(cfg, seed=3)
+    dec = tfm_decoder.build_decoder(cfg, dsd).eval()
+    tfm = dec.transformer
+    B, C, T, n = 2, cfg.dec_dim, cfg.num_frames, cfg.patches_per_frame
+    g = torch.Generator().manual_seed(2)
+    src = (torch.randn(B, C, T, n, generator=g)).to(torch.bfloat16).float()
+    pos = torch.randn(1, C, T, n, generator=g) * 0.1
+    mask = torch.zeros(B, T, n, dtype=torch.bool)
+    srcg = src.cuda().requires_grad_(True)
+    hs, memory, a, sa = tfm(srcg, mask.cuda(), dec.query_embed.weight, pos.cuda())
+    assert a == [] and sa == [] and hs.shape == (cfg.dec_layers, B, cfg.dec_queries, C) and memory.shape == (B, C, T, n)
+    sd = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    srcr = src.clone().requires_grad_(True)
+    rhs, rmem = OD.cross_attention_forward(srcr, mask, sd["query_embed.weight"], pos, sd, cfg)
+    assert scaled_err(hs, rhs) < 2e-2
+    assert scaled_err(memory, rmem) < 1e-4
+    w = torch.randn(rhs.shape, generator=g)
+    (hs * w.cuda()).sum().backward()
+    (rhs * w).sum().backward()
+    assert _rel(srcg.grad, srcr.grad) < 5e-2
+    rel = {}
+    for name, p in dec.named_parameters():
+        if name.startswith("transformer.") and sd[name].grad is not None:
+            gg, rg = p.grad.detach().cpu(), sd[name].grad
+            if "multihead_attn.in_proj_bias" in name:
+                sel = torch.cat([torch.arange(0, C), torch.arange(2 * C, 3 * C)])
+                gg, rg = gg[sel], rg[sel]
+            rel[name] = _rel(gg, rg)
+    worst = sorted(rel.items(), key=lambda kv_: -kv_[1])[:3]
+    print("reference-signature path grads: median %.2e, worst %s" % (float(np.median(list(rel.values()))), worst))
+    assert len(rel) > 100 and max(rel.values()) < 1.5e-1 and float(np.median(list(rel.values()))) < 5e-2, worst
+    # layer-level signature: one layer called directly, sequence-first, returns the (tgt, attn, self_attn) triple
+    layer = tfm.decoder.layers[0]
+    tgt = torch.zeros(cfg.dec_queries, B, C, device="cuda")
+    qpos = dec.query_embed.weight.detach()[:, None].expand(-1, B, -1)
+    mem = memory.detach().flatten(2).permute(2, 0, 1).contiguous()
+    out, a1, sa1 = layer(tgt, mem, memory_key_padding_mask=mask.flatten(1).cuda(), pos=pos.cuda().flatten(2).permute(2, 0, 1), query_pos=qpos)
+    assert out.shape == tgt.shape and a1 is None and sa1 is None
+    with pytest.raises(NotImplementedError):
+        layer(tgt, mem, tgt_mask=torch.zeros(5, 5, device="cuda"))
+
+
+def test_matcher_exclude_class_false():
+    """HungarianMatcher / SetCriterion with exclude_class=False (box_utils.py:62,83-85): class-probability cost on the device LSAP
+    path, indices bit-exact vs the oracle given the same fp32 class-cost term."""
+    g = torch.Generator().manual_seed(13)
+    matcher = box_utils.build_matcher(None)
+    for trial in range(6):
+        F_, q = 8, (2 if trial % 2 == 0 else 10)
+        pred = torch.rand(F_, q, 4, generator=g) * 0.5 + 0.2
+        logits = torch.randn(F_, q, 7, generator=g) * 2
+        boxes = synth.make_batch(TINY4, 2, seed=100 + trial)["boxes"][:, :, :2].flatten(0, 1)
+        tl = box_utils.prepare_targets(boxes.cuda(), None, None, center_crop=False)
+        for t in tl:
+            t["labels"] = torch.randint(0, 7, (len(t["boxes"]),), generator=g).cuda()
+        outputs = {"pred_boxes": pred.cuda(), "pred_logits": logits.cuda()}
+        got = matcher(outputs, tl, exclude_class=False)
+        want = OL.hungarian_match(pred, [t["boxes"].cpu() for t in tl], pred_logits=logits, labels=[t["labels"].cpu() for t in tl])
+        for (a, b), (c, d) in zip(got, want):
+            assert torch.equal(a, c) and torch.equal(b, d)
+        crit = box_utils.SetCriterion(22047, matcher, dict(loss_bbox_hand_boxes=5, loss_giou_hand_boxes=2), 0.1, ["boxes", "cardinality"])
+        losses, idx = crit(outputs, tl, "hand_boxes", exclude_class=False)
+        l1, giou, _ = OL.box_losses(pred, [t["boxes"].cpu() for t in tl], want)
+        torch.testing.assert_close(losses["loss_bbox_hand_boxes"].cpu(), l1, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(losses["loss_giou_hand_boxes"].cpu(), giou, rtol=1e-5, atol=1e-6)
+
+
+def test_optimizer_state_roundtrip_and_reference_format(tmp_path):
+    """TrainStep.state_dict() is torch.optim.AdamW's own format with optim_policy's two groups (utils/train_utils.py:28-48):
+    (1) save -> reload into a fresh TrainStep -> the next step is identical; (2) a real torch.optim.AdamW built the reference's
+    way loads it and produces the same update."""
+    from helping_hand_for_egocentric_videos_amd.utils import checkpoint as CK
+    cfg = TINY4
+    esd, dsd = synth.encoder_state(cfg, seed=4), synth.decoder_state(cfg, seed=4)
+    batch = to_dev(synth.make_batch(cfg, 2, seed=9))
+    backbone = LaviLa.build_backbone(cfg, esd)
+
+    def fresh():
+        d = tfm_decoder.build_decoder(cfg, dsd)
+        return TrainStep(cfg, backbone, d, lr=1e-4), d
+
+    def eval_step(ts, d):
+        d.eval()
+        ts.arena.zero_grad()
+        ts.losses(batch)["total_loss"].backward()
+        ts.iteration += 1
+        a = ts.arena
+        for s_, e_, decayed, t in a.update_plan():
+            ops.adamw_step(a.params[s_:e_], a.grads[s_:e_], ts.m[s_:e_], ts.v[s_:e_], ts.lr, *ts.betas, ts.eps, ts.wd if decayed else 0.0, t)
+
+    ts, dec = fresh()
+    for _ in range(3):
+        eval_step(ts, dec)
+    path = CK.save_runtime_checkpoint(CK.make_save_dict(dec, epoch=1, best_acc=0.5, iteration=ts.iteration, optimizer_state=ts),
+                                      str(tmp_path / "runtime.pth.tar"))
+    sd = ts.state_dict()
+    g0 = [n for n, p in dec.named_parameters() if OS.no_decay(n)]
+    assert len(sd["param_groups"]) == 2 and sd["param_groups"][0]["weight_decay"] == 0.0 and len(sd["param_groups"][0]["params"]) == len(g0)
+    assert all(float(v["step"]) == 3.0 for v in sd["state"].values())
+    names = g0 + [n for n, p in dec.named_parameters() if not OS.no_decay(n)]
+    assert not any(names[i].startswith(("class_embed", "vid_proj")) for i in sd["state"])         # never updated -> no state, as in torch
+    # (1) resume
+    ts2, dec2 = fresh()
+    info = CK.resume_train_step(ts2, path)
+    assert info == {"epoch": 1, "best_acc": 0.5, "iteration": 3} and ts2.iteration == 3
+    assert ts2.decoder.transformer._seed == ts.decoder.transformer._seed
+    eval_step(ts, dec)
+    eval_step(ts2, dec2)
+    torch.testing.assert_close(ts2.arena.params, ts.arena.params, rtol=1e-6, atol=1e-8)
+    # (2) the reference's optimizer (run/train.py:519-520 with optim_policy's groups) loads our state and agrees on the next update
+    ts3, dec3 = fresh()
+    CK.resume_train_step(ts3, path)
+    named = [(n, p) for n, p in dec3.named_parameters() if p.requires_grad]
+    opt = torch.optim.AdamW([{"params": [p for n, p in named if OS.no_decay(n)], "lr": 1e-4, "weight_decay": 0.0},
+                             {"params": [p for n, p in named if not OS.no_decay(n)], "lr": 1e-4, "weight_decay": 1e-5}], lr=1e-4, weight_decay=1e-5)
+    opt.load_state_dict(torch.load(path, weights_only=False)["optimizer"])
+    dec3.eval()
+    ts3.arena.zero_grad()
+    ts3.losses(batch)["total_loss"].backward()
+    for n, p in named:                                                   # torch.optim skips parameters without a gradient
+        if n not in ts3.arena.touched:
+            p.grad = None
+    opt.step()
+    torch.testing.assert_close(ts3.arena.params, ts.arena.params, rtol=1e-5, atol=1e-7)
+    # and back: a state dict written by torch.optim.AdamW itself loads into a TrainStep
+    ts4, dec4 = fresh()
+    dec4.load_state_dict(dec3.state_dict())
+    ts4.load_state_dict(opt.state_dict())
+    assert ts4.iteration == 4 and all(v == 4 for n, v in ts4.arena.steps.items())
+    eval_step(ts, dec)
+    eval_step(ts4, dec4)
+    torch.testing.assert_close(ts4.arena.params, ts.arena.params, rtol=1e-5, atol=1e-7)
