@@ -120,16 +120,7 @@ def objdecoder_forward(features, sd, cfg, compute_logits=True, kv=None):
         inter.append(_ln(tgt, sd, "transformer.decoder.norm"))
     hs = torch.stack(inter)                                                   # [L,B,Q,C]
     Q = hs.shape[2]
-    # frame-conditioned trajectory head (:210-216): cat[hs, frame_index[t]] -> frame_proj
-    fe = sd["frame_index.weight"][:T]
-    cond = torch.cat([hs[:, :, None].expand(L, B, T, Q, C), fe[None, None, :, None, :].expand(L, B, T, Q, C)], -1)
-    cond = F.linear(cond, sd["frame_proj.weight"], sd["frame_proj.bias"]).flatten(1, 2)   # [L,B*T,Q,C]
-    x = cond
-    for i in range(3):
-        x = F.linear(x, sd[f"bbox_embed.layers.{i}.weight"], sd[f"bbox_embed.layers.{i}.bias"])
-        if i < 2:
-            x = F.relu(x)
-    boxes = x.sigmoid()
+    boxes = box_head(hs, sd, cfg, T)
     out = {"pred_boxes": boxes[-1]}
     if compute_logits:
         logits = F.linear(hs, sd["class_embed.weight"], sd["class_embed.bias"])            # [L,B,Q,K]
@@ -139,6 +130,20 @@ def objdecoder_forward(features, sd, cfg, compute_logits=True, kv=None):
     else:
         out["aux_outputs"] = [{"pred_boxes": boxes[l]} for l in range(L - 1)]
     return out, hs
+
+
+def box_head(hs, sd, cfg, T):
+    """Frame-conditioned trajectory head of ObjDecoder.forward -- tfm_decoder.py:210-216,228: cat[hs, frame_index[t]] ->
+    frame_proj -> bbox_embed (3-layer MLP) -> sigmoid.  hs [L,B,Q,C] -> boxes [L,B*T,Q,4] (cx,cy,w,h)."""
+    L, B, Q, C = hs.shape
+    fe = sd["frame_index.weight"][:T]
+    cond = torch.cat([hs[:, :, None].expand(L, B, T, Q, C), fe[None, None, :, None, :].expand(L, B, T, Q, C)], -1)
+    x = F.linear(cond, sd["frame_proj.weight"], sd["frame_proj.bias"]).flatten(1, 2)      # [L,B*T,Q,C]
+    for i in range(3):
+        x = F.linear(x, sd[f"bbox_embed.layers.{i}.weight"], sd[f"bbox_embed.layers.{i}.bias"])
+        if i < 2:
+            x = F.relu(x)
+    return x.sigmoid()
 
 
 def txt_proj(x, sd):
