@@ -17,6 +17,13 @@ class GemmEpilogue(ctypes.Structure):
                 ("remap_offset", c_i64), ("splitk", c_int), ("split_stride", c_i64)]
 
 
+class QGemmOpts(ctypes.Structure):
+    _fields_ = [("a_scale", c_float), ("a_drop_p", c_float), ("a_drop_seed", ctypes.c_uint32), ("a_drop_ld", ctypes.c_int32),
+                ("bias", c_vp), ("scale", c_float), ("scale_ncols", ctypes.c_int32), ("relu", ctypes.c_int32),
+                ("drop_p", c_float), ("drop_seed", ctypes.c_uint32), ("relu_mask", c_vp), ("ldmask", c_i64), ("mask_scale", c_float),
+                ("resid", c_vp), ("ldr", c_i64), ("colsum", c_vp)]
+
+
 # name -> argtypes (restype is int unless listed in _RESTYPES); must list every symbol of include/hh.h
 SIGNATURES = {
     "hh_version": [],
@@ -50,6 +57,11 @@ SIGNATURES = {
     "hh_xattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
     "hh_xattn_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_float,
                      ctypes.c_uint32, c_vp],
+    "hh_qgemm_f32x3": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int, ctypes.POINTER(QGemmOpts), c_vp],
+    "hh_qself_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
+    "hh_qself_attn_bwd": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
+    "hh_layernorm_pos_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_float, c_vp],
+    "hh_layernorm_bwd_add": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
     "hh_match_boxes": [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_float, c_float, c_float, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "hh_lsap_rows": [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
     "hh_box_loss_fwd": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],

@@ -3,6 +3,9 @@
 // HBM-bound: algorithmic bytes per row = cols*(sizeof(in)+sizeof(out)).
 #include "common.h"
 
+static int ln_bwd_launch(const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
+                         float* dgamma, float* dbeta, int64_t rows, int cols, const float* dx_add, hipStream_t s);
+
 template <int NV, typename TIN>
 __device__ __forceinline__ void load_row(const TIN* x, int cols, int lane, float (&v)[NV][4]) {
 #pragma unroll
@@ -27,7 +30,8 @@ template <int NV, typename TIN, typename TOUT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, TOUT* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                     int64_t rows, int cols, float eps) {
+                                                     int64_t rows, int cols, float eps,
+                                                     TOUT* __restrict__ y2, const float* __restrict__ pos, int pos_rows) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -64,6 +68,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
             } else {
                 u32x2 o = {pack_bf16(o0, o1), pack_bf16(o2, o3)};
                 *(u32x2*)(y + row * cols + c) = o;
+            }
+            if (y2 != nullptr) {                  // second output: LN(x) + pos[row % pos_rows]  (the key / query operand of an attention)
+                const f32x4 pp = *(const f32x4*)(pos + (row % pos_rows) * cols + c);
+                if constexpr (sizeof(TOUT) == 4) {
+                    f32x4 o = {o0 + pp[0], o1 + pp[1], o2 + pp[2], o3 + pp[3]};
+                    *(f32x4*)(y2 + row * cols + c) = o;
+                } else {
+                    u32x2 o = {pack_bf16(o0 + pp[0], o1 + pp[1]), pack_bf16(o2 + pp[2], o3 + pp[3])};
+                    *(u32x2*)(y2 + row * cols + c) = o;
+                }
             }
         }
     }
@@ -133,7 +147,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIN* __restrict__ x, 
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ dy, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     int64_t rows, int cols, int rows_per_block) {
+                                                     int64_t rows, int cols, int rows_per_block, const float* dx_add) {
     __shared__ float red[2][4][NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float ag[NV][4], ab[NV][4];
@@ -177,6 +191,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIN* __restrict__ x, 
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = rs * (d[i][j] - s1 - v[i][j] * s2);
+                if (dx_add != nullptr) o += *(const f32x4*)(dx_add + row * cols + c);      // gradient of the residual path (may alias dx)
                 *(f32x4*)(dx + row * cols + c) = o;
             }
         }
@@ -199,16 +214,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIN* __restrict__ x, 
 
 template <int NV>
 static int ln_fwd_dispatch(const void* x, int xd, const float* g, const float* b, void* y, int yd, float* mo, float* ro,
-                           int64_t rows, int cols, float eps, hipStream_t s) {
+                           int64_t rows, int cols, float eps, hipStream_t s, void* y2 = nullptr, const float* pos = nullptr, int pos_rows = 1) {
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if (xd == HH_F32 && yd == HH_BF16)
-        hipLaunchKernelGGL((ln_fwd_kernel<NV, float, bf16_t>), grid, block, 0, s, (const float*)x, g, b, (bf16_t*)y, mo, ro, rows, cols, eps);
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, float, bf16_t>), grid, block, 0, s, (const float*)x, g, b, (bf16_t*)y, mo, ro, rows, cols, eps, (bf16_t*)y2, pos, pos_rows);
     else if (xd == HH_F32 && yd == HH_F32)
-        hipLaunchKernelGGL((ln_fwd_kernel<NV, float, float>), grid, block, 0, s, (const float*)x, g, b, (float*)y, mo, ro, rows, cols, eps);
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, float, float>), grid, block, 0, s, (const float*)x, g, b, (float*)y, mo, ro, rows, cols, eps, (float*)y2, pos, pos_rows);
     else if (xd == HH_BF16 && yd == HH_BF16)
-        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, g, b, (bf16_t*)y, mo, ro, rows, cols, eps);
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, g, b, (bf16_t*)y, mo, ro, rows, cols, eps, (bf16_t*)y2, pos, pos_rows);
     else
-        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, float>), grid, block, 0, s, (const bf16_t*)x, g, b, (float*)y, mo, ro, rows, cols, eps);
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, float>), grid, block, 0, s, (const bf16_t*)x, g, b, (float*)y, mo, ro, rows, cols, eps, (float*)y2, pos, pos_rows);
     return hh_check_launch("hh_layernorm_fwd");
 }
 
@@ -226,6 +241,33 @@ extern "C" int hh_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
     return ln_fwd_dispatch<8>(x, x_dtype, gamma, beta, y, y_dtype, mean_out, rstd_out, rows, cols, eps, s);
 }
 
+extern "C" int hh_layernorm_pos_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, void* y_plus_pos, int y_dtype,
+                                    const float* pos, int pos_rows, float* mean_out, float* rstd_out, int64_t rows, int cols, float eps,
+                                    hh_stream_t stream) {
+    HH_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 2048 && pos_rows > 0, HH_ERR_SHAPE, "hh_layernorm_pos_fwd: cols=%d must be a multiple of 8 and <= 2048, pos_rows > 0", cols);
+    HH_REQUIRE((x_dtype == HH_F32 || x_dtype == HH_BF16) && (y_dtype == HH_F32 || y_dtype == HH_BF16), HH_ERR_DTYPE, "hh_layernorm_pos_fwd: bad dtype");
+    HH_REQUIRE(y_plus_pos != nullptr && pos != nullptr, HH_ERR_SHAPE, "hh_layernorm_pos_fwd: y_plus_pos / pos are NULL (use hh_layernorm_fwd)");
+    HH_REQUIRE(HH_ALIGNED16(x) && HH_ALIGNED16(y) && HH_ALIGNED16(y_plus_pos) && HH_ALIGNED16(pos) && HH_ALIGNED16(gamma) && HH_ALIGNED16(beta), HH_ERR_ALIGN,
+               "hh_layernorm_pos_fwd: pointers must be 16-byte aligned");
+    HH_REQUIRE((mean_out == nullptr) == (rstd_out == nullptr), HH_ERR_SHAPE, "hh_layernorm_pos_fwd: mean_out/rstd_out must both be set or both NULL");
+    if (rows == 0) return HH_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int nv = (cols + 255) / 256;
+    if (nv <= 2) return ln_fwd_dispatch<2>(x, x_dtype, gamma, beta, y, y_dtype, mean_out, rstd_out, rows, cols, eps, s, y_plus_pos, pos, pos_rows);
+    if (nv <= 4) return ln_fwd_dispatch<4>(x, x_dtype, gamma, beta, y, y_dtype, mean_out, rstd_out, rows, cols, eps, s, y_plus_pos, pos, pos_rows);
+    return ln_fwd_dispatch<8>(x, x_dtype, gamma, beta, y, y_dtype, mean_out, rstd_out, rows, cols, eps, s, y_plus_pos, pos, pos_rows);
+}
+
+extern "C" int hh_layernorm_bwd_add(const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd,
+                                    const float* dy, const float* dx_add, float* dx, float* dgamma, float* dbeta, int64_t rows, int cols,
+                                    hh_stream_t stream) {
+    HH_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 1024, HH_ERR_SHAPE, "hh_layernorm_bwd_add: cols=%d must be a multiple of 8 and <= 1024", cols);
+    HH_REQUIRE(x_dtype == HH_F32 || x_dtype == HH_BF16, HH_ERR_DTYPE, "hh_layernorm_bwd_add: bad dtype");
+    HH_REQUIRE(HH_ALIGNED16(x) && HH_ALIGNED16(dy) && HH_ALIGNED16(dx) && HH_ALIGNED16(gamma) && HH_ALIGNED16(dx_add), HH_ERR_ALIGN, "hh_layernorm_bwd_add: pointers must be 16-byte aligned");
+    if (rows == 0) return HH_OK;
+    return ln_bwd_launch(x, x_dtype, gamma, mean, rstd, dy, dx, dgamma, dbeta, rows, cols, dx_add, (hipStream_t)stream);
+}
+
 extern "C" int hh_layernorm_bwd(const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd,
                                 const float* dy, float* dx, float* dgamma, float* dbeta, int64_t rows, int cols,
                                 hh_stream_t stream) {
@@ -233,11 +275,15 @@ extern "C" int hh_layernorm_bwd(const void* x, int x_dtype, const float* gamma, 
     HH_REQUIRE(x_dtype == HH_F32 || x_dtype == HH_BF16, HH_ERR_DTYPE, "hh_layernorm_bwd: bad dtype");
     HH_REQUIRE(HH_ALIGNED16(x) && HH_ALIGNED16(dy) && HH_ALIGNED16(dx) && HH_ALIGNED16(gamma), HH_ERR_ALIGN, "hh_layernorm_bwd: pointers must be 16-byte aligned");
     if (rows == 0) return HH_OK;
-    hipStream_t s = (hipStream_t)stream;
-    const int rpb = 64;
+    return ln_bwd_launch(x, x_dtype, gamma, mean, rstd, dy, dx, dgamma, dbeta, rows, cols, nullptr, (hipStream_t)stream);
+}
+
+static int ln_bwd_launch(const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd, const float* dy, float* dx,
+                         float* dgamma, float* dbeta, int64_t rows, int cols, const float* dx_add, hipStream_t s) {
+    const int rpb = rows >= 16384 ? 64 : 8;              // few rows (decoder query side): more workgroups, fewer rows each
     dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(256);
     int nv = (cols + 255) / 256;
-#define LAUNCH(NV, T) hipLaunchKernelGGL((ln_bwd_kernel<NV, T>), grid, block, 0, s, (const T*)x, gamma, mean, rstd, dy, dx, dgamma, dbeta, rows, cols, rpb)
+#define LAUNCH(NV, T) hipLaunchKernelGGL((ln_bwd_kernel<NV, T>), grid, block, 0, s, (const T*)x, gamma, mean, rstd, dy, dx, dgamma, dbeta, rows, cols, rpb, dx_add)
     if (x_dtype == HH_F32) { if (nv <= 2) LAUNCH(2, float); else LAUNCH(4, float); }
     else { if (nv <= 2) LAUNCH(2, bf16_t); else LAUNCH(4, bf16_t); }
 #undef LAUNCH

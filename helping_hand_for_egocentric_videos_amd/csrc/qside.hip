@@ -1,0 +1,388 @@
+// Query side of the object-query decoder (model/tfm_decoder.py:430-461 forward_pre, :208-233 heads; run/train.py:124-125,187-189
+// projections): 13 query rows per clip -- self-attention 13 x 13, q/out projections, FFN 512 -> 2048 -> 512, box / projection heads.
+// < 1 % of the step's FLOPs, but TRAINABLE fp32 weights and gradients that the 1e-3 loss bound leaves no room to round to bf16
+// (measured on the oracle: bf16 operands on these GEMMs double the error of hs, 2.6e-3 -> 5.7e-3, and push single loss terms to
+// 6-7.5e-4 before the encoder's own bf16 noise is added).  So the GEMMs run on the bf16 matrix cores at fp32-grade accuracy:
+//
+//   hh_qgemm_f32x3   C = epilogue(prologue(A) . B) with fp32 operands split on the fly into bf16 hi + lo halves
+//                    (x = hi + lo + O(2^-17 x)) and three MFMAs per product:  A.B ~= Ahi.Bhi + Alo.Bhi + Ahi.Blo   (the dropped
+//                    lo.lo term is 2^-16 relative).  v_mfma_f32_16x16x32_bf16 x 3 is 5.3x the rate of the fp32 MFMA
+//                    (v_mfma_f32_16x16x4_f32) at the same LDS operand bytes.  Three layouts = the three GEMMs of an nn.Linear:
+//                      NT  C[m,n] = sum_k A[m,k] B[n,k]   forward      (A activations [M,K], B weight [N,K])
+//                      NN  C[m,n] = sum_k A[m,k] B[k,n]   dgrad        (A = dY [M,K], B = weight [K,N])
+//                      TN  C[m,n] = sum_k A[k,m] B[k,n]   wgrad        (A = dY [K,M], B = X [K,N]; + column sums of A = bias gradient)
+//                    Prologue on A: scale, dropout mask (regenerated from the forward's counter-based hash).  Epilogue: bias, column
+//                    scale, ReLU, dropout, ReLU-mask of a stored activation, fp32 residual.  64 x 64 x 32 tiles, 4 waves; the
+//                    shapes are tiny (M = B*13 rows), so the kernel is built for launch economy, not for the MFMA roofline.
+//   hh_qself_attn_fwd / _bwd   the 13 x 13 self-attention of nn.MultiheadAttention (tfm_decoder.py:433-436) per (clip, head), one
+//                    wave each, fp32 VALU, attention-dropout by the same hash.
+#include "common.h"
+
+struct QGemm {
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    float* C; int64_t ldc;
+    int M, N, K, mode;
+    float a_scale;
+    unsigned a_drop_thresh; float a_drop_scale; unsigned a_drop_seed; int a_drop_ld;
+    const float* bias; float scale; int scale_ncols; int relu;
+    unsigned drop_thresh; float drop_scale; unsigned drop_seed;
+    const float* mask; int64_t ldmask; float mask_scale;
+    const float* resid; int64_t ldr;
+    float* colsum;
+};
+
+__device__ __forceinline__ bool q_keep(unsigned seed, unsigned idx, unsigned thresh) {
+    unsigned h = seed ^ (idx * 0x9E3779B9u);
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h >= thresh;
+}
+
+__device__ __forceinline__ void q_split(const f32x4& v, u32x2& hi, u32x2& lo) {
+    bf16_t h[4];
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h[e] = (bf16_t)v[e]; r[e] = v[e] - (float)h[e]; }
+    hi = (u32x2){pack_bf16((float)h[0], (float)h[1]), pack_bf16((float)h[2], (float)h[3])};
+    lo = (u32x2){pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3])};
+}
+
+#define QROW 40          // bf16 per LDS tile row: 32 k + 8 pad (80 B: 16-B aligned fragments)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
+    __shared__ __attribute__((aligned(16))) bf16_t sA[2][2][64][QROW];     // [buffer][hi | lo][tile row][k]
+    __shared__ __attribute__((aligned(16))) bf16_t sB[2][2][64][QROW];
+    __shared__ float scs[64];
+    constexpr bool A_T = MODE == 2, B_T = MODE != 0;                         // operand stored with the contraction index as its ROW
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int nk = (p.K + 31) / 32;
+    const bool want_cs = A_T && p.colsum != nullptr && blockIdx.x == 0;
+    if (tid < 64) scs[tid] = 0.f;
+
+    f32x4 ra[2], rb[2];
+    f32x4 cs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto prologue = [&](f32x4& v, int r, int c) {                            // (r, c) = row / first column of v in A's memory layout
+        if (p.a_scale != 1.f) v *= p.a_scale;
+        if (p.a_drop_thresh) {
+            const unsigned idx = (unsigned)r * (unsigned)p.a_drop_ld + (unsigned)c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = q_keep(p.a_drop_seed, idx + e, p.a_drop_thresh) ? v[e] * p.a_drop_scale : 0.f;
+        }
+    };
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * 32;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if constexpr (!A_T) {
+                const int i = (tid >> 3) + 32 * u, k = 4 * (tid & 7), r = m0 + i, kk = k0 + k;
+                ra[u] = (r < p.M && kk < p.K) ? *(const f32x4*)(p.A + (int64_t)r * p.lda + kk) : z4;
+                if (r < p.M && kk < p.K) prologue(ra[u], r, kk);
+            } else {
+                const int kl = (tid >> 4) + 16 * u, i = 4 * (tid & 15), r = k0 + kl, c = m0 + i;
+                ra[u] = (r < p.K && c < p.M) ? *(const f32x4*)(p.A + (int64_t)r * p.lda + c) : z4;
+                if (r < p.K && c < p.M) prologue(ra[u], r, c);
+                if (want_cs) cs[u] += ra[u];
+            }
+            if constexpr (!B_T) {
+                const int j = (tid >> 3) + 32 * u, k = 4 * (tid & 7), r = n0 + j, kk = k0 + k;
+                rb[u] = (r < p.N && kk < p.K) ? *(const f32x4*)(p.B + (int64_t)r * p.ldb + kk) : z4;
+            } else {
+                const int kl = (tid >> 4) + 16 * u, j = 4 * (tid & 15), r = k0 + kl, c = n0 + j;
+                rb[u] = (r < p.K && c < p.N) ? *(const f32x4*)(p.B + (int64_t)r * p.ldb + c) : z4;
+            }
+        }
+    };
+    auto store_one = [&](bf16_t (*dst)[64][QROW], const f32x4& v, bool transposed, int u) {
+        u32x2 hi, lo;
+        q_split(v, hi, lo);
+        if (!transposed) {
+            const int i = (tid >> 3) + 32 * u, k = 4 * (tid & 7);
+            *(u32x2*)&dst[0][i][k] = hi;
+            *(u32x2*)&dst[1][i][k] = lo;
+        } else {
+            const int kl = (tid >> 4) + 16 * u, i = 4 * (tid & 15);
+            const unsigned short* h = (const unsigned short*)&hi;
+            const unsigned short* l = (const unsigned short*)&lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                *(unsigned short*)&dst[0][i + e][kl] = h[e];
+                *(unsigned short*)&dst[1][i + e][kl] = l[e];
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            store_one(sA[buf], ra[u], A_T, u);
+            store_one(sB[buf], rb[u], B_T, u);
+        }
+    };
+
+    f32x4 acc[4] = {z4, z4, z4, z4};
+    const int fr = lane & 15, fk = 8 * (lane >> 4);
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        const bf16x8 ah = *(const bf16x8*)&sA[buf][0][16 * wave + fr][fk];
+        const bf16x8 al = *(const bf16x8*)&sA[buf][1][16 * wave + fr][fk];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 bh = *(const bf16x8*)&sB[buf][0][16 * t + fr][fk];
+            const bf16x8 bl = *(const bf16x8*)&sB[buf][1][16 * t + fr][fk];
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[t], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: lane owns C[m][n .. n+3], m = tile row (lane & 15), n = 16 t + 4 (lane >> 4)
+    const int m = m0 + 16 * wave + fr;
+    if (m < p.M) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = n0 + 16 * t + 4 * (lane >> 4);
+            if (n >= p.N) continue;
+            f32x4 v = acc[t];
+            if (p.bias) v += *(const f32x4*)(p.bias + n);
+            if (n < p.scale_ncols) v *= p.scale;
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (p.drop_thresh) {
+                const unsigned idx = (unsigned)m * (unsigned)p.N + (unsigned)n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = q_keep(p.drop_seed, idx + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
+            }
+            if (p.mask) {
+                const f32x4 mk = *(const f32x4*)(p.mask + (int64_t)m * p.ldmask + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] * p.mask_scale : 0.f;
+            }
+            if (p.resid) v += *(const f32x4*)(p.resid + (int64_t)m * p.ldr + n);
+            *(f32x4*)(p.C + (int64_t)m * p.ldc + n) = v;
+        }
+    }
+    if (want_cs) {                                                          // bias gradient: colsum[m] = sum_k A_eff[k, m]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&scs[4 * (tid & 15) + e], cs[0][e] + cs[1][e]);
+        __syncthreads();
+        if (tid < 64 && m0 + tid < p.M) p.colsum[m0 + tid] = scs[tid];
+    }
+}
+
+static void q_drop_params(float p, unsigned* thresh, float* scale) {
+    *thresh = 0u; *scale = 1.f;
+    if (p <= 0.f) return;
+    double t = (double)p * 4294967296.0;
+    *thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    if (*thresh == 0u) *thresh = 1u;
+    *scale = 1.f / (1.f - p);
+}
+
+extern "C" int hh_qgemm_f32x3(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
+                              int mode, const hh_qgemm_opts* o, hh_stream_t stream) {
+    HH_REQUIRE(o != nullptr && M >= 0 && N > 0 && K > 0 && mode >= 0 && mode <= 2, HH_ERR_SHAPE, "hh_qgemm_f32x3: bad shape / mode (M=%d N=%d K=%d mode=%d)", M, N, K, mode);
+    // contiguous dimension of every operand is read / written as float4
+    const int a_contig = mode == 2 ? M : K, b_contig = mode == 0 ? K : N;
+    HH_REQUIRE(a_contig % 4 == 0 && b_contig % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && lda >= a_contig && ldb >= b_contig && ldc >= N,
+               HH_ERR_SHAPE, "hh_qgemm_f32x3: contiguous dimensions and leading dimensions must be multiples of 4 (M=%d N=%d K=%d mode=%d)", M, N, K, mode);
+    HH_REQUIRE(HH_ALIGNED16(A) && HH_ALIGNED16(B) && HH_ALIGNED16(C) && HH_ALIGNED16(o->bias) && HH_ALIGNED16(o->resid) && HH_ALIGNED16(o->relu_mask),
+               HH_ERR_ALIGN, "hh_qgemm_f32x3: pointers must be 16-byte aligned");
+    HH_REQUIRE(o->colsum == nullptr || mode == 2, HH_ERR_UNSUPPORTED, "hh_qgemm_f32x3: colsum (bias gradient) is a by-product of the TN mode only");
+    HH_REQUIRE(o->a_drop_p >= 0.f && o->a_drop_p < 1.f && o->drop_p >= 0.f && o->drop_p < 1.f, HH_ERR_SHAPE, "hh_qgemm_f32x3: dropout p must be in [0,1)");
+    HH_REQUIRE((o->resid == nullptr || o->ldr % 4 == 0) && (o->relu_mask == nullptr || o->ldmask % 4 == 0), HH_ERR_SHAPE, "hh_qgemm_f32x3: ldr / ldmask must be multiples of 4");
+    if (M == 0) return HH_OK;
+    QGemm p;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.mode = mode;
+    p.a_scale = o->a_scale == 0.f ? 1.f : o->a_scale;
+    q_drop_params(o->a_drop_p, &p.a_drop_thresh, &p.a_drop_scale);
+    p.a_drop_seed = o->a_drop_seed; p.a_drop_ld = o->a_drop_ld;
+    p.bias = o->bias; p.scale = o->scale == 0.f ? 1.f : o->scale; p.scale_ncols = o->scale == 0.f ? 0 : (o->scale_ncols > 0 ? o->scale_ncols : N);
+    p.relu = o->relu;
+    q_drop_params(o->drop_p, &p.drop_thresh, &p.drop_scale);
+    p.drop_seed = o->drop_seed;
+    p.mask = o->relu_mask; p.ldmask = o->ldmask; p.mask_scale = o->mask_scale == 0.f ? 1.f : o->mask_scale;
+    p.resid = o->resid; p.ldr = o->ldr; p.colsum = o->colsum;
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(qgemm_kernel<0>, grid, dim3(256), 0, s, p);
+    else if (mode == 1) hipLaunchKernelGGL(qgemm_kernel<1>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(qgemm_kernel<2>, grid, dim3(256), 0, s, p);
+    return hh_check_launch("hh_qgemm_f32x3");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Self-attention over the Q <= 16 object queries of one clip (nn.MultiheadAttention inside forward_pre, tfm_decoder.py:433-436:
+// q = k = norm1(tgt) + query_pos, v = norm1(tgt)).  qkv fp32 [B*Q, 3C] (q | k | v, head h at columns 64 h .. 64 h + 63 of each
+// third, NOT pre-scaled), out fp32 [B*Q, C].  One wave per (clip, head): lane = (query i = lane & 15, group g = lane >> 4).
+#define QS 65            // LDS row stride (floats) of a 16 x 64 head tile
+
+__device__ __forceinline__ void qs_load_head(const float* src, int64_t ld, int Q, float (*dst)[QS], int lane) {
+    // 16 rows x 64 floats: lane loads row (lane >> 2) columns 16 (lane & 3) .. +15, rows >= Q are zero
+    const int r = lane >> 2, c = 16 * (lane & 3);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const f32x4 v = r < Q ? *(const f32x4*)(src + (int64_t)r * ld + c + 4 * e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        dst[r][c + 4 * e] = v[0]; dst[r][c + 4 * e + 1] = v[1]; dst[r][c + 4 * e + 2] = v[2]; dst[r][c + 4 * e + 3] = v[3];
+    }
+}
+
+// scores of query i against keys 4 g .. 4 g + 3, softmax over all 16 key slots (keys >= Q masked); returns p[4] and the row's
+// statistics; with dropout, pd[4] = mask * p / (1 - p_drop)
+__device__ __forceinline__ void qs_probs(const float (*q)[QS], const float (*k)[QS], int Q, int i, int g, float scale, unsigned bh,
+                                         unsigned thresh, float dscale, unsigned seed, float (&p)[4], float (&pd)[4], bool (&keep)[4]) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < 64; ++d) {
+        const float qv = q[i][d];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += qv * k[4 * g + e][d];
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s[e] = (4 * g + e < Q) ? s[e] * scale : -INFINITY; mx = fmaxf(mx, s[e]); }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { p[e] = (4 * g + e < Q) ? __expf(s[e] - mx) : 0.f; sum += p[e]; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        p[e] *= inv;
+        keep[e] = thresh == 0u || q_keep(seed, (bh * 16u + (unsigned)i) * 16u + (unsigned)(4 * g + e), thresh);
+        pd[e] = thresh == 0u ? p[e] : (keep[e] ? p[e] * dscale : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void qself_attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int Q, int heads,
+                                                             unsigned thresh, float dscale, unsigned seed) {
+    __shared__ float sq[4][16][QS], sk[4][16][QS], sv[4][16][QS], sp[4][16][17];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int bh = blockIdx.x * 4 + w;
+    if (bh >= B * heads) return;
+    const int b = bh / heads, h = bh % heads, C = heads * 64;
+    const float* base = qkv + (int64_t)b * Q * 3 * C + h * 64;
+    qs_load_head(base, 3 * C, Q, sq[w], lane);
+    qs_load_head(base + C, 3 * C, Q, sk[w], lane);
+    qs_load_head(base + 2 * C, 3 * C, Q, sv[w], lane);
+    __builtin_amdgcn_wave_barrier();
+    const int i = lane & 15, g = lane >> 4;
+    float p[4], pd[4];
+    bool keep[4];
+    qs_probs(sq[w], sk[w], Q, i, g, 0.125f, (unsigned)bh, thresh, dscale, seed, p, pd, keep);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sp[w][i][4 * g + e] = pd[e];
+    __builtin_amdgcn_wave_barrier();
+    // O[i][16 g .. 16 g + 15] = sum_j P[i][j] V[j][:]
+    float o[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) o[d] = 0.f;
+    for (int j = 0; j < Q; ++j) {
+        const float pj = sp[w][i][j];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) o[d] += pj * sv[w][j][16 * g + d];
+    }
+    if (i < Q) {
+        float* op = out + ((int64_t)b * Q + i) * C + h * 64 + 16 * g;
+#pragma unroll
+        for (int d = 0; d < 16; d += 4) *(f32x4*)(op + d) = (f32x4){o[d], o[d + 1], o[d + 2], o[d + 3]};
+    }
+}
+
+// backward: dqkv [B*Q, 3C] from dout [B*Q, C]; probabilities (and the dropout mask) are recomputed from qkv
+__global__ __launch_bounds__(128) void qself_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                             int B, int Q, int heads, unsigned thresh, float dscale, unsigned seed) {
+    __shared__ float sq[2][16][QS], sk[2][16][QS], sv[2][16][QS], sdo[2][16][QS], sp[2][16][17], sds[2][16][17];      // two waves per workgroup (LDS)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int bh = blockIdx.x * 2 + w;
+    if (bh >= B * heads) return;
+    const int b = bh / heads, h = bh % heads, C = heads * 64;
+    const float* base = qkv + (int64_t)b * Q * 3 * C + h * 64;
+    qs_load_head(base, 3 * C, Q, sq[w], lane);
+    qs_load_head(base + C, 3 * C, Q, sk[w], lane);
+    qs_load_head(base + 2 * C, 3 * C, Q, sv[w], lane);
+    qs_load_head(dout + (int64_t)b * Q * C + h * 64, C, Q, sdo[w], lane);
+    __builtin_amdgcn_wave_barrier();
+    const int i = lane & 15, g = lane >> 4;
+    float p[4], pd[4];
+    bool keep[4];
+    qs_probs(sq[w], sk[w], Q, i, g, 0.125f, (unsigned)bh, thresh, dscale, seed, p, pd, keep);
+    // dPd[i][j] = sum_d dO[i][d] V[j][d];  dP = dPd * mask / (1 - p_drop);  dS = P (dP - sum_j dP P)
+    float dp[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < 64; ++d) {
+        const float dv = sdo[w][i][d];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dp[e] += dv * sv[w][4 * g + e][d];
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (thresh) dp[e] = keep[e] ? dp[e] * dscale : 0.f;                              // same mask as the forward
+        dot += dp[e] * p[e];
+    }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sp[w][i][4 * g + e] = pd[e];
+        sds[w][i][4 * g + e] = (4 * g + e < Q && i < Q) ? p[e] * (dp[e] - dot) * 0.125f : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // lane (row i, d-slice 16 g ..): dQ[i] = sum_j dS[i][j] K[j];  dK[i] = sum_q dS[q][i] Q[q];  dV[i] = sum_q Pd[q][i] dO[q]
+    float dq[16], dk[16], dvv[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) { dq[d] = 0.f; dk[d] = 0.f; dvv[d] = 0.f; }
+    for (int j = 0; j < Q; ++j) {
+        const float ds_ij = sds[w][i][j], ds_ji = sds[w][j][i], p_ji = sp[w][j][i];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            dq[d] += ds_ij * sk[w][j][16 * g + d];
+            dk[d] += ds_ji * sq[w][j][16 * g + d];
+            dvv[d] += p_ji * sdo[w][j][16 * g + d];
+        }
+    }
+    if (i < Q) {
+        float* o = dqkv + ((int64_t)b * Q + i) * 3 * C + h * 64 + 16 * g;
+#pragma unroll
+        for (int d = 0; d < 16; d += 4) {
+            *(f32x4*)(o + d) = (f32x4){dq[d], dq[d + 1], dq[d + 2], dq[d + 3]};
+            *(f32x4*)(o + C + d) = (f32x4){dk[d], dk[d + 1], dk[d + 2], dk[d + 3]};
+            *(f32x4*)(o + 2 * C + d) = (f32x4){dvv[d], dvv[d + 1], dvv[d + 2], dvv[d + 3]};
+        }
+    }
+}
+
+extern "C" int hh_qself_attn_fwd(const float* qkv, float* out, int B, int Q, int heads, float dropout_p, uint32_t seed, hh_stream_t stream) {
+    HH_REQUIRE(B >= 0 && Q > 0 && Q <= 16 && heads > 0, HH_ERR_SHAPE, "hh_qself_attn_fwd: need 0 < Q <= 16 (Q=%d)", Q);
+    HH_REQUIRE(HH_ALIGNED16(qkv) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_qself_attn_fwd: pointers must be 16-byte aligned");
+    HH_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, HH_ERR_SHAPE, "hh_qself_attn_fwd: dropout_p must be in [0,1)");
+    if (B == 0) return HH_OK;
+    unsigned thr; float sc;
+    q_drop_params(dropout_p, &thr, &sc);
+    hipLaunchKernelGGL(qself_attn_fwd_kernel, dim3((unsigned)((B * heads + 3) / 4)), dim3(256), 0, (hipStream_t)stream, qkv, out, B, Q, heads, thr, sc, seed);
+    return hh_check_launch("hh_qself_attn_fwd");
+}
+
+extern "C" int hh_qself_attn_bwd(const float* qkv, const float* dout, float* dqkv, int B, int Q, int heads, float dropout_p, uint32_t seed,
+                                 hh_stream_t stream) {
+    HH_REQUIRE(B >= 0 && Q > 0 && Q <= 16 && heads > 0, HH_ERR_SHAPE, "hh_qself_attn_bwd: need 0 < Q <= 16 (Q=%d)", Q);
+    HH_REQUIRE(HH_ALIGNED16(qkv) && HH_ALIGNED16(dout) && HH_ALIGNED16(dqkv), HH_ERR_ALIGN, "hh_qself_attn_bwd: pointers must be 16-byte aligned");
+    HH_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, HH_ERR_SHAPE, "hh_qself_attn_bwd: dropout_p must be in [0,1)");
+    if (B == 0) return HH_OK;
+    unsigned thr; float sc;
+    q_drop_params(dropout_p, &thr, &sc);
+    hipLaunchKernelGGL(qself_attn_bwd_kernel, dim3((unsigned)((B * heads + 1) / 2)), dim3(128), 0, (hipStream_t)stream, qkv, dout, dqkv, B, Q, heads, thr, sc, seed);
+    return hh_check_launch("hh_qself_attn_bwd");
+}

@@ -1,0 +1,202 @@
+"""Query side of the object-query decoder on libhh kernels (csrc/qside.hip): the 13 query rows per clip of
+/root/reference/model/tfm_decoder.py:430-461 (TransformerDecoderLayer.forward_pre, sa_first) for all six layers, the per-layer
+`decoder.norm` of TransformerDecoder.forward (:281-282), and `nn.Linear` replacements for the heads / projections
+(:170-180,208-233; run/train.py:124-125,187-189).
+
+  * every GEMM is hh_qgemm_f32x3: fp32 operands, bf16 matrix cores, three MFMAs per product (fp32-grade accuracy -- the 1e-3 loss
+    bound leaves no room for bf16 weights / gradients here, see csrc/qside.hip);
+  * `QueryStack` is ONE autograd node for the six layers with an explicit backward: 11 launches per layer forward, 20 backward,
+    no autograd bookkeeping kernels -- bias / ReLU / dropout / residual / LayerNorm-residual ride in GEMM epilogues and prologues;
+    the weight gradient's bias column sums are a by-product of the TN GEMM;
+  * dropout (p = 0.1 on three residual branches, the FFN hidden layer and both attention maps, tfm_decoder.py:365-380) is a
+    counter-based hash of (seed, element index), regenerated in the backward instead of stored;
+  * the cross-attention core between the two halves of a layer is hh_xattn_fwd / hh_xattn_bwd on the K/V column slices that
+    `_MemorySide` (tfm_decoder.py of this package) projected for all layers at once.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+
+_SITE = {"sa": 1, "d1": 2, "x": 3, "d2": 4, "ff": 5, "d3": 6}
+
+
+def _seed(base, layer, site):
+    return (int(base) + 7919 * layer + 104729 * _SITE[site]) & 0xFFFFFFFF
+
+
+class _LinearX3(torch.autograd.Function):
+    """y = [relu](x.W^T + b) on hh_qgemm_f32x3 (NT); backward = NN input-gradient GEMM + TN weight-gradient GEMM whose by-product
+    is the bias gradient.  x [..., K] fp32, w [N, K] (a row-strided view is fine), b [N] or None."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        K = x.shape[-1]
+        x2 = x.detach().reshape(-1, K)
+        if x2.dtype != torch.float32 or x2.stride(-1) != 1 or x2.stride(0) % 4:
+            x2 = x2.float().contiguous()
+        wd = w.detach()
+        if wd.stride(-1) != 1 or wd.stride(0) % 4 or wd.data_ptr() % 16:
+            wd = wd.contiguous()
+        y = ops.qgemm(x2, wd, ops.NT, bias=None if b is None else b.detach().contiguous(), relu=relu)
+        ctx.save_for_backward(x2, wd, y if relu else None)
+        ctx.has_bias, ctx.relu, ctx.xshape = b is not None, relu, x.shape
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        N = w.shape[0]
+        dz = dy.reshape(-1, N)
+        if ctx.relu:
+            dz = dz * (y > 0)
+        dz = dz.float().contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.qgemm(dz, w, ops.NN).view(ctx.xshape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            db = torch.empty(N, dtype=torch.float32, device=dz.device) if ctx.has_bias else None
+            dw = ops.qgemm(dz, x2, ops.TN, colsum=db)
+        return dx, dw, db, None
+
+
+def linear_x3(x, w, b=None, relu=False):
+    return _LinearX3.apply(x, w, b, relu)
+
+
+class LinearX3(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) whose GPU forward and backward run on hh_qgemm_f32x3."""
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("LinearX3: the product path runs on libhh HIP kernels only (got a %s tensor)" % x.device)
+        return _LinearX3.apply(x, self.weight, self.bias, False)
+
+
+# parameters of one TransformerDecoderLayer in the order QueryStack receives them
+LAYER_PARAMS = ("norm1.weight", "norm1.bias", "self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+                "self_attn.out_proj.bias", "norm2.weight", "norm2.bias", "multihead_attn.in_proj_weight", "multihead_attn.in_proj_bias",
+                "multihead_attn.out_proj.weight", "multihead_attn.out_proj.bias", "norm3.weight", "norm3.bias", "linear1.weight",
+                "linear1.bias", "linear2.weight", "linear2.bias")
+NP = len(LAYER_PARAMS)
+
+
+class QueryStack(torch.autograd.Function):
+    """hs [L, B, Q, C] = decoder.norm(layer_l(...)) for l = 0..L-1, starting from tgt = 0 (tfm_decoder.py:85,255-295).
+
+    Inputs: query_embed [Q, C] (query_pos, broadcast over clips), `token` (the 1-element output of _MemorySide: orders that node's
+    backward after this one, which writes the K/V gradients into holder.dkv), decoder.norm weight / bias, then the LAYER_PARAMS
+    tensors of every layer.  Non-tensor arguments: holder (batched K/V of all layers), B, heads, eps, p (dropout probability, 0 in
+    eval mode)."""
+
+    @staticmethod
+    def forward(ctx, query_embed, token, dnw, dnb, holder, B, heads, eps, p, *params):
+        L = len(params) // NP
+        Q, C = query_embed.shape
+        R = B * Q
+        dev = query_embed.device
+        f = lambda t: t.detach().contiguous()
+        qpos = f(query_embed).float()
+        P = [[f(t) for t in params[l * NP:(l + 1) * NP]] for l in range(L)]
+        M, Lk = holder.M, holder.L
+        kvv = holder.kv.view(B, M, 2 * Lk * C)
+        tgt_all = torch.empty((L + 1, R, C), dtype=torch.float32, device=dev)
+        tgt_all[0].zero_()
+        saved = []
+        for l in range(L):
+            n1w, n1b, wi_s, bi_s, wo_s, bo_s, n2w, n2b, wi_c, bi_c, wo_c, bo_c, n3w, n3b, w1, b1, w2, b2 = P[l]
+            sd = lambda site: _seed(holder.seed, l, site)
+            x = tgt_all[l]
+            a, aq, mean1, rstd1 = ops.layernorm_pos(x, n1w, n1b, eps, qpos, save_stats=True)
+            qkv = torch.empty((R, 3 * C), dtype=torch.float32, device=dev)
+            ops.qgemm(aq, wi_s[:2 * C], ops.NT, bias=bi_s[:2 * C], out=qkv[:, :2 * C])                  # q = k = norm1(x) + query_pos
+            ops.qgemm(a, wi_s[2 * C:], ops.NT, bias=bi_s[2 * C:], out=qkv[:, 2 * C:])                   # v = norm1(x)
+            o = ops.qself_attn_fwd(qkv, B, Q, heads, p, sd("sa"))
+            tgt1 = ops.qgemm(o, wo_s, ops.NT, bias=bo_s, drop_p=p, drop_seed=sd("d1"), resid=x)
+            _, cq, mean2, rstd2 = ops.layernorm_pos(tgt1, n2w, n2b, eps, qpos, save_stats=True)
+            q = ops.qgemm(cq, wi_c[:C], ops.NT, bias=bi_c[:C], scale=0.125)                             # (norm2 + query_pos).Wq, scaled d^-1/2
+            k, v = kvv[:, :, l * C:(l + 1) * C], kvv[:, :, (Lk + l) * C:(Lk + l + 1) * C]
+            ca, lse = ops.xattn_fwd(q.view(B, Q, C), k, v, heads, p, sd("x"))
+            tgt2 = ops.qgemm(ca.view(R, C), wo_c, ops.NT, bias=bo_c, drop_p=p, drop_seed=sd("d2"), resid=tgt1)
+            e, mean3, rstd3 = ops.layernorm(tgt2, n3w, n3b, eps, out_dtype=torch.float32, save_stats=True)
+            hid = ops.qgemm(e, w1, ops.NT, bias=b1, relu=True, drop_p=p, drop_seed=sd("ff"))
+            ops.qgemm(hid, w2, ops.NT, bias=b2, drop_p=p, drop_seed=sd("d3"), resid=tgt2, out=tgt_all[l + 1])
+            saved.append((a, aq, mean1, rstd1, qkv, o, tgt1, cq, mean2, rstd2, q, ca, lse, tgt2, e, mean3, rstd3, hid))
+        hs, dmean, drstd = ops.layernorm(tgt_all[1:].reshape(L * R, C), f(dnw), f(dnb), eps, out_dtype=torch.float32, save_stats=True)
+        ctx.holder, ctx.dims, ctx.eps, ctx.p = holder, (L, B, Q, C, heads), eps, p
+        ctx.P, ctx.saved, ctx.tgt_all, ctx.dec = P, saved, tgt_all, (f(dnw), dmean, drstd)
+        return hs.view(L, B, Q, C)
+
+    @staticmethod
+    def backward(ctx, dhs):
+        L, B, Q, C, heads = ctx.dims
+        R, p, h = B * Q, ctx.p, ctx.holder
+        dev = dhs.device
+        dhs = dhs.contiguous().view(L, R, C)
+        dnw, dmean, drstd = ctx.dec
+        F_ = ctx.P[0][14].shape[0]
+        # LayerNorm weight / bias gradients are accumulated with atomics: one zeroed slab for all of them
+        lnbuf = torch.zeros((L * 3 + 1, 2, C), dtype=torch.float32, device=dev)
+        d_wi_c = torch.zeros((L, 3 * C, C), dtype=torch.float32, device=dev)             # key / value rows belong to _MemorySide
+        d_bi_c = torch.zeros((L, 3 * C), dtype=torch.float32, device=dev)
+        if h.dkv is None:
+            h.dkv = torch.empty_like(h.kv)
+        M, Lk = h.M, h.L
+        kvv, dkvv = h.kv.view(B, M, 2 * Lk * C), h.dkv.view(B, M, 2 * Lk * C)
+        keep = 1.0 / (1.0 - p) if p > 0 else 1.0
+        grads = [None] * (L * NP)
+        dqpos_parts = []
+        g = None
+        for l in reversed(range(L)):
+            n1w, n1b, wi_s, bi_s, wo_s, bo_s, n2w, n2b, wi_c, bi_c, wo_c, bo_c, n3w, n3b, w1, b1, w2, b2 = ctx.P[l]
+            a, aq, mean1, rstd1, qkv, o, tgt1, cq, mean2, rstd2, q, ca, lse, tgt2, e, mean3, rstd3, hid = ctx.saved[l]
+            sd = lambda site: _seed(h.seed, l, site)
+            x, tgt3 = ctx.tgt_all[l], ctx.tgt_all[l + 1]
+            # decoder.norm of this layer's output (+ the gradient arriving from layer l + 1)
+            sl = slice(l * R, (l + 1) * R)
+            g = ops.layernorm_bwd_add(tgt3, dnw, dmean[sl], drstd[sl], dhs[l], g, lnbuf[L * 3, 0], lnbuf[L * 3, 1], out=g)
+            drop = lambda site: dict(a_drop_p=p, a_drop_seed=sd(site), a_drop_ld=C) if p > 0 else {}
+            # FFN:  tgt3 = tgt2 + drop3(hid.W2^T + b2),  hid = drop(relu(e.W1^T + b1)),  e = norm3(tgt2)
+            db2 = torch.empty(C, dtype=torch.float32, device=dev)
+            dw2 = ops.qgemm(g, hid, ops.TN, colsum=db2, **drop("d3"))
+            dz = ops.qgemm(g, w2, ops.NN, relu_mask=hid, mask_scale=keep, **drop("d3"))
+            db1 = torch.empty(F_, dtype=torch.float32, device=dev)
+            dw1 = ops.qgemm(dz, e, ops.TN, colsum=db1)
+            de = ops.qgemm(dz, w1, ops.NN)
+            g2 = ops.layernorm_bwd_add(tgt2, n3w, mean3, rstd3, de, g, lnbuf[l * 3 + 2, 0], lnbuf[l * 3 + 2, 1])
+            # cross-attention:  tgt2 = tgt1 + drop2(ca.Wo^T + bo),  ca = xattn(q, K_l, V_l),  q = (cq.Wq^T + bq) / 8,  cq = norm2(tgt1) + qpos
+            dbo_c = torch.empty(C, dtype=torch.float32, device=dev)
+            dwo_c = ops.qgemm(g2, ca.view(R, C), ops.TN, colsum=dbo_c, **drop("d2"))
+            dca = ops.qgemm(g2, wo_c, ops.NN, **drop("d2"))
+            k, v = kvv[:, :, l * C:(l + 1) * C], kvv[:, :, (Lk + l) * C:(Lk + l + 1) * C]
+            dk, dv = dkvv[:, :, l * C:(l + 1) * C], dkvv[:, :, (Lk + l) * C:(Lk + l + 1) * C]
+            dq = ops.xattn_bwd(q.view(B, Q, C), k, v, ca, lse, dca.view(B, Q, C), dk, dv, heads, p, sd("x")).view(R, C)
+            ops.qgemm(dq, cq, ops.TN, a_scale=0.125, colsum=d_bi_c[l, :C], out=d_wi_c[l, :C])
+            dcq = ops.qgemm(dq, wi_c[:C], ops.NN, a_scale=0.125)
+            g1 = ops.layernorm_bwd_add(tgt1, n2w, mean2, rstd2, dcq, g2, lnbuf[l * 3 + 1, 0], lnbuf[l * 3 + 1, 1])
+            # self-attention:  tgt1 = x + drop1(o.Wo^T + bo),  o = attn(q = k = aq.W[:2C], v = a.W[2C:]),  a = norm1(x), aq = a + qpos
+            dbo_s = torch.empty(C, dtype=torch.float32, device=dev)
+            dwo_s = ops.qgemm(g1, o, ops.TN, colsum=dbo_s, **drop("d1"))
+            do = ops.qgemm(g1, wo_s, ops.NN, **drop("d1"))
+            dqkv = ops.qself_attn_bwd(qkv, do, B, Q, heads, p, sd("sa"))
+            dwi_s = torch.empty((3 * C, C), dtype=torch.float32, device=dev)
+            dbi_s = torch.empty(3 * C, dtype=torch.float32, device=dev)
+            ops.qgemm(dqkv[:, :2 * C], aq, ops.TN, colsum=dbi_s[:2 * C], out=dwi_s[:2 * C])
+            ops.qgemm(dqkv[:, 2 * C:], a, ops.TN, colsum=dbi_s[2 * C:], out=dwi_s[2 * C:])
+            daq = ops.qgemm(dqkv[:, :2 * C], wi_s[:2 * C], ops.NN)
+            da = ops.qgemm(dqkv[:, 2 * C:], wi_s[2 * C:], ops.NN, resid=daq)
+            g = ops.layernorm_bwd_add(x, n1w, mean1, rstd1, da, g1, lnbuf[l * 3, 0], lnbuf[l * 3, 1])
+            dqpos_parts += [dcq, daq]
+            grads[l * NP:(l + 1) * NP] = [lnbuf[l * 3, 0], lnbuf[l * 3, 1], dwi_s, dbi_s, dwo_s, dbo_s, lnbuf[l * 3 + 1, 0], lnbuf[l * 3 + 1, 1],
+                                          d_wi_c[l], d_bi_c[l], dwo_c, dbo_c, lnbuf[l * 3 + 2, 0], lnbuf[l * 3 + 2, 1], dw1, db1, dw2, db2]
+        dquery = torch.stack(dqpos_parts).sum(0).view(B, Q, C).sum(0)
+        ctx.saved = ctx.tgt_all = None
+        return (dquery, torch.zeros(1, dtype=torch.float32, device=dev), lnbuf[L * 3, 0], lnbuf[L * 3, 1], None, None, None, None, None, *grads)
+
+
+def stack_params(layers):
+    out = []
+    for layer in layers:
+        mods = dict(layer.named_parameters())
+        out += [mods[n] for n in LAYER_PARAMS]
+    return out

@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from torch import nn, Tensor
 
 from .. import ops
+from .qside import LinearX3, QueryStack, linear_x3, stack_params
 
 
 def _require_gpu(x, who):
@@ -56,8 +57,9 @@ class _MemorySide(torch.autograd.Function):
         M = pos.shape[0]
         B = BM // M
         mem0 = ops.gemm(feat_b, ops.to_bf16(w_proj.detach()), out_dtype=torch.float32)                   # [BM, C]
-        memory, mean, rstd = ops.layernorm(mem0, g_pre.detach().float(), b_pre.detach().float(), eps, save_stats=True)
-        mem_pos = (memory.view(B, M, C).float() + pos.detach()).to(torch.bfloat16).view(BM, C)
+        # pre_norm and the key operand memory + pos in ONE pass (tfm_decoder.py:86-88,438-441: key = memory + pos, value = memory)
+        memory, mem_pos, mean, rstd = ops.layernorm_pos(mem0, g_pre.detach().float(), b_pre.detach().float(), eps,
+                                                        pos.detach().float().contiguous(), out_dtype=torch.bfloat16, save_stats=True)
         wk = torch.cat([w.detach()[C:2 * C] for w in in_w])                                               # [L*C, C]
         wv = torch.cat([w.detach()[2 * C:] for w in in_w])
         bk = torch.cat([b.detach()[C:2 * C] for b in in_b]).float()
@@ -212,11 +214,11 @@ class MLP(nn.Module):
         super().__init__()
         self.num_layers = num_layers
         h = [hidden_dim] * (num_layers - 1)
-        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+        self.layers = nn.ModuleList(LinearX3(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+            x = linear_x3(x, layer.weight, layer.bias, relu=i < self.num_layers - 1)             # ReLU in the GEMM epilogue
         return x
 
 
@@ -229,9 +231,9 @@ class TransformerDecoderLayer(nn.Module):
         self.sa_first = sa_first
         self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
         self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
-        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear1 = LinearX3(d_model, dim_feedforward)
         self.dropout = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.linear2 = LinearX3(dim_feedforward, d_model)
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
         self.dropout1, self.dropout2, self.dropout3 = nn.Dropout(dropout), nn.Dropout(dropout), nn.Dropout(dropout)
         if activation != "relu":
@@ -253,13 +255,13 @@ class TransformerDecoderLayer(nn.Module):
         bq, bk, bv = m.in_proj_bias.chunk(3, dim=0)
         xq = x + qpos
         B, Q = x.shape[:2]
-        q = F.linear(xq, wq, bq).view(B, Q, h, C // h).transpose(1, 2)
-        k = F.linear(xq, wk, bk).view(B, Q, h, C // h).transpose(1, 2)
-        v = F.linear(x, wv, bv).view(B, Q, h, C // h).transpose(1, 2)
+        q = linear_x3(xq, wq, bq).view(B, Q, h, C // h).transpose(1, 2)
+        k = linear_x3(xq, wk, bk).view(B, Q, h, C // h).transpose(1, 2)
+        v = linear_x3(x, wv, bv).view(B, Q, h, C // h).transpose(1, 2)
         p = torch.softmax((q * (C // h) ** -0.5) @ k.transpose(-1, -2), dim=-1)
         p = F.dropout(p, self.p_attn, self.training)
         o = (p @ v).transpose(1, 2).reshape(B, Q, C)
-        return F.linear(o, m.out_proj.weight, m.out_proj.bias)
+        return linear_x3(o, m.out_proj.weight, m.out_proj.bias)
 
     def forward_tokens(self, tgt, qpos, token, holder, layer_idx):
         """Batch-first forward_pre (tfm_decoder.py:430-461) on the holder's batched K/V: tgt, qpos [B,Q,C] fp32."""
@@ -274,10 +276,10 @@ class TransformerDecoderLayer(nn.Module):
         tgt = tgt + self.dropout1(self._self_attention(a, qpos))
         c = self.norm2(tgt)
         m = self.multihead_attn
-        q = F.linear(c + qpos, m.in_proj_weight[:C], m.in_proj_bias[:C]) * ((C // h) ** -0.5)
-        tgt = tgt + self.dropout2(F.linear(xattn(q), m.out_proj.weight, m.out_proj.bias))
+        q = linear_x3(c + qpos, m.in_proj_weight[:C], m.in_proj_bias[:C]) * ((C // h) ** -0.5)
+        tgt = tgt + self.dropout2(linear_x3(xattn(q), m.out_proj.weight, m.out_proj.bias))
         e = self.norm3(tgt)
-        return tgt + self.dropout3(self.linear2(self.dropout(self.activation(self.linear1(e)))))
+        return tgt + self.dropout3(self.linear2(self.dropout(linear_x3(e, self.linear1.weight, self.linear1.bias, relu=True))))
 
     def forward_pre(self, tgt, memory, tgt_mask: Optional[Tensor] = None, memory_mask: Optional[Tensor] = None,
                     tgt_key_padding_mask: Optional[Tensor] = None, memory_key_padding_mask: Optional[Tensor] = None,
@@ -414,9 +416,12 @@ class Cross_Attention(nn.Module):
         in_b = [l.multihead_attn.in_proj_bias for l in layers]
         token = _MemorySide.apply(feat_b, w_proj, self.pre_norm.weight, self.pre_norm.bias, pos, holder,
                                   self.pre_norm.eps, *in_w, *in_b)
-        qpos = query_embed.unsqueeze(0).expand(B, -1, -1)
-        tgt = torch.zeros_like(qpos)
-        hs = self.decoder.forward_tokens(tgt, qpos, token, holder)
+        # the 13-row query side of all six layers + decoder.norm: one autograd node on libhh kernels (model/qside.py)
+        p = layers[0].p_attn if self.training else 0.0
+        norm = self.decoder.norm
+        hs = QueryStack.apply(query_embed, token, norm.weight, norm.bias, holder, B, self.nhead, norm.eps, p, *stack_params(layers))
+        if not self.decoder.return_intermediate:
+            hs = hs[-1:]
         if not torch.is_grad_enabled():
             holder.kv = None
         return hs
@@ -452,14 +457,14 @@ class ObjDecoder(nn.Module):
         self.transformer = transformer
         hidden_dim = transformer.d_model
         self.hidden_dim = hidden_dim
-        self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
+        self.class_embed = LinearX3(hidden_dim, num_classes + 1)
         self.bbox_embed = MLP(hidden_dim, hidden_dim, 4, 3)
         self.query_embed = nn.Embedding(num_queries, hidden_dim)
         self.pred_traj = pred_traj
         self.n_decode = 1
         if self.pred_traj:
             self.frame_index = nn.Embedding(num_frames, hidden_dim)
-            self.frame_proj = nn.Linear(hidden_dim * 2, hidden_dim)
+            self.frame_proj = LinearX3(hidden_dim * 2, hidden_dim)
         self.aux_loss = aux_loss
         self.pos_embed = nn.Parameter(torch.zeros(1, patches_per_frame + 1, hidden_dim))
         self.temporal_embed = nn.Parameter(torch.zeros(1, num_frames, hidden_dim))
@@ -480,11 +485,11 @@ class ObjDecoder(nn.Module):
         return (tile_pos_embed + tile_temporal_embed).view(1, T, self.patches_per_frame, self.pos_embed.shape[-1])
 
     def init_proj_layers(self):
-        self.txt_proj = nn.Sequential(nn.ReLU(), nn.Linear(768, 256))
-        self.vid_proj = nn.Sequential(nn.Linear(768, 256))
+        self.txt_proj = nn.Sequential(nn.ReLU(), LinearX3(768, 256))
+        self.vid_proj = nn.Sequential(LinearX3(768, 256))
 
     def init_obj_model(self):
-        self.obj_proj = nn.Sequential(nn.Linear(self.hidden_dim, self.hidden_dim), nn.ReLU(), nn.Linear(self.hidden_dim, 256))
+        self.obj_proj = nn.Sequential(LinearX3(self.hidden_dim, self.hidden_dim), nn.ReLU(), LinearX3(self.hidden_dim, 256))
 
     def forward(self, features, use_checkpoint=False):
         _require_gpu(features, "ObjDecoder")
@@ -497,8 +502,8 @@ class ObjDecoder(nn.Module):
         full = self.materialize_logits
         if self.pred_traj and T == self.num_frames:
             w = self.frame_proj.weight
-            base = F.linear(hs if full else hs[-1:], w[:, :C])                                               # [l,B,Q,C]
-            fr = F.linear(self.frame_index.weight[:T], w[:, C:], self.frame_proj.bias)                      # [T,C]
+            base = linear_x3(hs if full else hs[-1:], w[:, :C])                                              # [l,B,Q,C]
+            fr = linear_x3(self.frame_index.weight[:T], w[:, C:], self.frame_proj.bias)                     # [T,C]
             cond = (base[:, :, None] + fr[None, None, :, None, :]).flatten(1, 2)                             # [l,B*T,Q,C]
         else:
             cond = hs if full else hs[-1:]

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import GemmEpilogue
+from ._lib import GemmEpilogue, QGemmOpts
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_QUICKGELU, ACT_RELU = 0, 1, 2
@@ -108,6 +108,95 @@ def layernorm_bwd(x, gamma, mean, rstd, dy):
     _lib.check(L.hh_layernorm_bwd(_p(x), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dx), _p(dg), _p(db), rows, cols,
                                   _stream()), "hh_layernorm_bwd")
     return dx, dg, db
+
+
+def layernorm_pos(x, gamma, beta, eps, pos, out_dtype=torch.float32, save_stats=False):
+    """(LN(x), LN(x) + pos[row % pos_rows]) in one pass; x [rows, cols] fp32/bf16, pos fp32 [pos_rows, cols]."""
+    _chk(x, gamma, beta, pos)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    if pos.dtype != torch.float32 or pos.shape[-1] != cols:
+        raise TypeError("layernorm_pos: pos must be fp32 [pos_rows, cols]")
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    y2 = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hh_layernorm_pos_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(y), _p(y2), _dt(y), _p(pos), pos.numel() // cols,
+                                               _p(mean), _p(rstd), rows, cols, float(eps), _stream()), "hh_layernorm_pos_fwd")
+    return (y, y2, mean, rstd) if save_stats else (y, y2)
+
+
+def layernorm_bwd_add(x, gamma, mean, rstd, dy, dx_add, dgamma, dbeta, out=None):
+    """dx = dx_add + LayerNorm-backward(dy); dgamma / dbeta (fp32 [cols]) are ACCUMULATED into.  out may alias dx_add."""
+    _chk(x, gamma, mean, rstd, dy, dx_add, dgamma, dbeta, out)                  # dx_add None: plain LayerNorm backward
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if out is None else out
+    _lib.check(_lib.lib().hh_layernorm_bwd_add(_p(x), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dx_add), _p(dx), _p(dgamma), _p(dbeta),
+                                               rows, cols, _stream()), "hh_layernorm_bwd_add")
+    return dx
+
+
+NT, NN, TN = 0, 1, 2
+
+
+def qgemm(a, b, mode=NT, *, out=None, bias=None, scale=0.0, scale_ncols=0, relu=False, drop_p=0.0, drop_seed=0, relu_mask=None, mask_scale=1.0,
+          resid=None, a_scale=0.0, a_drop_p=0.0, a_drop_seed=0, a_drop_ld=0, colsum=None):
+    """Query-side GEMM at fp32-grade accuracy on the bf16 matrix cores (include/hh.h: hh_qgemm_f32x3).  All operands fp32, 2-D with
+    unit inner stride.  mode NT: a [M,K], b [N,K];  NN: a [M,K], b [K,N];  TN: a [K,M], b [K,N]  ->  out fp32 [M,N]."""
+    for t in (a, b, out, resid, relu_mask):
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("libhh ops need GPU tensors (got device %s); there is no CPU fallback" % t.device)
+        if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError("qgemm: operands must be fp32, 2-D, unit inner stride")
+    _chk(bias, colsum)
+    if mode == NT:
+        (M, K), (N, Kb) = a.shape, b.shape
+    elif mode == NN:
+        (M, K), (Kb, N) = a.shape, b.shape
+    else:
+        (K, M), (Kb, N) = a.shape, b.shape
+    if K != Kb:
+        raise ValueError("qgemm: contraction mismatch %s vs %s (mode %d)" % (tuple(a.shape), tuple(b.shape), mode))
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    o = QGemmOpts()
+    o.a_scale, o.a_drop_p, o.a_drop_seed, o.a_drop_ld = float(a_scale), float(a_drop_p), int(a_drop_seed) & 0xFFFFFFFF, int(a_drop_ld)
+    o.bias = bias.data_ptr() if bias is not None else None
+    o.scale, o.scale_ncols, o.relu = float(scale), int(scale_ncols), int(bool(relu))
+    o.drop_p, o.drop_seed = float(drop_p), int(drop_seed) & 0xFFFFFFFF
+    o.relu_mask = relu_mask.data_ptr() if relu_mask is not None else None
+    o.ldmask = relu_mask.stride(0) if relu_mask is not None else 0
+    o.mask_scale = float(mask_scale)
+    o.resid = resid.data_ptr() if resid is not None else None
+    o.ldr = resid.stride(0) if resid is not None else 0
+    o.colsum = colsum.data_ptr() if colsum is not None else None
+    _lib.check(_lib.lib().hh_qgemm_f32x3(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, int(mode), ctypes.byref(o),
+                                         _stream()), "hh_qgemm_f32x3")
+    return out
+
+
+def qself_attn_fwd(qkv, B, Q, heads, dropout_p=0.0, seed=0):
+    """qkv fp32 [B*Q, 3*heads*64] (not pre-scaled) -> fp32 [B*Q, heads*64]."""
+    _chk(qkv)
+    C = heads * 64
+    if qkv.dtype != torch.float32 or tuple(qkv.shape) != (B * Q, 3 * C):
+        raise ValueError("qself_attn_fwd: qkv must be fp32 [B*Q, 3*heads*64]")
+    out = torch.empty((B * Q, C), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().hh_qself_attn_fwd(_p(qkv), _p(out), B, Q, heads, float(dropout_p), int(seed) & 0xFFFFFFFF, _stream()), "hh_qself_attn_fwd")
+    return out
+
+
+def qself_attn_bwd(qkv, dout, B, Q, heads, dropout_p=0.0, seed=0):
+    _chk(qkv, dout)
+    dqkv = torch.empty_like(qkv)
+    _lib.check(_lib.lib().hh_qself_attn_bwd(_p(qkv), _p(dout), _p(dqkv), B, Q, heads, float(dropout_p), int(seed) & 0xFFFFFFFF, _stream()),
+               "hh_qself_attn_bwd")
+    return dqkv
 
 
 def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, resid=None, colscale=1.0,

@@ -184,6 +184,49 @@ int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_t ldkv, con
                  const float* dout, float* dq, int dq_splits, void* dk, void* dv, int64_t lddkv,
                  int B, int Q, int M, int heads, float dropout_p, uint32_t seed, hh_stream_t stream);
 
+/* ---- query side of the decoder (model/tfm_decoder.py:430-461 forward_pre on the 13 object queries, :208-233 heads, and the
+ * txt_proj / obj_proj projections of run/train.py:124-125,187-189): fp32 operands, bf16 matrix cores at fp32-grade accuracy.
+ * hh_qgemm_f32x3: C = epilogue(prologue(A) . B); every operand fp32; each fp32 value is split on the fly into bf16 hi + lo and
+ * a product takes three MFMAs (Ahi.Bhi + Alo.Bhi + Ahi.Blo).
+ *   mode 0 (NT, forward of nn.Linear)   C[m,n] = sum_k A[m,k] B[n,k]     A [M,K] (lda), B [N,K] (ldb)
+ *   mode 1 (NN, input gradient)         C[m,n] = sum_k A[m,k] B[k,n]     A [M,K],       B [K,N]
+ *   mode 2 (TN, weight gradient)        C[m,n] = sum_k A[k,m] B[k,n]     A [K,M],       B [K,N]
+ * C fp32 [M,N] (ldc).  Contiguous dimensions and leading dimensions must be multiples of 4; M, N, K otherwise arbitrary.
+ *   prologue on A:  A *= a_scale (0 = off);  dropout mask: element at memory (row r, col c) of A kept iff
+ *                   hash(a_drop_seed, r * a_drop_ld + c) >= a_drop_p * 2^32, scaled by 1/(1-a_drop_p)  [= the mask the forward
+ *                   epilogue drew for element (m, n) of an output with N = a_drop_ld columns]
+ *   epilogue:       + bias[n] -> * scale for n < scale_ncols (scale 0 = off, scale_ncols 0 = all) -> ReLU -> dropout(drop_p,
+ *                   drop_seed, element index m * N + n) -> * (relu_mask[m,n] > 0 ? mask_scale : 0) -> + resid[m,n]
+ *   colsum (mode 2 only, optional): colsum[m] = sum_k A_eff[k, m]  (bias gradient of the same nn.Linear) */
+typedef struct hh_qgemm_opts {
+    float a_scale;
+    float a_drop_p; uint32_t a_drop_seed; int32_t a_drop_ld;
+    const float* bias;
+    float scale; int32_t scale_ncols;
+    int32_t relu;
+    float drop_p; uint32_t drop_seed;
+    const float* relu_mask; int64_t ldmask; float mask_scale;
+    const float* resid; int64_t ldr;
+    float* colsum;
+} hh_qgemm_opts;
+int hh_qgemm_f32x3(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, int mode,
+                   const hh_qgemm_opts* opts, hh_stream_t stream);
+/* self-attention over the Q <= 16 queries of a clip (nn.MultiheadAttention(q = k = x + query_pos, v = x), tfm_decoder.py:433-436):
+ * qkv fp32 [B*Q, 3*heads*64] (q | k | v projections, not pre-scaled; the kernel applies 64^-1/2), out fp32 [B*Q, heads*64];
+ * attention dropout by the same counter-based hash (probabilities and mask are recomputed in the backward). */
+int hh_qself_attn_fwd(const float* qkv, float* out, int B, int Q, int heads, float dropout_p, uint32_t seed, hh_stream_t stream);
+int hh_qself_attn_bwd(const float* qkv, const float* dout, float* dqkv, int B, int Q, int heads, float dropout_p, uint32_t seed,
+                      hh_stream_t stream);
+/* LayerNorm with a second output y_plus_pos = LN(x) + pos[row % pos_rows] (pos fp32 [pos_rows, cols]): the operands of an attention
+ * whose keys / queries carry a positional embedding and whose values do not (tfm_decoder.py:431-441: q = k = x + query_pos, v = x;
+ * key = memory + pos, value = memory) come out of ONE pass.  Same dtypes / limits as hh_layernorm_fwd. */
+int hh_layernorm_pos_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, void* y_plus_pos, int y_dtype,
+                         const float* pos, int pos_rows, float* mean_out, float* rstd_out, int64_t rows, int cols, float eps,
+                         hh_stream_t stream);
+/* hh_layernorm_bwd with the gradient of the residual path added: dx = dx_add + LayerNorm-backward(dy)  (dx_add may alias dx) */
+int hh_layernorm_bwd_add(const void* x, int x_dtype, const float* gamma, const float* mean, const float* rstd, const float* dy,
+                         const float* dx_add, float* dx, float* dgamma, float* dbeta, int64_t rows, int cols, hh_stream_t stream);
+
 /* ---- Hungarian matching + box losses (model/box_utils.py:43-92,156-173,249-279; utils/box_ops.py:9-61)
  * pred fp32 [F, Qtot, 4] cxcywh; queries [q0, q0+q) are matched.  raw_boxes fp32 [F, k, 4] xyxy pixels
  * (zero / degenerate = absent, prepare_targets semantics, img = 224).  Outputs (all device):

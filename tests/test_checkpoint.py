@@ -54,7 +54,7 @@ def test_load_4_frame_checkpoints_into_16_frame_models(tmp_path):
     fn = str(tmp_path / "runtime.pth.tar")
     for i in range(12):
         p = ck.save_runtime_checkpoint(ck.make_save_dict(dec16, i, 0.0, i * 10, {"step": i}), fn, keep=10)
-        os.rename(p, p.replace(".pth.tar", f"_{i:02d}.pth.tar"))        # distinct names even within one second
+        os.rename(p, str(tmp_path / f"runtime_2000_01_01_00_{i:02d}.pth.tar"))   # the reference's stamp has minute resolution: give each file its own minute
     assert len(list(tmp_path.glob("runtime_*.pth.tar"))) <= 11
     last = sorted(tmp_path.glob("runtime_*.pth.tar"))[-1]
     dec_b = tfm_decoder.build_decoder(TINY16.with_(num_queries=4), None, device="cpu")

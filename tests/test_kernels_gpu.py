@@ -433,3 +433,127 @@ def test_errors_are_loud():
         ops.layernorm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64), 1e-5)          # CPU tensor
     with pytest.raises(RuntimeError, match="hh_gemm_bf16"):
         ops.gemm(torch.zeros(4, 32, dtype=torch.bfloat16, device=DEV), torch.zeros(128, 32, dtype=torch.bfloat16, device=DEV))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# query side of the decoder (csrc/qside.hip): fp32-grade GEMM on the bf16 matrix cores, 13 x 13 self-attention, LayerNorm variants
+
+def _ref_mm(a, b, mode):
+    a, b = a.double(), b.double()
+    return (a @ b.t()) if mode == ops.NT else (a @ b) if mode == ops.NN else (a.t() @ b)
+
+
+@pytest.mark.parametrize("mode", [ops.NT, ops.NN, ops.TN], ids=["NT", "NN", "TN"])
+@pytest.mark.parametrize("M,N,K", [(416, 512, 512), (416, 2048, 512), (416, 512, 2048), (10, 4, 512), (65, 256, 768), (26, 1536, 512),
+                                   (512, 2048, 416), (4, 512, 40), (130, 68, 36)])
+def test_qgemm_fp32_grade_accuracy_all_layouts(mode, M, N, K):
+    """hh_qgemm_f32x3 vs an fp64 product of the same fp32 operands: error at fp32 level (1e-5 of the output scale), far below one
+    bf16 rounding (4e-3) -- including ragged M / N / K tiles."""
+    if mode != ops.TN and K % 4:
+        pytest.skip("contiguous contraction dimension must be a multiple of 4")
+    if mode == ops.TN and M % 4:
+        pytest.skip("TN: M is the contiguous dimension of A")
+    sa = (M, K) if mode != ops.TN else (K, M)
+    sb = (N, K) if mode == ops.NT else (K, N)
+    a, b = rnd(*sa, seed=1), rnd(*sb, seed=2, scale=0.05)
+    ref = _ref_mm(a, b, mode)
+    out = ops.qgemm(a.to(DEV), b.to(DEV), mode)
+    err = (out.double().cpu() - ref).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item(), (err, ref.abs().max().item())
+
+
+def test_qgemm_prologue_epilogue_options():
+    M, N, K = 70, 132, 96
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    A, W = a.to(DEV), w.to(DEV)
+    ref = (a.double() @ w.double().t()).float()
+    tol = dict(rtol=1e-4, atol=2e-5 * ref.abs().max().item())
+    torch.testing.assert_close(ops.qgemm(A, W, bias=bias.to(DEV)).cpu(), ref + bias, **tol)
+    r = ref + bias
+    r2 = r.clone(); r2[:, :64] *= 0.125
+    torch.testing.assert_close(ops.qgemm(A, W, bias=bias.to(DEV), scale=0.125, scale_ncols=64).cpu(), r2, **tol)
+    torch.testing.assert_close(ops.qgemm(A, W, bias=bias.to(DEV), scale=0.125).cpu(), r * 0.125, **tol)
+    torch.testing.assert_close(ops.qgemm(A, W, bias=bias.to(DEV), relu=True, resid=res.to(DEV)).cpu(), torch.relu(r) + res, **tol)
+    mask = rnd(M, N, seed=5)
+    torch.testing.assert_close(ops.qgemm(A, W, relu_mask=mask.to(DEV), mask_scale=1.5).cpu(), torch.where(mask > 0, ref * 1.5, torch.zeros(())), **tol)
+    torch.testing.assert_close(ops.qgemm(A, W, a_scale=0.5).cpu(), ref * 0.5, **tol)
+    # strided views: output into a column slice, operand from a row slice
+    big = torch.zeros(M, 2 * N, device=DEV)
+    ops.qgemm(A, W, out=big[:, N:])
+    torch.testing.assert_close(big[:, N:].cpu(), ref, **tol)
+    assert float(big[:, :N].abs().max()) == 0
+    Wb = torch.cat([torch.zeros(3, K), w]).to(DEV)
+    torch.testing.assert_close(ops.qgemm(A, Wb[3:]).cpu(), ref, **tol)
+    # TN: weight gradient + bias gradient (column sums of dY) in one launch
+    dy = rnd(M, N, seed=6)
+    cs = torch.empty(N, device=DEV)
+    dw = ops.qgemm(dy.to(DEV), A, ops.TN, colsum=cs)
+    torch.testing.assert_close(dw.cpu(), (dy.double().t() @ a.double()).float(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(cs.cpu(), dy.sum(0), rtol=1e-5, atol=1e-5)
+    # dropout: the backward's A-prologue regenerates the forward epilogue's mask from (seed, element index)
+    p, seed = 0.25, 1234
+    y0, yd = ops.qgemm(A, W), ops.qgemm(A, W, drop_p=p, drop_seed=seed)
+    keep = yd != 0
+    assert 0.70 < float(keep.float().mean()) < 0.80
+    torch.testing.assert_close(yd, torch.where(keep, y0 / (1 - p), torch.zeros((), device=DEV)), rtol=1e-5, atol=1e-6)
+    assert not torch.equal(keep, ops.qgemm(A, W, drop_p=p, drop_seed=seed + 1) != 0)
+    ones, eye = torch.ones(M, N, device=DEV), torch.eye(N, device=DEV)
+    m_nn = ops.qgemm(ones, eye, ops.NN, a_drop_p=p, a_drop_seed=seed, a_drop_ld=N)                 # A[m, k] kept iff forward element (m, k) was
+    torch.testing.assert_close(m_nn, keep.float() / (1 - p), rtol=1e-5, atol=1e-6)
+    m_tn = ops.qgemm(ones, torch.eye(M, device=DEV), ops.TN, a_drop_p=p, a_drop_seed=seed, a_drop_ld=N)   # A[k, m] -> C[m, n] = mask[n, m]
+    torch.testing.assert_close(m_tn, (keep.float() / (1 - p)).t().contiguous(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,Q,heads", [(3, 13, 8), (2, 5, 8), (5, 16, 2), (1, 1, 1)])
+def test_query_self_attention_fwd_bwd(B, Q, heads):
+    C = heads * 64
+    qkv = rnd(B * Q, 3 * C, seed=1, scale=0.7)
+    dout = rnd(B * Q, C, seed=2)
+    x = qkv.clone().requires_grad_(True)
+    q, k, v = [t.view(B, Q, heads, 64).transpose(1, 2) for t in x.view(B * Q, 3, C).unbind(1)]
+    ref = (torch.softmax((q * 0.125) @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B * Q, C)
+    ref.backward(dout)
+    out = ops.qself_attn_fwd(qkv.to(DEV), B, Q, heads)
+    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    dqkv = ops.qself_attn_bwd(qkv.to(DEV), dout.to(DEV), B, Q, heads)
+    torch.testing.assert_close(dqkv.cpu(), x.grad, rtol=1e-4, atol=1e-5)
+    # dropout: deterministic in the seed, unbiased, and the backward uses the forward's mask (finite differences)
+    X = qkv.to(DEV)
+    o1, o2 = ops.qself_attn_fwd(X, B, Q, heads, 0.3, 7), ops.qself_attn_fwd(X, B, Q, heads, 0.3, 7)
+    assert torch.equal(o1, o2) and not torch.equal(o1, ops.qself_attn_fwd(X, B, Q, heads, 0.3, 8))
+    acc = sum(ops.qself_attn_fwd(X, B, Q, heads, 0.3, 100 + s) for s in range(200)) / 200
+    if Q > 1:
+        assert float((acc - out).abs().max()) < 0.25 * float(out.abs().max())
+    d = rnd(B * Q, 3 * C, seed=3).to(DEV)
+    eps = 1e-2
+    fd = float(((ops.qself_attn_fwd(X + eps * d, B, Q, heads, 0.3, 7) - ops.qself_attn_fwd(X - eps * d, B, Q, heads, 0.3, 7)) / (2 * eps) * dout.to(DEV)).sum())
+    an = float((ops.qself_attn_bwd(X, dout.to(DEV), B, Q, heads, 0.3, 7) * d).sum())
+    assert abs(fd - an) <= 2e-2 * abs(fd) + 1e-3, (fd, an)
+
+
+def test_layernorm_pos_and_backward_with_residual():
+    rows, cols, Q = 39, 512, 13
+    x = rnd(rows, cols, seed=1, scale=2.0)
+    g, b, pos = rnd(cols, seed=2) * 0.1 + 1, rnd(cols, seed=3) * 0.1, rnd(Q, cols, seed=4)
+    ref = torch.nn.functional.layer_norm(x, (cols,), g, b, 1e-5)
+    y, y2, mean, rstd = ops.layernorm_pos(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, pos.to(DEV), save_stats=True)
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(y2.cpu(), ref + pos.repeat(rows // Q, 1), rtol=1e-4, atol=1e-5)
+    yb, yb2 = ops.layernorm_pos(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, pos.to(DEV), out_dtype=torch.bfloat16)
+    assert_close_bf16(yb, ref, 5e-3, "ln_pos bf16")
+    assert_close_bf16(yb2, ref + pos.repeat(rows // Q, 1), 5e-3, "ln_pos bf16 + pos")
+    dy, add = rnd(rows, cols, seed=5), rnd(rows, cols, seed=6)
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (cols,), gr, br, 1e-5).backward(dy)
+    dg, db = torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+    dx = ops.layernorm_bwd_add(x.to(DEV), g.to(DEV), mean, rstd, dy.to(DEV), add.to(DEV), dg, db)
+    torch.testing.assert_close(dx.cpu(), xr.grad + add, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-4)
+    buf = add.to(DEV)                                                      # in place (dx aliases dx_add), gradients accumulate
+    ops.layernorm_bwd_add(x.to(DEV), g.to(DEV), mean, rstd, dy.to(DEV), buf, dg, db, out=buf)
+    torch.testing.assert_close(buf.cpu(), xr.grad + add, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dg.cpu(), 2 * gr.grad, rtol=1e-4, atol=2e-4)
+    dx0 = ops.layernorm_bwd_add(x.to(DEV), g.to(DEV), mean, rstd, dy.to(DEV), None, dg, db)
+    torch.testing.assert_close(dx0.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
