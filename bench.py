@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-mcq", action="store_true", help="skip the EgoMCQ forward sub-record (second half of BASELINE.json's metric)")
     ap.add_argument("--enc-cus", type=int, default=None, help="CU budget of the persistent GEMMs on the pipelined encoder stream (multiple of 8; 0 = all)")
+    ap.add_argument("--per-op-query-side", action="store_true", help="A/B: per-op autograd query side instead of the fused QueryStack node")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder forward with this step's decoder")
     args = ap.parse_args()
 
@@ -153,6 +154,7 @@ def main():
     dec_sd = synth.decoder_state(cfg, seed=0)
     backbone = LaviLa.build_backbone(cfg, enc_sd, device=dev)
     decoder = tfm_decoder.build_decoder(cfg, dec_sd, device=dev)
+    decoder.transformer.use_query_stack = not args.per_op_query_side
     B = args.batch
 
     STRIDE = 5      # every 5th launch of a class is timed (co-prime with the 6 GEMMs / 2 attention calls per block); bracketing every launch costs ~3 % in marker packets

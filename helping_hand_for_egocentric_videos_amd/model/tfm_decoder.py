@@ -386,6 +386,7 @@ class Cross_Attention(nn.Module):
         self._reset_parameters()
         self.d_model, self.nhead = d_model, nhead
         self.dec_layers, self.enc_layers = num_decoder_layers, num_encoder_layers
+        self.use_query_stack = True
         self.debug_keep_kv, self.last_holder = False, None        # tests: keep the batched K/V and their gradients after backward
         self._seed = None            # dropout-mask stream of the cross-attention kernels; see next_dropout_seed()
 
@@ -416,6 +417,12 @@ class Cross_Attention(nn.Module):
         in_b = [l.multihead_attn.in_proj_bias for l in layers]
         token = _MemorySide.apply(feat_b, w_proj, self.pre_norm.weight, self.pre_norm.bias, pos, holder,
                                   self.pre_norm.eps, *in_w, *in_b)
+        if not self.use_query_stack:                  # A/B only: per-op autograd path (the round-1 structure; torch RNG dropout)
+            qp = query_embed.unsqueeze(0).expand(B, -1, -1)
+            hs = self.decoder.forward_tokens(torch.zeros_like(qp), qp, token, holder)
+            if not torch.is_grad_enabled():
+                holder.kv = None
+            return hs
         # the 13-row query side of all six layers + decoder.norm: one autograd node on libhh kernels (model/qside.py)
         p = layers[0].p_attn if self.training else 0.0
         norm = self.decoder.norm
