@@ -21,7 +21,7 @@ class QGemmOpts(ctypes.Structure):
     _fields_ = [("a_scale", c_float), ("a_drop_p", c_float), ("a_drop_seed", ctypes.c_uint32), ("a_drop_ld", ctypes.c_int32),
                 ("bias", c_vp), ("scale", c_float), ("scale_ncols", ctypes.c_int32), ("relu", ctypes.c_int32),
                 ("drop_p", c_float), ("drop_seed", ctypes.c_uint32), ("relu_mask", c_vp), ("ldmask", c_i64), ("mask_scale", c_float),
-                ("resid", c_vp), ("ldr", c_i64), ("colsum", c_vp)]
+                ("resid", c_vp), ("ldr", c_i64), ("colsum", c_vp), ("splitk", ctypes.c_int32)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); must list every symbol of include/hh.h
@@ -52,7 +52,7 @@ SIGNATURES = {
     "hh_space_attn_fwd": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "hh_time_attn_fwd": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "hh_cls_combine": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp],
-    "hh_cls_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
+    "hh_cls_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "hh_text_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "hh_xattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
     "hh_xattn_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_float,

@@ -5,7 +5,7 @@
 #include "common.h"
 
 __global__ __launch_bounds__(256) void cls_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                       int B, int N, int heads) {
+                                                       int B, int N, int heads, float exp2_scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [N] scores + 64 q + 32*64 partial o + 8 red
     float* sc = sm;
     float* qs = sm + ((N + 3) & ~3);
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void cls_attn_kernel(const bf16_t* __restrict_
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float l = 0.f;
     for (int j = tid; j < N; j += 256) {
-        const float p = __builtin_amdgcn_exp2f((sc[j] - mx) * 1.4426950408889634f);
+        const float p = __builtin_amdgcn_exp2f((sc[j] - mx) * exp2_scale);      // log2(e), or 1 when q already carries it (space attention)
         sc[j] = p;
         l += p;
     }
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void cls_attn_kernel(const bf16_t* __restrict_
     }
 }
 
-extern "C" int hh_cls_attn_fwd(const void* qkv, void* out, int B, int N, int heads, hh_stream_t stream) {
+extern "C" int hh_cls_attn_fwd(const void* qkv, void* out, int B, int N, int heads, int q_log2, hh_stream_t stream) {
     HH_REQUIRE(B >= 0 && N > 0 && heads > 0, HH_ERR_SHAPE, "hh_cls_attn_fwd: bad shape");
     HH_REQUIRE(HH_ALIGNED16(qkv) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_cls_attn_fwd: pointers must be 16-byte aligned");
     if (B == 0) return HH_OK;
@@ -90,6 +90,6 @@ extern "C" int hh_cls_attn_fwd(const void* qkv, void* out, int B, int N, int hea
         attr_set = lds;
     }
     hipLaunchKernelGGL(cls_attn_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, (hipStream_t)stream,
-                       (const bf16_t*)qkv, (bf16_t*)out, B, N, heads);
+                       (const bf16_t*)qkv, (bf16_t*)out, B, N, heads, q_log2 ? 1.f : 1.4426950408889634f);
     return hh_check_launch("hh_cls_attn_fwd");
 }

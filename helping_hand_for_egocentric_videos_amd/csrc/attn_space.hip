@@ -5,6 +5,8 @@
 // Structure: K tile and V tile, both row-major [KP][64] with XOR-swizzled 16-B chunks, staged once in LDS by LDS-DMA
 // (global_load_lds_dwordx4: no VGPR round trip, no VALU), then each wave walks 16-query blocks on v_mfma_f32_16x16x32_bf16
 // (see "16-query blocks" below).  Frame keys sit at rows 0..n-1, the CLS key at row n, rows > n are zero/masked.
+// The q columns arrive pre-scaled by d^-1/2 * log2(e) (QKV GEMM epilogue), so scores are base-2 logits and a probability is ONE
+// v_exp_f32 -- see "fast path" below for how the softmax's VALU work was moved onto the matrix core.
 // The first generation (32-query blocks on 32x32x16 MFMAs, 4 waves per workgroup: 418 us per call at B = 32, VALU busy 49 %, MFMA
 // 18 %) was measured against this kernel in round 1 (365 -> 352 us) and removed in round 2.
 #include "common.h"
@@ -30,7 +32,9 @@ __device__ __forceinline__ bf16x4 lds_tr4(const char* addr) {
 // MI355X_MICROARCH.md: K rows are read as ds_read_b128 fragments by 32 consecutive rows x 2 chunks -> (r ^ (r >> 3)) & 7 is
 // conflict-free (plain r & 7 is 2-way: rows 8/16/24 apart alias); V rows are read by ds_read_b64_tr_b16 as 4 rows x 64 B per
 // half-wave -> flipping the 64-B half with row bit 1 is conflict-free.
-__device__ __forceinline__ int kswz(int r) { return (r ^ (r >> 3)) & 7; }
+// Round 2: the K key uses row bits 0-3 only ((r & 7) ^ bit 3) -- the same bank picture for the 16 consecutive rows a fragment read
+// touches, but constant for a lane across key tiles, so a fragment address is lane base + tile * 2048 (an immediate offset).
+__device__ __forceinline__ int kswz(int r) { return (r & 7) ^ ((r >> 3) & 1); }
 __device__ __forceinline__ int vswz(int r) { return ((r >> 1) & 1) << 2; }
 
 // stage K and V of one (clip, frame, head) problem by LDS-DMA (1 KiB = 8 rows per wave instruction); rows >= n take the CLS
@@ -66,7 +70,6 @@ __device__ __forceinline__ void space16_chunk(const char* Ks, const char* Vs, co
                                               f32x4 (&o)[4], float& m_run, float& l_run) {
     const int c = lane & 15, g = lane >> 4;
     const int trq = c >> 2, trp = c & 3;
-    const float LOG2E = 1.4426950408889634f;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 s[NTC];
 #pragma unroll
@@ -91,14 +94,13 @@ __device__ __forceinline__ void space16_chunk(const char* Ks, const char* Vs, co
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-    const float mb = m_new * LOG2E;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);              // scores are base-2 logits
     float lsum = 0.f;
 #pragma unroll
     for (int ti = 0; ti < NTC; ++ti)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float pv = __builtin_amdgcn_exp2f(s[ti][j] * LOG2E - mb);
+            const float pv = __builtin_amdgcn_exp2f(s[ti][j] - m_new);
             s[ti][j] = pv;
             lsum += pv;
         }
@@ -127,10 +129,82 @@ __device__ __forceinline__ void space16_chunk(const char* Ks, const char* Vs, co
     }
 }
 
+
+// ---- fast path (round 2).  The chunk above issues 261 vector instructions per 9 key tiles against 38 MFMAs (VALU busy 71 %, MFMA
+// 24 % in profiles/r1_final_sq_summary.md): 87 of them LDS address arithmetic, 36 fma + 36 exp for the probabilities, 36 adds for
+// the row sums, 19 max3.  Here
+//   * fragment addresses are lane constants + tile * 2048: one v_add per fragment stream and chunk, the rest immediates;
+//   * ONE reference maximum per 16-query block, taken from the first two key tiles, enters the score MFMA as its accumulator
+//     initialiser (C = -m_ref), so S - m_ref comes out of the matrix core and a probability is a bare v_exp_f32; exact maths (the
+//     final o / l does not depend on the reference), and safe in fp32 unless a later score exceeds that reference by more than
+//     127 in base 2 -- then l is not finite and the block is redone on the running-maximum path above;
+//   * the row sum l = sum_j P_j is a fifth PV MFMA against an all-ones A operand (it sums the same bf16 probabilities the PV
+//     product uses).
+// Left per chunk of 9 tiles: 36 exp + 18 cvt_pk + ~20 moves / address instructions against 43 MFMAs (first chunk of a block: + 13 max,
+// 8 sub, 28 accumulator-initialiser moves): 182 vector instructions per 17-tile block instead of 483.
+// Measured (scripts/space_probe.py, B = 32): 352 -> 331 us per call.  The VALU count fell 2.65x but the kernel is no longer VALU-bound:
+// staging + Q loads + O stores alone take 252 us, compute alone 251 us -- every MFMA consumes a fresh 1 KB LDS fragment (4 SIMDs x
+// 1 KB / 16 clk = the 256 B/clk LDS peak), so LDS, MFMA and VALU issue are three comparable ~80-100 us streams of in-order waves.
+// Tried on top of this and measured slower: streaming key tiles in pairs (16 live score registers, less ILP: 359 us) and a
+// persistent 16-wave workgroup with double-buffered K/V and prefetched Q (375 us; 8 spilled VGPRs at the 128-register cap).
+template <int NTC, bool CLS, bool FIRST>
+__device__ __forceinline__ void space16_fast(const char* kc0, const char* kc1, const char* vc0, const char* vc1, const char* vc2, const char* vc3,
+                                             const bf16x8 (&q)[2], int lane, f32x4 (&o)[4], f32x4& ol, float& m_ref) {
+    static_assert(!(FIRST && CLS), "the first chunk of a block never holds the CLS tile (n >= 144 on this path)");
+    const int g = lane >> 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
+    f32x4 s[NTC];
+    constexpr int NR = FIRST ? 2 : 0;
+    if (FIRST) {
+#pragma unroll
+        for (int ti = 0; ti < NR; ++ti) {
+            s[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kc0 + ti * 2048), q[0], z4, 0, 0, 0);
+            s[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kc1 + ti * 2048), q[1], s[ti], 0, 0, 0);
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        m_ref = mx;
+#pragma unroll
+        for (int ti = 0; ti < NR; ++ti) s[ti] -= mx;
+    }
+    const f32x4 minit = {-m_ref, -m_ref, -m_ref, -m_ref};
+#pragma unroll
+    for (int ti = NR; ti < NTC; ++ti) {
+        s[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kc0 + ti * 2048), q[0], minit, 0, 0, 0);
+        s[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kc1 + ti * 2048), q[1], s[ti], 0, 0, 0);
+    }
+    if (CLS) {                                        // the chunk's last tile holds nothing but the CLS key (its row 0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (!(g == 0 && j == 0)) s[NTC - 1][j] = -INFINITY;
+    }
+#pragma unroll
+    for (int ti = 0; ti < NTC; ++ti)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[ti][j] = __builtin_amdgcn_exp2f(s[ti][j]);
+#pragma unroll
+    for (int pr = 0; pr < (NTC + 1) / 2; ++pr) {
+        const bool has_b = 2 * pr + 1 < NTC;
+        const f32x4 pa = s[2 * pr], pb = s[has_b ? 2 * pr + 1 : 2 * pr];
+        const bf16x8 pf = {(bf16_t)pa[0], (bf16_t)pa[1], (bf16_t)pa[2], (bf16_t)pa[3],
+                           (bf16_t)(has_b ? pb[0] : 0.f), (bf16_t)(has_b ? pb[1] : 0.f), (bf16_t)(has_b ? pb[2] : 0.f), (bf16_t)(has_b ? pb[3] : 0.f)};
+        const int oa = 2 * pr * 2048, ob = has_b ? oa + 2048 : oa;
+#define S16_PV(DT, VC) do { const bf16x4 a0 = lds_tr4(VC + oa), a1 = lds_tr4(VC + ob);                                   \
+                            const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};                     \
+                            o[DT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf, o[DT], 0, 0, 0); } while (0)
+        S16_PV(0, vc0); S16_PV(1, vc1); S16_PV(2, vc2); S16_PV(3, vc3);
+#undef S16_PV
+        ol = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, ol, 0, 0, 0);
+    }
+}
+
 // CLS query (model/LaviLa.py:255-258) over THIS frame's keys on the matrix core: wave w takes the 16-key tiles w, w + NW16, ...
 // (the CLS key's own tile is counted by frame 0 only) with B = q_cls replicated in all 16 columns, keeps an online-softmax partial
 // (m, l, o[64]) and the workgroup merges its NW16 partials through LDS.  The VALU version (space_cls_partial) issued ~350 vector
 // instructions per wave -- 36 % of this kernel's VALU work.
+template <int NWV>
 __device__ __forceinline__ void space16_cls_partial(const char* Ks, const char* Vs, float* scratch, const bf16_t* base, float* rec,
                                                     int n, bool first_frame, int tid, int lane, int wave) {
     const int c = lane & 15, g = lane >> 4;
@@ -143,7 +217,7 @@ __device__ __forceinline__ void space16_cls_partial(const char* Ks, const char* 
     const int nfull = n >> 4, ntiles = nfull + (first_frame ? 1 : 0);
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 o[4] = {z4, z4, z4, z4};
-    for (int t = wave; t < ntiles; t += NW16) {
+    for (int t = wave; t < ntiles; t += NWV) {
         const int krow = t * 16 + c;
         f32x4 s = z4;
 #pragma unroll
@@ -160,11 +234,10 @@ __device__ __forceinline__ void space16_cls_partial(const char* Ks, const char* 
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-        const float mb = m_new * LOG2E;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // base-2 logits (q carries log2 e)
         float p[4], ls = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { p[j] = __builtin_amdgcn_exp2f(s[j] * LOG2E - mb); ls += p[j]; }
+        for (int j = 0; j < 4; ++j) { p[j] = __builtin_amdgcn_exp2f(s[j] - m_new); ls += p[j]; }
         ls += __shfl_xor(ls, 16, 64);
         ls += __shfl_xor(ls, 32, 64);
         l_run = l_run * alpha + ls;
@@ -191,21 +264,81 @@ __device__ __forceinline__ void space16_cls_partial(const char* Ks, const char* 
     if (tid < 64) {
         float m = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < NW16; ++w) m = fmaxf(m, scratch[w * CLS_REC]);
+        for (int w = 0; w < NWV; ++w) m = fmaxf(m, scratch[w * CLS_REC]);
         float l = 0.f, ot = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW16; ++w) {
-            const float e = __builtin_amdgcn_exp2f((scratch[w * CLS_REC] - m) * LOG2E);
+        for (int w = 0; w < NWV; ++w) {
+            const float e = __builtin_amdgcn_exp2f(scratch[w * CLS_REC] - m);
             l += scratch[w * CLS_REC + 1] * e;
             ot += scratch[w * CLS_REC + 4 + tid] * e;
         }
         rec[4 + tid] = ot;
-        if (tid == 0) { rec[0] = m; rec[1] = l; }
+        if (tid == 0) { rec[0] = m * 0.6931471805599453f; rec[1] = l; }      // the record's maximum is in natural-log units (hh_cls_combine)
     }
 }
 
+// One 16-query block of one (clip, frame, head) problem against the nt key tiles staged in LDS: fast path, running-maximum redo, store.
+__device__ __forceinline__ void space16_block(const char* Ks, const char* Vs, const bf16x8 (&q)[2], int nt, int lane, bf16_t* op) {
+    const int c = lane & 15, g = lane >> 4;
+    // lane-constant fragment addresses of key tile 0 (see kswz / vswz: the swizzle keys do not depend on the tile)
+    const int kz = (c & 7) ^ (c >> 3), trq = c >> 2, trp = c & 3, vz = ((trq >> 1) & 1) << 2;
+    const char* kb0 = Ks + c * 128 + ((g ^ kz) << 4);
+    const char* kb1 = Ks + c * 128 + (((g + 4) ^ kz) << 4);
+    const char* vb0 = Vs + (4 * g + trq) * 128 + (((2 * trp) ^ vz) << 4);
+    const char* vb1 = vb0 + 8;
+    const char* vb2 = Vs + (4 * g + trq) * 128 + (((2 * trp + 1) ^ vz) << 4);
+    const char* vb3 = vb2 + 8;
+    const bool fast = nt > CH16;                       // short frames (n <= 128) take the running-maximum path (first chunk would hold the CLS tile)
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 o[4] = {z4, z4, z4, z4};
+    float l_run = 0.f;
+    bool redo = !fast;
+    if (fast) {
+        f32x4 ol = z4;
+        float m_ref = 0.f;
+        space16_fast<CH16, false, true>(kb0, kb1, vb0, vb1, vb2, vb3, q, lane, o, ol, m_ref);
+        int t0 = CH16;
+        for (; t0 + CH16 < nt; t0 += CH16) {
+            const int off = t0 * 2048;
+            space16_fast<CH16, false, false>(kb0 + off, kb1 + off, vb0 + off, vb1 + off, vb2 + off, vb3 + off, q, lane, o, ol, m_ref);
+        }
+        const int off = t0 * 2048;
+#define S16_FT(R) space16_fast<R, true, false>(kb0 + off, kb1 + off, vb0 + off, vb1 + off, vb2 + off, vb3 + off, q, lane, o, ol, m_ref)
+        switch (nt - t0) {                             // 1 .. CH16 tiles left, the last one is the CLS tile
+            case 1: S16_FT(1); break;
+            case 2: S16_FT(2); break;
+            case 3: S16_FT(3); break;
+            case 4: S16_FT(4); break;
+            case 5: S16_FT(5); break;
+            case 6: S16_FT(6); break;
+            case 7: S16_FT(7); break;
+            case 8: S16_FT(8); break;
+            default: S16_FT(9); break;
+        }
+#undef S16_FT
+        l_run = ol[0];
+        // a score more than 2^127 above the block's reference maximum: l is not finite -> redo this block with the running maximum
+        redo = __builtin_amdgcn_ballot_w64(!(l_run <= 3.0e38f)) != 0;
+    }
+    if (redo) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = z4;
+        float m_run = -INFINITY;
+        l_run = 0.f;
+        for (int t0 = 0; t0 + 1 < nt; ++t0) space16_chunk<1, false>(Ks, Vs, q, t0, lane, o, m_run, l_run);
+        space16_chunk<1, true>(Ks, Vs, q, nt - 1, lane, o, m_run, l_run);
+    }
+    const float inv = 1.f / l_run;
+    const u32x4 w0 = {pack_bf16(o[0][0] * inv, o[0][1] * inv), pack_bf16(o[0][2] * inv, o[0][3] * inv),
+                      pack_bf16(o[1][0] * inv, o[1][1] * inv), pack_bf16(o[1][2] * inv, o[1][3] * inv)};
+    const u32x4 w1 = {pack_bf16(o[2][0] * inv, o[2][1] * inv), pack_bf16(o[2][2] * inv, o[2][3] * inv),
+                      pack_bf16(o[3][0] * inv, o[3][1] * inv), pack_bf16(o[3][2] * inv, o[3][3] * inv)};
+    *(u32x4*)(op) = w0;
+    *(u32x4*)(op + 8) = w1;
+}
+
 __global__ __launch_bounds__(64 * NW16, 4) void space_attn16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                  float* __restrict__ cls_partial, int B, int T, int n, int heads, int KP) {
+                                                                  float* __restrict__ cls_partial, int B, int T, int n, int heads, int KP, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + (size_t)KP * 128;
@@ -221,46 +354,31 @@ __global__ __launch_bounds__(64 * NW16, 4) void space_attn16_kernel(const bf16_t
     const int b = bid / T;
     const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;
     const bf16_t* q_ptr = base + (int64_t)(1 + f * n) * ld;
-    space_stage<NW16>(Ks, Vs, base, q_ptr, ld, D, n, KP, lane, wave);
+    if (dbg != 2) space_stage<NW16>(Ks, Vs, base, q_ptr, ld, D, n, KP, lane, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int c = lane & 15, g = lane >> 4;
     const int nt = (n >> 4) + 1;                       // 16-key tiles incl. the CLS tile
+    if (dbg == 1) {                                    // debug: memory traffic only
+        for (int qb = wave; qb < (n >> 4); qb += NW16) {
+            const bf16_t* qrow = q_ptr + (int64_t)(qb * 16 + c) * ld + 8 * g;
+            const u32x4 a = *(const u32x4*)(qrow), bq = *(const u32x4*)(qrow + 32);
+            bf16_t* op = out + ((int64_t)b * N + 1 + f * n + qb * 16 + c) * D + head * 64 + 16 * g;
+            *(u32x4*)(op) = a; *(u32x4*)(op + 8) = bq;
+        }
+        return;
+    }
     for (int qb = wave; qb < (n >> 4); qb += NW16) {
         bf16x8 q[2];
         const bf16_t* qrow = q_ptr + (int64_t)(qb * 16 + c) * ld + 8 * g;
         q[0] = *(const bf16x8*)(qrow);
         q[1] = *(const bf16x8*)(qrow + 32);
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 o[4] = {z4, z4, z4, z4};
-        float m_run = -INFINITY, l_run = 0.f;
-        int t0 = 0;
-        for (; t0 + CH16 < nt; t0 += CH16) space16_chunk<CH16, false>(Ks, Vs, q, t0, lane, o, m_run, l_run);
-#define S16_TAIL(R) space16_chunk<R, true>(Ks, Vs, q, t0, lane, o, m_run, l_run)
-        switch (nt - t0) {                             // 1 .. CH16 tiles left, the last one is the CLS tile
-            case 1: S16_TAIL(1); break;
-            case 2: S16_TAIL(2); break;
-            case 3: S16_TAIL(3); break;
-            case 4: S16_TAIL(4); break;
-            case 5: S16_TAIL(5); break;
-            case 6: S16_TAIL(6); break;
-            case 7: S16_TAIL(7); break;
-            case 8: S16_TAIL(8); break;
-            default: S16_TAIL(9); break;
-        }
-#undef S16_TAIL
-        const float inv = 1.f / l_run;
-        bf16_t* op = out + ((int64_t)b * N + 1 + f * n + qb * 16 + c) * D + head * 64 + 16 * g;
-        const u32x4 w0 = {pack_bf16(o[0][0] * inv, o[0][1] * inv), pack_bf16(o[0][2] * inv, o[0][3] * inv),
-                          pack_bf16(o[1][0] * inv, o[1][1] * inv), pack_bf16(o[1][2] * inv, o[1][3] * inv)};
-        const u32x4 w1 = {pack_bf16(o[2][0] * inv, o[2][1] * inv), pack_bf16(o[2][2] * inv, o[2][3] * inv),
-                          pack_bf16(o[3][0] * inv, o[3][1] * inv), pack_bf16(o[3][2] * inv, o[3][3] * inv)};
-        *(u32x4*)(op) = w0;
-        *(u32x4*)(op + 8) = w1;
+        space16_block(Ks, Vs, q, nt, lane, out + ((int64_t)b * N + 1 + f * n + qb * 16 + c) * D + head * 64 + 16 * g);
     }
     if (cls_partial == nullptr) return;
-    space16_cls_partial(Ks, Vs, scratch, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
+    space16_cls_partial<NW16>(Ks, Vs, scratch, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
 }
+
 
 // merge G partial records per (clip, head) into out row 0:  o = sum_g o_g e^{m_g - m} / sum_g l_g e^{m_g - m}
 __global__ __launch_bounds__(64) void cls_combine_kernel(const float* __restrict__ partial, int G, bf16_t* __restrict__ out,
@@ -290,6 +408,8 @@ extern "C" int hh_cls_combine(const float* partial, int G, void* out, int B, int
     return hh_check_launch("hh_cls_combine");
 }
 
+int hh_tuning_space_debug();
+
 extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream) {
     HH_REQUIRE(B >= 0 && T > 0 && heads > 0 && n > 0 && n % 32 == 0, HH_ERR_SHAPE, "hh_space_attn_fwd: n=%d must be a multiple of 32", n);
     HH_REQUIRE(HH_ALIGNED16(qkv) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_space_attn_fwd: pointers must be 16-byte aligned");
@@ -305,6 +425,6 @@ extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial,
     }
     HHProfScope prof(HH_PROF_SPACE_ATTN, 8.0 * B * (1.0 + (double)T * n) * heads * 64, (hipStream_t)stream);
     hipLaunchKernelGGL(space_attn16_kernel, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW16), lds16, (hipStream_t)stream,
-                       (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP);
+                       (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP, hh_tuning_space_debug());
     return hh_check_launch("hh_space_attn_fwd");
 }

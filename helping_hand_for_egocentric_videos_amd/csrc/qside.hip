@@ -12,7 +12,7 @@
 //                      NN  C[m,n] = sum_k A[m,k] B[k,n]   dgrad        (A = dY [M,K], B = weight [K,N])
 //                      TN  C[m,n] = sum_k A[k,m] B[k,n]   wgrad        (A = dY [K,M], B = X [K,N]; + column sums of A = bias gradient)
 //                    Prologue on A: scale, dropout mask (regenerated from the forward's counter-based hash).  Epilogue: bias, column
-//                    scale, ReLU, dropout, ReLU-mask of a stored activation, fp32 residual.  64 x 64 x 32 tiles, 4 waves; the
+//                    scale, ReLU, dropout, ReLU-mask of a stored activation, fp32 residual.  64 x 64 x 64 tiles, 4 waves; the
 //                    shapes are tiny (M = B*13 rows), so the kernel is built for launch economy, not for the MFMA roofline.
 //   hh_qself_attn_fwd / _bwd   the 13 x 13 self-attention of nn.MultiheadAttention (tfm_decoder.py:433-436) per (clip, head), one
 //                    wave each, fp32 VALU, attention-dropout by the same hash.
@@ -30,6 +30,7 @@ struct QGemm {
     const float* mask; int64_t ldmask; float mask_scale;
     const float* resid; int64_t ldr;
     float* colsum;
+    int k_per_split;           // k-steps (of 64) per blockIdx.z slice; gridDim.z > 1: partial products are ADDED atomically into a zeroed C / colsum
 };
 
 __device__ __forceinline__ bool q_keep(unsigned seed, unsigned idx, unsigned thresh) {
@@ -47,23 +48,31 @@ __device__ __forceinline__ void q_split(const f32x4& v, u32x2& hi, u32x2& lo) {
     lo = (u32x2){pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3])};
 }
 
-#define QROW 40          // bf16 per LDS tile row: 32 k + 8 pad (80 B: 16-B aligned fragments)
+#define QBK 64           // contraction elements per k-step
+#define QROW 72          // bf16 per LDS tile row: 64 k + 8 pad (144 B: 16-B aligned fragments, rows spread over the banks)
 
+// One operand tile (64 rows x 64 k) per k-step and thread = 16 fp32 values:
+//   direct     (contraction index contiguous in memory): row tid >> 2, k = 16 (tid & 3) .. + 15        -> 4 x float4 along k
+//   transposed (contraction index is the memory ROW):     k = 4 (tid >> 4) .. + 3, rows 4 (tid & 15) .. + 3 -> 4 x float4, one per k,
+//              transposed in registers so that both flavours store 4 consecutive k per row (8-byte LDS writes, no 2-byte scatter)
 template <int MODE>
 __global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
-    __shared__ __attribute__((aligned(16))) bf16_t sA[2][2][64][QROW];     // [buffer][hi | lo][tile row][k]
-    __shared__ __attribute__((aligned(16))) bf16_t sB[2][2][64][QROW];
+    __shared__ __attribute__((aligned(16))) bf16_t sA[2][64][QROW];        // [hi | lo][tile row][k]
+    __shared__ __attribute__((aligned(16))) bf16_t sB[2][64][QROW];
     __shared__ float scs[64];
     constexpr bool A_T = MODE == 2, B_T = MODE != 0;                         // operand stored with the contraction index as its ROW
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int nk = (p.K + 31) / 32;
+    const int nk_all = (p.K + QBK - 1) / QBK;
+    const int kt0 = blockIdx.z * p.k_per_split;
+    const int nk = min(nk_all - kt0, p.k_per_split);                          // this slice's k-steps (split-K over blockIdx.z)
+    const bool split = gridDim.z > 1;
     const bool want_cs = A_T && p.colsum != nullptr && blockIdx.x == 0;
     if (tid < 64) scs[tid] = 0.f;
 
-    f32x4 ra[2], rb[2];
-    f32x4 cs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 ra[4], rb[4];
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
     auto prologue = [&](f32x4& v, int r, int c) {                            // (r, c) = row / first column of v in A's memory layout
@@ -75,74 +84,75 @@ __global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
         }
     };
     auto load_tiles = [&](int kt) {
-        const int k0 = kt * 32;
+        const int k0 = (kt0 + kt) * QBK;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             if constexpr (!A_T) {
-                const int i = (tid >> 3) + 32 * u, k = 4 * (tid & 7), r = m0 + i, kk = k0 + k;
-                ra[u] = (r < p.M && kk < p.K) ? *(const f32x4*)(p.A + (int64_t)r * p.lda + kk) : z4;
-                if (r < p.M && kk < p.K) prologue(ra[u], r, kk);
+                const int r = m0 + (tid >> 2), kk = k0 + 16 * (tid & 3) + 4 * u;
+                const bool ok = r < p.M && kk < p.K;
+                ra[u] = ok ? *(const f32x4*)(p.A + (int64_t)r * p.lda + kk) : z4;
+                if (ok) prologue(ra[u], r, kk);
             } else {
-                const int kl = (tid >> 4) + 16 * u, i = 4 * (tid & 15), r = k0 + kl, c = m0 + i;
-                ra[u] = (r < p.K && c < p.M) ? *(const f32x4*)(p.A + (int64_t)r * p.lda + c) : z4;
-                if (r < p.K && c < p.M) prologue(ra[u], r, c);
-                if (want_cs) cs[u] += ra[u];
+                const int r = k0 + 4 * (tid >> 4) + u, c = m0 + 4 * (tid & 15);
+                const bool ok = r < p.K && c < p.M;
+                ra[u] = ok ? *(const f32x4*)(p.A + (int64_t)r * p.lda + c) : z4;
+                if (ok) prologue(ra[u], r, c);
+                if (want_cs) cs += ra[u];
             }
             if constexpr (!B_T) {
-                const int j = (tid >> 3) + 32 * u, k = 4 * (tid & 7), r = n0 + j, kk = k0 + k;
+                const int r = n0 + (tid >> 2), kk = k0 + 16 * (tid & 3) + 4 * u;
                 rb[u] = (r < p.N && kk < p.K) ? *(const f32x4*)(p.B + (int64_t)r * p.ldb + kk) : z4;
             } else {
-                const int kl = (tid >> 4) + 16 * u, j = 4 * (tid & 15), r = k0 + kl, c = n0 + j;
+                const int r = k0 + 4 * (tid >> 4) + u, c = n0 + 4 * (tid & 15);
                 rb[u] = (r < p.K && c < p.N) ? *(const f32x4*)(p.B + (int64_t)r * p.ldb + c) : z4;
             }
         }
     };
-    auto store_one = [&](bf16_t (*dst)[64][QROW], const f32x4& v, bool transposed, int u) {
-        u32x2 hi, lo;
-        q_split(v, hi, lo);
+    auto store_op = [&](bf16_t (*dst)[64][QROW], const f32x4 (&v)[4], bool transposed) {
         if (!transposed) {
-            const int i = (tid >> 3) + 32 * u, k = 4 * (tid & 7);
-            *(u32x2*)&dst[0][i][k] = hi;
-            *(u32x2*)&dst[1][i][k] = lo;
+            const int i = tid >> 2, k = 16 * (tid & 3);
+            u32x2 h[4], l[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q_split(v[u], h[u], l[u]);
+            *(u32x4*)&dst[0][i][k] = (u32x4){h[0][0], h[0][1], h[1][0], h[1][1]};
+            *(u32x4*)&dst[0][i][k + 8] = (u32x4){h[2][0], h[2][1], h[3][0], h[3][1]};
+            *(u32x4*)&dst[1][i][k] = (u32x4){l[0][0], l[0][1], l[1][0], l[1][1]};
+            *(u32x4*)&dst[1][i][k + 8] = (u32x4){l[2][0], l[2][1], l[3][0], l[3][1]};
         } else {
-            const int kl = (tid >> 4) + 16 * u, i = 4 * (tid & 15);
-            const unsigned short* h = (const unsigned short*)&hi;
-            const unsigned short* l = (const unsigned short*)&lo;
+            const int k = 4 * (tid >> 4), i = 4 * (tid & 15);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                *(unsigned short*)&dst[0][i + e][kl] = h[e];
-                *(unsigned short*)&dst[1][i + e][kl] = l[e];
+            for (int e = 0; e < 4; ++e) {                                    // row i + e of the tile: the 4 consecutive k this thread loaded
+                const f32x4 t = {v[0][e], v[1][e], v[2][e], v[3][e]};
+                u32x2 h, l;
+                q_split(t, h, l);
+                *(u32x2*)&dst[0][i + e][k] = h;
+                *(u32x2*)&dst[1][i + e][k] = l;
             }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            store_one(sA[buf], ra[u], A_T, u);
-            store_one(sB[buf], rb[u], B_T, u);
         }
     };
 
     f32x4 acc[4] = {z4, z4, z4, z4};
     const int fr = lane & 15, fk = 8 * (lane >> 4);
     load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
-        const bf16x8 ah = *(const bf16x8*)&sA[buf][0][16 * wave + fr][fk];
-        const bf16x8 al = *(const bf16x8*)&sA[buf][1][16 * wave + fr][fk];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const bf16x8 bh = *(const bf16x8*)&sB[buf][0][16 * t + fr][fk];
-            const bf16x8 bl = *(const bf16x8*)&sB[buf][1][16 * t + fr][fk];
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[t], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();                                                    // everyone is done reading the previous k-step's tiles
+        store_op(sA, ra, A_T);
+        store_op(sB, rb, B_T);
         __syncthreads();
+        if (kt + 1 < nk) load_tiles(kt + 1);                                // global loads of the next k-step fly under the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 ah = *(const bf16x8*)&sA[0][16 * wave + fr][32 * ks + fk];
+            const bf16x8 al = *(const bf16x8*)&sA[1][16 * wave + fr][32 * ks + fk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 bh = *(const bf16x8*)&sB[0][16 * t + fr][32 * ks + fk];
+                const bf16x8 bl = *(const bf16x8*)&sB[1][16 * t + fr][32 * ks + fk];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[t], 0, 0, 0);
+            }
+        }
     }
     // epilogue: lane owns C[m][n .. n+3], m = tile row (lane & 15), n = 16 t + 4 (lane >> 4)
     const int m = m0 + 16 * wave + fr;
@@ -169,14 +179,21 @@ __global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
                 for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] * p.mask_scale : 0.f;
             }
             if (p.resid) v += *(const f32x4*)(p.resid + (int64_t)m * p.ldr + n);
-            *(f32x4*)(p.C + (int64_t)m * p.ldc + n) = v;
+            if (split) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) unsafeAtomicAdd(p.C + (int64_t)m * p.ldc + n + e, v[e]);
+            } else {
+                *(f32x4*)(p.C + (int64_t)m * p.ldc + n) = v;
+            }
         }
     }
     if (want_cs) {                                                          // bias gradient: colsum[m] = sum_k A_eff[k, m]
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(&scs[4 * (tid & 15) + e], cs[0][e] + cs[1][e]);
+        for (int e = 0; e < 4; ++e) atomicAdd(&scs[4 * (tid & 15) + e], cs[e]);
         __syncthreads();
-        if (tid < 64 && m0 + tid < p.M) p.colsum[m0 + tid] = scs[tid];
+        if (tid < 64 && m0 + tid < p.M) {
+            if (split) unsafeAtomicAdd(p.colsum + m0 + tid, scs[tid]); else p.colsum[m0 + tid] = scs[tid];
+        }
     }
 }
 
@@ -213,7 +230,14 @@ extern "C" int hh_qgemm_f32x3(const float* A, int64_t lda, const float* B, int64
     p.drop_seed = o->drop_seed;
     p.mask = o->relu_mask; p.ldmask = o->ldmask; p.mask_scale = o->mask_scale == 0.f ? 1.f : o->mask_scale;
     p.resid = o->resid; p.ldr = o->ldr; p.colsum = o->colsum;
-    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+    const int nk_all = (K + QBK - 1) / QBK;
+    int splits = o->splitk > 1 ? o->splitk : 1;
+    if (splits > nk_all) splits = nk_all;
+    HH_REQUIRE(splits == 1 || (!o->bias && !o->relu && o->drop_p == 0.f && !o->relu_mask && !o->resid && p.scale_ncols == 0), HH_ERR_UNSUPPORTED,
+               "hh_qgemm_f32x3: split-K adds partial products atomically into a zeroed C: no epilogue options");
+    p.k_per_split = (nk_all + splits - 1) / splits;
+    splits = (nk_all + p.k_per_split - 1) / p.k_per_split;
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)splits);
     hipStream_t s = (hipStream_t)stream;
     if (mode == 0) hipLaunchKernelGGL(qgemm_kernel<0>, grid, dim3(256), 0, s, p);
     else if (mode == 1) hipLaunchKernelGGL(qgemm_kernel<1>, grid, dim3(256), 0, s, p);

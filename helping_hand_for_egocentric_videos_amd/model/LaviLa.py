@@ -124,7 +124,9 @@ class VarAttention(nn.Module):
     def core(self, xn, pk, B, T, n, mode):
         """xn bf16 [B*N, D] (already normalised) -> attention output bf16 [B*N, D] (before proj)."""
         D = xn.shape[1]
-        qkv = ops.gemm(xn, pk["wqkv"], pk["bqkv"], colscale=self.scale, colscale_cols=D)
+        # q *= d^-1/2 (LaviLa.py:252) in the GEMM epilogue; the space kernel takes base-2 logits (x log2 e, ops.attention_q_scale)
+        qscale = self.scale * (ops.LOG2E if mode == "space" else 1.0)
+        qkv = ops.gemm(xn, pk["wqkv"], pk["bqkv"], colscale=qscale, colscale_cols=D)
         return ops.divided_attention(qkv, B, T, n, self.num_heads, mode)
 
     def forward(self, x, einops_from, einops_to, einops_dims):

@@ -55,8 +55,15 @@ class _LinearX3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.qgemm(dz, w, ops.NN).view(ctx.xshape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            db = torch.empty(N, dtype=torch.float32, device=dz.device) if ctx.has_bias else None
-            dw = ops.qgemm(dz, x2, ops.TN, colsum=db)
+            rows, K = x2.shape
+            tiles = ((N + 63) // 64) * ((K + 63) // 64)
+            if rows >= 2048 and tiles < 256:          # long contraction, few output tiles (box heads: 6656 rows): split-K, atomic accumulate
+                buf = torch.zeros(N * K + N, dtype=torch.float32, device=dz.device)
+                dw, db = buf[:N * K].view(N, K), (buf[N * K:] if ctx.has_bias else None)
+                ops.qgemm(dz, x2, ops.TN, colsum=db, out=dw, splitk=max(2, min(32, rows // 256, 512 // tiles)))
+            else:
+                db = torch.empty(N, dtype=torch.float32, device=dz.device) if ctx.has_bias else None
+                dw = ops.qgemm(dz, x2, ops.TN, colsum=db)
         return dx, dw, db, None
 
 

@@ -143,9 +143,11 @@ NT, NN, TN = 0, 1, 2
 
 
 def qgemm(a, b, mode=NT, *, out=None, bias=None, scale=0.0, scale_ncols=0, relu=False, drop_p=0.0, drop_seed=0, relu_mask=None, mask_scale=1.0,
-          resid=None, a_scale=0.0, a_drop_p=0.0, a_drop_seed=0, a_drop_ld=0, colsum=None):
+          resid=None, a_scale=0.0, a_drop_p=0.0, a_drop_seed=0, a_drop_ld=0, colsum=None, splitk=1):
     """Query-side GEMM at fp32-grade accuracy on the bf16 matrix cores (include/hh.h: hh_qgemm_f32x3).  All operands fp32, 2-D with
-    unit inner stride.  mode NT: a [M,K], b [N,K];  NN: a [M,K], b [K,N];  TN: a [K,M], b [K,N]  ->  out fp32 [M,N]."""
+    unit inner stride.  mode NT: a [M,K], b [N,K];  NN: a [M,K], b [K,N];  TN: a [K,M], b [K,N]  ->  out fp32 [M,N].
+    splitk > 1: the contraction is split over workgroups that ADD into `out` / `colsum` atomically (both must be zero on entry; a fresh
+    `out` is allocated zeroed here); no epilogue options."""
     for t in (a, b, out, resid, relu_mask):
         if t is None:
             continue
@@ -163,8 +165,9 @@ def qgemm(a, b, mode=NT, *, out=None, bias=None, scale=0.0, scale_ncols=0, relu=
     if K != Kb:
         raise ValueError("qgemm: contraction mismatch %s vs %s (mode %d)" % (tuple(a.shape), tuple(b.shape), mode))
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        out = (torch.zeros if splitk > 1 else torch.empty)((M, N), dtype=torch.float32, device=a.device)
     o = QGemmOpts()
+    o.splitk = int(splitk)
     o.a_scale, o.a_drop_p, o.a_drop_seed, o.a_drop_ld = float(a_scale), float(a_drop_p), int(a_drop_seed) & 0xFFFFFFFF, int(a_drop_ld)
     o.bias = bias.data_ptr() if bias is not None else None
     o.scale, o.scale_ncols, o.relu = float(scale), int(scale_ncols), int(bool(relu))
@@ -334,8 +337,17 @@ def gemm_tn(at, bt, splits=None):
     return part[0] if splits == 1 else part.sum(0)
 
 
+LOG2E = 1.4426950408889634
+
+
+def attention_q_scale(mode, head_dim=64):
+    """Scale the QKV GEMM epilogue applies to the q columns for divided_attention(mode): d^-1/2 (LaviLa.py:252) for "time"; the
+    space kernel takes base-2 logits, d^-1/2 * log2(e) (include/hh.h)."""
+    return head_dim ** -0.5 * (LOG2E if mode == "space" else 1.0)
+
+
 def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
-    """qkv bf16 [B*N, 3D] (q pre-scaled) -> bf16 [B*N, D].  Rows 1.. come from the space/time kernel; the CLS row
+    """qkv bf16 [B*N, 3D] (q pre-scaled by attention_q_scale(mode)) -> bf16 [B*N, D].  Rows 1.. come from the space/time kernel; the CLS row
     (query 0 attends all N keys) is folded into the same kernels as per-group partials + hh_cls_combine
     (fold_cls=False runs the stand-alone hh_cls_attn_fwd pass instead)."""
     _chk(qkv, out)
@@ -353,7 +365,7 @@ def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
         G = T if mode == "space" else (n + (128 // T) - 1) // (128 // T)
         part = _workspace("attn_cls_partial", B, T, n, heads, int(mode == "time"), device=qkv.device).view(B, heads, G, 68)
     else:
-        _lib.check(L.hh_cls_attn_fwd(_p(qkv), _p(out), B, N, heads, _stream()), "hh_cls_attn_fwd")
+        _lib.check(L.hh_cls_attn_fwd(_p(qkv), _p(out), B, N, heads, int(mode == "space"), _stream()), "hh_cls_attn_fwd")
     if mode == "space":
         _lib.check(L.hh_space_attn_fwd(_p(qkv), _p(out), _p(part), B, T, n, heads, _stream()), "hh_space_attn_fwd")
     else:

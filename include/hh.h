@@ -156,7 +156,9 @@ int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int64_t ldb, fl
                     int splits, hh_stream_t stream);
 
 /* ---- divided space-time attention cores (model/LaviLa.py:246-283, attn() :194-198)
- * qkv bf16 [B, N=1+T*n, 3*D] (q|k|v, head-major inside D, q pre-scaled), out bf16 [B, N, D]; head dim 64.
+ * qkv bf16 [B, N=1+T*n, 3*D] (q|k|v, head-major inside D), out bf16 [B, N, D]; head dim 64.  The q columns are PRE-SCALED by the
+ * QKV GEMM epilogue: by d^-1/2 for hh_time_attn_fwd (LaviLa.py:252), by d^-1/2 * log2(e) for hh_space_attn_fwd -- its scores are
+ * base-2 logits, so that a probability costs one v_exp_f32 (hh_cls_attn_fwd: q_log2 = 1 for such a buffer, 0 otherwise).
  * space: per (b, head, frame): n queries x (CLS + n) keys.  time: per (b, head, patch): T queries x (CLS + T) keys.
  * cls: the CLS query attends all N keys (row 0 of out).  Rows 1.. are written by space/time, row 0 by cls.
  * cls_partial (optional, fp32 [B, heads, G, 68], G = T for space, ceil(n / (128/T)) for time): when non-NULL the kernel
@@ -164,7 +166,7 @@ int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int64_t ldb, fl
  * hh_cls_combine merges the G records into out row 0, which replaces the separate hh_cls_attn_fwd pass. */
 int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream);
 int hh_time_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream);
-int hh_cls_attn_fwd(const void* qkv, void* out, int B, int N, int heads, hh_stream_t stream);
+int hh_cls_attn_fwd(const void* qkv, void* out, int B, int N, int heads, int q_log2, hh_stream_t stream);
 int hh_cls_combine(const float* partial, int G, void* out, int B, int N, int heads, hh_stream_t stream);
 
 /* ---- causal self-attention of the CLIP text tower (model/openai_model.py:182-232; mask model/LaviLa.py:636-642)
@@ -197,7 +199,8 @@ int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_t ldkv, con
  *                   epilogue drew for element (m, n) of an output with N = a_drop_ld columns]
  *   epilogue:       + bias[n] -> * scale for n < scale_ncols (scale 0 = off, scale_ncols 0 = all) -> ReLU -> dropout(drop_p,
  *                   drop_seed, element index m * N + n) -> * (relu_mask[m,n] > 0 ? mask_scale : 0) -> + resid[m,n]
- *   colsum (mode 2 only, optional): colsum[m] = sum_k A_eff[k, m]  (bias gradient of the same nn.Linear) */
+ *   colsum (mode 2 only, optional): colsum[m] = sum_k A_eff[k, m]  (bias gradient of the same nn.Linear)
+ *   splitk: see the struct */
 typedef struct hh_qgemm_opts {
     float a_scale;
     float a_drop_p; uint32_t a_drop_seed; int32_t a_drop_ld;
@@ -208,6 +211,9 @@ typedef struct hh_qgemm_opts {
     const float* relu_mask; int64_t ldmask; float mask_scale;
     const float* resid; int64_t ldr;
     float* colsum;
+    int32_t splitk;           /* > 1: the contraction is cut into that many slices whose partial products are added ATOMICALLY into C
+                                 (and colsum): the caller zeroes them first; no epilogue options.  For long contractions with few
+                                 output tiles (weight gradients of the box heads: 512 x 512 outputs over 6656 rows) */
 } hh_qgemm_opts;
 int hh_qgemm_f32x3(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, int mode,
                    const hh_qgemm_opts* opts, hh_stream_t stream);

@@ -266,9 +266,12 @@ def test_uint8_front_end_equals_float_path(channels_last):
 
 
 def _ref_divided(qkv, B, T, n, heads, mode):
-    """fp32 reference of the attention core on the same bf16 qkv (q pre-scaled): oracle maths, LaviLa.py:255-279."""
+    """fp32 reference of the attention core on the same bf16 qkv (q pre-scaled): oracle maths, LaviLa.py:255-279.  The space kernel's
+    q carries an extra log2(e) (base-2 logits, include/hh.h): taken out again here."""
     N, D = 1 + T * n, heads * 64
     q, k, v = qkv.float().view(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    if mode == "space":
+        q = q / ops.LOG2E
     cls = torch.softmax(q[:, :, :1] @ k.transpose(-1, -2), -1) @ v
     ql, kl, vl = (t[:, :, 1:].reshape(B, heads, T, n, 64) for t in (q, k, v))
     if mode == "time":
@@ -284,12 +287,16 @@ def _ref_divided(qkv, B, T, n, heads, mode):
 
 
 @pytest.mark.parametrize("mode", ["space", "time"])
-@pytest.mark.parametrize("B,T,n,heads", [(2, 4, 256, 2), (1, 16, 256, 16), (1, 2, 576, 2), (1, 32, 64, 2)])
+@pytest.mark.parametrize("B,T,n,heads", [(2, 4, 256, 2), (1, 16, 256, 16), (1, 2, 576, 2), (1, 32, 64, 2), (1, 3, 160, 2), (1, 2, 128, 1)])
 def test_divided_attention(mode, B, T, n, heads):
+    if mode == "time" and T not in (1, 2, 4, 8, 16, 32):
+        pytest.skip("hh_time_attn_fwd: num_frames in {1,2,4,8,16,32}")
     N, D = 1 + T * n, heads * 64
     qkv = rnd(B * N, 3 * D, seed=T + n)
     qkv[:, :D] *= 0.6            # realistic logits (|s| up to ~15)
     qkv[5, :64] += 6.0            # spike one query
+    if mode == "space":
+        qkv[:, :D] *= ops.LOG2E   # the kernel's contract: q pre-scaled by d^-1/2 * log2(e)
     qkv = bf(qkv)
     out = ops.divided_attention(qkv.to(DEV), B, T, n, heads, mode)
     ref = _ref_divided(qkv, B, T, n, heads, mode)
@@ -302,6 +309,26 @@ def test_divided_attention(mode, B, T, n, heads):
     err = (out.float().cpu() - ref).abs().amax(1)
     scale = ref.abs().amax(1) + 1e-3
     assert (err / scale).max() < 5e-2
+
+
+def test_space_attention_redo_path_when_the_reference_maximum_is_exceeded():
+    """The fast path of the space kernel fixes one reference maximum per 16-query block (from the first 32 keys) and redoes the block
+    with a running maximum when a later score exceeds it by more than 2^127: plant such keys and compare with the fp32 reference."""
+    B, T, n, heads = 1, 2, 256, 2
+    N, D = 1 + T * n, heads * 64
+    qkv = rnd(B * N, 3 * D, seed=3)
+    qkv[:, :D] *= 0.3
+    q0 = qkv[1 + 40, :64].clone()                                  # query 40 of frame 0, head 0
+    qkv[1 + 200, D:D + 64] = q0 * (160.0 / float(q0 @ q0))        # key 200 (beyond the first chunk): logit ~ +160 for that query
+    qkv[1 + n + 7, :64] *= 30.0                                    # frame 1: a query with huge logits everywhere
+    qkv[:, :D] *= ops.LOG2E
+    qkv = bf(qkv)
+    out = ops.divided_attention(qkv.to(DEV), B, T, n, heads, "space")
+    ref = _ref_divided(qkv, B, T, n, heads, "space")
+    assert torch.isfinite(out.float()).all()
+    assert_close_bf16(out, ref, 1.2e-2, "attn-space-redo")
+    err = (out.float().cpu() - ref).abs().amax(1)
+    assert (err / (ref.abs().amax(1) + 1e-3)).max() < 5e-2
 
 
 @pytest.mark.parametrize("B,T,n,heads", [(2, 4, 50, 2), (1, 16, 37, 1), (2, 8, 96, 3), (1, 1, 70, 2), (1, 2, 5, 1), (3, 16, 256, 2),
@@ -492,6 +519,15 @@ def test_qgemm_prologue_epilogue_options():
     rdw = (dy.double().t() @ a.double()).float()
     torch.testing.assert_close(dw.cpu(), rdw, rtol=1e-4, atol=2e-5 * rdw.abs().max().item())
     torch.testing.assert_close(cs.cpu(), dy.sum(0), rtol=1e-5, atol=1e-5)
+    # split-K (atomic accumulation into a zeroed output) for long contractions with few output tiles
+    big_dy, big_x = rnd(6656, 128, seed=8), rnd(6656, 64, seed=9)
+    cs2 = torch.zeros(128, device=DEV)
+    dw2 = ops.qgemm(big_dy.to(DEV), big_x.to(DEV), ops.TN, colsum=cs2, splitk=13)
+    r2w = (big_dy.double().t() @ big_x.double()).float()
+    torch.testing.assert_close(dw2.cpu(), r2w, rtol=1e-4, atol=2e-5 * r2w.abs().max().item())
+    torch.testing.assert_close(cs2.cpu(), big_dy.sum(0), rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError, match="split-K"):
+        ops.qgemm(A, W, bias=bias.to(DEV), splitk=2)
     # dropout: the backward's A-prologue regenerates the forward epilogue's mask from (seed, element index)
     p, seed = 0.25, 1234
     y0, yd = ops.qgemm(A, W), ops.qgemm(A, W, drop_p=p, drop_seed=seed)
