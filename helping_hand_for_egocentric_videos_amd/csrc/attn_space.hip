@@ -64,7 +64,15 @@ __device__ __forceinline__ void space_stage(char* Ks, char* Vs, const bf16_t* ba
 // 4g+jj, jj >= 4 -> second tile) with V^T fetched by the transposing LDS read, d permuted so that a lane ends with 16 consecutive d
 // of its query; the 1/l normalisation is applied to the 16 output registers instead of the probabilities.
 #define NW16 8
+#ifndef CH16
 #define CH16 9
+#endif
+#ifndef SB_S
+#define SB_S 4          // key tiles between scheduling barriers in the score loop
+#endif
+#ifndef SB_P
+#define SB_P 2          // tile pairs between scheduling barriers in the PV loop
+#endif
 template <int NTC, bool CLS>
 __device__ __forceinline__ void space16_chunk(const char* Ks, const char* Vs, const bf16x8 (&q)[2], int t0, int lane,
                                               f32x4 (&o)[4], float& m_run, float& l_run) {
@@ -142,7 +150,8 @@ __device__ __forceinline__ void space16_chunk(const char* Ks, const char* Vs, co
 //     product uses).
 // Left per chunk of 9 tiles: 36 exp + 18 cvt_pk + ~20 moves / address instructions against 43 MFMAs (first chunk of a block: + 13 max,
 // 8 sub, 28 accumulator-initialiser moves): 182 vector instructions per 17-tile block instead of 483.
-// Measured (scripts/space_probe.py, B = 32): 352 -> 331 us per call.  The VALU count fell 2.65x but the kernel is no longer VALU-bound:
+// Measured (scripts/space_probe.py, B = 32): 352 -> 331 us per call, 316 us with scheduling barriers every 4 score tiles / 2 PV pairs
+// (they stop the scheduler from hoisting every LDS fragment read to the top of a chunk: 5 -> 2 spilled VGPRs at the 128-register cap).  The VALU count fell 2.65x but the kernel is no longer VALU-bound:
 // staging + Q loads + O stores alone take 252 us, compute alone 251 us -- every MFMA consumes a fresh 1 KB LDS fragment (4 SIMDs x
 // 1 KB / 16 clk = the 256 B/clk LDS peak), so LDS, MFMA and VALU issue are three comparable ~80-100 us streams of in-order waves.
 // Tried on top of this and measured slower: streaming key tiles in pairs (16 live score registers, less ILP: 359 us) and a
@@ -174,6 +183,7 @@ __device__ __forceinline__ void space16_fast(const char* kc0, const char* kc1, c
     for (int ti = NR; ti < NTC; ++ti) {
         s[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kc0 + ti * 2048), q[0], minit, 0, 0, 0);
         s[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kc1 + ti * 2048), q[1], s[ti], 0, 0, 0);
+        if (ti % SB_S == SB_S - 1) __builtin_amdgcn_sched_barrier(0);     // keep the scheduler from hoisting every K fragment read (128-VGPR cap)
     }
     if (CLS) {                                        // the chunk's last tile holds nothing but the CLS key (its row 0)
 #pragma unroll
@@ -197,6 +207,7 @@ __device__ __forceinline__ void space16_fast(const char* kc0, const char* kc1, c
         S16_PV(0, vc0); S16_PV(1, vc1); S16_PV(2, vc2); S16_PV(3, vc3);
 #undef S16_PV
         ol = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, ol, 0, 0, 0);
+        if (pr % SB_P == SB_P - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -313,7 +324,7 @@ __device__ __forceinline__ void space16_block(const char* Ks, const char* Vs, co
             case 6: S16_FT(6); break;
             case 7: S16_FT(7); break;
             case 8: S16_FT(8); break;
-            default: S16_FT(9); break;
+            default: S16_FT(CH16); break;
         }
 #undef S16_FT
         l_run = ol[0];
