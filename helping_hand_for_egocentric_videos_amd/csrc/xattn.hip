@@ -11,11 +11,19 @@
 //  backward: per 16-key tile, non-swapped S, dP give P and dS with key on the lane -> they are the B operands of
 //            dV^T = dO^T.P and dK^T = Q^T.dS (mfma 16x16x16, contraction over the 16 query slots); swapped S^T, dP^T
 //            give dS^T for dQ^T += K^T.dS^T (contraction over keys, K^T via the wave-private LDS transpose).
+// Round 2: every operand that comes from the 13-row query side (q, dO, the probabilities P and the score gradients dS) enters the
+// MFMAs as a bf16 hi + lo pair (x = hi + lo + O(2^-17 x)), so the products are exact with respect to the bf16 K / V the memory side
+// stores: 2 MFMAs where one side is K or V, 3 (hi.hi + lo.hi + hi.lo) where both sides are query-side values.  The kernels stay
+// HBM-bound (K, V streamed once); the point is parity -- with K/V shared, decoder gradients now agree with the fp32 oracle at the
+// level of its own ReLU-kink noise instead of one bf16 rounding per operand.
 #include "common.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 #define VSTRIDE 36
+
+// hi = bf16(x), lo = bf16(x - hi); a macro because vector elements cannot bind to references
+#define split_hl(X, HI, LO) do { const float x_ = (X); const bf16_t h_ = (bf16_t)x_; (HI) = h_; (LO) = (bf16_t)(x_ - (float)h_); } while (0)
 
 // counter-based dropout mask for element (clip*heads+head, query, key): keep iff hash >= thresh (thresh = p * 2^32)
 __device__ __forceinline__ bool drop_keep(unsigned seed, unsigned bh, unsigned qq, unsigned key, unsigned thresh) {
@@ -52,6 +60,17 @@ __device__ __forceinline__ bf16x8 tile_frag(const bf16_t* tile, int dt, int lane
     return r;
 }
 
+__device__ __forceinline__ void load_row_frag_f32_hl(const float* row, bool valid, bf16x8& hi, bf16x8& lo) {
+    if (valid) {
+        const f32x4 a = *(const f32x4*)row, b = *(const f32x4*)(row + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { split_hl(a[j], hi[j], lo[j]); split_hl(b[j], hi[4 + j], lo[4 + j]); }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi[j] = (bf16_t)0.f; lo[j] = (bf16_t)0.f; }
+    }
+}
+
 __device__ __forceinline__ bf16x8 load_row_frag_f32(const float* row, bool valid) {
     bf16x8 r;
     if (valid) {
@@ -78,10 +97,10 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
     const int head = blockIdx.x % heads, b = blockIdx.x / heads;
     const int C = heads * 64;
     const float LOG2E = 1.4426950408889634f;
-    bf16x8 qf[2];
+    bf16x8 qf[2], qfl[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
-        qf[ks] = load_row_frag_f32(q + ((int64_t)b * Q + (ql < Q ? ql : 0)) * C + head * 64 + 32 * ks + 8 * g, ql < Q);
+        load_row_frag_f32_hl(q + ((int64_t)b * Q + (ql < Q ? ql : 0)) * C + head * 64 + 32 * ks + 8 * g, ql < Q, qf[ks], qfl[ks]);
     const bf16_t* kb = k + (int64_t)b * M * ldkv + head * 64;
     const bf16_t* vb = v + (int64_t)b * M * ldkv + head * 64;
     bf16_t* tile = tiles[wave];
@@ -99,6 +118,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 kf = *(const bf16x8*)(kr + 32 * ks);
                 s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfl[ks], s[t], 0, 0, 0);
             }
         }
         stage_transposed(vb + (int64_t)k0 * ldkv, ldkv, tile, lane);
@@ -109,7 +129,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
         const float mb = m_new * LOG2E;
         float lsum = 0.f;
-        bf16x8 pf;
+        bf16x8 pf, pfl;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
                 float p = __builtin_amdgcn_exp2f(s[t][r] * LOG2E - mb);
                 lsum += p;
                 if (drop_thresh) p = drop_keep(seed, blockIdx.x, ql, k0 + 16 * t + 4 * g + r, drop_thresh) ? p * drop_scale : 0.f;
-                pf[4 * t + r] = (bf16_t)p;
+                split_hl(p, pf[4 * t + r], pfl[4 * t + r]);
             }
         lsum += __shfl_xor(lsum, 16, 64);
         lsum += __shfl_xor(lsum, 32, 64);
@@ -128,7 +148,9 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             o[dt] *= alpha;
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag(tile, dt, lane), pf, o[dt], 0, 0, 0);
+            const bf16x8 vt = tile_frag(tile, dt, lane);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf, o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pfl, o[dt], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -189,28 +211,30 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
     }
     __syncthreads();
     // row fragments (lane row/col = ql, d = 32ks + 8g + j) and transposed fragments (lane d = 16dt + ql, q = 4g + jj)
-    bf16x8 qf[2], dof[2];
+    bf16x8 qf[2], dof[2], qfl[2], dofl[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        qf[ks] = load_row_frag_f32(qrow + (int64_t)(ql < Q ? ql : 0) * C + 32 * ks + 8 * g, ql < Q);
-        dof[ks] = load_row_frag_f32(dorow + (int64_t)(ql < Q ? ql : 0) * C + 32 * ks + 8 * g, ql < Q);
+        load_row_frag_f32_hl(qrow + (int64_t)(ql < Q ? ql : 0) * C + 32 * ks + 8 * g, ql < Q, qf[ks], qfl[ks]);
+        load_row_frag_f32_hl(dorow + (int64_t)(ql < Q ? ql : 0) * C + 32 * ks + 8 * g, ql < Q, dof[ks], dofl[ks]);
     }
-    s16x4 qT[4], doT[4];
+    s16x4 qT[4], doT[4], qTl[4], doTl[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
         // row m = ql of transposed tile dt is d = 16 (m >> 2) + 4 dt + (m & 3): the dV^T / dK^T accumulators of the four tiles then give a
         // lane (key, g) the 16 CONSECUTIVE d 16 g .. 16 g + 15 -> two 16-B stores per key row and matrix (a full 128-B line per 4 lanes)
         // instead of eight 8-B stores scattered 32 B apart
         const int dperm = 16 * (ql >> 2) + 4 * dt + (ql & 3);
-        bf16x4 a, c;
+        bf16x4 a, c, al, cl;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int qq = 4 * g + jj;
-            a[jj] = (bf16_t)((qq < Q) ? qrow[(int64_t)qq * C + dperm] : 0.f);
-            c[jj] = (bf16_t)((qq < Q) ? dorow[(int64_t)qq * C + dperm] : 0.f);
+            split_hl((qq < Q) ? qrow[(int64_t)qq * C + dperm] : 0.f, a[jj], al[jj]);
+            split_hl((qq < Q) ? dorow[(int64_t)qq * C + dperm] : 0.f, c[jj], cl[jj]);
         }
         qT[dt] = __builtin_bit_cast(s16x4, a);
         doT[dt] = __builtin_bit_cast(s16x4, c);
+        qTl[dt] = __builtin_bit_cast(s16x4, al);
+        doTl[dt] = __builtin_bit_cast(s16x4, cl);
     }
     // per-lane row constants: non-swapped form has q = 4g + r in the registers, swapped form has q = ql on the lane
     float lse_r[4], del_r[4];
@@ -233,7 +257,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
     const int m_lo = blockIdx.y * m_per, m_hi = min(M, m_lo + m_per);
     for (int k0 = m_lo + wave * 32; k0 < m_hi; k0 += 128) {
         stage_transposed(kb + (int64_t)k0 * ldkv, ldkv, tile, lane);
-        bf16x8 dsT;
+        bf16x8 dsT, dsTl;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int64_t key = k0 + 16 * t + ql;
@@ -248,9 +272,11 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfl[ks], kf[ks], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[ks], vf[ks], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofl[ks], vf[ks], dp, 0, 0, 0);
             }
-            bf16x4 pb, dsb;
+            bf16x4 pb, dsb, pbl, dsbl;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool live = (4 * g + r) < Q;
@@ -261,15 +287,20 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
                     pd = keep ? p * drop_scale : 0.f;
                     dpm = keep ? dp[r] * drop_scale : 0.f;
                 }
-                pb[r] = (bf16_t)pd;
-                dsb[r] = (bf16_t)(p * (dpm - del_r[r]));
+                split_hl(pd, pb[r], pbl[r]);
+                split_hl(p * (dpm - del_r[r]), dsb[r], dsbl[r]);
             }
             const s16x4 pbs = __builtin_bit_cast(s16x4, pb), dsbs = __builtin_bit_cast(s16x4, dsb);
+            const s16x4 pbls = __builtin_bit_cast(s16x4, pbl), dsbls = __builtin_bit_cast(s16x4, dsbl);
             unsigned wv[8], wk[8];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 f32x4 gv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(doT[dt], pbs, zero, 0, 0, 0);   // dV^T[d = 16 g + 4 dt + j][key]
+                gv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(doTl[dt], pbs, gv, 0, 0, 0);
+                gv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(doT[dt], pbls, gv, 0, 0, 0);
                 f32x4 gk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT[dt], dsbs, zero, 0, 0, 0);   // dK^T
+                gk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qTl[dt], dsbs, gk, 0, 0, 0);
+                gk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT[dt], dsbls, gk, 0, 0, 0);
                 wv[2 * dt] = pack_bf16(gv[0], gv[1]); wv[2 * dt + 1] = pack_bf16(gv[2], gv[3]);
                 wk[2 * dt] = pack_bf16(gk[0], gk[1]); wk[2 * dt + 1] = pack_bf16(gk[2], gk[3]);
             }
@@ -282,21 +313,26 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[ks], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qfl[ks], st, 0, 0, 0);
                 dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks], dof[ks], dpt, 0, 0, 0);
+                dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks], dofl[ks], dpt, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float p = (ql < Q) ? __builtin_amdgcn_exp2f(st[r] * LOG2E - lse_l) : 0.f;
                 float dpm = dpt[r];
                 if (drop_thresh) dpm = drop_keep(seed, blockIdx.x, ql, (unsigned)(k0 + 16 * t + 4 * g + r), drop_thresh) ? dpt[r] * drop_scale : 0.f;
-                dsT[4 * t + r] = (bf16_t)(p * (dpm - del_l));
+                split_hl(p * (dpm - del_l), dsT[4 * t + r], dsTl[4 * t + r]);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-            dqa[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag(tile, dt, lane), dsT, dqa[dt], 0, 0, 0);
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8 kt = tile_frag(tile, dt, lane);
+            dqa[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsT, dqa[dt], 0, 0, 0);
+            dqa[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsTl, dqa[dt], 0, 0, 0);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }

@@ -350,6 +350,9 @@ def test_time_attention_ragged_patch_counts(B, T, n, heads):
 
 @pytest.mark.parametrize("B,Q,M,heads", [(2, 13, 4096, 8), (3, 5, 1024, 8), (1, 16, 96, 2), (1, 13, 18432, 8)])   # last: config 4 (32 x 576 keys)
 def test_xattn_fwd_bwd(B, Q, M, heads):
+    """Cross-attention core vs fp32 PyTorch on the same fp32 q / dO and bf16 K / V.  Query-side operands enter the MFMAs as bf16
+    hi + lo pairs, so the result is exact with respect to the stored K / V: fp32 outputs agree to ~1e-4 of their scale (the old
+    single-bf16 operands gave 1e-2); dK / dV are stored in bf16 (one rounding, 8e-3)."""
     C = heads * 64
     q = rnd(B, Q, C, seed=1, scale=0.3)
     kv = bf(rnd(B, M, 2 * C, seed=2))
@@ -357,7 +360,7 @@ def test_xattn_fwd_bwd(B, Q, M, heads):
     Kd = kv.to(DEV)
     k, v = Kd[:, :, :C], Kd[:, :, C:]
     out, lse = ops.xattn_fwd(q.to(DEV), k, v, heads)
-    qb = bf(q).float().requires_grad_(True)
+    qb = q.clone().requires_grad_(True)
     kr = kv[:, :, :C].float().requires_grad_(True)
     vr = kv[:, :, C:].float().requires_grad_(True)
     qh = qb.view(B, Q, heads, 64).transpose(1, 2)
@@ -365,14 +368,14 @@ def test_xattn_fwd_bwd(B, Q, M, heads):
     vh = vr.view(B, M, heads, 64).transpose(1, 2)
     s = qh @ kh.transpose(-1, -2)
     ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Q, C)
-    assert_close_bf16(out, ref.detach(), 1e-2, "xattn out")
-    torch.testing.assert_close(lse.cpu(), torch.logsumexp(s, -1).detach(), rtol=1e-3, atol=1e-3)
+    assert_close_bf16(out, ref.detach(), 3e-4, "xattn out")
+    torch.testing.assert_close(lse.cpu(), torch.logsumexp(s, -1).detach(), rtol=1e-4, atol=1e-4)
     ref.backward(dout)
     dkv = torch.zeros_like(Kd)
     dq = ops.xattn_bwd(q.to(DEV), k, v, out, lse, dout.to(DEV), dkv[:, :, :C], dkv[:, :, C:], heads)
-    assert_close_bf16(dq, qb.grad, 2e-2, "dq")
-    assert_close_bf16(dkv[:, :, :C], kr.grad, 2e-2, "dk")
-    assert_close_bf16(dkv[:, :, C:], vr.grad, 2e-2, "dv")
+    assert_close_bf16(dq, qb.grad, 1e-3, "dq")
+    assert_close_bf16(dkv[:, :, :C], kr.grad, 8e-3, "dk")
+    assert_close_bf16(dkv[:, :, C:], vr.grad, 8e-3, "dv")
 
 
 def test_match_boxes_bit_exact_and_losses():

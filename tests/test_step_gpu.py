@@ -5,9 +5,9 @@ Stated tolerances (north_star: "decoder loss within 1e-3 rel of CPU reference, b
   * losses: |gpu - ref| <= 1e-3 * |ref| for EVERY term (total, hand / object box loss, EgoNCE, word loss) -- the north-star bound;
   * activations (hs, pred_boxes): scale-relative 2e-2 / absolute 5e-3 (bf16 operands, fp32 accumulation);
   * gradients: (1) with the oracle fed the GPU path's OWN bf16 K/V (query side) and the GPU's own dK/dV (memory side), so that
-    both sides differentiate the same function at the same point: relative L2 per tensor <= 2e-2
-    (test_decoder_gradients_on_shared_kv); (2) end to end against the fp32 oracle / the reference golden, where bf16 noise of
-    K/V flips single ReLU units of the FFN (B*Q ~ 10 rows feed a weight row): per tensor <= 1.5e-1, median <= 5e-2, and the
+    both sides differentiate the same function at the same point: relative L2 per tensor <= 5e-3 (heads <= 1e-2)
+    (test_decoder_gradients_on_shared_kv); (2) end to end against the fp32 oracle / the reference golden, where the bf16 rounding
+    of K/V flips single ReLU units of the FFN (B*Q ~ 10 rows feed a weight row): per tensor <= 1.5e-1, median <= 5e-2, and the
     fixture's gradient samples <= 1e-1 relative L2;
   * matching indices: bit-exact vs the oracle run on the SAME fp32 pred_boxes (index stability across precisions
     is not defined for untrained queries -- SURVEY.md section 8a R12 -- and is reported as a statistic only).
@@ -331,7 +331,7 @@ def test_headline_config_c2_losses_vs_oracle():
     print("C2 end-to-end object-index agreement with the fp32 oracle: %.3f" % (sum(agree) / len(agree)))
 
 
-QUERY_SIDE_GRAD_TOL = 5e-2     # per-tensor relative L2 of the query-side gradients on shared K/V (see test_decoder_gradients_on_shared_kv)
+QUERY_SIDE_GRAD_TOL = 5e-3     # per-tensor relative L2 of the query-side gradients on shared K/V (measured: parameters ~1e-5, dK/dV 1.7e-3 = their bf16 storage)
 
 
 def _rel(a, b):
@@ -345,10 +345,10 @@ def test_decoder_gradients_on_shared_kv(cfg):
 
     Heads: the oracle's frame-conditioned box MLP runs on the GPU's OWN hs -> head gradients to 1e-2, d(hs) to 1e-3.
     Query side: the oracle's six 13-row layers run on the GPU path's OWN bf16 K/V (holder.kv) and are back-propagated from the
-      GPU's own d(hs) -> every layer / query-embedding gradient and dK/dV.  What is left between the two sides is the rounding
-      inside hh_xattn_fwd/bwd (bf16 P, q, dO operands) and the few FFN units that this rounding pushes across their ReLU kink.
+      GPU's own d(hs) -> every layer / query-embedding gradient (<= 5e-3 per tensor, median <= 1e-3; measured ~1e-5: the x3 GEMMs
+      and the hi/lo-split cross-attention are fp32-grade) and dK/dV (1.7e-3: stored in bf16).
     Memory side: the oracle's proj -> pre_norm -> (+pos) -> K/V chain is back-propagated from the GPU's own dK/dV ->
-      proj / pre_norm / key-value in-projection / positional-embedding gradients."""
+      proj / pre_norm / key-value in-projection / positional-embedding gradients (<= 5e-3; bf16 GEMM operands)."""
     C, L = cfg.dec_dim, cfg.dec_layers
     dsd = synth.decoder_state(cfg, seed=3)
     dec = tfm_decoder.build_decoder(cfg, dsd).eval()
@@ -399,7 +399,7 @@ def test_decoder_gradients_on_shared_kv(cfg):
         rel[f"dK[{l}]"], rel[f"dV[{l}]"] = _rel(dK[l], K.grad[l]), _rel(dV[l], V.grad[l])
     worst = sorted(rel.items(), key=lambda kv_: -kv_[1])[:4]
     print("query side on shared K/V: %d tensors, median %.2e, worst %s" % (len(rel), float(np.median(list(rel.values()))), worst))
-    assert len(rel) > 100 and max(rel.values()) < QUERY_SIDE_GRAD_TOL and float(np.median(list(rel.values()))) < 2e-2, worst
+    assert len(rel) > 100 and max(rel.values()) < QUERY_SIDE_GRAD_TOL and float(np.median(list(rel.values()))) < 1e-3, worst
     # ---- memory side from the GPU's own dK/dV
     params2 = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
     K2, V2 = OD.memory_kv(feats, params2, cfg)
@@ -420,7 +420,7 @@ def test_decoder_gradients_on_shared_kv(cfg):
                 rel2[name + "[k]"] = _rel(gg[C:2 * C], rg[C:2 * C])
     worst2 = sorted(rel2.items(), key=lambda kv_: -kv_[1])[:4]
     print("memory side from shared dK/dV: median %.2e, worst %s" % (float(np.median(list(rel2.values()))), worst2))
-    assert max(rel2.values()) < 2e-2, worst2
+    assert max(rel2.values()) < 5e-3, worst2
 
 
 def test_long_clip_decoder_and_step_c4_shapes():
