@@ -12,7 +12,8 @@ MI355X design:
     and the LayerNorm backward kernel.  K/V and their gradients live in one [B*M, 6144] bf16 buffer each; the six
     cross-attention backward kernels write their column slices directly (no autograd slice/accumulate copies).
   * cross-attention core: hh_xattn_fwd / hh_xattn_bwd (13 x 4096 per clip and head), attention-dropout inside.
-  * query side (13 rows per clip, < 1 % of FLOPs): stock PyTorch-ROCm ops under autograd.
+  * query side (13 rows per clip, < 1 % of FLOPs): model/qside.py -- ONE autograd node for the six layers on hh_qgemm_f32x3
+    (fp32-grade GEMM on the bf16 matrix cores), hh_qself_attn_*, LayerNorm kernels; heads on LinearX3.
   * the frame-conditioning `cat[hs, frame_index] -> frame_proj` is evaluated in its exact decomposed form
     hs.W[:, :C]^T + (frame_index.W[:, C:]^T + b)[t]  (T x fewer FLOPs).
 """

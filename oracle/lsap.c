@@ -7,8 +7,9 @@
  * order; among equal reduced costs an unassigned column is preferred; the column scan order is the
  * `remaining` list, initialised descending and compacted by swap-with-last.  Costs are double.
  * Wide-or-square problems (nr <= nc) are solved directly; tall ones are solved transposed and the
- * result is re-sorted by row.  Output: rows ascending, len = min(nr, nc).  Checked against scipy
- * itself (random, integer-tie-heavy and degenerate matrices) in tests/test_oracle_lsap.py.
+ * result is re-sorted by row.  Output: rows ascending, len = min(nr, nc).  Checked against scipy's
+ * own answers on 400 problems (random, integer-tie-heavy, wide, empty and degenerate matrices) stored in
+ * tests/golden/lsap_scipy.npz: tests/test_oracle_golden.py::test_lsap_known_answers.
  *
  * Returns the number of assigned pairs, or -1 when infeasible / on bad input.
  */
