@@ -350,8 +350,9 @@ class CLIP(nn.Module):
             return x_cls, x
         return x_cls @ self.image_projection, x
 
-    def encode_text(self, text, use_checkpoint=False):
-        """LaviLa.py:660-670.  Frozen weights on the GPU (the training / MCQ path): Linears and LayerNorms of the 12 text
+    def encode_text(self, text, use_checkpoint=False, apply_project=True):
+        """LaviLa.py:660-670 (apply_project=False, as encode_image has it, skips the EOT-token projection: the training step only
+        uses the feature map).  Frozen weights on the GPU (the training / MCQ path): Linears and LayerNorms of the 12 text
         blocks on libhh kernels (`Transformer.forward_frozen`); otherwise stock PyTorch ops (bf16 autocast on the GPU)."""
         frozen = text.is_cuda and not torch.is_grad_enabled() or (text.is_cuda and not any(p.requires_grad for p in self.transformer.parameters()))
         if frozen and self.text_autocast is not None:
@@ -366,8 +367,12 @@ class CLIP(nn.Module):
                 x = self.transformer(x.permute(1, 0, 2), use_checkpoint=use_checkpoint).permute(1, 0, 2)
                 x = self.ln_final(x)
             x = x.float()
-        x_cls = x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)] @ self.text_projection
-        return x_cls, x
+        x_cls = x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)]
+        if not apply_project:
+            return x_cls, x
+        if frozen and x_cls.dtype == torch.float32:
+            return ops.qgemm(x_cls.contiguous(), self.text_projection.detach().float().contiguous(), ops.NN), x
+        return x_cls @ self.text_projection, x
 
     def forward(self, image, text, use_checkpoint=False, norm_embed=True, return_feature_map=False):
         image_embed, image_fmap = self.encode_image(image, use_checkpoint=use_checkpoint)

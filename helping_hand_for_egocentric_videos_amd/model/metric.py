@@ -1,13 +1,27 @@
 """Metrics on the hot path: mirror of /root/reference/model/metric.py:363-392,209-225 (sim_matrix,
 compute_tv_accuracy, egomcq_accuracy_metrics).  Legacy retrieval metrics of the reference are out of scope."""
 import torch
+import torch.nn.functional as F
 
 
 def sim_matrix(a, b, eps=1e-8, norm=True):
-    """Cosine similarity with eps-clamped norms (metric.py:363-375); 2-D -> mm, 3-D -> bmm."""
+    """Cosine similarity with eps-clamped norms (metric.py:363-375).  On the GPU the 2-D product runs on hh_qgemm_f32x3 (fp32-grade,
+    differentiable; the contraction is zero-padded to a multiple of 4), the small batched form of the word loss as a broadcast
+    multiply + sum -- no vendor BLAS on the step.  CPU tensors (tests, host-side use) take torch's matmul."""
     if norm:
         a = a / a.norm(dim=-1, keepdim=True).clamp_min(eps)
         b = b / b.norm(dim=-1, keepdim=True).clamp_min(eps)
+    if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32:
+        if a.dim() == 2 and b.dim() == 2:
+            from .qside import linear_x3
+            n = b.shape[0]
+            pad_k, pad_n = (-a.shape[-1]) % 4, (-n) % 4              # the kernel wants its contiguous dimensions in multiples of 4
+            if pad_k or pad_n:
+                a, b = F.pad(a, (0, pad_k)), F.pad(b, (0, pad_k, 0, pad_n))
+            out = linear_x3(a, b)
+            return out[:, :n] if pad_n else out
+        if a.dim() == 3 and b.dim() == 3 and a.shape[0] * a.shape[1] * b.shape[1] * a.shape[2] <= (1 << 22):
+            return (a[:, :, None, :] * b[:, None, :, :]).sum(-1)
     return a @ b.transpose(-1, -2)
 
 

@@ -65,7 +65,7 @@ class TrainStep:
         side.wait_stream(cur)
         with torch.no_grad():
             with torch.cuda.stream(side):
-                _, tmap = self.backbone.encode_text(text)
+                _, tmap = self.backbone.encode_text(text, apply_project=False)
             _, fmap = self.backbone.visual.forward_features(video, out_dtype=torch.bfloat16)
         cur.wait_stream(side)
         tmap.record_stream(cur)
@@ -241,7 +241,7 @@ def mcq_forward(backbone, decoder, video, text, cfg):
         side = _mcq_side_stream(video.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            _, tmap = backbone.encode_text(text)
+            _, tmap = backbone.encode_text(text, apply_project=False)
         _, fmap = backbone.visual.forward_features(video.flatten(0, 1), out_dtype=torch.bfloat16)
         cur.wait_stream(side)
         tmap.record_stream(cur)
