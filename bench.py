@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-mcq", action="store_true", help="skip the EgoMCQ forward sub-record (second half of BASELINE.json's metric)")
     ap.add_argument("--enc-cus", type=int, default=None, help="CU budget of the persistent GEMMs on the pipelined encoder stream (multiple of 8; 0 = all)")
+    ap.add_argument("--force-comm", action="store_true", help="1 GPU only: run the RCCL collectives of the data-parallel path in a 1-rank group (A/B of the CU reservation)")
     ap.add_argument("--per-op-query-side", action="store_true", help="A/B: per-op autograd query side instead of the fused QueryStack node")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder forward with this step's decoder")
     args = ap.parse_args()
@@ -144,6 +145,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
+        if args.force_comm:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     dev = torch.device("cuda", local if world > 1 else 0)
 
     cfg = C2
@@ -162,7 +167,7 @@ def main():
 
     if args.workload == "train":
         batch = {k: v.to(dev) for k, v in synth.make_batch(cfg, B, seed=1000 + rank).items()}
-        ts = TrainStep(cfg, backbone, decoder, enc_cus=args.enc_cus)
+        ts = TrainStep(cfg, backbone, decoder, enc_cus=args.enc_cus, force_comm=args.force_comm)
         run = lambda: ts.step(batch, next_batch=None if args.no_pipeline else batch)
         clips_per_step = B
         metric = "train clips/sec (16-frame 224p, nq=12)"
@@ -294,7 +299,7 @@ def main():
         if args.workload == "train":
             line["loss"] = round(float(out["total_loss"]), 4)
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or args.force_comm:
         dist.destroy_process_group()
 
 

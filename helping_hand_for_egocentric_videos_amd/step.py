@@ -16,7 +16,7 @@ from .model.metric import compute_tv_accuracy, sim_matrix
 from .parallel import BucketedAllReduce, FlatArena, gather_contrastive, no_decay, world
 
 ZEROED_NOUNS = [102, 504, 364, 321, 556]          # run/train.py:73
-DP_ENC_CUS = 248                                  # encoder-stream CU budget under data parallelism (31 of 32 CUs per XCD)
+DP_ENC_CUS = 0                                    # default encoder-stream CU budget under data parallelism: 0 = no reservation (see TrainStep)
 WEIGHT_DICT = {"loss_bbox_hand_boxes": 5, "loss_bbox_obj_boxes": 5, "loss_giou_hand_boxes": 2, "loss_giou_obj_boxes": 2}
 
 
@@ -42,9 +42,12 @@ class TrainStep:
         self.iteration = 0
         self._text_stream = None
         self.enc_stream = None
-        # CU budget of the persistent GEMMs on the pipelined encoder stream (0 = all CUs); see prefetch().  With gradient
-        # collectives in flight (W > 1) the default leaves one CU per XCD (8 of 256) to the RCCL kernels of the comm stream:
-        # a persistent grid that owns every CU would make each all-reduce bucket wait for a whole GEMM to drain.
+        # CU budget of the persistent GEMMs on the pipelined encoder stream (0 = all CUs); see prefetch().  A reservation for the
+        # RCCL kernels of the comm stream (e.g. 248 = one CU per XCD left free) is available through `enc_cus`, but it is NOT the
+        # default: measured with the real RCCL collectives in flight (bench.py --force-comm, 1 rank) 248 CUs cost 2.1 % and 240 CUs
+        # 2.9 % of the step (2048 / 6144 / 8192 tiles no longer divide into whole rounds of workgroups), while without a
+        # reservation the collectives showed no cost: a bucket's all-reduce (<= 16 MB) is scheduled in the same gaps between
+        # persistent GEMMs as the decoder's own kernels and has the whole backward to finish.
         self.enc_cus = (DP_ENC_CUS if self.comm.enabled else 0) if enc_cus is None else int(enc_cus)
         self._pending = None
         self._zeroed_idx = None

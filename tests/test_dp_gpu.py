@@ -129,11 +129,11 @@ def _rccl_worker(rank, world, port, ret):
         def build(force):
             backbone = LaviLa.build_backbone(cfg, synth.encoder_state(cfg, seed=4))
             dec = tfm_decoder.build_decoder(cfg, synth.decoder_state(cfg, seed=4))
-            return TrainStep(cfg, backbone, dec, lr=1e-4, bucket_bytes=1 << 20, force_comm=force), dec
+            return TrainStep(cfg, backbone, dec, lr=1e-4, bucket_bytes=1 << 20, force_comm=force, enc_cus=248 if force else None), dec
 
         ts, dec = build(True)
         assert ts.comm.enabled and ts.comm.avg and ts.comm.comm_stream is not None and len(ts.arena.buckets) >= 4
-        assert ts.enc_cus == DP_ENC_CUS
+        assert ts.enc_cus == 248                      # explicit reservation: exercised here, not the default (DP_ENC_CUS)
         ref, rdec = build(False)
         assert not ref.comm.enabled
         # (a) one eval-mode backward: gradients through the RCCL path == gradients without it (AVG over one rank is the identity)
@@ -148,7 +148,7 @@ def _rccl_worker(rank, world, port, ret):
         for _ in range(3):
             out = ts.step(batch, next_batch=batch)
         torch.cuda.synchronize()
-        assert ops.stream_cu_budget(ts.enc_stream) == DP_ENC_CUS
+        assert ops.stream_cu_budget(ts.enc_stream) == 248
         assert ts.comm.launched == 4 * len(ts.arena.buckets)
         ret["loss"] = float(out["total_loss"])
         ret["finite"] = bool(torch.isfinite(ts.arena.params).all())
