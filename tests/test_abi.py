@@ -41,6 +41,23 @@ def test_host_side_argument_validation_needs_no_gpu():
     assert L.hh_time_attn_fwd(None, None, None, 1, 5, 256, 2, None) == -3
     assert L.hh_xattn_fwd(None, None, None, 512, None, None, 1, 17, 4096, 8, 0.0, 0, None) == -1
     assert L.hh_adamw_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None) == -1
+    # query-side entry points (round 2)
+    o = _lib.QGemmOpts()
+    assert L.hh_qgemm_f32x3(None, 512, None, 512, None, 512, 16, 512, 510, 0, ctypes.byref(o), None) == -1       # K % 4 != 0
+    assert b"multiples of 4" in L.hh_last_error_string()
+    assert L.hh_qgemm_f32x3(None, 512, None, 512, None, 512, 16, 512, 512, 3, ctypes.byref(o), None) == -1       # bad mode
+    o.splitk, o.relu = 4, 1
+    assert L.hh_qgemm_f32x3(None, 512, None, 512, None, 512, 16, 512, 512, 0, ctypes.byref(o), None) == -3       # split-K takes no epilogue
+    assert L.hh_qself_attn_fwd(None, None, 2, 17, 8, 0.0, 0, None) == -1                                           # Q <= 16
+    assert L.hh_layernorm_pos_fwd(None, 0, None, None, None, None, 0, None, 13, None, None, 10, 512, 1e-5, None) == -1
+    # caller-owned workspace sizes and the timing facility need no GPU
+    assert L.hh_workspace_bytes_gemm_tn(512, 2048, 3) == 3 * 512 * 2048 * 4
+    assert L.hh_workspace_bytes_xattn_bwd(32, 13, 8, 4) == 4 * 32 * 13 * 512 * 4
+    assert L.hh_workspace_bytes_attn_cls_partial(32, 16, 256, 16, 0) == 32 * 16 * 16 * 68 * 4
+    assert L.hh_workspace_bytes_attn_cls_partial(32, 16, 256, 16, 1) == 32 * 16 * 32 * 68 * 4
+    assert L.hh_workspace_bytes_gemm_splitk(-1, 128, 2) < 0
+    assert L.hh_set_tuning(b"gemm256", 9) == -3 and L.hh_set_tuning(b"gemm256", 3) == 0
+    assert L.hh_set_tuning(b"no_such_knob", 1) == -3
 
 
 def test_product_ops_refuse_cpu_tensors():
@@ -50,3 +67,8 @@ def test_product_ops_refuse_cpu_tensors():
         ops.layernorm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64), 1e-5)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(128, 64, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.qgemm(torch.zeros(4, 64), torch.zeros(128, 64))
+    from helping_hand_for_egocentric_videos_amd.model.qside import LinearX3
+    with pytest.raises(RuntimeError, match="libhh HIP kernels only"):
+        LinearX3(8, 8)(torch.zeros(2, 8))
