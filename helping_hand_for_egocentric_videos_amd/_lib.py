@@ -37,6 +37,7 @@ SIGNATURES = {
     "hh_workspace_bytes_gemm_splitk": [c_i64, c_int, c_int],
     "hh_workspace_bytes_gemm_tn": [c_int, c_int, c_int],
     "hh_workspace_bytes_xattn_bwd": [c_int, c_int, c_int, c_int],
+    "hh_workspace_bytes_xattn_fwd": [c_int, c_int, c_int, c_int],
     "hh_workspace_bytes_attn_cls_partial": [c_int, c_int, c_int, c_int, c_int],
     "hh_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_float, c_vp],
     "hh_add_layernorm_fwd": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_float, c_vp],
@@ -55,6 +56,7 @@ SIGNATURES = {
     "hh_cls_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "hh_text_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "hh_xattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
+    "hh_xattn_fwd_split": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
     "hh_xattn_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_float,
                      ctypes.c_uint32, c_vp],
     "hh_qgemm_f32x3": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int, ctypes.POINTER(QGemmOpts), c_vp],
@@ -69,7 +71,7 @@ SIGNATURES = {
     "hh_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_float, c_float, c_float, c_float, c_float, c_int, c_vp],
 }
 _RESTYPES = {"hh_last_error_string": ctypes.c_char_p, "hh_workspace_bytes_gemm_splitk": c_i64, "hh_workspace_bytes_gemm_tn": c_i64,
-             "hh_workspace_bytes_xattn_bwd": c_i64, "hh_workspace_bytes_attn_cls_partial": c_i64}
+             "hh_workspace_bytes_xattn_bwd": c_i64, "hh_workspace_bytes_xattn_fwd": c_i64, "hh_workspace_bytes_attn_cls_partial": c_i64}
 
 _lib = None
 

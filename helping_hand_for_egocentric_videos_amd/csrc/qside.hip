@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
     const bool want_cs = A_T && p.colsum != nullptr && blockIdx.x == 0;
     if (tid < 64) scs[tid] = 0.f;
 
-    f32x4 ra[4], rb[4];
+    f32x4 ra0[4], rb0[4], ra1[4], rb1[4];           // two register stages: the global loads run TWO k-steps ahead of the MFMAs
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
             for (int e = 0; e < 4; ++e) v[e] = q_keep(p.a_drop_seed, idx + e, p.a_drop_thresh) ? v[e] * p.a_drop_scale : 0.f;
         }
     };
-    auto load_tiles = [&](int kt) {
+    auto load_tiles = [&](int kt, f32x4 (&ra)[4], f32x4 (&rb)[4]) {
         const int k0 = (kt0 + kt) * QBK;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -133,13 +133,7 @@ __global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
 
     f32x4 acc[4] = {z4, z4, z4, z4};
     const int fr = lane & 15, fk = 8 * (lane >> 4);
-    load_tiles(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                                                    // everyone is done reading the previous k-step's tiles
-        store_op(sA, ra, A_T);
-        store_op(sB, rb, B_T);
-        __syncthreads();
-        if (kt + 1 < nk) load_tiles(kt + 1);                                // global loads of the next k-step fly under the MFMAs
+    auto mma = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const bf16x8 ah = *(const bf16x8*)&sA[0][16 * wave + fr][32 * ks + fk];
@@ -153,6 +147,23 @@ __global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[t], 0, 0, 0);
             }
         }
+    };
+    load_tiles(0, ra0, rb0);
+    if (nk > 1) load_tiles(1, ra1, rb1);
+    for (int kt = 0; kt < nk; kt += 2) {
+        __syncthreads();                                                    // everyone is done reading the previous k-step's tiles
+        store_op(sA, ra0, A_T);
+        store_op(sB, rb0, B_T);
+        __syncthreads();
+        if (kt + 2 < nk) load_tiles(kt + 2, ra0, rb0);                      // lands two k-steps from now
+        mma();
+        if (kt + 1 >= nk) break;
+        __syncthreads();
+        store_op(sA, ra1, A_T);
+        store_op(sB, rb1, B_T);
+        __syncthreads();
+        if (kt + 3 < nk) load_tiles(kt + 3, ra1, rb1);
+        mma();
     }
     // epilogue: lane owns C[m][n .. n+3], m = tile row (lane & 15), n = 16 t + 4 (lane >> 4)
     const int m = m0 + 16 * wave + fr;

@@ -89,6 +89,9 @@ extern "C" int64_t hh_workspace_bytes_gemm_tn(int M, int N, int splits) {
 extern "C" int64_t hh_workspace_bytes_xattn_bwd(int B, int Q, int heads, int dq_splits) {
     return (B < 0 || Q <= 0 || heads <= 0 || dq_splits < 1) ? -1 : (int64_t)dq_splits * B * Q * heads * 64 * 4;   // dq partials
 }
+extern "C" int64_t hh_workspace_bytes_xattn_fwd(int B, int Q, int heads, int splits) {
+    return (B < 0 || Q <= 0 || heads <= 0 || splits < 1) ? -1 : (int64_t)splits * B * Q * heads * (64 + 1) * 4;   // out planes, then lse planes
+}
 extern "C" int64_t hh_workspace_bytes_attn_cls_partial(int B, int T, int n, int heads, int time_mode) {
     if (B < 0 || T <= 0 || n <= 0 || heads <= 0 || (time_mode && T > 128)) return -1;
     const int64_t G = time_mode ? (n + (128 / T) - 1) / (128 / T) : T;                         // key groups per (clip, head)

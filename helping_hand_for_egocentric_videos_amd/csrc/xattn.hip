@@ -87,7 +87,9 @@ __device__ __forceinline__ bf16x8 load_row_frag_f32(const float* row, bool valid
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict__ q, const bf16_t* __restrict__ k,
                                                         const bf16_t* __restrict__ v, int64_t ldkv, float* __restrict__ out,
                                                         float* __restrict__ lse, int B, int Q, int M, int heads, unsigned drop_thresh,
-                                                        float drop_scale, unsigned seed) {
+                                                        float drop_scale, unsigned seed, int chunk) {
+    // gridDim.y > 1: blockIdx.y owns the key slice [y*chunk, (y+1)*chunk) and writes a slice-normalised (out, lse) pair into the
+    // y-th plane of out/lse (the caller passes the workspace there); xattn_fwd_merge_kernel folds the planes
     __shared__ __attribute__((aligned(16))) bf16_t tiles[4][64 * VSTRIDE];
     __shared__ float ml[2][4][16];
     __shared__ __attribute__((aligned(16))) float obuf[4][16][64];
@@ -108,7 +110,10 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
-    for (int k0 = wave * 32; k0 < M; k0 += 128) {
+    const int k_begin = blockIdx.y * chunk, k_end = min(M, k_begin + chunk);
+    out += (int64_t)blockIdx.y * B * Q * C;
+    lse += (int64_t)blockIdx.y * B * heads * Q;
+    for (int k0 = k_begin + wave * 32; k0 < k_end; k0 += 128) {
         f32x4 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -175,6 +180,33 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
         float ll = 0.f;
         for (int w = 0; w < 4; ++w) ll += ml[1][w][tid] * __builtin_amdgcn_exp2f((ml[0][w][tid] - mm) * LOG2E);
         lse[((int64_t)b * heads + head) * Q + tid] = mm + logf(ll);
+    }
+}
+
+// out[b,q,c] = sum_s part_out[s,b,q,c] * exp(part_lse[s,b,h,q] - lse[b,h,q]),  lse = logsumexp_s part_lse: one block per (clip, head)
+__global__ __launch_bounds__(256) void xattn_fwd_merge_kernel(const float* __restrict__ part_out, const float* __restrict__ part_lse,
+                                                              float* __restrict__ out, float* __restrict__ lse, int B, int Q, int heads,
+                                                              int splits) {
+    __shared__ float w[64][16];
+    const int tid = threadIdx.x, head = blockIdx.x % heads, b = blockIdx.x / heads, C = heads * 64;
+    if (tid < Q) {
+        const int64_t base = ((int64_t)b * heads + head) * Q + tid, plane = (int64_t)B * heads * Q;
+        float m = -INFINITY;
+        for (int s = 0; s < splits; ++s) m = fmaxf(m, part_lse[s * plane + base]);
+        float l = 0.f;
+        for (int s = 0; s < splits; ++s) l += expf(part_lse[s * plane + base] - m);
+        const float tot = m + logf(l);
+        lse[base] = tot;
+        for (int s = 0; s < splits; ++s) w[s][tid] = expf(part_lse[s * plane + base] - tot);
+    }
+    __syncthreads();
+    const int64_t plane = (int64_t)B * Q * C;
+    for (int e = tid; e < Q * 64; e += 256) {
+        const int qq = e >> 6, d = e & 63;
+        const int64_t at = ((int64_t)b * Q + qq) * C + head * 64 + d;
+        float a = 0.f;
+        for (int s = 0; s < splits; ++s) a += part_out[s * plane + at] * w[s][qq];
+        out[at] = a;
     }
 }
 
@@ -352,12 +384,42 @@ static int xattn_check(const char* what, int B, int Q, int M, int heads, int64_t
     return HH_OK;
 }
 
+extern "C" int hh_xattn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out, float* lse,
+                            int B, int Q, int M, int heads, float dropout_p, uint32_t seed, hh_stream_t stream);
+
 static void drop_params(float p, unsigned* thresh, float* scale) {
     if (p <= 0.f) { *thresh = 0u; *scale = 1.f; return; }
     double t = (double)p * 4294967296.0;
     *thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     if (*thresh == 0u) *thresh = 1u;
     *scale = 1.f / (1.f - p);
+}
+
+extern "C" int hh_xattn_fwd_split(const float* q, const void* k, const void* v, int64_t ldkv, float* out, float* lse, float* workspace,
+                                  int splits, int B, int Q, int M, int heads, float dropout_p, uint32_t seed, hh_stream_t stream) {
+    int rc = xattn_check("hh_xattn_fwd_split", B, Q, M, heads, ldkv);
+    if (rc) return rc;
+    HH_REQUIRE(splits >= 1 && splits <= 64, HH_ERR_SHAPE, "hh_xattn_fwd_split: splits must be in [1, 64]");
+    HH_REQUIRE(splits == 1 || workspace, HH_ERR_SHAPE, "hh_xattn_fwd_split: splits > 1 needs hh_workspace_bytes_xattn_fwd() bytes of workspace");
+    HH_REQUIRE(HH_ALIGNED16(q) && HH_ALIGNED16(k) && HH_ALIGNED16(v) && HH_ALIGNED16(out) && HH_ALIGNED16(workspace), HH_ERR_ALIGN,
+               "hh_xattn_fwd_split: pointers must be 16-byte aligned");
+    HH_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, HH_ERR_SHAPE, "hh_xattn_fwd_split: dropout_p must be in [0,1)");
+    if (B == 0) return HH_OK;
+    int chunk = (((M + splits - 1) / splits) + 127) / 128 * 128;           // whole 128-key rounds of the four waves
+    splits = (M + chunk - 1) / chunk;                                       // no empty slice
+    if (splits == 1) return hh_xattn_fwd(q, k, v, ldkv, out, lse, B, Q, M, heads, dropout_p, seed, stream);
+    unsigned thr; float sc;
+    drop_params(dropout_p, &thr, &sc);
+    float* part_out = workspace;
+    float* part_lse = workspace + (int64_t)splits * B * Q * heads * 64;
+    {
+        HHProfScope prof(HH_PROF_XATTN_FWD, 4.0 * (double)B * M * heads * 64, (hipStream_t)stream);
+        hipLaunchKernelGGL(xattn_fwd_kernel, dim3((unsigned)(B * heads), (unsigned)splits), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)k,
+                           (const bf16_t*)v, ldkv, part_out, part_lse, B, Q, M, heads, thr, sc, seed, chunk);
+    }
+    hipLaunchKernelGGL(xattn_fwd_merge_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream, part_out, part_lse, out, lse,
+                       B, Q, heads, splits);
+    return hh_check_launch("hh_xattn_fwd_split");
 }
 
 extern "C" int hh_xattn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out, float* lse,
@@ -371,7 +433,7 @@ extern "C" int hh_xattn_fwd(const float* q, const void* k, const void* v, int64_
     drop_params(dropout_p, &thr, &sc);
     HHProfScope prof(HH_PROF_XATTN_FWD, 4.0 * (double)B * M * heads * 64, (hipStream_t)stream);         // K and V rows, bf16
     hipLaunchKernelGGL(xattn_fwd_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, (hipStream_t)stream, q, (const bf16_t*)k,
-                       (const bf16_t*)v, ldkv, out, lse, B, Q, M, heads, thr, sc, seed);
+                       (const bf16_t*)v, ldkv, out, lse, B, Q, M, heads, thr, sc, seed, M);
     return hh_check_launch("hh_xattn_fwd");
 }
 

@@ -386,8 +386,10 @@ def text_attention(qkv, S, L, heads):
     return out
 
 
-def xattn_fwd(q, k, v, heads, dropout_p=0.0, seed=0):
-    """q fp32 [B,Q,C] (pre-scaled); k, v bf16 [B,M,C] views with a common row stride -> (out fp32 [B,Q,C], lse [B,h,Q])."""
+def xattn_fwd(q, k, v, heads, dropout_p=0.0, seed=0, splits=None):
+    """q fp32 [B,Q,C] (pre-scaled); k, v bf16 [B,M,C] views with a common row stride -> (out fp32 [B,Q,C], lse [B,h,Q]).
+    `splits` > 1 cuts the keys into slices (one workgroup per (clip, head, slice)); the default does so only when B*heads leaves
+    most CUs idle (long clips at small batch)."""
     for t in (q, k, v):
         if not t.is_cuda:
             raise RuntimeError("libhh ops need GPU tensors; there is no CPU fallback")
@@ -397,8 +399,15 @@ def xattn_fwd(q, k, v, heads, dropout_p=0.0, seed=0):
         raise RuntimeError("xattn_fwd: k/v must be row-strided views [B,M,C] with dense batch stride")
     out = torch.empty_like(q)
     lse = torch.empty((B, heads, Q), dtype=torch.float32, device=q.device)
-    _lib.check(_lib.lib().hh_xattn_fwd(_p(q), _p(k), _p(v), k.stride(1), _p(out), _p(lse), B, Q, M, heads,
-                                       float(dropout_p), int(seed) & 0xFFFFFFFF, _stream()), "hh_xattn_fwd")
+    if splits is None:
+        splits = max(1, min(32, M // 512, 256 // max(B * heads, 1)))
+    if splits > 1:
+        ws = _workspace("xattn_fwd", B, Q, heads, int(splits), device=q.device)
+        _lib.check(_lib.lib().hh_xattn_fwd_split(_p(q), _p(k), _p(v), k.stride(1), _p(out), _p(lse), _p(ws), int(splits), B, Q, M, heads,
+                                                 float(dropout_p), int(seed) & 0xFFFFFFFF, _stream()), "hh_xattn_fwd_split")
+    else:
+        _lib.check(_lib.lib().hh_xattn_fwd(_p(q), _p(k), _p(v), k.stride(1), _p(out), _p(lse), B, Q, M, heads,
+                                           float(dropout_p), int(seed) & 0xFFFFFFFF, _stream()), "hh_xattn_fwd")
     return out, lse
 
 
@@ -409,7 +418,8 @@ def xattn_bwd(q, k, v, out, lse, dout, dk, dv, heads, dropout_p=0.0, seed=0, spl
     M = k.shape[1]
     _chk(q, out, lse, dout)
     if splits is None:
-        splits = max(1, min(8, M // 1024))
+        # enough (clip, head, slice) workgroups to cover 256 CUs twice, slices never shorter than 512 keys
+        splits = max(1, min(8, M // 1024), min(32, M // 512, -(-512 // (B * heads))))
     dq = _workspace("xattn_bwd", B, Q, heads, int(splits), device=q.device).view(splits, B, Q, C)
     _lib.check(_lib.lib().hh_xattn_bwd(_p(q), _p(k), _p(v), k.stride(1), _p(out), _p(lse), _p(dout), _p(dq), int(splits), _p(dk), _p(dv),
                                        dk.stride(1), B, Q, M, heads, float(dropout_p), int(seed) & 0xFFFFFFFF, _stream()),

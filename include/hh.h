@@ -82,6 +82,7 @@ int hh_prof_read(int klass, int64_t* launches_timed, int64_t* launches_seen, dou
 int64_t hh_workspace_bytes_gemm_splitk(int64_t M, int N, int splitk);
 int64_t hh_workspace_bytes_gemm_tn(int M, int N, int splits);
 int64_t hh_workspace_bytes_xattn_bwd(int B, int Q, int heads, int dq_splits);
+int64_t hh_workspace_bytes_xattn_fwd(int B, int Q, int heads, int splits);
 int64_t hh_workspace_bytes_attn_cls_partial(int B, int T, int n, int heads, int time_mode);
 
 /* ---- LayerNorm over the last dim (model/LaviLa.py:439,456 eps 1e-6 / 1e-5; tfm_decoder.py:57,375-377)
@@ -180,6 +181,11 @@ int hh_text_attn_fwd(const void* qkv, void* out, int S, int L, int heads, hh_str
  * tfm_decoder.py:365) with a counter-based mask keyed by (seed, clip, head, query, key); the backward regenerates it. */
 int hh_xattn_fwd(const float* q, const void* k, const void* v, int64_t ldkv, float* out, float* lse,
                  int B, int Q, int M, int heads, float dropout_p, uint32_t seed, hh_stream_t stream);
+/* the same forward with the keys cut into `splits` slices, one workgroup per (clip, head, slice), folded by a merge kernel: for
+ * small B*heads (long clips at small batch) where hh_xattn_fwd's B*heads workgroups leave most of the CUs idle.  workspace:
+ * hh_workspace_bytes_xattn_fwd(B, Q, heads, splits) bytes.  Same dropout mask as hh_xattn_fwd for the same seed. */
+int hh_xattn_fwd_split(const float* q, const void* k, const void* v, int64_t ldkv, float* out, float* lse, float* workspace, int splits,
+                       int B, int Q, int M, int heads, float dropout_p, uint32_t seed, hh_stream_t stream);
 /* backward: the keys are cut into dq_splits slices (one workgroup each per (clip, head)); dq fp32 [dq_splits, B, Q, C] holds the
  * slices' partial dq (the caller sums them); dk/dv bf16 [B, M, lddkv] */
 int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_t ldkv, const float* out, const float* lse,

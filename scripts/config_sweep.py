@@ -16,7 +16,10 @@ def timed(f, steps, warm=2):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(steps): out = f()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / steps, out
+only = set(sys.argv[1:])                                                   # e.g. `config_sweep.py C4`: just that config
 for name, cfg, Bs in [("C1 T=4 224p nq=4", C1, [2, 32]), ("C2 T=16 224p nq=12", C2, [8, 16, 32, 48]), ("C4 T=32 336p nq=12", C4, [2, 4])]:
+    if only and name.split()[0] not in only:
+        continue
     bb, dec = build(cfg)
     for B in Bs:
         batch = {k: v.to(dev) for k, v in synth.make_batch(cfg, B, seed=1).items()}

@@ -378,6 +378,26 @@ def test_xattn_fwd_bwd(B, Q, M, heads):
     assert_close_bf16(dkv[:, :, C:], vr.grad, 8e-3, "dv")
 
 
+@pytest.mark.parametrize("B,M,splits", [(2, 4096, 8), (1, 18432, 32), (3, 1184, 4), (2, 160, 64)])
+def test_xattn_fwd_key_slices_equal_the_single_pass(B, M, splits):
+    """hh_xattn_fwd_split (one workgroup per (clip, head, key slice) + merge) against hh_xattn_fwd on the same inputs, with and
+    without dropout: the slices see the same (seed, clip, head, query, key) mask, so the outputs differ only by fp32 summation order.
+    (3, 1184, 4): ragged last slice; (2, 160, 64): more slices asked for than 128-key rounds exist."""
+    heads, Q = 8, 13
+    C = heads * 64
+    q = rnd(B, Q, C, seed=4, scale=0.3).to(DEV)
+    kv = bf(rnd(B, M, 2 * C, seed=5)).to(DEV)
+    k, v = kv[:, :, :C], kv[:, :, C:]
+    for p, seed in ((0.0, 0), (0.1, 1234)):
+        one, lse1 = ops.xattn_fwd(q, k, v, heads, dropout_p=p, seed=seed, splits=1)
+        many, lse2 = ops.xattn_fwd(q, k, v, heads, dropout_p=p, seed=seed, splits=splits)
+        torch.testing.assert_close(lse2, lse1, rtol=1e-5, atol=1e-5)
+        assert_close_bf16(many, one.cpu(), 2e-5, "xattn split p=%g" % p)
+    if M >= 1024:
+        dflt, _ = ops.xattn_fwd(q, k, v, heads)                              # the default takes the sliced path at this B*heads
+        assert_close_bf16(dflt, ops.xattn_fwd(q, k, v, heads, splits=1)[0], 2e-5, "xattn default split")
+
+
 def test_match_boxes_bit_exact_and_losses():
     from helping_hand_for_egocentric_videos_amd import synth, TINY4
     from oracle import losses as OL
