@@ -391,6 +391,207 @@ __global__ __launch_bounds__(64 * NW16, 4) void space_attn16_kernel(const bf16_t
 }
 
 
+// ---- joint query blocks (round 2, second pass).  In the kernel above every MFMA consumes a fresh 1 KB LDS fragment: per workgroup
+// 16 blocks x 70 KB of fragment reads against 1264 MFMAs, and the measured compute-only time (230-250 us) is about the SUM of the
+// LDS, MFMA and VALU streams (~100 + 80 + 80 us) rather than their maximum.  Here a wave owns JB query blocks AT ONCE: a K or V^T
+// fragment is read once and feeds JB MFMAs (LDS fragment traffic / JB), and the JB blocks are independent dependency chains inside
+// one in-order wave.  4 waves per workgroup and two workgroups per CU = 2 waves per SIMD, so a wave may hold 256 registers:
+// JB x (NTJ score tiles + 4 output tiles + row sums + Q + the -m_ref accumulator initialiser).  Every wave has exactly
+// n / 16 / (4 JB) groups (the host picks JB so that this divides), and the Q rows of a wave's first group are requested BEFORE the
+// K / V staging wait, so staging and Q latency overlap.  Same LDS layout, swizzles, fragment addressing and softmax scheme
+// (fixed per-block reference maximum inside the MFMA accumulator, all-ones row-sum MFMA, running-maximum redo) as above.
+#define NWJ 4
+template <int JB, int NT, bool CLS, bool FIRST>
+__device__ __forceinline__ void spacej_chunk(const char* kc0, const char* kc1, const char* vc0, const char* vc1, const char* vc2,
+                                             const char* vc3, const bf16x8 (&q)[JB][2], int lane, f32x4 (&o)[JB][4], f32x4 (&ol)[JB],
+                                             float (&m_ref)[JB]) {
+    static_assert(!(FIRST && CLS) && (!FIRST || NT >= 2), "the first chunk holds two plain key tiles");
+    const int g = lane >> 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
+    f32x4 s[JB][NT];
+    constexpr int NR = FIRST ? 2 : 0;
+    if (FIRST) {
+#pragma unroll
+        for (int ti = 0; ti < NR; ++ti) {
+            const bf16x8 k0 = *(const bf16x8*)(kc0 + ti * 2048), k1 = *(const bf16x8*)(kc1 + ti * 2048);
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+                s[j][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q[j][0], z4, 0, 0, 0);
+                s[j][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q[j][1], s[j][ti], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            float mx = fmaxf(fmaxf(fmaxf(s[j][0][0], s[j][0][1]), fmaxf(s[j][0][2], s[j][0][3])),
+                             fmaxf(fmaxf(s[j][1][0], s[j][1][1]), fmaxf(s[j][1][2], s[j][1][3])));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            m_ref[j] = mx;
+            s[j][0] -= mx;
+            s[j][1] -= mx;
+        }
+    }
+    f32x4 minit[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) minit[j] = (f32x4){-m_ref[j], -m_ref[j], -m_ref[j], -m_ref[j]};
+#pragma unroll
+    for (int ti = NR; ti < NT; ++ti) {
+        const bf16x8 k0 = *(const bf16x8*)(kc0 + ti * 2048), k1 = *(const bf16x8*)(kc1 + ti * 2048);
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            s[j][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q[j][0], minit[j], 0, 0, 0);
+            s[j][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q[j][1], s[j][ti], 0, 0, 0);
+        }
+    }
+    if (CLS) {                                        // the chunk's last tile holds nothing but the CLS key (its row 0)
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (!(g == 0 && r == 0)) s[j][NT - 1][r] = -INFINITY;
+    }
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[j][ti][r] = __builtin_amdgcn_exp2f(s[j][ti][r]);
+#pragma unroll
+    for (int pr = 0; pr < (NT + 1) / 2; ++pr) {
+        const bool has_b = 2 * pr + 1 < NT;
+        bf16x8 pf[JB];
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const f32x4 pa = s[j][2 * pr], pb = s[j][has_b ? 2 * pr + 1 : 2 * pr];
+            pf[j] = (bf16x8){(bf16_t)pa[0], (bf16_t)pa[1], (bf16_t)pa[2], (bf16_t)pa[3],
+                             (bf16_t)(has_b ? pb[0] : 0.f), (bf16_t)(has_b ? pb[1] : 0.f), (bf16_t)(has_b ? pb[2] : 0.f), (bf16_t)(has_b ? pb[3] : 0.f)};
+        }
+        const int oa = 2 * pr * 2048, ob = has_b ? oa + 2048 : oa;
+#define SJ_PV(DT, VC) do { const bf16x4 a0 = lds_tr4(VC + oa), a1 = lds_tr4(VC + ob);                                     \
+                           const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};                       \
+                           _Pragma("unroll") for (int j = 0; j < JB; ++j)                                                    \
+                               o[j][DT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf[j], o[j][DT], 0, 0, 0); } while (0)
+        SJ_PV(0, vc0); SJ_PV(1, vc1); SJ_PV(2, vc2); SJ_PV(3, vc3);
+#undef SJ_PV
+#pragma unroll
+        for (int j = 0; j < JB; ++j) ol[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[j], ol[j], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void space_store_block(const f32x4 (&o)[4], float l, bf16_t* op) {
+    const float inv = 1.f / l;
+    const u32x4 w0 = {pack_bf16(o[0][0] * inv, o[0][1] * inv), pack_bf16(o[0][2] * inv, o[0][3] * inv),
+                      pack_bf16(o[1][0] * inv, o[1][1] * inv), pack_bf16(o[1][2] * inv, o[1][3] * inv)};
+    const u32x4 w1 = {pack_bf16(o[2][0] * inv, o[2][1] * inv), pack_bf16(o[2][2] * inv, o[2][3] * inv),
+                      pack_bf16(o[3][0] * inv, o[3][1] * inv), pack_bf16(o[3][2] * inv, o[3][3] * inv)};
+    *(u32x4*)(op) = w0;
+    *(u32x4*)(op + 8) = w1;
+}
+
+template <int JB, int NTJ, bool DBG>
+__global__ __launch_bounds__(64 * NWJ, 2) void space_attnj_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                 float* __restrict__ cls_partial, int B, int T, int n, int heads, int KP,
+                                                                 int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + (size_t)KP * 128;
+    float* scratch = (float*)(smem + (size_t)KP * 256);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = heads * 64;
+    const int64_t ld = 3 * (int64_t)D;
+    const int N = 1 + T * n;
+    int bid = blockIdx.x;
+    const int head = bid % heads; bid /= heads;
+    const int f = bid % T;
+    const int b = bid / T;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;
+    const bf16_t* q_ptr = base + (int64_t)(1 + f * n) * ld;
+    const int c = lane & 15, g = lane >> 4;
+    const int nqb = n >> 4, nt = nqb + 1;              // 16-key tiles incl. the CLS tile
+    bf16x8 q[JB][2];
+    auto load_q = [&](int gb) {
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const bf16_t* qrow = q_ptr + (int64_t)((gb + j) * 16 + c) * ld + 8 * g;
+            q[j][0] = *(const bf16x8*)(qrow);
+            q[j][1] = *(const bf16x8*)(qrow + 32);
+        }
+    };
+    load_q(wave * JB);                                 // in flight together with the K / V staging
+    if (!DBG || dbg != 2) space_stage<NWJ>(Ks, Vs, base, q_ptr, ld, D, n, KP, lane, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (DBG && dbg == 1) {                             // debug: memory traffic only
+        for (int gb = wave * JB; gb < nqb; gb += NWJ * JB) {
+            if (gb != wave * JB) load_q(gb);
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+                bf16_t* op = out + ((int64_t)b * N + 1 + f * n + (gb + j) * 16 + c) * D + head * 64 + 16 * g;
+                *(bf16x8*)(op) = q[j][0]; *(bf16x8*)(op + 8) = q[j][1];
+            }
+        }
+        return;
+    }
+    const int kz = (c & 7) ^ (c >> 3), trq = c >> 2, trp = c & 3, vz = ((trq >> 1) & 1) << 2;
+    const char* kb0 = Ks + c * 128 + ((g ^ kz) << 4);
+    const char* kb1 = Ks + c * 128 + (((g + 4) ^ kz) << 4);
+    const char* vb0 = Vs + (4 * g + trq) * 128 + (((2 * trp) ^ vz) << 4);
+    const char* vb1 = vb0 + 8;
+    const char* vb2 = Vs + (4 * g + trq) * 128 + (((2 * trp + 1) ^ vz) << 4);
+    const char* vb3 = vb2 + 8;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int gb = wave * JB; gb < nqb; gb += NWJ * JB) {
+        if (gb != wave * JB) load_q(gb);
+        f32x4 o[JB][4], ol[JB];
+        float m_ref[JB];
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            ol[j] = z4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[j][dt] = z4;
+        }
+        spacej_chunk<JB, NTJ, false, true>(kb0, kb1, vb0, vb1, vb2, vb3, q, lane, o, ol, m_ref);
+        int t0 = NTJ;
+        for (; t0 + NTJ < nt; t0 += NTJ) {
+            const int off = t0 * 2048;
+            spacej_chunk<JB, NTJ, false, false>(kb0 + off, kb1 + off, vb0 + off, vb1 + off, vb2 + off, vb3 + off, q, lane, o, ol, m_ref);
+        }
+        {
+            const int off = t0 * 2048;
+#define SJ_FT(R) spacej_chunk<JB, (R), true, false>(kb0 + off, kb1 + off, vb0 + off, vb1 + off, vb2 + off, vb3 + off, q, lane, o, ol, m_ref)
+            static_assert(NTJ % 2 == 0 && NTJ >= 2 && NTJ <= 8, "chunks of an even number of key tiles");
+            switch (nt - t0) {                         // an ODD number (n / 16 is even) of 1 .. NTJ - 1 tiles left, the last one is the CLS tile
+                case 1: SJ_FT(1); break;
+                case 3: if (NTJ > 3) SJ_FT(NTJ > 3 ? 3 : 1); break;
+                case 5: if (NTJ > 5) SJ_FT(NTJ > 5 ? 5 : 1); break;
+                default: if (NTJ > 7) SJ_FT(NTJ > 7 ? 7 : 1); break;
+            }
+#undef SJ_FT
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            bf16_t* op = out + ((int64_t)b * N + 1 + f * n + (gb + j) * 16 + c) * D + head * 64 + 16 * g;
+            float l_run = ol[j][0];
+            // a score more than 2^127 above the block's reference maximum: l is not finite -> redo this block with the running maximum
+            if (__builtin_amdgcn_ballot_w64(!(l_run <= 3.0e38f)) != 0) {
+                f32x4 o2[4] = {z4, z4, z4, z4};
+                float m_run = -INFINITY;
+                l_run = 0.f;
+                for (int t = 0; t + 1 < nt; ++t) space16_chunk<1, false>(Ks, Vs, q[j], t, lane, o2, m_run, l_run);
+                space16_chunk<1, true>(Ks, Vs, q[j], nt - 1, lane, o2, m_run, l_run);
+                space_store_block(o2, l_run, op);
+            } else {
+                space_store_block(o[j], l_run, op);
+            }
+        }
+    }
+    if (cls_partial == nullptr) return;
+    space16_cls_partial<NWJ>(Ks, Vs, scratch, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
+}
+
+
 // merge G partial records per (clip, head) into out row 0:  o = sum_g o_g e^{m_g - m} / sum_g l_g e^{m_g - m}
 __global__ __launch_bounds__(64) void cls_combine_kernel(const float* __restrict__ partial, int G, bf16_t* __restrict__ out,
                                                          int N, int heads) {
@@ -420,6 +621,16 @@ extern "C" int hh_cls_combine(const float* partial, int G, void* out, int B, int
 }
 
 int hh_tuning_space_debug();
+int hh_tuning_space_joint();
+#ifndef JNT4
+#define JNT4 2          // key tiles per chunk of the joint kernel at 4 / 3 / 2 query blocks per wave
+#endif
+#ifndef JNT3
+#define JNT3 2
+#endif
+#ifndef JNT2
+#define JNT2 6
+#endif
 
 extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream) {
     HH_REQUIRE(B >= 0 && T > 0 && heads > 0 && n > 0 && n % 32 == 0, HH_ERR_SHAPE, "hh_space_attn_fwd: n=%d must be a multiple of 32", n);
@@ -435,6 +646,24 @@ extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial,
         attr16 = lds16;
     }
     HHProfScope prof(HH_PROF_SPACE_ATTN, 8.0 * B * (1.0 + (double)T * n) * heads * 64, (hipStream_t)stream);
+    const int nqb = n >> 4, joint = hh_tuning_space_joint();
+    int jb = !joint ? 0 : nqb % (NWJ * 4) == 0 ? 4 : nqb % (NWJ * 3) == 0 ? 3 : nqb % (NWJ * 2) == 0 ? 2 : 0;
+    if (jb) {
+        typedef void (*kern_t)(const bf16_t*, bf16_t*, float*, int, int, int, int, int, int);
+        const int dbg = hh_tuning_space_debug();
+        const kern_t kern = jb == 4 ? (dbg ? (kern_t)space_attnj_kernel<4, JNT4, true> : (kern_t)space_attnj_kernel<4, JNT4, false>)
+                          : jb == 3 ? (kern_t)space_attnj_kernel<3, JNT3, false> : (kern_t)space_attnj_kernel<2, JNT2, false>;
+        if (dbg) jb = 1;                                // (slot of the LDS-size attribute cache)
+        static size_t attrj[5] = {0, 0, 0, 0, 0};
+        if (lds16 > attrj[jb]) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+            HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds16);
+            attrj[jb] = lds16;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NWJ), lds16, (hipStream_t)stream,
+                           (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP, dbg);
+        return hh_check_launch("hh_space_attn_fwd");
+    }
     hipLaunchKernelGGL(space_attn16_kernel, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW16), lds16, (hipStream_t)stream,
                        (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP, hh_tuning_space_debug());
     return hh_check_launch("hh_space_attn_fwd");

@@ -526,11 +526,14 @@ static int g_tail = 1;             // "gemm_tail": 1 = row tails on the split-K-
 int hh_tuning_gemm_tail() { return g_tail; }
 static int g_space_dbg = 0;
 int hh_tuning_space_debug() { return g_space_dbg; }
+static int g_space_joint = 1;
+int hh_tuning_space_joint() { return g_space_joint; }
 
 extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm256") && value >= 0 && value <= 3) { g_mode = value; return HH_OK; }
     if (name && !strcmp(name, "gemm_tail") && (value == 0 || value == 1)) { g_tail = value; return HH_OK; }
     if (name && !strcmp(name, "space_debug")) { g_space_dbg = value; return HH_OK; }
+    if (name && !strcmp(name, "space_joint")) { g_space_joint = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_skew")) { g_skew = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_pskew") && value >= 0 && value <= 64) { g_pskew = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_debug_nostore")) { g_nostore = value; return HH_OK; }

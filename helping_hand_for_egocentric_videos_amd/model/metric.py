@@ -9,6 +9,8 @@ def sim_matrix(a, b, eps=1e-8, norm=True):
     differentiable; the contraction is zero-padded to a multiple of 4), the small batched form of the word loss as a broadcast
     multiply + sum -- no vendor BLAS on the step.  CPU tensors (tests, host-side use) take torch's matmul."""
     if norm:
+        if a.is_cuda:                                # torch's row reductions pick their summation order by memory layout: normalise
+            a, b = a.contiguous(), b.contiguous()    # dense copies, so that a strided view (the packed all-gather) gives the same bits
         a = a / a.norm(dim=-1, keepdim=True).clamp_min(eps)
         b = b / b.norm(dim=-1, keepdim=True).clamp_min(eps)
     if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32:

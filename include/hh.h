@@ -36,6 +36,8 @@ int hh_version(void);
  *   "gemm256_group" m-tiles per XCD-local group of the tile walk (0 = per-shape default)
  *   "gemm256_skew"  -1 auto / 0 off / 1 on: start-time skew of the one-tile-per-block kernel (spreads the epilogue HBM bursts)
  *   "gemm256_pskew" 0..64: start skew quantum of the persistent kernel (default 0)
+ *   "space_joint"   1 (default) = space attention on the joint-block kernel where n / 16 divides by 4 waves x {4, 3, 2} blocks,
+ *                   0 = always the 16-query-block kernel;  "space_debug" 0 / 1 / 2: full kernel / memory traffic only / no staging
  *   "gemm256_debug_ts", "gemm256_debug_nostore": diagnostics (timeline recording; skip the epilogue stores) */
 int hh_set_tuning(const char* name, int value);
 const char* hh_last_error_string(void);

@@ -311,9 +311,37 @@ def test_divided_attention(mode, B, T, n, heads):
     assert (err / scale).max() < 5e-2
 
 
-def test_space_attention_redo_path_when_the_reference_maximum_is_exceeded():
+@pytest.mark.parametrize("n,blocks_per_wave", [(256, 4), (576, 3), (128, 2), (512, 4), (384, 3)])
+def test_space_attention_joint_blocks_equal_the_16_query_kernel(n, blocks_per_wave):
+    """hh_space_attn_fwd picks the joint-block kernel (a wave owns 4 / 3 / 2 query blocks at once and shares every K / V fragment
+    between them) when n / 16 divides by 4 waves x blocks; the 16-query kernel is the generic path.  Same arithmetic per block
+    (reference maximum from the block's first 32 keys, bf16 probabilities, MFMA row sums); only the pairing of key tiles inside the
+    PV MFMAs differs (chunks of 2 / 6 tiles instead of 9), i.e. the fp32 summation order: outputs agree to one bf16 rounding."""
+    B, T, heads = 2, 2, 2
+    N, D = 1 + T * n, heads * 64
+    qkv = rnd(B * N, 3 * D, seed=n)
+    qkv[:, :D] *= 0.6 * ops.LOG2E
+    qkv = bf(qkv).to(DEV)
+    try:
+        ops.set_tuning("space_joint", 0)
+        generic = ops.divided_attention(qkv, B, T, n, heads, "space")
+    finally:
+        ops.set_tuning("space_joint", 1)
+    joint = ops.divided_attention(qkv, B, T, n, heads, "space")
+    # (the CLS rows also merge 4 instead of 8 per-wave partial softmax records; at n = 128 the 16-query kernel has no fast path --
+    # its first chunk would hold the CLS tile -- and runs the running-maximum softmax: probabilities round differently)
+    assert_close_bf16(joint, generic, 8e-3, "joint vs 16-query")
+    if n > 128:
+        torch.testing.assert_close(joint.float(), generic.float(), rtol=2.0 ** -7, atol=1e-3 * float(generic.float().abs().max()))
+        assert (joint != generic).float().mean() < 0.02
+    assert_close_bf16(joint, _ref_divided(qkv.cpu(), B, T, n, heads, "space"), 1.2e-2, "attn-space-joint")
+
+
+@pytest.mark.parametrize("joint", [1, 0])
+def test_space_attention_redo_path_when_the_reference_maximum_is_exceeded(joint):
     """The fast path of the space kernel fixes one reference maximum per 16-query block (from the first 32 keys) and redoes the block
     with a running maximum when a later score exceeds it by more than 2^127: plant such keys and compare with the fp32 reference."""
+    ops.set_tuning("space_joint", joint)
     B, T, n, heads = 1, 2, 256, 2
     N, D = 1 + T * n, heads * 64
     qkv = rnd(B * N, 3 * D, seed=3)
@@ -325,6 +353,7 @@ def test_space_attention_redo_path_when_the_reference_maximum_is_exceeded():
     qkv = bf(qkv)
     out = ops.divided_attention(qkv.to(DEV), B, T, n, heads, "space")
     ref = _ref_divided(qkv, B, T, n, heads, "space")
+    ops.set_tuning("space_joint", 1)
     assert torch.isfinite(out.float()).all()
     assert_close_bf16(out, ref, 1.2e-2, "attn-space-redo")
     err = (out.float().cpu() - ref).abs().amax(1)
