@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--enc-cus", type=int, default=None, help="CU budget of the persistent GEMMs on the pipelined encoder stream (multiple of 8; 0 = all)")
     ap.add_argument("--force-comm", action="store_true", help="1 GPU only: run the RCCL collectives of the data-parallel path in a 1-rank group (A/B of the CU reservation)")
     ap.add_argument("--per-op-query-side", action="store_true", help="A/B: per-op autograd query side instead of the fused QueryStack node")
+    ap.add_argument("--token-major-qkv", action="store_true", help="A/B: the QKV projections write nn.Linear's token-major [B*N, 3D] instead of head-major planes")
+    ap.add_argument("--space-16q", action="store_true", help="A/B: space attention on the 16-query-block kernel instead of the joint-block kernel")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder forward with this step's decoder")
     args = ap.parse_args()
 
@@ -160,6 +162,11 @@ def main():
     backbone = LaviLa.build_backbone(cfg, enc_sd, device=dev)
     decoder = tfm_decoder.build_decoder(cfg, dec_sd, device=dev)
     decoder.transformer.use_query_stack = not args.per_op_query_side
+    if args.token_major_qkv:
+        from helping_hand_for_egocentric_videos_amd.model import LaviLa as _L
+        _L.QKV_HEAD_MAJOR_PLANES = False
+    if args.space_16q:
+        ops.set_tuning("space_joint", 0)
     B = args.batch
 
     STRIDE = 5      # every 5th launch of a class is timed (co-prime with the 6 GEMMs / 2 attention calls per block); bracketing every launch costs ~3 % in marker packets

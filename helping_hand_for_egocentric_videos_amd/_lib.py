@@ -14,7 +14,7 @@ c_i64, c_int, c_float, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctyp
 class GemmEpilogue(ctypes.Structure):
     _fields_ = [("bias", c_vp), ("resid", c_vp), ("ldr", c_i64), ("colscale", c_float), ("colscale_cols", c_int),
                 ("act", c_int), ("c_dtype", c_int), ("remap_group", c_i64), ("remap_skip", c_i64),
-                ("remap_offset", c_i64), ("splitk", c_int), ("split_stride", c_i64)]
+                ("remap_offset", c_i64), ("splitk", c_int), ("split_stride", c_i64), ("c_block_stride", c_i64)]
 
 
 class QGemmOpts(ctypes.Structure):
@@ -50,10 +50,10 @@ SIGNATURES = {
     "hh_patch_im2col": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp],
     "hh_patch_im2col_u8": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_vp],
     "hh_embed_ln_pre": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, c_vp],
-    "hh_space_attn_fwd": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
-    "hh_time_attn_fwd": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "hh_space_attn_fwd": [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "hh_time_attn_fwd": [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "hh_cls_combine": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp],
-    "hh_cls_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "hh_cls_attn_fwd": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "hh_text_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "hh_xattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
     "hh_xattn_fwd_split": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],

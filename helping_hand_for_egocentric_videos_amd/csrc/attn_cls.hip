@@ -5,7 +5,7 @@
 #include "common.h"
 
 __global__ __launch_bounds__(256) void cls_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                       int B, int N, int heads, float exp2_scale) {
+                                                       int B, int N, int heads, float exp2_scale, int layout) {
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [N] scores + 64 q + 32*64 partial o + 8 red
     float* sc = sm;
     float* qs = sm + ((N + 3) & ~3);
@@ -13,9 +13,11 @@ __global__ __launch_bounds__(256) void cls_attn_kernel(const bf16_t* __restrict_
     float* red = part + 32 * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = heads * 64;
-    const int64_t ld = 3 * (int64_t)D;
+    // qkv layout (include/hh.h, hh_qkv_layout): element (row, which, head, d) at row * ld + which * ws + head * hs + d
+    const int64_t ld = layout ? 64 : 3 * (int64_t)D;
+    const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
     const int head = blockIdx.x % heads, b = blockIdx.x / heads;
-    const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + head * hs;
     if (tid < 64) qs[tid] = (float)base[tid];
     __syncthreads();
     float q[64];
@@ -23,7 +25,7 @@ __global__ __launch_bounds__(256) void cls_attn_kernel(const bf16_t* __restrict_
     for (int d = 0; d < 64; ++d) q[d] = qs[d];
     float mx = -INFINITY;
     for (int j = tid; j < N; j += 256) {
-        const bf16_t* kp = base + (int64_t)j * ld + D;
+        const bf16_t* kp = base + (int64_t)j * ld + ws;
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void cls_attn_kernel(const bf16_t* __restrict_
     for (int d = 0; d < 8; ++d) o[d] = 0.f;
     for (int j = kl; j < N; j += 32) {
         const float p = sc[j];
-        u32x4 u = *(const u32x4*)(base + (int64_t)j * ld + 2 * D + c * 8);
+        u32x4 u = *(const u32x4*)(base + (int64_t)j * ld + 2 * ws + c * 8);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             o[2 * w] = fmaf(p, bf16_lo_to_f32(u[w]), o[2 * w]);
@@ -77,7 +79,8 @@ __global__ __launch_bounds__(256) void cls_attn_kernel(const bf16_t* __restrict_
     }
 }
 
-extern "C" int hh_cls_attn_fwd(const void* qkv, void* out, int B, int N, int heads, int q_log2, hh_stream_t stream) {
+extern "C" int hh_cls_attn_fwd(const void* qkv, int qkv_layout, void* out, int B, int N, int heads, int q_log2, hh_stream_t stream) {
+    HH_REQUIRE(qkv_layout == HH_QKV_TOKEN_MAJOR || qkv_layout == HH_QKV_HEAD_MAJOR, HH_ERR_SHAPE, "hh_cls_attn_fwd: bad qkv_layout");
     HH_REQUIRE(B >= 0 && N > 0 && heads > 0, HH_ERR_SHAPE, "hh_cls_attn_fwd: bad shape");
     HH_REQUIRE(HH_ALIGNED16(qkv) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_cls_attn_fwd: pointers must be 16-byte aligned");
     if (B == 0) return HH_OK;
@@ -90,6 +93,6 @@ extern "C" int hh_cls_attn_fwd(const void* qkv, void* out, int B, int N, int hea
         attr_set = lds;
     }
     hipLaunchKernelGGL(cls_attn_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, (hipStream_t)stream,
-                       (const bf16_t*)qkv, (bf16_t*)out, B, N, heads, q_log2 ? 1.f : 1.4426950408889634f);
+                       (const bf16_t*)qkv, (bf16_t*)out, B, N, heads, q_log2 ? 1.f : 1.4426950408889634f, qkv_layout);
     return hh_check_launch("hh_cls_attn_fwd");
 }

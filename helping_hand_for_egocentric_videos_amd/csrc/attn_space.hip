@@ -40,20 +40,20 @@ __device__ __forceinline__ int vswz(int r) { return ((r >> 1) & 1) << 2; }
 // stage K and V of one (clip, frame, head) problem by LDS-DMA (1 KiB = 8 rows per wave instruction); rows >= n take the CLS
 // token's row (key n is the CLS key; rows > n are masked in S and multiplied by P = 0, they only have to be finite)
 template <int NWV>
-__device__ __forceinline__ void space_stage(char* Ks, char* Vs, const bf16_t* base, const bf16_t* q_ptr, int64_t ld, int D, int n,
+__device__ __forceinline__ void space_stage(char* Ks, char* Vs, const bf16_t* base, const bf16_t* q_ptr, int64_t ld, int64_t ws, int n,
                                             int KP, int lane, int wave) {
     const int pieces = KP >> 3;
     for (int pc = wave; pc < pieces; pc += NWV) {
         const int row = pc * 8 + (lane >> 3);
         const int c = (lane & 7) ^ kswz(row);
         const bf16_t* src = (row < n) ? q_ptr + (int64_t)row * ld : base;
-        glds16(src + D + c * 8, Ks + pc * 1024);
+        glds16(src + ws + c * 8, Ks + pc * 1024);
     }
     for (int pc = wave; pc < pieces; pc += NWV) {
         const int row = pc * 8 + (lane >> 3);
         const int c = (lane & 7) ^ vswz(row);
         const bf16_t* src = (row < n) ? q_ptr + (int64_t)row * ld : base;
-        glds16(src + 2 * D + c * 8, Vs + pc * 1024);
+        glds16(src + 2 * ws + c * 8, Vs + pc * 1024);
     }
 }
 
@@ -349,7 +349,7 @@ __device__ __forceinline__ void space16_block(const char* Ks, const char* Vs, co
 }
 
 __global__ __launch_bounds__(64 * NW16, 4) void space_attn16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                  float* __restrict__ cls_partial, int B, int T, int n, int heads, int KP, int dbg) {
+                                                                  float* __restrict__ cls_partial, int B, int T, int n, int heads, int KP, int dbg, int layout) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + (size_t)KP * 128;
@@ -357,15 +357,17 @@ __global__ __launch_bounds__(64 * NW16, 4) void space_attn16_kernel(const bf16_t
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = heads * 64;
-    const int64_t ld = 3 * (int64_t)D;
     const int N = 1 + T * n;
+    // qkv layout (include/hh.h, hh_qkv_layout): element (row, which, head, d) at row * ld + which * ws + head * hs + d
+    const int64_t ld = layout ? 64 : 3 * (int64_t)D;
+    const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
     int bid = blockIdx.x;
     const int head = bid % heads; bid /= heads;
     const int f = bid % T;
     const int b = bid / T;
-    const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + head * hs;
     const bf16_t* q_ptr = base + (int64_t)(1 + f * n) * ld;
-    if (dbg != 2) space_stage<NW16>(Ks, Vs, base, q_ptr, ld, D, n, KP, lane, wave);
+    if (dbg != 2) space_stage<NW16>(Ks, Vs, base, q_ptr, ld, ws, n, KP, lane, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int c = lane & 15, g = lane >> 4;
@@ -492,7 +494,7 @@ __device__ __forceinline__ void space_store_block(const f32x4 (&o)[4], float l, 
 template <int JB, int NTJ, bool DBG>
 __global__ __launch_bounds__(64 * NWJ, 2) void space_attnj_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                  float* __restrict__ cls_partial, int B, int T, int n, int heads, int KP,
-                                                                 int dbg) {
+                                                                 int dbg, int layout) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + (size_t)KP * 128;
@@ -500,13 +502,15 @@ __global__ __launch_bounds__(64 * NWJ, 2) void space_attnj_kernel(const bf16_t* 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = heads * 64;
-    const int64_t ld = 3 * (int64_t)D;
     const int N = 1 + T * n;
+    // qkv layout (include/hh.h, hh_qkv_layout): element (row, which, head, d) at row * ld + which * ws + head * hs + d
+    const int64_t ld = layout ? 64 : 3 * (int64_t)D;
+    const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
     int bid = blockIdx.x;
     const int head = bid % heads; bid /= heads;
     const int f = bid % T;
     const int b = bid / T;
-    const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + head * hs;
     const bf16_t* q_ptr = base + (int64_t)(1 + f * n) * ld;
     const int c = lane & 15, g = lane >> 4;
     const int nqb = n >> 4, nt = nqb + 1;              // 16-key tiles incl. the CLS tile
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(64 * NWJ, 2) void space_attnj_kernel(const bf16_t* 
         }
     };
     load_q(wave * JB);                                 // in flight together with the K / V staging
-    if (!DBG || dbg != 2) space_stage<NWJ>(Ks, Vs, base, q_ptr, ld, D, n, KP, lane, wave);
+    if (!DBG || dbg != 2) space_stage<NWJ>(Ks, Vs, base, q_ptr, ld, ws, n, KP, lane, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (DBG && dbg == 1) {                             // debug: memory traffic only
@@ -632,7 +636,9 @@ int hh_tuning_space_joint();
 #define JNT2 6
 #endif
 
-extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream) {
+extern "C" int hh_space_attn_fwd(const void* qkv, int qkv_layout, void* out, float* cls_partial, int B, int T, int n, int heads,
+                                 hh_stream_t stream) {
+    HH_REQUIRE(qkv_layout == HH_QKV_TOKEN_MAJOR || qkv_layout == HH_QKV_HEAD_MAJOR, HH_ERR_SHAPE, "hh_space_attn_fwd: bad qkv_layout");
     HH_REQUIRE(B >= 0 && T > 0 && heads > 0 && n > 0 && n % 32 == 0, HH_ERR_SHAPE, "hh_space_attn_fwd: n=%d must be a multiple of 32", n);
     HH_REQUIRE(HH_ALIGNED16(qkv) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_space_attn_fwd: pointers must be 16-byte aligned");
     if (B == 0) return HH_OK;
@@ -649,7 +655,7 @@ extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial,
     const int nqb = n >> 4, joint = hh_tuning_space_joint();
     int jb = !joint ? 0 : nqb % (NWJ * 4) == 0 ? 4 : nqb % (NWJ * 3) == 0 ? 3 : nqb % (NWJ * 2) == 0 ? 2 : 0;
     if (jb) {
-        typedef void (*kern_t)(const bf16_t*, bf16_t*, float*, int, int, int, int, int, int);
+        typedef void (*kern_t)(const bf16_t*, bf16_t*, float*, int, int, int, int, int, int, int);
         const int dbg = hh_tuning_space_debug();
         const kern_t kern = jb == 4 ? (dbg ? (kern_t)space_attnj_kernel<4, JNT4, true> : (kern_t)space_attnj_kernel<4, JNT4, false>)
                           : jb == 3 ? (kern_t)space_attnj_kernel<3, JNT3, false> : (kern_t)space_attnj_kernel<2, JNT2, false>;
@@ -661,10 +667,10 @@ extern "C" int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial,
             attrj[jb] = lds16;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NWJ), lds16, (hipStream_t)stream,
-                           (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP, dbg);
+                           (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP, dbg, qkv_layout);
         return hh_check_launch("hh_space_attn_fwd");
     }
     hipLaunchKernelGGL(space_attn16_kernel, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW16), lds16, (hipStream_t)stream,
-                       (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP, hh_tuning_space_debug());
+                       (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP, hh_tuning_space_debug(), qkv_layout);
     return hh_check_launch("hh_space_attn_fwd");
 }

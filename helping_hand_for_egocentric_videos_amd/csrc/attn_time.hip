@@ -55,22 +55,24 @@ __device__ __forceinline__ unsigned lds_u32(const char* p) { return (unsigned)(s
 
 template <int T>
 __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                             float* __restrict__ cls_partial, int B, int n, int heads) {
+                                                             float* __restrict__ cls_partial, int B, int n, int heads, int layout) {
     constexpr int P = 128 / T;         // patch locations per wave (= per CLS partial record)
     constexpr int PT = 16 / T;         // patch locations per 16-row tile
     __shared__ __attribute__((aligned(16))) char Vsm[4 * 2 * 2048];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = heads * 64;
-    const int64_t ld = 3 * (int64_t)D;
     const int N = 1 + T * n;
+    // qkv layout (include/hh.h, hh_qkv_layout): element (row, which, head, d) at row * ld + which * ws + head * hs + d
+    const int64_t ld = layout ? 64 : 3 * (int64_t)D;
+    const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
     const int groups = (n + P - 1) / P;
     int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     if (wid >= (int64_t)B * heads * groups) return;
     const int pg = (int)(wid % groups); wid /= groups;
     const int head = (int)(wid % heads);
     const int b = (int)(wid / heads);
-    const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + head * hs;
     const int p0 = pg * P;
     const int ntiles = min(8, (n - p0 + PT - 1) / PT);
     const int c = lane & 15, g = lane >> 4;
@@ -86,12 +88,12 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
         char* dst = vbuf + (t & 1) * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            tglds16(base + tokrow(t, (lane >> 3) + 8 * i) * ld + 2 * D + (lane & 7) * 8, dst + i * 1024);
+            tglds16(base + tokrow(t, (lane >> 3) + 8 * i) * ld + 2 * ws + (lane & 7) * 8, dst + i * 1024);
         const bf16_t* rp = base + tokrow(t, c) * ld + 8 * g;
         qq[0] = *(const bf16x8*)(rp);
         qq[1] = *(const bf16x8*)(rp + 32);
-        kk[0] = *(const bf16x8*)(rp + D);
-        kk[1] = *(const bf16x8*)(rp + D + 32);
+        kk[0] = *(const bf16x8*)(rp + ws);
+        kk[1] = *(const bf16x8*)(rp + ws + 32);
     };
 
     // per-(clip, head) constants: CLS key as an A tile (rows 0, 4, 8, 12), CLS query as a B tile (every column), CLS value slot
@@ -99,14 +101,14 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 kc = *(const bf16x8*)(base + D + 8 * g + 32 * ks);
+        const bf16x8 kc = *(const bf16x8*)(base + ws + 8 * g + 32 * ks);
         a2[ks] = (c & 3) == 0 ? kc : zero8;
         qc[ks] = *(const bf16x8*)(base + 8 * g + 32 * ks);
     }
     bf16_t vcls[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-        const bf16_t v = base[2 * D + 16 * (c >> 2) + 4 * dt + (c & 3)];
+        const bf16_t v = base[2 * ws + 16 * (c >> 2) + 4 * dt + (c & 3)];
         vcls[dt] = g == 0 ? v : (bf16_t)0.f;
     }
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -238,21 +240,23 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
 // product of a query tile contracts over all 32 frame keys in ONE 16x16x32 MFMA (k-slots jj < 4 -> key row 4g+jj of tile 0,
 // jj >= 4 -> key row 16+4g+jj-4 of tile 1) and takes the CLS key in a second MFMA whose only non-zero k-slot is slot 0 of g = 0.
 __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                               float* __restrict__ cls_partial, int B, int n, int heads) {
+                                                               float* __restrict__ cls_partial, int B, int n, int heads, int layout) {
     constexpr int T = 32, P = 4;
     __shared__ __attribute__((aligned(16))) char Vsm[4 * 2 * 4096];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = heads * 64;
-    const int64_t ld = 3 * (int64_t)D;
     const int N = 1 + T * n;
+    // qkv layout (include/hh.h, hh_qkv_layout): element (row, which, head, d) at row * ld + which * ws + head * hs + d
+    const int64_t ld = layout ? 64 : 3 * (int64_t)D;
+    const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
     const int groups = (n + P - 1) / P;
     int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     if (wid >= (int64_t)B * heads * groups) return;
     const int pg = (int)(wid % groups); wid /= groups;
     const int head = (int)(wid % heads);
     const int b = (int)(wid / heads);
-    const bf16_t* base = qkv + (int64_t)b * N * ld + head * 64;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + head * hs;
     const int p0 = pg * P;
     const int npatch = min(P, n - p0);
     const int c = lane & 15, g = lane >> 4;
@@ -263,28 +267,28 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
         char* dst = vbuf + (u & 1) * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            tglds16(base + tok(u, (lane >> 3) + 8 * i) * ld + 2 * D + (lane & 7) * 8, dst + i * 1024);
+            tglds16(base + tok(u, (lane >> 3) + 8 * i) * ld + 2 * ws + (lane & 7) * 8, dst + i * 1024);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             const bf16_t* rp = base + tok(u, 16 * kt + c) * ld + 8 * g;
             qq[kt][0] = *(const bf16x8*)(rp);
             qq[kt][1] = *(const bf16x8*)(rp + 32);
-            kk[kt][0] = *(const bf16x8*)(rp + D);
-            kk[kt][1] = *(const bf16x8*)(rp + D + 32);
+            kk[kt][0] = *(const bf16x8*)(rp + ws);
+            kk[kt][1] = *(const bf16x8*)(rp + ws + 32);
         }
     };
     bf16x8 a2[2], qc[2];
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 kc = *(const bf16x8*)(base + D + 8 * g + 32 * ks);
+        const bf16x8 kc = *(const bf16x8*)(base + ws + 8 * g + 32 * ks);
         a2[ks] = (c & 3) == 0 ? kc : zero8;
         qc[ks] = *(const bf16x8*)(base + 8 * g + 32 * ks);
     }
     bf16_t vcls[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-        const bf16_t v = base[2 * D + 16 * (c >> 2) + 4 * dt + (c & 3)];
+        const bf16_t v = base[2 * ws + 16 * (c >> 2) + 4 * dt + (c & 3)];
         vcls[dt] = g == 0 ? v : (bf16_t)0.f;
     }
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -432,7 +436,9 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
     }
 }
 
-extern "C" int hh_time_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream) {
+extern "C" int hh_time_attn_fwd(const void* qkv, int qkv_layout, void* out, float* cls_partial, int B, int T, int n, int heads,
+                                hh_stream_t stream) {
+    HH_REQUIRE(qkv_layout == HH_QKV_TOKEN_MAJOR || qkv_layout == HH_QKV_HEAD_MAJOR, HH_ERR_SHAPE, "hh_time_attn_fwd: bad qkv_layout");
     HH_REQUIRE(B >= 0 && n > 0 && heads > 0, HH_ERR_SHAPE, "hh_time_attn_fwd: bad shape");
     HH_REQUIRE(T == 1 || T == 2 || T == 4 || T == 8 || T == 16 || T == 32, HH_ERR_UNSUPPORTED,
                "hh_time_attn_fwd: num_frames=%d unsupported (1,2,4,8,16,32)", T);
@@ -445,11 +451,11 @@ extern "C" int hh_time_attn_fwd(const void* qkv, void* out, float* cls_partial, 
     bf16_t* o = (bf16_t*)out;
     HHProfScope prof(HH_PROF_TIME_ATTN, 8.0 * B * (1.0 + (double)T * n) * heads * 64, s);
     if (T == 32) {
-        hipLaunchKernelGGL(time_attn_mfma32_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, s, in, o, cls_partial, B, n, heads);
+        hipLaunchKernelGGL(time_attn_mfma32_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout);
         return hh_check_launch("hh_time_attn_fwd(T=32)");
     }
     const unsigned wg = (unsigned)((blocks + 3) / 4);           // one wave per record, four waves per workgroup
-#define LAUNCHM(TT) hipLaunchKernelGGL(time_attn_mfma_kernel<TT>, dim3(wg), dim3(256), 0, s, in, o, cls_partial, B, n, heads)
+#define LAUNCHM(TT) hipLaunchKernelGGL(time_attn_mfma_kernel<TT>, dim3(wg), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout)
     switch (T) {
         case 1: LAUNCHM(1); break;
         case 2: LAUNCHM(2); break;

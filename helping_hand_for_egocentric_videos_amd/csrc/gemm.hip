@@ -232,15 +232,18 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     HH_REQUIRE(epi != nullptr, HH_ERR_SHAPE, "hh_gemm_bf16: epilogue descriptor is NULL");
     HH_REQUIRE(M >= 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0, HH_ERR_SHAPE,
                "hh_gemm_bf16: need N %% 128 == 0 and K %% 64 == 0 (M=%lld N=%d K=%d)", (long long)M, N, K);
-    HH_REQUIRE(lda >= K && ldw >= K && ldc >= N && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, HH_ERR_SHAPE,
+    const bool cblk = epi->c_block_stride != 0;      // column-blocked C: N / 64 planes [rows, 64] (ldc is 64 by definition)
+    HH_REQUIRE(lda >= K && ldw >= K && (cblk || ldc >= N) && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0, HH_ERR_SHAPE,
                "hh_gemm_bf16: bad leading dimensions lda=%lld ldw=%lld ldc=%lld", (long long)lda, (long long)ldw, (long long)ldc);
+    HH_REQUIRE(!cblk || (epi->c_block_stride >= 64 * M && epi->c_block_stride % 8 == 0 && epi->splitk <= 1 && epi->remap_group == 0),
+               HH_ERR_SHAPE, "hh_gemm_bf16: c_block_stride must be >= 64 * M and a multiple of 8 (no split-K / row remap with it)");
     HH_REQUIRE(HH_ALIGNED16(A) && HH_ALIGNED16(W) && HH_ALIGNED16(C) && HH_ALIGNED16(epi->bias) && HH_ALIGNED16(epi->resid),
                HH_ERR_ALIGN, "hh_gemm_bf16: pointers must be 16-byte aligned");
     HH_REQUIRE(epi->c_dtype == HH_F32 || epi->c_dtype == HH_BF16, HH_ERR_DTYPE, "hh_gemm_bf16: bad output dtype");
     HH_REQUIRE(epi->resid == nullptr || epi->ldr % 4 == 0, HH_ERR_SHAPE, "hh_gemm_bf16: ldr must be a multiple of 4");
     if (M == 0) return HH_OK;
     GemmParams p;
-    p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.C = C; p.ldc = ldc;
+    p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.C = C; p.ldc = cblk ? 64 : ldc;
     p.M = M; p.N = N; p.K = K; p.e = *epi;
     p.m_start = 0;
     p.skew_iters = 0;

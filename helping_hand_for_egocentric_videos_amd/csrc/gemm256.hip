@@ -233,10 +233,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 if (!live[tm] || p.debug_nostore) continue;
                 if constexpr (OUT_BF16) {
                     u32x4 o = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
-                    *(u32x4*)((bf16_t*)Cbase + orow[tm] * p.ldc + n) = o;
+                    *(u32x4*)((bf16_t*)Cbase + orow[tm] * p.ldc + gemm_ccol(e, n)) = o;
                 } else {
-                    *(f32x4*)((float*)Cbase + orow[tm] * p.ldc + n) = v0;
-                    *(f32x4*)((float*)Cbase + orow[tm] * p.ldc + n + TN_OFF) = v1;
+                    *(f32x4*)((float*)Cbase + orow[tm] * p.ldc + gemm_ccol(e, n)) = v0;
+                    *(f32x4*)((float*)Cbase + orow[tm] * p.ldc + gemm_ccol(e, n) + TN_OFF) = v1;
                 }
             }
     }
@@ -474,6 +474,7 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(GemmParams p) {
         if (has_next) stage_from(nA, nW, SLOT_AHI, 1, (kpar + nk + 1) & 1);
         stamp(3);
         char* Cbase = (char*)p.C;
+        const int64_t ccol[2] = {gemm_ccol(e, ncol), gemm_ccol(e, ncol + 128)};
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -494,10 +495,10 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(GemmParams p) {
                     }
                     if constexpr (OUT_BF16) {
                         u32x4 o = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
-                        *(u32x4*)((bf16_t*)Cbase + orow * p.ldc + n) = o;
+                        *(u32x4*)((bf16_t*)Cbase + orow * p.ldc + ccol[nh]) = o;
                     } else {
-                        *(f32x4*)((float*)Cbase + orow * p.ldc + n) = v0;
-                        *(f32x4*)((float*)Cbase + orow * p.ldc + n + 4) = v1;
+                        *(f32x4*)((float*)Cbase + orow * p.ldc + ccol[nh]) = v0;
+                        *(f32x4*)((float*)Cbase + orow * p.ldc + ccol[nh] + 4) = v1;
                     }
                 }
             }

@@ -25,6 +25,12 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// Column term of a C address: row-major C -> n; column-blocked C (hh_gemm_epilogue.c_block_stride, ldc = 64) -> plane n / 64, column
+// n % 64.  The 4 / 8 consecutive columns a lane stores never straddle a 64-column block.
+__device__ __forceinline__ int64_t gemm_ccol(const hh_gemm_epilogue& e, int n) {
+    return e.c_block_stride ? (int64_t)(n >> 6) * e.c_block_stride + (n & 63) : (int64_t)n;
+}
+
 // Epilogue for one accumulator tile in the swapped (C^T) layout: lane owns C[orow][n .. n+3].
 template <bool OUT_BF16>
 __device__ __forceinline__ void gemm_store4(const hh_gemm_epilogue& e, char* Cbase, int64_t ldc, int64_t orow, int n, f32x4 v) {
@@ -40,9 +46,9 @@ __device__ __forceinline__ void gemm_store4(const hh_gemm_epilogue& e, char* Cba
     if (e.resid) v += *(const f32x4*)(e.resid + orow * e.ldr + n);
     if constexpr (OUT_BF16) {
         u32x2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-        *(u32x2*)((bf16_t*)Cbase + orow * ldc + n) = o;
+        *(u32x2*)((bf16_t*)Cbase + orow * ldc + gemm_ccol(e, n)) = o;
     } else {
-        *(f32x4*)((float*)Cbase + orow * ldc + n) = v;
+        *(f32x4*)((float*)Cbase + orow * ldc + gemm_ccol(e, n)) = v;
     }
 }
 
@@ -61,10 +67,10 @@ __device__ __forceinline__ void gemm_store8(const hh_gemm_epilogue& e, char* Cba
     if (e.resid) { v0 += *(const f32x4*)(e.resid + orow * e.ldr + n); v1 += *(const f32x4*)(e.resid + orow * e.ldr + n + 4); }
     if constexpr (OUT_BF16) {
         u32x4 o = {pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
-        *(u32x4*)((bf16_t*)Cbase + orow * ldc + n) = o;
+        *(u32x4*)((bf16_t*)Cbase + orow * ldc + gemm_ccol(e, n)) = o;
     } else {
-        *(f32x4*)((float*)Cbase + orow * ldc + n) = v0;
-        *(f32x4*)((float*)Cbase + orow * ldc + n + 4) = v1;
+        *(f32x4*)((float*)Cbase + orow * ldc + gemm_ccol(e, n)) = v0;
+        *(f32x4*)((float*)Cbase + orow * ldc + gemm_ccol(e, n) + 4) = v1;
     }
 }
 

@@ -89,6 +89,9 @@ class VideoPatchEmbed(nn.Module):
         return tok.view(B * Fr, H // P, W // P, self.embed_dim).permute(0, 3, 1, 2)
 
 
+QKV_HEAD_MAJOR_PLANES = True       # False: the QKV projection writes nn.Linear's token-major [B*N, 3D] (A/B measurements)
+
+
 class VarAttention(nn.Module):
     """Divided space-time attention (LaviLa.py:226-283)."""
 
@@ -126,7 +129,8 @@ class VarAttention(nn.Module):
         D = xn.shape[1]
         # q *= d^-1/2 (LaviLa.py:252) in the GEMM epilogue; the space kernel takes base-2 logits (x log2 e, ops.attention_q_scale)
         qscale = self.scale * (ops.LOG2E if mode == "space" else 1.0)
-        qkv = ops.gemm(xn, pk["wqkv"], pk["bqkv"], colscale=qscale, colscale_cols=D)
+        # head-major planes [3*heads, B*N, 64]: a head's rows are contiguous 128-byte lines for the attention kernels (ops.gemm col_blocked)
+        qkv = ops.gemm(xn, pk["wqkv"], pk["bqkv"], colscale=qscale, colscale_cols=D, col_blocked=QKV_HEAD_MAJOR_PLANES)
         return ops.divided_attention(qkv, B, T, n, self.num_heads, mode)
 
     def forward(self, x, einops_from, einops_to, einops_dims):

@@ -203,11 +203,13 @@ def qself_attn_bwd(qkv, dout, B, Q, heads, dropout_p=0.0, seed=0):
 
 
 def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, resid=None, colscale=1.0,
-         colscale_cols=0, remap=None, out_rows=None, splitk=1):
+         colscale_cols=0, remap=None, out_rows=None, splitk=1, col_blocked=False):
     """C = epilogue(A @ W^T).  a bf16 [M,K], w bf16 [N,K] (nn.Linear weight layout), bias fp32 [N].
 
     resid fp32 [rows,N] is added after the activation; `out` may alias `resid` (in-place residual update).
     remap=(group, skip, offset) scatters output row m to m + (m//group)*skip + offset (token-major scatter).
+    col_blocked=True returns C as N/64 planes [N/64, M, 64] (plane j = columns 64j .. 64j+63; include/hh.h c_block_stride):
+    the QKV projection written this way is the head-major buffer of divided_attention.
     """
     _chk(bias)
     for t in (a, w, resid, out):                     # 2-D operands may be row-strided views (unit inner stride)
@@ -232,6 +234,16 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
         _lib.check(_lib.lib().hh_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(part), N, M, N, K, ctypes.byref(e),
                                            _stream()), "hh_gemm_bf16")
         return part.sum(0)
+    if col_blocked:
+        if out is not None or resid is not None or remap is not None or out_rows is not None:
+            raise ValueError("gemm: col_blocked takes no preallocated output / residual / row remap")
+        planes = torch.empty((N // 64, M, 64), dtype=out_dtype, device=a.device)
+        e = GemmEpilogue()
+        e.bias = bias.data_ptr() if bias is not None else None
+        e.colscale, e.colscale_cols, e.act, e.c_dtype, e.c_block_stride = float(colscale), int(colscale_cols), int(act), _dt(planes), M * 64
+        _lib.check(_lib.lib().hh_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(planes), 64, M, N, K, ctypes.byref(e), _stream()),
+                   "hh_gemm_bf16")
+        return planes
     if out is None:
         out = torch.empty((out_rows if out_rows is not None else M, N), dtype=out_dtype, device=a.device)
     e = GemmEpilogue()
@@ -346,15 +358,23 @@ def attention_q_scale(mode, head_dim=64):
     return head_dim ** -0.5 * (LOG2E if mode == "space" else 1.0)
 
 
+QKV_TOKEN_MAJOR, QKV_HEAD_MAJOR = 0, 1                  # include/hh.h: enum hh_qkv_layout
+
+
 def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
-    """qkv bf16 [B*N, 3D] (q pre-scaled by attention_q_scale(mode)) -> bf16 [B*N, D].  Rows 1.. come from the space/time kernel; the CLS row
+    """qkv bf16 (q pre-scaled by attention_q_scale(mode)), token-major [B*N, 3D] or head-major planes [3*heads, B*N, 64]
+    (gemm(..., col_blocked=True)) -> bf16 [B*N, D].  Rows 1.. come from the space/time kernel; the CLS row
     (query 0 attends all N keys) is folded into the same kernels as per-group partials + hh_cls_combine
     (fold_cls=False runs the stand-alone hh_cls_attn_fwd pass instead)."""
     _chk(qkv, out)
     N = 1 + T * n
     D = heads * 64
-    if qkv.dtype != torch.bfloat16 or qkv.shape != (B * N, 3 * D):
-        raise ValueError("divided_attention: qkv must be bf16 [B*N, 3*heads*64], got %s" % (tuple(qkv.shape),))
+    if qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and qkv.shape == (3 * heads, B * N, 64) and qkv.is_contiguous():
+        lay = QKV_HEAD_MAJOR
+    elif qkv.dtype == torch.bfloat16 and qkv.shape == (B * N, 3 * D) and qkv.is_contiguous():
+        lay = QKV_TOKEN_MAJOR
+    else:
+        raise ValueError("divided_attention: qkv must be contiguous bf16 [B*N, 3*heads*64] or [3*heads, B*N, 64], got %s" % (tuple(qkv.shape),))
     if mode not in ("space", "time"):
         raise ValueError(mode)
     if out is None:
@@ -365,11 +385,11 @@ def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
         G = T if mode == "space" else (n + (128 // T) - 1) // (128 // T)
         part = _workspace("attn_cls_partial", B, T, n, heads, int(mode == "time"), device=qkv.device).view(B, heads, G, 68)
     else:
-        _lib.check(L.hh_cls_attn_fwd(_p(qkv), _p(out), B, N, heads, int(mode == "space"), _stream()), "hh_cls_attn_fwd")
+        _lib.check(L.hh_cls_attn_fwd(_p(qkv), lay, _p(out), B, N, heads, int(mode == "space"), _stream()), "hh_cls_attn_fwd")
     if mode == "space":
-        _lib.check(L.hh_space_attn_fwd(_p(qkv), _p(out), _p(part), B, T, n, heads, _stream()), "hh_space_attn_fwd")
+        _lib.check(L.hh_space_attn_fwd(_p(qkv), lay, _p(out), _p(part), B, T, n, heads, _stream()), "hh_space_attn_fwd")
     else:
-        _lib.check(L.hh_time_attn_fwd(_p(qkv), _p(out), _p(part), B, T, n, heads, _stream()), "hh_time_attn_fwd")
+        _lib.check(L.hh_time_attn_fwd(_p(qkv), lay, _p(out), _p(part), B, T, n, heads, _stream()), "hh_time_attn_fwd")
     if fold_cls:
         _lib.check(L.hh_cls_combine(_p(part), G, _p(out), B, N, heads, _stream()), "hh_cls_combine")
     return out

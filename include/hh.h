@@ -26,6 +26,11 @@ enum hh_status { HH_OK = 0, HH_ERR_SHAPE = -1, HH_ERR_DTYPE = -2, HH_ERR_UNSUPPO
                  HH_ERR_ALIGN = -5 };
 enum hh_dtype { HH_F32 = 0, HH_BF16 = 1 };
 enum hh_act { HH_ACT_NONE = 0, HH_ACT_QUICKGELU = 1, HH_ACT_RELU = 2 };
+/* layout of a packed q|k|v buffer of R = B*N token rows and `heads` heads of 64: element (row, which in {q,k,v}, head, d) sits at
+ *   HH_QKV_TOKEN_MAJOR: row * 3*heads*64 + which * heads*64 + head * 64 + d        (what nn.Linear writes, LaviLa.py:249)
+ *   HH_QKV_HEAD_MAJOR : ((which * heads + head) * R + row) * 64 + d                (3*heads planes of [R, 64]: a head's rows are
+ *                       contiguous 128-byte lines; written by hh_gemm_bf16 with c_block_stride = R * 64) */
+enum hh_qkv_layout { HH_QKV_TOKEN_MAJOR = 0, HH_QKV_HEAD_MAJOR = 1 };
 
 int hh_version(void);
 /* Performance knobs for A/B measurements (never change results).  Together with the per-stream CU budget below this is the
@@ -125,6 +130,9 @@ typedef struct hh_gemm_epilogue {
     int splitk;               /* <=1: off.  S>1: split s handles k-tiles [s*ceil(nk/S), ...) and writes its partial
                                  (same epilogue, caller passes no bias/resid) at C + s*split_stride; caller sums */
     int64_t split_stride;     /* elements between partial slabs */
+    int64_t c_block_stride;   /* 0: C is row-major [M, ldc].  S > 0: C is column-blocked -- N / 64 planes of [M, 64], plane j at
+                                 C + j * S (S >= 64 * M): element (m, n) at (n / 64) * S + m * 64 + n % 64; ldc is ignored.  With
+                                 N = 3 * heads * 64 this is the HH_QKV_HEAD_MAJOR layout of the attention kernels */
 } hh_gemm_epilogue;
 
 int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
@@ -159,7 +167,8 @@ int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int64_t ldb, fl
                     int splits, hh_stream_t stream);
 
 /* ---- divided space-time attention cores (model/LaviLa.py:246-283, attn() :194-198)
- * qkv bf16 [B, N=1+T*n, 3*D] (q|k|v, head-major inside D), out bf16 [B, N, D]; head dim 64.  The q columns are PRE-SCALED by the
+ * qkv bf16 [B, N=1+T*n, 3*D] (q|k|v, head-major inside D) or its head-major planes (qkv_layout: enum hh_qkv_layout), out bf16
+ * [B, N, D] token-major in both cases; head dim 64.  The q columns are PRE-SCALED by the
  * QKV GEMM epilogue: by d^-1/2 for hh_time_attn_fwd (LaviLa.py:252), by d^-1/2 * log2(e) for hh_space_attn_fwd -- its scores are
  * base-2 logits, so that a probability costs one v_exp_f32 (hh_cls_attn_fwd: q_log2 = 1 for such a buffer, 0 otherwise).
  * space: per (b, head, frame): n queries x (CLS + n) keys.  time: per (b, head, patch): T queries x (CLS + T) keys.
@@ -167,9 +176,11 @@ int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int64_t ldb, fl
  * cls_partial (optional, fp32 [B, heads, G, 68], G = T for space, ceil(n / (128/T)) for time): when non-NULL the kernel
  * also emits the CLS query's partial softmax statistics over its own key group (record = m, l, 0, 0, o[64]);
  * hh_cls_combine merges the G records into out row 0, which replaces the separate hh_cls_attn_fwd pass. */
-int hh_space_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream);
-int hh_time_attn_fwd(const void* qkv, void* out, float* cls_partial, int B, int T, int n, int heads, hh_stream_t stream);
-int hh_cls_attn_fwd(const void* qkv, void* out, int B, int N, int heads, int q_log2, hh_stream_t stream);
+int hh_space_attn_fwd(const void* qkv, int qkv_layout, void* out, float* cls_partial, int B, int T, int n, int heads,
+                      hh_stream_t stream);
+int hh_time_attn_fwd(const void* qkv, int qkv_layout, void* out, float* cls_partial, int B, int T, int n, int heads,
+                     hh_stream_t stream);
+int hh_cls_attn_fwd(const void* qkv, int qkv_layout, void* out, int B, int N, int heads, int q_log2, hh_stream_t stream);
 int hh_cls_combine(const float* partial, int G, void* out, int B, int N, int heads, hh_stream_t stream);
 
 /* ---- causal self-attention of the CLIP text tower (model/openai_model.py:182-232; mask model/LaviLa.py:636-642)

@@ -11,8 +11,10 @@ qkv = torch.randn(B * N, 3 * D, device="cuda", generator=g)
 qkv[:, :D] *= 0.5
 qkv = qkv.to(torch.bfloat16)
 out = torch.empty(B * N, D, dtype=torch.bfloat16, device="cuda")
+planes = qkv.view(B * N, 3 * heads, 64).transpose(0, 1).contiguous()          # head-major planes [3*heads, B*N, 64]
 L = _lib.lib()
-def run(): _lib.check(L.hh_space_attn_fwd(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(out.data_ptr()), None, B, T, n, heads, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "x")
+LAYOUT = 0
+def run(): _lib.check(L.hh_space_attn_fwd(ctypes.c_void_p((planes if LAYOUT else qkv).data_ptr()), LAYOUT, ctypes.c_void_p(out.data_ptr()), None, B, T, n, heads, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "x")
 def t(reps=10):
     for _ in range(3): run()
     torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
@@ -24,6 +26,9 @@ ops.set_tuning("space_joint", 1); a = t(); ref = out.clone()
 ops.set_tuning("space_joint", 0); b = t()
 print("joint-block kernel %7.1f us   16-query kernel %7.1f us   max |diff| %.3e" % (a, b, (out.float() - ref.float()).abs().max().item()))
 ops.set_tuning("space_joint", 1); print("joint again        %7.1f us" % t())
+LAYOUT = 1; c = t(); print("joint, head-major qkv planes %7.1f us   max |diff| vs token-major %.3e" % (c, (out[1:].float() - ref[1:].float()).abs().max().item()))
+ops.set_tuning("space_debug", 1); print("joint, head-major, memory only %7.1f us" % t()); ops.set_tuning("space_debug", 0)
+LAYOUT = 0
 for dbg, name in ((1, "memory only (stage K/V, read Q, write O)"), (2, "compute only (no K/V staging)")):
     ops.set_tuning("space_debug", dbg)
     print("joint kernel,    %-45s %7.1f us" % (name, t()))

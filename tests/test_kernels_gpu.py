@@ -106,6 +106,18 @@ def test_gemm_plain_and_epilogues(M, N, K):
     torch.testing.assert_close(R.cpu(), ref + bias + res, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(4097, 3072, 1024), (300, 384, 128), (2 * 4097, 768, 256), (33, 128, 512), (256 * 6, 256, 64)])
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+def test_gemm_column_blocked_output(M, N, K, odt):
+    """c_block_stride: C as N / 64 planes [M, 64] (the head-major q|k|v buffer) -- every kernel of hh_gemm_bf16 (persistent 256x256,
+    128x128, row-tail) stores the same values at the blocked addresses: equal bit for bit to the row-major result."""
+    a, w, bias = bf(rnd(M, K, seed=1)).to(DEV), bf(rnd(N, K, seed=2) * 0.1).to(DEV), rnd(N, seed=3).to(DEV)
+    rows = ops.gemm(a, w, bias, out_dtype=odt, colscale=0.125, colscale_cols=N // 3 // 128 * 128)
+    planes = ops.gemm(a, w, bias, out_dtype=odt, colscale=0.125, colscale_cols=N // 3 // 128 * 128, col_blocked=True)
+    assert planes.shape == (N // 64, M, 64)
+    assert torch.equal(planes.transpose(0, 1).reshape(M, N), rows)
+
+
 @pytest.mark.parametrize("mode", [2, 3])
 @pytest.mark.parametrize("M,N,K", [(256 * 40, 2048, 256), (256 * 24, 3072, 192), (256 * 300, 256, 128), (256 * 20, 4096, 1024),
                                    (256 * 33 + 17, 1024, 512), (256 * 300, 256, 64), (256 * 40, 8192 + 256, 128)])
@@ -300,6 +312,10 @@ def test_divided_attention(mode, B, T, n, heads):
     qkv = bf(qkv)
     out = ops.divided_attention(qkv.to(DEV), B, T, n, heads, mode)
     ref = _ref_divided(qkv, B, T, n, heads, mode)
+    # head-major planes [3*heads, B*N, 64] (what the QKV GEMM writes with col_blocked=True): same kernels, other strides
+    planes = qkv.view(B * N, 3 * heads, 64).transpose(0, 1).contiguous().to(DEV)
+    assert torch.equal(ops.divided_attention(planes, B, T, n, heads, mode), out)
+    assert torch.equal(ops.divided_attention(planes, B, T, n, heads, mode, fold_cls=False), ops.divided_attention(qkv.to(DEV), B, T, n, heads, mode, fold_cls=False))
     sep = ops.divided_attention(qkv.to(DEV), B, T, n, heads, mode, fold_cls=False)       # stand-alone CLS kernel
     assert torch.equal(sep.view(B, -1, heads * 64)[:, 1:], out.view(B, -1, heads * 64)[:, 1:])
     assert_close_bf16(sep.view(B, -1, heads * 64)[:, 0], ref.view(B, -1, heads * 64)[:, 0], 1.2e-2, "cls-separate")
