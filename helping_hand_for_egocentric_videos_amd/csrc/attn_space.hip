@@ -216,52 +216,73 @@ __device__ __forceinline__ void space16_fast(const char* kc0, const char* kc1, c
 // (m, l, o[64]) and the workgroup merges its NW16 partials through LDS.  The VALU version (space_cls_partial) issued ~350 vector
 // instructions per wave -- 36 % of this kernel's VALU work.
 template <int NWV>
-__device__ __forceinline__ void space16_cls_partial(const char* Ks, const char* Vs, float* scratch, const bf16_t* base, float* rec,
-                                                    int n, bool first_frame, int tid, int lane, int wave) {
+__device__ __forceinline__ void space16_cls_wave(const char* Ks, const char* Vs, float* scratch, const bf16x8 (&qc)[2],
+                                                 int n, bool first_frame, int lane, int wave) {
     const int c = lane & 15, g = lane >> 4;
     const int trq = c >> 2, trp = c & 3;
-    const float LOG2E = 1.4426950408889634f;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    bf16x8 qc[2];
-    qc[0] = *(const bf16x8*)(base + 8 * g);
-    qc[1] = *(const bf16x8*)(base + 8 * g + 32);
     const int nfull = n >> 4, ntiles = nfull + (first_frame ? 1 : 0);
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 o[4] = {z4, z4, z4, z4};
-    for (int t = wave; t < ntiles; t += NWV) {
-        const int krow = t * 16 + c;
-        f32x4 s = z4;
+    // batches of up to CB of this wave's tiles: all scores first (independent MFMAs), ONE maximum / row-sum reduction per batch,
+    // then the PV products two tiles per MFMA -- at n = 256 a wave's 3-5 tiles are one batch (the tile-by-tile online softmax this
+    // replaces was a ~1500-cycle dependent chain at the tail of every workgroup)
+    constexpr int CB = 6;
+    for (int t0 = wave; t0 < ntiles; t0 += NWV * CB) {
+        f32x4 s[CB];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((g + 4 * ks) ^ kswz(krow)) << 4));
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qc[ks], s, 0, 0, 0);
-        }
-        if (t == nfull) {                              // CLS tile: only its row 0 is a key
+        for (int i = 0; i < CB; ++i) {
+            const int t = t0 + i * NWV;
+            s[i] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (t < ntiles) {                          // wave-uniform
+                const int krow = t * 16 + c;
+                f32x4 a = z4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (!(g == 0 && j == 0)) s[j] = -INFINITY;
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 kf = *(const bf16x8*)(Ks + krow * 128 + (((g + 4 * ks) ^ kswz(krow)) << 4));
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qc[ks], a, 0, 0, 0);
+                }
+                if (t == nfull) {                      // CLS tile: only its row 0 is a key
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (!(g == 0 && j == 0)) a[j] = -INFINITY;
+                }
+                s[i] = a;
+            }
         }
-        float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) mx = fmaxf(mx, fmaxf(fmaxf(s[i][0], s[i][1]), fmaxf(s[i][2], s[i][3])));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // base-2 logits (q carries log2 e)
-        float p[4], ls = 0.f;
+        float ls = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { p[j] = __builtin_amdgcn_exp2f(s[j] - m_new); ls += p[j]; }
+        for (int i = 0; i < CB; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[i][j] = __builtin_amdgcn_exp2f(s[i][j] - m_new); ls += s[i][j]; }
         ls += __shfl_xor(ls, 16, 64);
         ls += __shfl_xor(ls, 32, 64);
         l_run = l_run * alpha + ls;
         m_run = m_new;
-        const bf16x8 pf = {(bf16_t)p[0], (bf16_t)p[1], (bf16_t)p[2], (bf16_t)p[3], 0, 0, 0, 0};
-        const int ra = t * 16 + 4 * g + trq;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int ch = 2 * trp + (dt >> 1), sub = (dt & 1) * 8;
-            const bf16x4 a0 = lds_tr4(Vs + ra * 128 + ((ch ^ vswz(ra)) << 4) + sub);
-            const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a0[0], a0[1], a0[2], a0[3]};      // second half meets zero probabilities
-            o[dt] *= alpha;
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf, o[dt], 0, 0, 0);
+        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+#pragma unroll
+        for (int i = 0; i < CB; i += 2) {
+            const int ta = t0 + i * NWV, tb = ta + NWV;
+            if (ta >= ntiles) break;                   // wave-uniform
+            const bf16x8 pf = {(bf16_t)s[i][0], (bf16_t)s[i][1], (bf16_t)s[i][2], (bf16_t)s[i][3],
+                               (bf16_t)s[i + 1][0], (bf16_t)s[i + 1][1], (bf16_t)s[i + 1][2], (bf16_t)s[i + 1][3]};   // tile b missing: zeros
+            const int ra = ta * 16 + 4 * g + trq, rb = (tb < ntiles ? tb : ta) * 16 + 4 * g + trq;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int ch = 2 * trp + (dt >> 1), sub = (dt & 1) * 8;
+                const bf16x4 a0 = lds_tr4(Vs + ra * 128 + ((ch ^ vswz(ra)) << 4) + sub);
+                const bf16x4 a1 = lds_tr4(Vs + rb * 128 + ((ch ^ vswz(rb)) << 4) + sub);
+                const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf, o[dt], 0, 0, 0);
+            }
         }
     }
     // per-wave partial -> LDS: [wave][m, l, -, -, o[64]]; accumulator lane (c, g) register (dt, j) = d 16 g + 4 dt + j, same for every c
@@ -271,8 +292,12 @@ __device__ __forceinline__ void space16_cls_partial(const char* Ks, const char* 
         for (int dt = 0; dt < 4; ++dt) *(f32x4*)(wrec + 4 + 16 * g + 4 * dt) = o[dt];
         if (g == 0) { wrec[0] = m_run; wrec[1] = l_run; }
     }
-    __syncthreads();
-    if (tid < 64) {
+}
+
+// merge the NWV per-wave partials of a workgroup (one wave calls this, after a barrier) into the frame's record
+template <int NWV>
+__device__ __forceinline__ void space16_cls_merge(const float* scratch, float* rec, int tid) {
+    {
         float m = -INFINITY;
 #pragma unroll
         for (int w = 0; w < NWV; ++w) m = fmaxf(m, scratch[w * CLS_REC]);
@@ -286,6 +311,17 @@ __device__ __forceinline__ void space16_cls_partial(const char* Ks, const char* 
         rec[4 + tid] = ot;
         if (tid == 0) { rec[0] = m * 0.6931471805599453f; rec[1] = l; }      // the record's maximum is in natural-log units (hh_cls_combine)
     }
+}
+
+template <int NWV>
+__device__ __forceinline__ void space16_cls_partial(const char* Ks, const char* Vs, float* scratch, const bf16_t* base, float* rec,
+                                                    int n, bool first_frame, int tid, int lane, int wave) {
+    bf16x8 qc[2];                                     // the CLS query of this clip and head (row 0 of the clip)
+    qc[0] = *(const bf16x8*)(base + 8 * (lane >> 4));
+    qc[1] = *(const bf16x8*)(base + 8 * (lane >> 4) + 32);
+    space16_cls_wave<NWV>(Ks, Vs, scratch, qc, n, first_frame, lane, wave);
+    __syncthreads();
+    if (tid < 64) space16_cls_merge<NWV>(scratch, rec, tid);
 }
 
 // One 16-query block of one (clip, frame, head) problem against the nt key tiles staged in LDS: fast path, running-maximum redo, store.

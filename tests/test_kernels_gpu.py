@@ -353,6 +353,23 @@ def test_space_attention_joint_blocks_equal_the_16_query_kernel(n, blocks_per_wa
     assert_close_bf16(joint, _ref_divided(qkv.cpu(), B, T, n, heads, "space"), 1.2e-2, "attn-space-joint")
 
 
+def test_space_attention_joint_kernel_many_problems():
+    """B*T*heads = 3*6*16 = 288 (clip, frame, head) problems, folded CLS partials, against the 16-query kernel."""
+    B, T, n, heads = 3, 6, 256, 16
+    N, D = 1 + T * n, heads * 64
+    qkv = rnd(B * N, 3 * D, seed=77)
+    qkv[:, :D] *= 0.5 * ops.LOG2E
+    qkv = bf(qkv).to(DEV)
+    out = ops.divided_attention(qkv, B, T, n, heads, "space")
+    try:
+        ops.set_tuning("space_joint", 0)
+        generic = ops.divided_attention(qkv, B, T, n, heads, "space")
+    finally:
+        ops.set_tuning("space_joint", 1)
+    assert_close_bf16(out, generic, 8e-3, "joint, many problems")
+    torch.testing.assert_close(out.float(), generic.float(), rtol=2.0 ** -7, atol=1e-3 * float(generic.float().abs().max()))
+
+
 @pytest.mark.parametrize("joint", [1, 0])
 def test_space_attention_redo_path_when_the_reference_maximum_is_exceeded(joint):
     """The fast path of the space kernel fixes one reference maximum per 16-query block (from the first 32 keys) and redoes the block
