@@ -286,7 +286,7 @@ def main():
                 "roofline": roof}
         if region is not None:
             att = {}
-            for key, kname in (("space_attn", "space_attn16_kernel"), ("time_attn", "time_attn_mfma_kernel<16>"), ("add_ln", "add_ln_kernel")):
+            for key, kname in (("space_attn", "space_attnj_kernel<4, 2> (joint-block kernel, head-major q|k|v planes)"), ("time_attn", "time_attn_mfma_kernel<16>"), ("add_ln", "add_ln_kernel")):
                 r, n, _, ms = rate(region, key, 1e9)
                 if r is None:
                     continue

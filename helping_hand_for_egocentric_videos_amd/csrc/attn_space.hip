@@ -559,10 +559,14 @@ __global__ __launch_bounds__(64 * NWJ, 2) void space_attnj_kernel(const bf16_t* 
             q[j][1] = *(const bf16x8*)(qrow + 32);
         }
     };
+    // debug mode 3: cls_partial is a [workgroups, 4] uint64 buffer of s_memtime stamps (start / staged / computed / done) of wave 0
+    unsigned long long* stamps = (DBG && dbg == 3) ? (unsigned long long*)cls_partial + (int64_t)blockIdx.x * 4 : nullptr;
+    if (DBG && dbg == 3) { cls_partial = nullptr; if (tid == 0) stamps[0] = __builtin_readcyclecounter(); }
     load_q(wave * JB);                                 // in flight together with the K / V staging
     if (!DBG || dbg != 2) space_stage<NWJ>(Ks, Vs, base, q_ptr, ld, ws, n, KP, lane, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (DBG && dbg == 3 && tid == 0) stamps[1] = __builtin_readcyclecounter();
     if (DBG && dbg == 1) {                             // debug: memory traffic only
         for (int gb = wave * JB; gb < nqb; gb += NWJ * JB) {
             if (gb != wave * JB) load_q(gb);
@@ -610,6 +614,7 @@ __global__ __launch_bounds__(64 * NWJ, 2) void space_attnj_kernel(const bf16_t* 
             }
 #undef SJ_FT
         }
+        if (DBG && dbg == 3 && tid == 0) stamps[2] = __builtin_readcyclecounter();
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             bf16_t* op = out + ((int64_t)b * N + 1 + f * n + (gb + j) * 16 + c) * D + head * 64 + 16 * g;
@@ -627,6 +632,7 @@ __global__ __launch_bounds__(64 * NWJ, 2) void space_attnj_kernel(const bf16_t* 
             }
         }
     }
+    if (DBG && dbg == 3 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[3] = __builtin_readcyclecounter(); }
     if (cls_partial == nullptr) return;
     space16_cls_partial<NWJ>(Ks, Vs, scratch, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
 }

@@ -530,6 +530,7 @@ int hh_tuning_space_debug() { return g_space_dbg; }
 static int g_space_joint = 1;
 int hh_tuning_space_joint() { return g_space_joint; }
 
+
 extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm256") && value >= 0 && value <= 3) { g_mode = value; return HH_OK; }
     if (name && !strcmp(name, "gemm_tail") && (value == 0 || value == 1)) { g_tail = value; return HH_OK; }

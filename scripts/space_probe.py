@@ -38,3 +38,17 @@ for dbg, name in ((1, "memory only (stage K/V, read Q, write O)"), (2, "compute 
     ops.set_tuning("space_debug", dbg)
     print("16-query kernel, %-45s %7.1f us" % (name, t()))
 ops.set_tuning("space_debug", 0); ops.set_tuning("space_joint", 1)
+# ---- per-workgroup timeline of the joint kernel (debug mode 3: s_memtime stamps of wave 0; 100 MHz reference clock)
+stamps = torch.zeros(B * T * heads, 4, dtype=torch.int64, device="cuda")
+ops.set_tuning("space_debug", 3)
+_lib.check(L.hh_space_attn_fwd(ctypes.c_void_p(planes.data_ptr()), 1, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stamps.data_ptr()), B, T, n, heads, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "x")
+torch.cuda.synchronize(); ops.set_tuning("space_debug", 0)
+st = stamps.double().cpu()
+life = (st[:, 3] - st[:, 0]).mean()
+ops.set_tuning("space_joint", 1); LAYOUT = 1; dur = t(); LAYOUT = 0
+rounds = B * T * heads / 512.0                       # two workgroups per CU, 256 CUs
+tick = dur / rounds / float(life)                    # the stamp counter's rate is not documented: calibrate on the kernel's own duration
+print("joint kernel, per-workgroup timeline of wave 0 (head-major planes; %.1f us kernel / %.0f rounds -> %.2f us mean lifetime):" % (dur, rounds, dur / rounds))
+for name, a, b_ in (("launch -> K / V / Q landed + barrier", 0, 1), ("compute (all chunks)", 1, 2), ("normalise, store, stores acknowledged", 2, 3)):
+    d = (st[:, b_] - st[:, a])
+    print("   %-40s %5.1f %% of the lifetime  (~%5.2f us; p10 %5.2f, p90 %5.2f)" % (name, 100 * float(d.mean() / life), float(d.mean()) * tick, float(d.quantile(0.1)) * tick, float(d.quantile(0.9)) * tick))
