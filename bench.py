@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--per-op-query-side", action="store_true", help="A/B: per-op autograd query side instead of the fused QueryStack node")
     ap.add_argument("--token-major-qkv", action="store_true", help="A/B: the QKV projections write nn.Linear's token-major [B*N, 3D] instead of head-major planes")
     ap.add_argument("--space-16q", action="store_true", help="A/B: space attention on the 16-query-block kernel instead of the joint-block kernel")
+    ap.add_argument("--gemm-tail", type=int, default=None, help="A/B: hh_set_tuning('gemm_tail', v) (2 = skip the row tails: timing experiment, wrong rows)")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder forward with this step's decoder")
     args = ap.parse_args()
 
@@ -167,6 +168,8 @@ def main():
         _L.QKV_HEAD_MAJOR_PLANES = False
     if args.space_16q:
         ops.set_tuning("space_joint", 0)
+    if args.gemm_tail is not None:
+        ops.set_tuning("gemm_tail", args.gemm_tail)
     B = args.batch
 
     STRIDE = 5      # every 5th launch of a class is timed (co-prime with the 6 GEMMs / 2 attention calls per block); bracketing every launch costs ~3 % in marker packets

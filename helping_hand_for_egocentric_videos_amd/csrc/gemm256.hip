@@ -268,6 +268,50 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #define TS_TILES 8
 __device__ unsigned long long g_gemm_ts[512 * TS_TILES * 7];       // 5 x s_memrealtime + s_memtime at stamps 1, 2
 
+// <= 32 rows x 32 columns of the row tail inside the persistent kernel (see gemm.hip: gemm_tail_kernel, same arithmetic): the 8 waves
+// split K, each streaming its operands from global memory directly in MFMA layout, the partial accumulators meet in `red` (32 KiB
+// of the still unused staging ring) and wave 0 finishes the piece with the common epilogue.
+template <bool OUT_BF16>
+__device__ __forceinline__ void gemm256_tail_piece(const GemmParams& p, int piece, float* red, int tid) {
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n0 = piece * 32;
+    const int kslice = p.K / 8;                                   // multiple of 64 (K % 512 == 0, checked by the launcher)
+    const int k_begin = wave * kslice;
+    const bf16_t* ap = p.A + (p.tail_m + min(l31, p.tail_rows - 1)) * p.lda + k_begin + 8 * h;
+    const bf16_t* wp = p.W + (int64_t)(n0 + l31) * p.ldw + k_begin + 8 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = 0; k < kslice; k += 64) {
+        bf16x8 af[4], wf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { wf[s] = *(const bf16x8*)(wp + k + 16 * s); af[s] = *(const bf16x8*)(ap + k + 16 * s); }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], af[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave == 0 && l31 < p.tail_rows) {
+        f32x16 t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[(w * 16 + r) * 64 + lane];
+            t[r] = v;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                             // accumulator register r: n = 8 (r >> 2) + 4 h + (r & 3)
+            const f32x4 v = {t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
+            gemm_store4<OUT_BF16>(p.e, (char*)p.C, p.ldc, p.tail_m + l31, n0 + 8 * g + 4 * h, v);
+        }
+    }
+    __syncthreads();                                              // `red` is staging-ring memory
+}
+
 template <bool OUT_BF16, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256d_kernel(GemmParams p) {
     constexpr bool STAGGER = true;
@@ -298,6 +342,8 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(GemmParams p) {
     int64_t m0, nm0 = 0;
     int n0, nn0 = 0;
     int v = next_valid(blockIdx.x, m0, n0);
+    if (p.tail_rows > 0)
+        for (int piece = blockIdx.x; piece < p.N / 32; piece += gridDim.x) gemm256_tail_piece<OUT_BF16>(p, piece, (float*)smem, tid);
     if (v < 0) return;
     // ---- staging sources: wave w stages pieces 2w, 2w+1 (8 rows each) of every half-tile.  The per-lane part of a source address
     // (row inside the half-tile, swizzled 16-B chunk) does not depend on the tile: 4 x 32-bit byte offsets; the tile part is a
@@ -522,7 +568,7 @@ static int g_group = 0;            // m-tiles per XCD-local group (weight-panel 
 static int g_pskew = 0;            // persistent kernel: start skew quantum (s_sleep(8) units per workgroup index in its XCD)
 static int g_skew = -1;            // start skew of the one-tile-per-block kernel: -1 auto (on with an fp32 residual), 0 off, 1 on
 static int g_mode = 3;             // "gemm256": 0 = 128x128 kernel only, 1 = one tile per block, 2 = + wave-row stagger, 3 = persistent (default)
-static int g_tail = 1;             // "gemm_tail": 1 = row tails on the split-K-in-workgroup kernel (gemm.hip), 0 = on the 128x128 kernel
+static int g_tail = 1;             // "gemm_tail": 1 = <= 32-row tails inside the persistent kernel, else the split-K-in-workgroup tail kernel (gemm.hip); 2 = always the tail kernel; 0 = the 128x128 kernel
 
 int hh_tuning_gemm_tail() { return g_tail; }
 static int g_space_dbg = 0;
@@ -533,7 +579,7 @@ int hh_tuning_space_joint() { return g_space_joint; }
 
 extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm256") && value >= 0 && value <= 3) { g_mode = value; return HH_OK; }
-    if (name && !strcmp(name, "gemm_tail") && (value == 0 || value == 1)) { g_tail = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm_tail") && value >= 0 && value <= 2) { g_tail = value; return HH_OK; }
     if (name && !strcmp(name, "space_debug")) { g_space_dbg = value; return HH_OK; }
     if (name && !strcmp(name, "space_joint")) { g_space_joint = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_skew")) { g_skew = value; return HH_OK; }
@@ -553,7 +599,8 @@ bool hh_gemm256_eligible(const GemmParams& p) {
     return g_mode > 0 && p.N % 256 == 0 && p.M >= 2048 && p.e.splitk <= 1 && (p.M / 256) * (p.N / 256) >= 192;
 }
 
-int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
+int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
+    if (tail_done) *tail_done = false;
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute((const void*)gemm256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
@@ -609,6 +656,7 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s) {
                 default: LAUNCHD(true, 3); break;
             }
 #undef LAUNCHD
+            if (tail_done) *tail_done = p.tail_rows > 0;
             return hh_check_launch("hh_gemm_bf16(256x256 persistent)");
         }
     }

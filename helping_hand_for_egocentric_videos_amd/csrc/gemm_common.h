@@ -13,6 +13,8 @@ struct GemmParams {
     int group_m;              // 256x256 kernel: m-tiles per XCD-local group
     int skew_iters;           // 256x256 kernel: start-time skew quantum (0 = off)
     int64_t m_start;          // first row handled by this launch (rows [m_start, M) are tiled)
+    int64_t tail_m;           // persistent 256x256 kernel: rows [tail_m, tail_m + tail_rows) (<= 32 rows behind the last full tile)
+    int tail_rows;            //   are computed by the first N / 32 workgroups before their tile walk (0 = none)
     hh_gemm_epilogue e;
 };
 
@@ -74,5 +76,5 @@ __device__ __forceinline__ void gemm_store8(const hh_gemm_epilogue& e, char* Cba
     }
 }
 
-int hh_gemm256_launch(const GemmParams& p, hipStream_t s);   // gemm256.hip; returns HH_OK or an error
+int hh_gemm256_launch(const GemmParams& p, hipStream_t s, bool* tail_done);   // gemm256.hip; returns HH_OK or an error; *tail_done: p.tail_rows were computed
 bool hh_gemm256_eligible(const GemmParams& p);

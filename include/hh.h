@@ -37,7 +37,8 @@ int hh_version(void);
  * library's ONLY process-global mutable state; no entry point reads the environment.
  *   "gemm256"       0 = 128x128 kernel only, 1 = 256x256 one tile per block, 2 = + wave-row stagger, 3 (default) = persistent
  *                   256x256: one workgroup per CU walks its tiles in one continuous k-tile stream, four barriers per k-tile
- *   "gemm_tail"     1 (default) = (< 64)-row tails on the split-K-in-workgroup kernel, 0 = on the 128x128 kernel
+ *   "gemm_tail"     1 (default) = (<= 32)-row tails inside the persistent kernel where it runs, else as 2; 2 = (< 64)-row tails on
+ *                   the split-K-in-workgroup kernel; 0 = on the 128x128 kernel
  *   "gemm256_group" m-tiles per XCD-local group of the tile walk (0 = per-shape default)
  *   "gemm256_skew"  -1 auto / 0 off / 1 on: start-time skew of the one-tile-per-block kernel (spreads the epilogue HBM bursts)
  *   "gemm256_pskew" 0..64: start skew quantum of the persistent kernel (default 0)

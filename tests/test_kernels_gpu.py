@@ -165,6 +165,38 @@ def test_stream_cu_budget_changes_the_grid_not_the_results():
     assert ops.stream_cu_budget(s) == ops.stream_cu_budget()
 
 
+@pytest.mark.parametrize("M,N,K,act", [(256 * 12 + 32, 4096, 1024, ops.ACT_QUICKGELU), (256 * 48 + 17, 1024, 4096, ops.ACT_NONE),
+                                        (256 * 16 + 32, 3072, 1024, ops.ACT_NONE), (256 * 12 + 1, 4096, 512, ops.ACT_NONE)])
+@pytest.mark.parametrize("budget", [0, 64])
+def test_gemm_row_tail_inside_the_persistent_kernel(M, N, K, act, budget):
+    """The <= 32 rows behind the last full 256-row tile are computed by the first N / 32 workgroups of the persistent kernel before
+    their tile walk (hh_set_tuning("gemm_tail", 1), default) -- same arithmetic as the stand-alone tail kernel ("gemm_tail" 2): equal
+    bit for bit, also on a stream with a 64-CU budget (two or three pieces per workgroup) and with column-blocked output."""
+    a, w, bias = bf(rnd(M, K, seed=5)).to(DEV), bf(rnd(N, K, seed=6) * 0.05).to(DEV), rnd(N, seed=7).to(DEV)
+    kw = dict(act=act, colscale=0.125 if act == ops.ACT_NONE else 1.0, colscale_cols=N // 4 // 128 * 128 if act == ops.ACT_NONE else 0)
+    try:
+        ops.set_tuning("gemm_tail", 2)
+        ref = ops.gemm(a, w, bias, **kw)
+    finally:
+        ops.set_tuning("gemm_tail", 1)
+    s = torch.cuda.Stream()
+    ops.set_stream_cu_budget(s, budget)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        out = ops.gemm(a, w, bias, **kw)
+        planes = ops.gemm(a, w, bias, col_blocked=True, **kw)
+    s.synchronize()
+    ops.set_stream_cu_budget(s, 0)
+    assert torch.equal(out, ref)
+    assert torch.equal(planes.transpose(0, 1).reshape(M, N), ref)
+    tail = slice(M // 256 * 256, M)
+    full = (a[tail].float() @ w.float().t() + bias)
+    full[:, :kw["colscale_cols"]] *= kw["colscale"]
+    if act == ops.ACT_QUICKGELU:
+        full = full * torch.sigmoid(1.702 * full)
+    assert_close_bf16(out[tail], full, 8e-3, "tail rows")
+
+
 def test_gemm_timeline_debug_records_monotonic_stamps_and_a_plausible_clock():
     import ctypes
     import numpy as np
