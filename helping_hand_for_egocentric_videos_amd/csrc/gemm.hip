@@ -257,10 +257,10 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         // cost a whole extra round of 256x256 blocks (M = B*4097 is never a multiple of 256)
         GemmParams pm = p;
         pm.M = (M / 256) * 256;
-        // the <= 32 rows behind the last full tile (M = B * 4097: the B CLS-ish rows) ride inside the persistent kernel: its first
-        // N / 32 workgroups each finish one 32 x 32 piece (8 waves split K) before their tile walk -- the separate row-tail launch cost
+        // the <= 64 rows behind the last full tile (M = B * 4097: the B mod 256 CLS-ish rows) ride inside the persistent kernel: its
+        // first N / 32 (x 2 beyond 32 rows) workgroups each finish one 32 x 32 piece (8 waves split K) before their tile walk -- the separate row-tail launch cost
         // ~11 us per GEMM, 144 times per step (skipping the tails altogether, a timing experiment, gave +1.3 % step throughput)
-        const bool fold = hh_tuning_gemm_tail() == 1 && pm.M != M && M - pm.M <= 32 && K % 512 == 0 && epi->splitk <= 1;
+        const bool fold = hh_tuning_gemm_tail() == 1 && pm.M != M && M - pm.M <= 64 && K % 512 == 0 && epi->splitk <= 1;
         pm.tail_m = pm.M;
         pm.tail_rows = fold ? (int)(M - pm.M) : 0;
         bool folded = false;

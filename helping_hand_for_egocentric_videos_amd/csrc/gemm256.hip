@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #define TS_TILES 8
 __device__ unsigned long long g_gemm_ts[512 * TS_TILES * 7];       // 5 x s_memrealtime + s_memtime at stamps 1, 2
 
-// <= 32 rows x 32 columns of the row tail inside the persistent kernel (see gemm.hip: gemm_tail_kernel, same arithmetic): the 8 waves
+// <= 32 rows x 32 columns of the (<= 64-row) tail inside the persistent kernel (see gemm.hip: gemm_tail_kernel, same arithmetic): the 8 waves
 // split K, each streaming its operands from global memory directly in MFMA layout, the partial accumulators meet in `red` (32 KiB
 // of the still unused staging ring) and wave 0 finishes the piece with the common epilogue.
 template <bool OUT_BF16>
@@ -276,10 +276,11 @@ __device__ __forceinline__ void gemm256_tail_piece(const GemmParams& p, int piec
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
-    const int n0 = piece * 32;
+    const int ncb = p.N / 32;                                     // pieces [0, ncb): tail rows 0..31, [ncb, 2 ncb): rows 32..63
+    const int n0 = (piece % ncb) * 32, r0 = (piece / ncb) * 32;
     const int kslice = p.K / 8;                                   // multiple of 64 (K % 512 == 0, checked by the launcher)
     const int k_begin = wave * kslice;
-    const bf16_t* ap = p.A + (p.tail_m + min(l31, p.tail_rows - 1)) * p.lda + k_begin + 8 * h;
+    const bf16_t* ap = p.A + (p.tail_m + min(r0 + l31, p.tail_rows - 1)) * p.lda + k_begin + 8 * h;
     const bf16_t* wp = p.W + (int64_t)(n0 + l31) * p.ldw + k_begin + 8 * h;
     f32x16 acc;
 #pragma unroll
@@ -294,7 +295,7 @@ __device__ __forceinline__ void gemm256_tail_piece(const GemmParams& p, int piec
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
-    if (wave == 0 && l31 < p.tail_rows) {
+    if (wave == 0 && r0 + l31 < p.tail_rows) {
         f32x16 t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -306,7 +307,7 @@ __device__ __forceinline__ void gemm256_tail_piece(const GemmParams& p, int piec
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                             // accumulator register r: n = 8 (r >> 2) + 4 h + (r & 3)
             const f32x4 v = {t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
-            gemm_store4<OUT_BF16>(p.e, (char*)p.C, p.ldc, p.tail_m + l31, n0 + 8 * g + 4 * h, v);
+            gemm_store4<OUT_BF16>(p.e, (char*)p.C, p.ldc, p.tail_m + r0 + l31, n0 + 8 * g + 4 * h, v);
         }
     }
     __syncthreads();                                              // `red` is staging-ring memory
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(GemmParams p) {
     int n0, nn0 = 0;
     int v = next_valid(blockIdx.x, m0, n0);
     if (p.tail_rows > 0)
-        for (int piece = blockIdx.x; piece < p.N / 32; piece += gridDim.x) gemm256_tail_piece<OUT_BF16>(p, piece, (float*)smem, tid);
+        for (int piece = blockIdx.x; piece < (p.N / 32) * ((p.tail_rows + 31) / 32); piece += gridDim.x) gemm256_tail_piece<OUT_BF16>(p, piece, (float*)smem, tid);
     if (v < 0) return;
     // ---- staging sources: wave w stages pieces 2w, 2w+1 (8 rows each) of every half-tile.  The per-lane part of a source address
     // (row inside the half-tile, swizzled 16-B chunk) does not depend on the tile: 4 x 32-bit byte offsets; the tile part is a

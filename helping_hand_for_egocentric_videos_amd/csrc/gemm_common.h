@@ -13,7 +13,7 @@ struct GemmParams {
     int group_m;              // 256x256 kernel: m-tiles per XCD-local group
     int skew_iters;           // 256x256 kernel: start-time skew quantum (0 = off)
     int64_t m_start;          // first row handled by this launch (rows [m_start, M) are tiled)
-    int64_t tail_m;           // persistent 256x256 kernel: rows [tail_m, tail_m + tail_rows) (<= 32 rows behind the last full tile)
+    int64_t tail_m;           // persistent 256x256 kernel: rows [tail_m, tail_m + tail_rows) (<= 64 rows behind the last full tile)
     int tail_rows;            //   are computed by the first N / 32 workgroups before their tile walk (0 = none)
     hh_gemm_epilogue e;
 };

@@ -166,10 +166,11 @@ def test_stream_cu_budget_changes_the_grid_not_the_results():
 
 
 @pytest.mark.parametrize("M,N,K,act", [(256 * 12 + 32, 4096, 1024, ops.ACT_QUICKGELU), (256 * 48 + 17, 1024, 4096, ops.ACT_NONE),
-                                        (256 * 16 + 32, 3072, 1024, ops.ACT_NONE), (256 * 12 + 1, 4096, 512, ops.ACT_NONE)])
+                                        (256 * 16 + 32, 3072, 1024, ops.ACT_NONE), (256 * 12 + 1, 4096, 512, ops.ACT_NONE),
+                                        (256 * 12 + 40, 4096, 1024, ops.ACT_NONE), (256 * 48 + 64, 1024, 1024, ops.ACT_QUICKGELU)])
 @pytest.mark.parametrize("budget", [0, 64])
 def test_gemm_row_tail_inside_the_persistent_kernel(M, N, K, act, budget):
-    """The <= 32 rows behind the last full 256-row tile are computed by the first N / 32 workgroups of the persistent kernel before
+    """The <= 64 rows behind the last full 256-row tile are computed by the first N / 32 (x 2 beyond 32 rows) workgroups of the persistent kernel before
     their tile walk (hh_set_tuning("gemm_tail", 1), default) -- same arithmetic as the stand-alone tail kernel ("gemm_tail" 2): equal
     bit for bit, also on a stream with a 64-CU budget (two or three pieces per workgroup) and with column-blocked output."""
     a, w, bias = bf(rnd(M, K, seed=5)).to(DEV), bf(rnd(N, K, seed=6) * 0.05).to(DEV), rnd(N, seed=7).to(DEV)
