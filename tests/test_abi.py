@@ -73,3 +73,15 @@ def test_product_ops_refuse_cpu_tensors():
     from helping_hand_for_egocentric_videos_amd.model.qside import LinearX3
     with pytest.raises(RuntimeError, match="libhh HIP kernels only"):
         LinearX3(8, 8)(torch.zeros(2, 8))
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/hh.h is the drop-in boundary: it must compile as C99 on its own (plain pointers and sizes, no C++ in the signatures)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "hh.h")
+    r = subprocess.run([gcc, "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
