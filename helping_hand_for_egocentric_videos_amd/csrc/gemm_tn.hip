@@ -27,6 +27,7 @@ struct TnParams {
     const bf16_t* At; int64_t lda;
     const bf16_t* Bt; int64_t ldb;
     float* C; int64_t split_stride;        // partials [splits][M][N]
+    float* colsum;                         // optional [splits][M]: sum_k At[k, m] of the slice (the bias gradient of dY = At), or NULL
     int M, N; int64_t K;
     int k_per_split;                       // multiple of 64
 };
@@ -70,6 +71,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
         return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     };
 
+    // column sums of At as a by-product (bias gradient of the nn.Linear whose dY is At): the workgroups of n-tile 0, waves wn == 0,
+    // run one more MFMA per A fragment against an all-ones operand -- every row of that C^T tile is sum_k At[k, m]
+    const bool want_cs = p.colsum != nullptr && n0 == 0 && wn == 0;
+    const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
+    f32x4 cs[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 acc[4][4];                                                      // [tn][tm]: C^T tiles (rows n, columns m)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -97,10 +103,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+            if (want_cs) {
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) cs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[tm], cs[tm], 0, 0, 0);
+            }
         }
     }
     // accumulator tile [tn][tm]: lane (c = lane & 15 -> m, g -> n rows 4g .. 4g+3)
     const int mrow = lane & 15;
+    if (want_cs && g == 0) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) p.colsum[(int64_t)blockIdx.y * p.M + m0 + wm * 64 + tm * 16 + mrow] = cs[tm][0];
+    }
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
         const int m = m0 + wm * 64 + tm * 16 + mrow;
@@ -112,15 +126,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
     }
 }
 
-extern "C" int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int64_t ldb, float* partials, int M, int N, int64_t K,
-                               int splits, hh_stream_t stream) {
+extern "C" int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int64_t ldb, float* partials, float* colsum_partials, int M,
+                               int N, int64_t K, int splits, hh_stream_t stream) {
     HH_REQUIRE(M > 0 && N > 0 && K > 0 && M % 128 == 0 && N % 128 == 0, HH_ERR_SHAPE,
                "hh_gemm_tn_bf16: need M %% 128 == 0 and N %% 128 == 0 (M=%d N=%d K=%lld)", M, N, (long long)K);
     HH_REQUIRE(lda >= M && ldb >= N && lda % 8 == 0 && ldb % 8 == 0, HH_ERR_SHAPE, "hh_gemm_tn_bf16: bad leading dimensions");
     HH_REQUIRE(HH_ALIGNED16(At) && HH_ALIGNED16(Bt) && HH_ALIGNED16(partials), HH_ERR_ALIGN, "hh_gemm_tn_bf16: pointers must be 16-byte aligned");
     HH_REQUIRE(splits >= 1 && splits <= 4096, HH_ERR_SHAPE, "hh_gemm_tn_bf16: splits out of range");
     TnParams p;
-    p.At = (const bf16_t*)At; p.lda = lda; p.Bt = (const bf16_t*)Bt; p.ldb = ldb; p.C = partials; p.split_stride = (int64_t)M * N;
+    p.At = (const bf16_t*)At; p.lda = lda; p.Bt = (const bf16_t*)Bt; p.ldb = ldb; p.C = partials; p.split_stride = (int64_t)M * N; p.colsum = colsum_partials;
     p.M = M; p.N = N; p.K = K;
     const int64_t ktiles = (K + 63) / 64;
     p.k_per_split = (int)(((ktiles + splits - 1) / splits) * 64);

@@ -330,9 +330,10 @@ def embed_ln_pre(tok, cls, pos, temporal, gamma, beta, B, T, n, eps=1e-5):
     return x
 
 
-def gemm_tn(at, bt, splits=None):
+def gemm_tn(at, bt, splits=None, colsum=False):
     """Weight-gradient GEMM: at bf16 [K, M], bt bf16 [K, N] (token-major, row-strided views allowed) -> fp32 [M, N] = at^T @ bt.
-    Split-K over the tokens; the partial tiles are summed here."""
+    Split-K over the tokens; the partial tiles are summed here.  colsum=True also returns sum_k at[k, :] (fp32 [M]: the bias
+    gradient when `at` is dY), accumulated by the same kernel from the A fragments it already holds."""
     for t_ in (at, bt):
         if not t_.is_cuda:
             raise RuntimeError("libhh ops need GPU tensors; there is no CPU fallback")
@@ -344,9 +345,13 @@ def gemm_tn(at, bt, splits=None):
         tiles = (M // 128) * (N // 128)
         splits = max(1, min(256, 1024 // max(tiles, 1), (K + 511) // 512))
     part = _workspace("gemm_tn", M, N, int(splits), device=at.device).view(splits, M, N)
-    _lib.check(_lib.lib().hh_gemm_tn_bf16(_p(at), at.stride(0), _p(bt), bt.stride(0), _p(part), M, N, K, int(splits), _stream()),
+    cs = torch.empty((splits, M), dtype=torch.float32, device=at.device) if colsum else None
+    _lib.check(_lib.lib().hh_gemm_tn_bf16(_p(at), at.stride(0), _p(bt), bt.stride(0), _p(part), _p(cs), M, N, K, int(splits), _stream()),
                "hh_gemm_tn_bf16")
-    return part[0] if splits == 1 else part.sum(0)
+    out = part[0] if splits == 1 else part.sum(0)
+    if colsum:
+        return out, (cs[0] if splits == 1 else cs.sum(0))
+    return out
 
 
 LOG2E = 1.4426950408889634

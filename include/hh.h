@@ -163,9 +163,10 @@ int hh_embed_ln_pre(const float* tok, const float* cls, const float* pos, const 
 /* ---- weight-gradient GEMM in its natural layout (backward of the nn.Linear layers of tfm_decoder.py:156,438-441):
  * partials[s, m, n] (fp32, [splits, M, N]) = sum over the s-th token slice of At[k, m] * Bt[k, n]; At bf16 [K, M] (row stride lda),
  * Bt bf16 [K, N] (row stride ldb), i.e. dY and X exactly as they sit in memory (token-major) -- no transposed copies.
- * M % 128 == 0, N % 128 == 0, any K; the caller sums the `splits` partials. */
-int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int64_t ldb, float* partials, int M, int N, int64_t K,
-                    int splits, hh_stream_t stream);
+ * M % 128 == 0, N % 128 == 0, any K; the caller sums the `splits` partials.  colsum_partials (optional, fp32 [splits, M]):
+ * sum over the s-th token slice of At[k, m] -- the bias gradient of the nn.Linear whose dY is At -- as a by-product. */
+int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int64_t ldb, float* partials, float* colsum_partials, int M, int N,
+                    int64_t K, int splits, hh_stream_t stream);
 
 /* ---- divided space-time attention cores (model/LaviLa.py:246-283, attn() :194-198)
  * qkv bf16 [B, N=1+T*n, 3*D] (q|k|v, head-major inside D) or its head-major planes (qkv_layout: enum hh_qkv_layout), out bf16

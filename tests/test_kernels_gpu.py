@@ -233,6 +233,11 @@ def test_gemm_tn_weight_gradient_layout(K, M, N, splits):
     ref = at.float().t() @ bt.float()
     assert out.shape == (M, N)
     assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    # column sums of At (the bias gradient when At is dY) as a by-product of the same launch
+    out2, cs = ops.gemm_tn(at, bt, splits=splits, colsum=True)
+    assert torch.equal(out2, out)
+    cref = at.double().sum(0)
+    assert cs.shape == (M,) and (cs.double() - cref).abs().max().item() <= 1e-5 * at.float().abs().sum(0).max().item() + 1e-4
 
 
 @pytest.mark.parametrize("S,L,heads", [(7, 77, 12), (3, 16, 2), (2, 33, 1), (5, 80, 3), (1, 1, 2), (160, 77, 12)])
