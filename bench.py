@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--per-op-query-side", action="store_true", help="A/B: per-op autograd query side instead of the fused QueryStack node")
     ap.add_argument("--token-major-qkv", action="store_true", help="A/B: the QKV projections write nn.Linear's token-major [B*N, 3D] instead of head-major planes")
     ap.add_argument("--space-16q", action="store_true", help="A/B: space attention on the 16-query-block kernel instead of the joint-block kernel")
-    ap.add_argument("--gemm-tail", type=int, default=None, help="A/B: hh_set_tuning('gemm_tail', v) (2 = skip the row tails: timing experiment, wrong rows)")
+    ap.add_argument("--gemm-tail", type=int, default=None, help="A/B: hh_set_tuning('gemm_tail', v): 1 (default) = row tails of <= 64 rows inside the persistent kernel, 2 = always the separate tail kernel, 0 = the 128x128 kernel; same results")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder forward with this step's decoder")
     args = ap.parse_args()
 

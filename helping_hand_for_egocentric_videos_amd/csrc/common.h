@@ -24,7 +24,7 @@ int hh_stream_cu_count(hipStream_t s);      // CUs the stream may use (runtime.c
 struct HHProfScope {
     HHProfScope(int klass, double work, hipStream_t s);
     ~HHProfScope();
-    int rec_;
+    int rec_, gen_;
     hipStream_t stream_;
 };
 

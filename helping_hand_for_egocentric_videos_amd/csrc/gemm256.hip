@@ -569,7 +569,7 @@ static int g_group = 0;            // m-tiles per XCD-local group (weight-panel 
 static int g_pskew = 0;            // persistent kernel: start skew quantum (s_sleep(8) units per workgroup index in its XCD)
 static int g_skew = -1;            // start skew of the one-tile-per-block kernel: -1 auto (on with an fp32 residual), 0 off, 1 on
 static int g_mode = 3;             // "gemm256": 0 = 128x128 kernel only, 1 = one tile per block, 2 = + wave-row stagger, 3 = persistent (default)
-static int g_tail = 1;             // "gemm_tail": 1 = <= 32-row tails inside the persistent kernel, else the split-K-in-workgroup tail kernel (gemm.hip); 2 = always the tail kernel; 0 = the 128x128 kernel
+static int g_tail = 1;             // "gemm_tail": 1 = row tails of <= 64 rows inside the persistent kernel (in <= 32-row pieces), else the split-K-in-workgroup tail kernel (gemm.hip); 2 = always the tail kernel; 0 = the 128x128 kernel
 
 int hh_tuning_gemm_tail() { return g_tail; }
 static int g_space_dbg = 0;

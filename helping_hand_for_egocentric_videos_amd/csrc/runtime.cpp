@@ -108,6 +108,8 @@ static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
 static long long g_prof_seen[HH_PROF_CLASSES];
+static int g_prof_gen = 0;                       // bumped by every hh_prof_enable: a scope opened before the call must not touch the new records
+static const size_t HH_PROF_MAX_RECS = 1u << 16; // bound on the records (and events) kept while profiling stays enabled; later launches are only counted
 
 static hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
@@ -116,21 +118,23 @@ static hipEvent_t prof_event() {
     return e;
 }
 
-HHProfScope::HHProfScope(int klass, double work, hipStream_t s) : rec_(-1), stream_(s) {
+HHProfScope::HHProfScope(int klass, double work, hipStream_t s) : rec_(-1), gen_(0), stream_(s) {
     const int stride = g_prof_stride.load(std::memory_order_relaxed);
     if (stride <= 0 || klass < 0 || klass >= HH_PROF_CLASSES) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if ((g_prof_seen[klass]++ % stride) != 0) return;
+    if ((g_prof_seen[klass]++ % stride) != 0 || g_prof_recs.size() >= HH_PROF_MAX_RECS) return;
     ProfRec r{klass, prof_event(), prof_event(), work};
     hipEventRecord(r.e0, s);
     g_prof_recs.push_back(r);
     rec_ = (int)g_prof_recs.size() - 1;
+    gen_ = g_prof_gen;
 }
 
 HHProfScope::~HHProfScope() {
     if (rec_ < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (rec_ < (int)g_prof_recs.size()) hipEventRecord(g_prof_recs[rec_].e1, stream_);
+    // hh_prof_enable() between the constructor and here cleared the records (and recycled this scope's events): leave the new ones alone
+    if (gen_ == g_prof_gen && rec_ < (int)g_prof_recs.size()) hipEventRecord(g_prof_recs[rec_].e1, stream_);
 }
 
 extern "C" int hh_prof_enable(int stride) {
@@ -138,6 +142,7 @@ extern "C" int hh_prof_enable(int stride) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
     g_prof_recs.clear();
+    ++g_prof_gen;
     for (int i = 0; i < HH_PROF_CLASSES; ++i) g_prof_seen[i] = 0;
     g_prof_stride.store(stride, std::memory_order_relaxed);
     return HH_OK;

@@ -144,10 +144,11 @@ class SetCriterion(nn.Module):
             dist.all_reduce(nb)
         return torch.clamp(nb / get_world_size(), min=1)[0]
 
-    def forward_raw(self, outputs, q0, q, raw_boxes, box_type, num_boxes=None):
-        """Training path: outputs['pred_boxes'] [F,Qtot,4], queries [q0,q0+q), raw xyxy boxes [F,k,4]."""
+    def forward_raw(self, outputs, q0, q, raw_boxes, box_type, num_boxes=None, match=None):
+        """Training path: outputs['pred_boxes'] [F,Qtot,4], queries [q0,q0+q), raw xyxy boxes [F,k,4].  num_boxes: the normaliser as
+        a device scalar if the caller has already reduced it; match: a match_raw result for the same slice if already computed."""
         pred = outputs['pred_boxes']
-        m = self.matcher.match_raw(pred, q0, q, raw_boxes)
+        m = self.matcher.match_raw(pred, q0, q, raw_boxes) if match is None else match
         nb = self.num_boxes(m["count"]) if num_boxes is None else num_boxes
         losses = {}
         if 'boxes' in self.losses:
@@ -221,10 +222,16 @@ def split_detr_out(detr_out, start=0, end=2):
     return o
 
 
-def compute_box_loss(box_type, criterion, detr_out, target_boxes, target_classes, all_image_size, n_queries=10):
+def compute_box_loss(box_type, criterion, detr_out, target_boxes, target_classes, all_image_size, n_queries=10, *, num_boxes=None,
+                     match=None, return_loss_dict=False):
     """box_utils.py:445-461: ((5*L1 + 2*GIoU)/num_boxes summed) / (len(weight_dict)/3), plus the matching.
 
-    target_boxes: raw xyxy pixel boxes [F,k,4] (hand: k=2 / object: k=2) exactly as run/train.py:161-181 passes them."""
+    target_boxes: raw xyxy pixel boxes [F,k,4] (hand: k=2 / object: k=2) exactly as run/train.py:161-181 passes them.
+    num_boxes: the already world-averaged, clamped normaliser of box_utils.py:218-222 as a device scalar (the step reduces all of
+    its target counts in one collective, parallel.gather_contrastive); None = compute (and all-reduce) it here as the reference does.
+    match: the result of criterion.matcher.match_raw on the same slice, if the caller already ran it.
+    return_loss_dict=True appends the criterion's unweighted loss dict (incl. the no-grad `cardinality_error_<type>` the reference
+    computes at :142-154 and drops at :457-461)."""
     if target_classes is not None:
         raise NotImplementedError("compute_box_loss: run/train.py passes target_classes=None")
     if box_type == 'hand_boxes':
@@ -235,7 +242,7 @@ def compute_box_loss(box_type, criterion, detr_out, target_boxes, target_classes
         q0, q = 0, detr_out['pred_boxes'].shape[1]
     else:
         raise ValueError(box_type)
-    loss_dict, matched = criterion.forward_raw(detr_out, q0, q, target_boxes, box_type)
+    loss_dict, matched = criterion.forward_raw(detr_out, q0, q, target_boxes, box_type, num_boxes=num_boxes, match=match)
     wd = criterion.weight_dict
-    total = sum(v * wd[k] for k, v in loss_dict.items() if k in wd)
-    return total / (len(wd) / 3), matched
+    total = sum(v * wd[k] for k, v in loss_dict.items() if k in wd) / (len(wd) / 3)
+    return (total, matched, loss_dict) if return_loss_dict else (total, matched)

@@ -5,7 +5,10 @@ WordContrastiveLoss :72-106) without the reference's host round trips.
     here dropped rows are masked in place (identical value and gradient), so the step never syncs.
   * WordContrastiveLoss: scipy.optimize.linear_sum_assignment on `.cpu()` costs (loss.py:87-93) is replaced by the
     on-device exact LSAP kernel hh_lsap_rows (bit-identical assignment, csrc/match.hip).
-  * Under data parallelism the word loss divides by the all-reduced valid-word count / W (the reference has no DP semantics).
+  * Under data parallelism the word loss divides by the global valid-word count / W (the reference has no DP semantics): the
+    returned value is this rank's share x W -- its MEAN over ranks is the global mean cross-entropy, which is what the mean-reduced
+    gradients optimise (as `num_boxes` does for the box losses, box_utils.py:218-222).  The step passes the count it already
+    gathered (parallel.gather_contrastive); stand-alone use all-reduces it here.
 Small fp32 reductions (log-softmax over a [5B,B] matrix, CE over 582 nouns) stay on stock PyTorch-ROCm ops.
 """
 import torch
@@ -74,8 +77,9 @@ class WordContrastiveLoss(nn.Module):
         super().__init__()
         self.temperature, self.noun_threshold = temperature, noun_threshold
 
-    def forward(self, noun_embeds, pred_noun_embeds, noun_gt_inds, return_assignment=False):
-        """noun_embeds [V,256], pred_noun_embeds [B,Q-1,256], noun_gt_inds int64 [B,W] (0 = pad) -> scalar."""
+    def forward(self, noun_embeds, pred_noun_embeds, noun_gt_inds, return_assignment=False, count=None):
+        """noun_embeds [V,256], pred_noun_embeds [B,Q-1,256], noun_gt_inds int64 [B,W] (0 = pad) -> scalar.
+        count: the normaliser (global valid-word count / world size) as a device scalar when the caller has already reduced it."""
         Bn, W = noun_gt_inds.shape
         gt = noun_embeds.index_select(0, noun_gt_inds.flatten()).view(Bn, W, -1)
         cost = -sim_matrix(gt, pred_noun_embeds)                                   # [B,W,Q-1]
@@ -88,12 +92,15 @@ class WordContrastiveLoss(nn.Module):
         noun_mask = noun_sim.index_select(0, noun_gt_inds.flatten()) > self.noun_threshold
         ce = F.cross_entropy(sim_all.masked_fill(noun_mask, -1) / self.temperature, noun_gt_inds.flatten(), reduction='none')
         v = valid.flatten()
-        count = v.sum().float()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if count is not None:
+            count = count.clamp(min=1)                  # a rank (or the whole global batch) without valid words contributes 0, not NaN
+        elif dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             # data parallel: normalise by the mean word count over ranks (as SetCriterion.num_boxes does, box_utils.py:218-222), so
             # that mean-reduced parameter gradients equal those of one process on the concatenated batch
-            count = count.reshape(1).clone()
+            count = v.sum().float().reshape(1)
             dist.all_reduce(count)
-            count = count[0] / dist.get_world_size()
+            count = (count[0] / dist.get_world_size()).clamp(min=1)
+        else:
+            count = v.sum().float()                     # single process: the reference's plain mean over valid words (loss.py:104)
         loss = torch.where(v, ce, torch.zeros((), device=ce.device)).sum() / count
         return (loss, cols) if return_assignment else loss

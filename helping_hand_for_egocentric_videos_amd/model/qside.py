@@ -38,22 +38,34 @@ class _LinearX3(torch.autograd.Function):
         wd = w.detach()
         if wd.stride(-1) != 1 or wd.stride(0) % 4 or wd.data_ptr() % 16:
             wd = wd.contiguous()
-        y = ops.qgemm(x2, wd, ops.NT, bias=None if b is None else b.detach().contiguous(), relu=relu)
+        bd = None if b is None else b.detach().contiguous()
+        # hh_qgemm_f32x3 wants N % 4 == 0 and K % 4 == 0 (16-byte rows); nn.Linear in the reference takes any size (e.g. a class head
+        # with num_classes + 1 not a multiple of 4): zero-pad the operands and slice the results
+        N = wd.shape[0]
+        Kp, Np = (K + 3) // 4 * 4, (N + 3) // 4 * 4
+        if Kp != K or Np != N:
+            x2 = torch.nn.functional.pad(x2, (0, Kp - K)) if Kp != K else x2
+            wd = torch.nn.functional.pad(wd, (0, Kp - K, 0, Np - N))
+            bd = None if bd is None else torch.nn.functional.pad(bd, (0, Np - N))
+        y = ops.qgemm(x2, wd, ops.NT, bias=bd, relu=relu)
         ctx.save_for_backward(x2, wd, y if relu else None)
-        ctx.has_bias, ctx.relu, ctx.xshape = b is not None, relu, x.shape
-        return y.view(*x.shape[:-1], w.shape[0])
+        ctx.has_bias, ctx.relu, ctx.xshape, ctx.N, ctx.K = b is not None, relu, x.shape, N, K
+        return (y if Np == N else y[:, :N]).reshape(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         x2, w, y = ctx.saved_tensors
-        N = w.shape[0]
-        dz = dy.reshape(-1, N)
+        N = w.shape[0]                                    # padded sizes from here on; results are sliced back at the end
+        dz = dy.reshape(-1, ctx.N)
+        if N != ctx.N:
+            dz = torch.nn.functional.pad(dz, (0, N - ctx.N))
         if ctx.relu:
             dz = dz * (y > 0)
         dz = dz.float().contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.qgemm(dz, w, ops.NN).view(ctx.xshape)
+            dx = ops.qgemm(dz, w, ops.NN)
+            dx = (dx if dx.shape[1] == ctx.K else dx[:, :ctx.K]).reshape(ctx.xshape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             rows, K = x2.shape
             tiles = ((N + 63) // 64) * ((K + 63) // 64)
@@ -64,6 +76,9 @@ class _LinearX3(torch.autograd.Function):
             else:
                 db = torch.empty(N, dtype=torch.float32, device=dz.device) if ctx.has_bias else None
                 dw = ops.qgemm(dz, x2, ops.TN, colsum=db)
+            if dw.shape != (ctx.N, ctx.K):
+                dw = dw[:ctx.N, :ctx.K]
+                db = None if db is None else db[:ctx.N]
         return dx, dw, db, None
 
 

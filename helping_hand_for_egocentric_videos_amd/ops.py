@@ -504,3 +504,14 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     _chk(p, g, m, v)
     _lib.check(_lib.lib().hh_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
                                         float(eps), float(weight_decay), int(step), _stream()), "hh_adamw_step")
+
+
+def adamw_arena_step(p, g, m, v, seg_off, seg_decay, seg_step, seg_flag, seg_coef, lr, beta1, beta2, eps, weight_decay, zero_grads=True):
+    """hh_adamw_arena_step: AdamW over the whole flat arena, per-parameter skip / step count / bias correction decided on the device."""
+    _chk(p, g, m, v)
+    n_seg = seg_decay.numel()
+    assert seg_off.dtype == torch.int64 and seg_off.numel() == n_seg + 1 and seg_decay.dtype == torch.int32
+    assert seg_step.dtype == torch.int32 and seg_flag.dtype == torch.float32 and seg_coef.numel() >= 2 * n_seg
+    _lib.check(_lib.lib().hh_adamw_arena_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(seg_off), _p(seg_decay), _p(seg_step),
+                                              _p(seg_flag), _p(seg_coef), n_seg, float(lr), float(beta1), float(beta2), float(eps),
+                                              float(weight_decay), int(bool(zero_grads)), _stream()), "hh_adamw_arena_step")

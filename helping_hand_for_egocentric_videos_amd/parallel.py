@@ -9,8 +9,13 @@ build's own:
   * buckets are all-reduced asynchronously on a communication stream as soon as every parameter in the bucket has
     its final gradient (post-accumulate hooks) -> overlapped with the rest of backward; mean over ranks,
   * the contrastive batch is gathered with ONE packed all-gather per step (embeddings + pad flags + verb/noun
-    vectors); its backward returns W x the local slice, which under mean-reduction of parameter gradients makes
-    W ranks equivalent to one process on the concatenated batch.
+    vectors + the step's three normaliser counts: hand boxes, object boxes, valid words -- the reference's scalar
+    `num_boxes` all-reduces, box_utils.py:218-222, ride in the same rows); its backward returns W x the local slice,
+    which under mean-reduction of parameter gradients makes W ranks equivalent to one process on the concatenated batch,
+  * which parameters AdamW updates is decided on the device from per-parameter "received a gradient" flags that are
+    all-reduced with the gradients (one small collective per step), so ranks whose graphs differ (a parameter unused on
+    one rank only) still take identical optimizer decisions.
+Collectives per step: 1 all-gather (forward) + #buckets gradient all-reduces + 1 flag all-reduce (backward).
 xGMI note: 110 MB of fp32 gradients in ~8 buckets of ~14 MB; each bucket is one RCCL all-reduce, far below the
 >= 90 ms of compute per step, so exposed communication is only the last bucket.
 """
@@ -75,9 +80,19 @@ class FlatArena:
         # parameters whose gradient was written in the current step (torch.optim.AdamW skips grad-less parameters entirely, no
         # weight decay either: e.g. frame_index / frame_proj when a clip length != num_frames skips the trajectory branch)
         self.touched = set()
-        self.steps = {n: 0 for n, _ in self.entries}            # per-parameter AdamW step count (bias correction)
         self._sizes = dict(zip((n for n, _ in self.entries), sizes))
-        self._plan_cache = {}
+        self.names = [n for n, _ in self.entries]
+        # device-side segment table of hh_adamw_arena_step: one segment per parameter
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + sz)
+        self.seg_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self.seg_decay = torch.tensor([0 if no_decay(n) else 1 for n in self.names], dtype=torch.int32, device=dev)
+        self.seg_step = torch.zeros(len(self.names), dtype=torch.int32, device=dev)      # per-parameter AdamW step count (bias correction)
+        self.seg_flag = torch.zeros(len(self.names), dtype=torch.float32, device=dev)    # this step's flags (all-reduced under DP)
+        self.seg_coef = torch.zeros(2 * len(self.names), dtype=torch.float32, device=dev)
+        self._flag_cache = {}
+        self.grads_clean = True                                  # the gradient arena is all zero (fresh, or cleared by the last update)
         self._touch_hooks = [p.register_post_accumulate_grad_hook(self._make_touch_hook(n)) for n, p in self.entries]
 
     def _make_touch_hook(self, name):
@@ -85,40 +100,31 @@ class FlatArena:
             self.touched.add(name)
         return hook
 
-    def update_plan(self):
-        """AdamW launch plan for the parameters touched in this step: list of (start, end, weight_decayed, step) over contiguous
-        arena ranges.  Adjacent entries of the same decay group and the same step count share a range -- when every parameter has a
-        gradient every step (the normal case) that is two ranges.  Advances the per-parameter step counts."""
-        key = frozenset(self.touched)
-        ranges = self._plan_cache.get(key)
-        if ranges is None:                                      # [start, end, decayed, names] ignoring step counts
-            ranges, off = [], 0
-            for n, _ in self.entries:
-                sz = self._sizes[n]
-                if n in key:
-                    dec = not no_decay(n)
-                    if ranges and ranges[-1][1] == off and ranges[-1][2] == dec:
-                        ranges[-1][1] = off + sz
-                        ranges[-1][3].append(n)
-                    else:
-                        ranges.append([off, off + sz, dec, [n]])
-                off += sz
-            self._plan_cache[key] = ranges
-        plan = []
-        for a, b, dec, names in ranges:
-            if len({self.steps[n] for n in names}) == 1:
-                plan.append((a, b, dec, self.steps[names[0]] + 1))
-            else:                                               # parameters that skipped earlier steps: one launch per parameter
-                for n in names:
-                    o, _ = self.offsets[n]
-                    plan.append((o, o + self._sizes[n], dec, self.steps[n] + 1))
-        for n in key:
-            self.steps[n] += 1
-        return plan
+    @property
+    def steps(self):
+        """{parameter name: AdamW step count} read back from the device (synchronises: checkpointing / tests only)."""
+        return dict(zip(self.names, self.seg_step.cpu().tolist()))
 
-    def zero_grad(self):
+    def set_steps(self, steps):
+        self.seg_step.copy_(torch.tensor([int(steps.get(n, 0)) for n in self.names], dtype=torch.int32))
+
+    def local_flags(self):
+        """fp32 [n_params] device tensor, 1 where this rank's backward wrote the parameter's gradient.  One tensor per distinct
+        touched-set is built (a small H2D copy) and cached: in steady state this costs no transfer and no synchronisation."""
+        key = frozenset(self.touched)
+        t = self._flag_cache.get(key)
+        if t is None:
+            t = torch.tensor([1.0 if n in key else 0.0 for n in self.names], dtype=torch.float32).to(self.params.device)
+            self._flag_cache[key] = t
+        return t
+
+    def zero_grad(self, force=True):
+        """optimizer.zero_grad() (run/train.py:199).  force=False skips the fill when the last hh_adamw_arena_step already cleared
+        the arena (TrainStep.step does that)."""
         self.touched.clear()
-        self.grads.zero_()
+        if force or not self.grads_clean:
+            self.grads.zero_()
+        self.grads_clean = False                     # a backward is about to write it
         for n, p in self.entries:                    # autograd may have replaced .grad; re-point it at the arena
             o, k = self.offsets[n]
             if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + o * 4:
@@ -139,7 +145,8 @@ class BucketedAllReduce:
         self.pending = []
         self.comm_stream = torch.cuda.Stream() if (self.enabled and arena.params.is_cuda) else None
         self.avg = self.enabled and dist.get_backend(group) == "nccl"
-        self.launched = 0                                        # collectives issued so far (tests / diagnostics)
+        self.launched = 0                                        # gradient-bucket collectives issued so far (tests / diagnostics)
+        self.flag_reduces = 0
         self._remaining = []
         self._bucket_of = {}
         for bi, (_, _, names) in enumerate(arena.buckets):
@@ -153,6 +160,7 @@ class BucketedAllReduce:
 
     def reset(self):
         self._remaining = [len(names) for _, _, names in self.arena.buckets]
+        self._next = 0                                           # buckets are launched strictly in arena order on every rank
         self.pending = []
 
     def _make_hook(self, name):
@@ -161,11 +169,18 @@ class BucketedAllReduce:
             if param.grad is not None and param.grad.data_ptr() != self.arena.grads.data_ptr() + o * 4:
                 self.arena.grads[o:o + k].copy_(param.grad.reshape(-1))      # autograd produced a fresh tensor
                 param.grad = self.arena.grads[o:o + k].view_as(param)
-            bi = self._bucket_of[name]
-            self._remaining[bi] -= 1
-            if self._remaining[bi] == 0:
-                self._launch(bi)
+            self._remaining[self._bucket_of[name]] -= 1
+            self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Launch every leading bucket whose gradients are final.  The ORDER of collectives must be identical on all ranks even when
+        their graphs differ (a parameter unused on one rank finishes its bucket only in finish()), so a bucket never overtakes an
+        earlier one; the arena is laid out in backward order, so in the common case this is the order of completion anyway."""
+        nb = len(self._remaining)
+        while self._next < nb and self._remaining[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, bi):
         s, e, _ = self.arena.buckets[bi]
@@ -182,16 +197,26 @@ class BucketedAllReduce:
 
     def finish(self):
         """Wait for every bucket (launching the ones whose hooks never fired, e.g. unused parameters); gradients are then the
-        mean over ranks."""
+        mean over ranks, and arena.seg_flag holds, per parameter, whether ANY rank's backward produced its gradient (a parameter
+        unused on this rank only still receives the other ranks' averaged gradient, and every rank must then update it -- as
+        torch DDP does; a rank-local decision would let weights, moments and step counts diverge silently)."""
+        a = self.arena
+        a.seg_flag.copy_(a.local_flags())
         if not self.enabled:
             return
-        for bi, rem in enumerate(self._remaining):
-            if rem > 0:
-                self._remaining[bi] = 0
-                self._launch(bi)
+        self._remaining = [0] * len(self._remaining)
+        self._launch_ready()
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                work = dist.all_reduce(a.seg_flag, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            work = dist.all_reduce(a.seg_flag, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.flag_reduces += 1
+        self.pending.append((work, None))
         for w, buf in self.pending:
             w.wait()
-            if not self.avg and self.W > 1:
+            if buf is not None and not self.avg and self.W > 1:
                 buf.mul_(1.0 / self.W)
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
@@ -209,34 +234,50 @@ class _AllGatherScaled(torch.autograd.Function):
     def forward(ctx, x, group):
         W, r = world()
         ctx.W, ctx.r, ctx.b = W, r, x.shape[0]
-        out = [torch.empty_like(x) for _ in range(W)]
-        dist.all_gather(out, x.contiguous(), group=group)
-        return torch.cat(out, 0)
+        x = x.contiguous()
+        out = x.new_empty((W * x.shape[0],) + tuple(x.shape[1:]))
+        dist.all_gather_into_tensor(out, x, group=group)         # one output buffer: no W temporaries + cat
+        return out
 
     @staticmethod
     def backward(ctx, g):
         return g[ctx.b * ctx.r: ctx.b * (ctx.r + 1)] * ctx.W, None
 
 
-def gather_contrastive(video_embeds, text_embeds, pad_flag, verb_vec, noun_vec, group=None, force=False):
-    """ONE packed all-gather of everything EgoNCE needs across ranks (run/train.py:126-140 uses 5-6 collectives).
+def gather_contrastive(video_embeds, text_embeds, pad_flag, verb_vec, noun_vec, group=None, force=False, counts=None):
+    """ONE packed all-gather of everything the step needs from the other ranks (run/train.py:126-140 uses 5-6 collectives for the
+    contrastive batch, box_utils.py:218-222 one more per box type for `num_boxes`).
 
-    video_embeds [b,E], text_embeds [R*b,E] (differentiable), pad_flag [R*b], verb_vec [b,V], noun_vec [b,Nn].
-    Returns the global tensors in rank-major order.  force=True runs the collective in a 1-rank group too (RCCL smoke test)."""
+    video_embeds [b,E], text_embeds [R*b,E] (differentiable), pad_flag [R*b], verb_vec [b,V], noun_vec [b,Nn]; counts: optional fp32
+    [k] of this rank's normaliser counts (TrainStep: matched hand boxes, object boxes, valid words), carried in k extra columns of
+    the first local row.  Returns (ve, te, pf, vv, nv, sums) with the global tensors in rank-major order and sums [k] = the counts
+    summed over ranks (None when counts is None).  force=True runs the collective in a 1-rank group too (RCCL smoke test)."""
     W, _ = world()
     if W == 1 and not (force and dist.is_available() and dist.is_initialized()):
-        return video_embeds, text_embeds, pad_flag, verb_vec, noun_vec
+        return video_embeds, text_embeds, pad_flag, verb_vec, noun_vec, (None if counts is None else counts.float())
     b, E = video_embeds.shape
     Rb = text_embeds.shape[0]
     R = Rb // b
-    # one row per clip: [video | R text embeds | R pad flags | verb | noun]
-    row = torch.cat([video_embeds.float(), text_embeds.float().reshape(b, R * E), pad_flag.float().reshape(b, R),
-                     verb_vec.float(), noun_vec.float()], dim=1)
+    # one row per clip: [video | R text embeds | R pad flags | verb | noun | counts (row 0 only)]
+    cols = [video_embeds.float(), text_embeds.float().reshape(b, R * E), pad_flag.float().reshape(b, R), verb_vec.float(), noun_vec.float()]
+    k = 0 if counts is None else counts.numel()
+    if k:
+        cpad = torch.zeros((b, k), dtype=torch.float32, device=video_embeds.device)
+        cpad[0] = counts.detach().float()
+        cols.append(cpad)
+    row = torch.cat(cols, dim=1)
     g = _AllGatherScaled.apply(row, group)                                   # [W*b, ...]
     o = 0
     ve = g[:, o:o + E]; o += E
     te = g[:, o:o + R * E].reshape(-1, E); o += R * E
     pf = g[:, o:o + R].reshape(-1).detach(); o += R
     vv = g[:, o:o + verb_vec.shape[1]].detach(); o += verb_vec.shape[1]
-    nv = g[:, o:o + noun_vec.shape[1]].detach()
-    return ve, te, pf, vv, nv
+    nv = g[:, o:o + noun_vec.shape[1]].detach(); o += noun_vec.shape[1]
+    sums = g[:, o:o + k].detach().sum(0) if k else None
+    return ve, te, pf, vv, nv, sums
+
+
+def normaliser(global_count):
+    """clamp(global count / world, 1): SetCriterion's num_boxes (box_utils.py:218-222) from an already reduced count."""
+    W, _ = world()
+    return torch.clamp(global_count / W, min=1)

@@ -13,7 +13,7 @@ from . import ops
 from .model import box_utils
 from .model.loss import EgoNCE, WordContrastiveLoss
 from .model.metric import compute_tv_accuracy, sim_matrix
-from .parallel import BucketedAllReduce, FlatArena, gather_contrastive, no_decay, world
+from .parallel import BucketedAllReduce, FlatArena, gather_contrastive, no_decay, normaliser, world
 
 ZEROED_NOUNS = [102, 504, 364, 321, 556]          # run/train.py:73
 DP_ENC_CUS = 0                                    # default encoder-stream CU budget under data parallelism: 0 = no reservation (see TrainStep)
@@ -120,7 +120,20 @@ class TrainStep:
             self._zeroed_idx = torch.tensor(ZEROED_NOUNS, device=text.device)              # once: a Python-list index is an H2D copy + sync per step
         noun_vec = batch["noun_vec"].clone().index_fill_(1, self._zeroed_idx, 0)
         pad_flag = ((text != 0).sum(-1) != 2).float()                               # run/train.py:144
-        ve, te, pf, vv, nv = gather_contrastive(video_embeds, text_embeds, pad_flag, batch["verb_vec"], noun_vec, force=self.force_comm)
+        # matching first (it needs only pred_boxes): the matched-target counts of both box types and the valid-word count are the
+        # normalisers of three loss terms (box_utils.py:218-222 all-reduces `num_boxes` per box type; the word loss is a mean over
+        # valid words) -- under data parallelism they ride in the packed contrastive all-gather instead of three blocking scalar
+        # all-reduces in the middle of the forward
+        hand = batch["boxes"][:, :, :2].flatten(0, 1)
+        objb = batch["boxes"][:, :, 2:].flatten(0, 1)
+        nq = cfg.num_queries if cfg.num_queries != 0 else 10
+        matcher = self.criterion.matcher
+        mh = matcher.match_raw(det["pred_boxes"], 0, 2, hand)
+        mo = matcher.match_raw(det["pred_boxes"], 2, nq - 2, objb)
+        counts = torch.stack([mh["count"].sum(), mo["count"].sum(), (batch["nouns"] != 0).sum()]).float()
+        ve, te, pf, vv, nv, sums = gather_contrastive(video_embeds, text_embeds, pad_flag, batch["verb_vec"], noun_vec,
+                                                      force=self.force_comm, counts=counts)
+        norm = normaliser(sums)                                                     # clamp(global / W, 1) x 3
         Bg = ve.shape[0]
         sim = sim_matrix(te, ve)                                                    # [5Bg, Bg]
         sim_v, sim_n = sim_matrix(vv, vv), sim_matrix(nv, nv)
@@ -128,34 +141,43 @@ class TrainStep:
         R = te.shape[0] // Bg
         with torch.no_grad():
             acc_vt, acc_tv = compute_tv_accuracy(sim.view(Bg, R, Bg)[:, 0], te, sim_v, sim_n, Bg)
-        hand = batch["boxes"][:, :, :2].flatten(0, 1)
-        objb = batch["boxes"][:, :, 2:].flatten(0, 1)
-        nq = cfg.num_queries if cfg.num_queries != 0 else 10
-        lh, mh = box_utils.compute_box_loss("hand_boxes", self.criterion, det, hand, None, None, n_queries=nq)
-        lo, mo = box_utils.compute_box_loss("obj_boxes", self.criterion, det, objb, None, None, n_queries=nq)
+        lh, mh, dh = box_utils.compute_box_loss("hand_boxes", self.criterion, det, hand, None, None, n_queries=nq, num_boxes=norm[0],
+                                                match=mh, return_loss_dict=True)
+        lo, mo, do = box_utils.compute_box_loss("obj_boxes", self.criterion, det, objb, None, None, n_queries=nq, num_boxes=norm[1],
+                                                match=mo, return_loss_dict=True)
         noun_embeds = self.decoder.txt_proj(batch["all_nouns"])
-        word = self.word(noun_embeds, obj[:, :-1], batch["nouns"])
+        word = self.word(noun_embeds, obj[:, :-1], batch["nouns"], count=sums[2] / W if W > 1 else None)
         total = nce + lh + lo + 0.5 * word                                          # run/train.py:149,183,191
         return {"total_loss": total, "nce_loss": nce.detach(), "box_loss_hand": lh.detach(), "box_loss_obj": lo.detach(),
                 "word_loss": word.detach(), "acc_vt": acc_vt, "acc_tv": acc_tv, "match_hand": mh, "match_obj": mo,
-                "pred_boxes": det["pred_boxes"], "hs": hs}
+                "pred_boxes": det["pred_boxes"], "hs": hs,
+                "cardinality_error_hand_boxes": dh.get("cardinality_error_hand_boxes"),
+                "cardinality_error_obj_boxes": do.get("cardinality_error_obj_boxes"),
+                "pred_logits": det.get("pred_logits"), "pred_logits_argmax": det.get("pred_logits_argmax")}
 
     # ------------------------------------------------------------------ step
     def step(self, batch, next_batch=None):
         """One optimisation step on `batch`; if `next_batch` is given its frozen-tower forward is launched concurrently."""
         self.decoder.train()
         self.backbone.eval()
-        self.arena.zero_grad()
+        self.arena.zero_grad(force=False)                       # the previous update already cleared the gradient arena
         out = self.losses(batch, next_batch)
         out["total_loss"].backward()
+        self.optimizer_step()
+        out["total_loss"] = out["total_loss"].detach()
+        return out
+
+    def optimizer_step(self, zero_grads=True):
+        """Gradient all-reduce completion + AdamW (run/train.py:199-203) over the whole arena in one call.  Which parameters are
+        updated (torch.optim.AdamW skips parameters without a gradient entirely, per-parameter step counts included) is decided on
+        the device from the flags BucketedAllReduce.finish() leaves in arena.seg_flag -- global under data parallelism -- so there is
+        no host-side launch plan and no synchronisation.  zero_grads: clear the gradient arena in the same pass."""
         self.comm.finish()
         self.iteration += 1
         a = self.arena
-        for start, end, decayed, t in a.update_plan():          # two launches when every parameter has a gradient (the normal case)
-            ops.adamw_step(a.params[start:end], a.grads[start:end], self.m[start:end], self.v[start:end], self.lr, *self.betas, self.eps,
-                           self.wd if decayed else 0.0, t)
-        out["total_loss"] = out["total_loss"].detach()
-        return out
+        ops.adamw_arena_step(a.params, a.grads, self.m, self.v, a.seg_off, a.seg_decay, a.seg_step, a.seg_flag, a.seg_coef,
+                             self.lr, *self.betas, self.eps, self.wd, zero_grads=zero_grads)
+        a.grads_clean = bool(zero_grads)
 
 
     # ------------------------------------------------------------------ optimizer state (checkpoint exchange with the reference)
@@ -173,10 +195,11 @@ class TrainStep:
         top-level key 'hh' (ignored by torch's loader) carries the attention-dropout seed stream and the step counter."""
         g0, g1 = self._reference_param_order()
         state = {}
+        steps = self.arena.steps                                  # one device read
         for idx, n in enumerate(g0 + g1):
-            if n in self.arena.offsets and self.arena.steps[n] > 0:
+            if n in self.arena.offsets and steps[n] > 0:
                 o, k = self.arena.offsets[n]
-                state[idx] = {"step": torch.tensor(float(self.arena.steps[n])),
+                state[idx] = {"step": torch.tensor(float(steps[n])),
                               "exp_avg": self.m[o:o + k].detach().clone(), "exp_avg_sq": self.v[o:o + k].detach().clone()}
         shapes = {n: p.shape for n, p in self.decoder.named_parameters()}
         for idx, n in enumerate(g0 + g1):
@@ -204,8 +227,7 @@ class TrainStep:
         self.wd = groups[1]["weight_decay"]
         self.m.zero_()
         self.v.zero_()
-        for n in self.arena.steps:
-            self.arena.steps[n] = 0
+        steps = {}
         for pid, n in zip(ids, names):
             st = sd["state"].get(pid)
             if st is None:
@@ -215,10 +237,16 @@ class TrainStep:
             o, k = self.arena.offsets[n]
             self.m[o:o + k].copy_(st["exp_avg"].reshape(-1))
             self.v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
-            self.arena.steps[n] = int(float(st["step"]))
+            steps[n] = int(float(st["step"]))
+        self.arena.set_steps(steps)
         extra = sd.get("hh") or {}
-        self.iteration = int(extra.get("iteration", max(self.arena.steps.values(), default=0)))
-        self.decoder.transformer._seed = extra.get("xattn_seed", None)
+        self.iteration = int(extra.get("iteration", max(steps.values(), default=0)))
+        # the checkpoint is written by one rank: re-mix the rank into the saved dropout-seed stream so that, as from a fresh start
+        # (Cross_Attention.next_dropout_seed), ranks keep drawing different attention-dropout masks after a resume; rank 0 (and a
+        # single process) continues the saved stream exactly
+        seed = extra.get("xattn_seed", None)
+        _, rank = world()
+        self.decoder.transformer._seed = None if seed is None else (int(seed) ^ (40503 * rank)) & 0x7FFFFFFF
 
 
 _MCQ_STREAMS = {}

@@ -37,8 +37,9 @@ int hh_version(void);
  * library's ONLY process-global mutable state; no entry point reads the environment.
  *   "gemm256"       0 = 128x128 kernel only, 1 = 256x256 one tile per block, 2 = + wave-row stagger, 3 (default) = persistent
  *                   256x256: one workgroup per CU walks its tiles in one continuous k-tile stream, four barriers per k-tile
- *   "gemm_tail"     1 (default) = (<= 32)-row tails inside the persistent kernel where it runs, else as 2; 2 = (< 64)-row tails on
- *                   the split-K-in-workgroup kernel; 0 = on the 128x128 kernel
+ *   "gemm_tail"     1 (default) = row tails of <= 64 rows (M - 256*floor(M/256), K % 512 == 0) inside the persistent kernel where it
+ *                   runs (pieces of <= 32 rows x 32 columns per workgroup), else as 2; 2 = tails of <= 64 rows always on the separate
+ *                   split-K-in-workgroup kernel; 0 = on the 128x128 kernel.  Same results in all three.
  *   "gemm256_group" m-tiles per XCD-local group of the tile walk (0 = per-shape default)
  *   "gemm256_skew"  -1 auto / 0 off / 1 on: start-time skew of the one-tile-per-block kernel (spreads the epilogue HBM bursts)
  *   "gemm256_pskew" 0..64: start skew quantum of the persistent kernel (default 0)
@@ -69,7 +70,7 @@ int hh_stream_get_cu_budget(hh_stream_t stream, int* out);
 enum hh_prof_class {
     HH_PROF_GEMM256 = 0,      /* persistent 256x256 GEMM kernel (gemm256d_kernel): 2*M*N*K of the full-tile rows */
     HH_PROF_GEMM_OTHER = 1,   /* row tails, 128x128 kernel, one-tile-per-block 256x256 kernel: 2*M*N*K of their rows */
-    HH_PROF_SPACE_ATTN = 2,   /* space_attn16_kernel: 8*B*N*D bytes (q,k,v read + o written, bf16) */
+    HH_PROF_SPACE_ATTN = 2,   /* space_attnj_kernel (joint blocks, default) / space_attn16_kernel: 8*B*N*D bytes (q,k,v read + o written, bf16) */
     HH_PROF_TIME_ATTN = 3,    /* time_attn_mfma*_kernel: 8*B*N*D bytes */
     HH_PROF_ADD_LN = 4,       /* fused residual add + LayerNorm: bytes read + written */
     HH_PROF_GEMM_TN = 5,      /* weight-gradient GEMM: 2*M*N*K */
@@ -286,6 +287,17 @@ int hh_box_loss_bwd(const float* pred, int Qtot, int q0, const float* tgt_cxcywh
  * p,g,m,v fp32 [n]; decay_mask uint8 [n] or per-segment handled by caller through two calls.  step >= 1. */
 int hh_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, hh_stream_t stream);
+/* The whole arena in one call, with the per-parameter decisions of torch.optim.AdamW taken on the DEVICE (no host-side launch plan,
+ * no host synchronisation): the arena is n_seg segments [seg_off[s], seg_off[s+1]) (int64 [n_seg+1], 4-element aligned, seg_off[0]
+ * = 0, seg_off[n_seg] = n), one per parameter.  A segment is updated iff seg_flag[s] > 0 (the parameter received a gradient this
+ * step -- torch skips grad-less parameters entirely, no weight decay either; under data parallelism the caller all-reduces the
+ * flags so that every rank decides alike); its step counter seg_step[s] (int32, in/out) is then incremented and supplies the bias
+ * correction.  seg_decay[s] != 0 selects weight_decay, else 0 (utils/train_utils.py:28-48: the two param groups).  seg_coef: fp32
+ * [2*n_seg] scratch.  zero_grads != 0 additionally clears g (the next step's optimizer.zero_grad(), run/train.py:199).  Updates
+ * are bit-identical to hh_adamw_step on the same segment and step. */
+int hh_adamw_arena_step(float* p, float* g, float* m, float* v, int64_t n, const int64_t* seg_off, const int* seg_decay,
+                        int* seg_step, const float* seg_flag, float* seg_coef, int n_seg, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int zero_grads, hh_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -49,7 +49,13 @@ def step_losses(enc_sd, dec_sd, batch, cfg, world_size=1):
     noun_embeds = D.txt_proj(batch["all_nouns"], dec_sd)
     word, wassign = L.word_contrastive(noun_embeds, obj[:, :-1], batch["nouns"], return_assign=True)
     total = nce + lh + lo + 0.5 * word
-    return {"total_loss": total, "nce_loss": nce, "box_loss_hand": lh, "box_loss_obj": lo, "word_loss": word,
+    # the no-grad cardinality metric of the criterion (box_utils.py:142-154; computed per box type on the query slice of
+    # split_detr_out :433-442, then dropped by compute_box_loss :457-461)
+    with torch.no_grad():
+        card_h = L.cardinality_error(det["pred_logits"][:, 0:2], L.prepare_targets(hand))
+        card_o = L.cardinality_error(det["pred_logits"][:, 2:nq], L.prepare_targets(objb))
+    return {"total_loss": total, "pred_logits": det["pred_logits"], "cardinality_error_hand_boxes": card_h,
+            "cardinality_error_obj_boxes": card_o, "nce_loss": nce, "box_loss_hand": lh, "box_loss_obj": lo, "word_loss": word,
             "acc_vt": acc_vt, "acc_tv": acc_tv, "idx_hand": ih, "idx_obj": io, "word_assign": wassign,
             "pred_boxes": det["pred_boxes"], "hs": hs, "image_feature_map": fmap,
             "video_embeds": video_embeds, "text_embeds": text_embeds,

@@ -58,7 +58,15 @@ def emit_step(R, cfg, name, B=2):
     out["pred_boxes"] = res["pred_boxes"].detach().numpy()
     out["video_embeds"] = res["video_embeds"].detach().numpy()
     out["text_embeds"] = res["text_embeds"].detach().numpy()
-    out["logits_argmax"] = res["pred_logits"].argmax(-1).numpy()
+    lg = res["pred_logits"].detach()                                       # [B*T, Q, classes + 1]
+    out["logits_argmax"] = lg.argmax(-1).numpy()
+    top2 = lg.topk(2, dim=-1).values
+    out["logits_top2_margin"] = (top2[..., 0] - top2[..., 1]).numpy()
+    out["logits_absmax"] = np.array(float(lg.abs().max()))
+    out["logits_sample"] = lg[:, :, ::173].numpy()                         # every 173rd class (128 of 22048) of every (frame, query)
+    out["logits_last_class"] = lg[:, :, -1].numpy()                        # the "no object" logit the cardinality metric tests against
+    for bt in ("hand_boxes", "obj_boxes"):
+        out["cardinality_error_" + bt] = np.array(float(res["cardinality_error_" + bt]))
     for key in ("idx_hand", "idx_obj"):
         lens = np.array([len(a) for a, _ in res[key]])
         out[key + "_len"] = lens

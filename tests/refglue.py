@@ -92,10 +92,18 @@ def reference_step(R, backbone, decoder, criterion, batch, cfg):
     with no_cuda_calls():
         lh, ih = R.box_utils.compute_box_loss("hand_boxes", criterion, det, hand, None, size, n_queries=nq)
         lo, io_ = R.box_utils.compute_box_loss("obj_boxes", criterion, det, objb, None, size, n_queries=nq)
+        # the cardinality metric (box_utils.py:142-154) is computed by the criterion and dropped by compute_box_loss (:455-461):
+        # call the criterion the way compute_box_loss does (:447-454) and keep it
+        card = {}
+        for bt, raw, (s0, s1) in (("hand_boxes", hand, (0, 2)), ("obj_boxes", objb, (2, nq))):
+            tg = R.box_utils.prepare_targets(raw.clone(), None, size, center_crop=False)
+            ld, _ = criterion(R.box_utils.split_detr_out(det, start=s0, end=s1), tg, bt, exclude_class=True)
+            card[bt] = ld[f"cardinality_error_{bt}"]
     noun_embeds = decoder.txt_proj(batch["all_nouns"])
     word = R.loss.WordContrastiveLoss()(noun_embeds, decoder.obj_proj(hs[-1])[:, :-1], batch["nouns"])
     total = nce + lh + lo + 0.5 * word
     return {"total_loss": total, "nce_loss": nce, "box_loss_hand": lh, "box_loss_obj": lo, "word_loss": word,
             "acc_vt": acc_vt, "acc_tv": acc_tv, "idx_hand": ih, "idx_obj": io_, "pred_boxes": det["pred_boxes"],
             "hs": hs, "image_feature_map": fmap, "video_embeds": video_embeds, "text_embeds": text_embeds,
-            "pred_logits": det["pred_logits"]}
+            "pred_logits": det["pred_logits"], "cardinality_error_hand_boxes": card["hand_boxes"],
+            "cardinality_error_obj_boxes": card["obj_boxes"]}

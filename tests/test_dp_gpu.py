@@ -39,11 +39,7 @@ def _one_step(ts, dec, batch):
     ts.arena.zero_grad()
     out = ts.losses(batch)
     out["total_loss"].backward()
-    ts.comm.finish()
-    ts.iteration += 1
-    a = ts.arena
-    for s, e, decayed, t in a.update_plan():
-        ops.adamw_step(a.params[s:e], a.grads[s:e], ts.m[s:e], ts.v[s:e], ts.lr, *ts.betas, ts.eps, ts.wd if decayed else 0.0, t)
+    ts.optimizer_step()
     return out
 
 
@@ -142,14 +138,15 @@ def _rccl_worker(rank, world, port, ret):
             t.arena.zero_grad()
             t.losses(batch)["total_loss"].backward()
             t.comm.finish()
-        assert ts.comm.launched == len(ts.arena.buckets)
+        assert ts.comm.launched == len(ts.arena.buckets) and ts.comm.flag_reduces == 1
         torch.testing.assert_close(ts.arena.grads, ref.arena.grads, rtol=1e-4, atol=1e-7)
+        assert torch.equal(ts.arena.seg_flag, ref.arena.seg_flag) and float(ts.arena.seg_flag.min()) == 1.0
         # (b) the call bench.py makes at N > 1: pipelined train-mode steps, collectives overlapping the next batch's encoder
         for _ in range(3):
             out = ts.step(batch, next_batch=batch)
         torch.cuda.synchronize()
         assert ops.stream_cu_budget(ts.enc_stream) == 248
-        assert ts.comm.launched == 4 * len(ts.arena.buckets)
+        assert ts.comm.launched == 4 * len(ts.arena.buckets) and ts.comm.flag_reduces == 4
         ret["loss"] = float(out["total_loss"])
         ret["finite"] = bool(torch.isfinite(ts.arena.params).all())
     finally:

@@ -2,7 +2,9 @@
 
 Tolerance: the tower computes with bf16 GEMM/attention operands, fp32 accumulation and an fp32 residual
 stream; SURVEY.md section 7 measured rel-L2 6.6e-3 for bf16-autocast of the REFERENCE itself at full width.
-We require rel-L2 <= 1.5e-2 on the feature map and cosine >= 0.999 on embeddings.
+(Our tower measures 5.2-5.3e-3 at full width -- T = 4, 16 and 32 x 336 px alike -- and 2.2e-3 on the 2-block fixtures.)
+Every bound below is set at <= 2x the value measured on MI355X (tests/_record.py logs the measured value of every
+check; one run's log is committed as profiles/r3_parity_measured.json); embeddings: cosine >= 0.999.
 """
 import os
 
@@ -13,6 +15,7 @@ import torch
 from helping_hand_for_egocentric_videos_amd import synth, TINY4, TINY16, HHConfig
 from helping_hand_for_egocentric_videos_amd.model import LaviLa
 from oracle import encoder as OE
+from _record import check
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -33,14 +36,15 @@ def test_clip_forward_vs_oracle_and_golden(cfg, name):
         out = model(batch["video"].cuda(), batch["text"].cuda(), return_feature_map=True)
         ref = OE.clip_forward(batch["video"], batch["text"], sd, cfg)
     assert out["image_feature_map"].shape == ref["image_feature_map"].shape
-    assert rel_l2(out["image_feature_map"], ref["image_feature_map"]) < 1.5e-2
-    assert rel_l2(out["text_feature_map"], ref["text_feature_map"]) < 2e-2
+    check("clip_forward_" + name, "image_feature_map rel-L2 vs oracle", rel_l2(out["image_feature_map"], ref["image_feature_map"]), 4.4e-3)
+    check("clip_forward_" + name, "text_feature_map rel-L2 vs oracle", rel_l2(out["text_feature_map"], ref["text_feature_map"]), 1.05e-2)
     for k in ("image_embed", "text_embed"):
         cos = torch.nn.functional.cosine_similarity(out[k].float().cpu(), ref[k], dim=-1)
         assert cos.min() > 0.999, (k, cos.min())
     # golden (emitted by the imported reference): strided sample of the feature map
     samp = out["image_feature_map"][:, ::97, ::7].float().cpu().numpy()
-    assert np.linalg.norm(samp - g["fmap_sample"]) / np.linalg.norm(g["fmap_sample"]) < 1.5e-2
+    check("clip_forward_" + name, "fmap_sample rel-L2 vs reference golden",
+          float(np.linalg.norm(samp - g["fmap_sample"]) / np.linalg.norm(g["fmap_sample"])), 4.3e-3)
 
 
 def test_block_by_block_drift_is_bounded():
@@ -59,11 +63,12 @@ def test_block_by_block_drift_is_bounded():
     patches = ops.patch_im2col(video.cuda(), cfg.patch_size, vis.patch_embed.kpad())
     tok = ops.gemm(patches, pk["wpatch"], out_dtype=torch.float32)
     xs = ops.embed_ln_pre(tok, pk["cls"], pk["pos"], pk["tmp"], *pk["ln_pre"][:2], B, T, n, pk["ln_pre"][2]).view(-1, D)
-    assert rel_l2(xs.view(1, -1, D), inter[0]) < 5e-3
+    check("block_drift", "embed + ln_pre rel-L2", rel_l2(xs.view(1, -1, D), inter[0]), 4.4e-3)
     pending = None
     for i, blk in enumerate(vis.blocks):
         pending = blk.fused(xs, B, T, n, pending)
-        assert rel_l2(((xs + pending[0].float()) + pending[1].float()).view(1, -1, D), inter[i + 1]) < 8e-3 * (i + 2), i
+        check("block_drift", f"residual stream after block {i} rel-L2",
+              rel_l2(((xs + pending[0].float()) + pending[1].float()).view(1, -1, D), inter[i + 1]), 4.4e-3)
 
 
 def test_module_api_shapes_and_standalone_forms():
@@ -81,10 +86,10 @@ def test_module_api_shapes_and_standalone_forms():
     xin = torch.randn(2, cfg.tokens, cfg.embed_dim, generator=torch.Generator().manual_seed(0))
     ref = OE.block(xin, sd, "visual.blocks.0.", cfg.num_heads, cfg.num_frames, cfg.patches_per_frame)
     got = blk(xin.cuda(), 'b (f n) d', '(b f) n d', 'b (f n) d', '(b n) f d', time_n=cfg.patches_per_frame, space_f=cfg.num_frames)
-    assert rel_l2(got, ref) < 1e-2
+    check("standalone_forms", "SpaceTimeBlock rel-L2 vs oracle", rel_l2(got, ref), 4e-4)
     ref_t = OE.divided_attention(xin, sd, "visual.blocks.0.timeattn", cfg.num_heads, cfg.num_frames, cfg.patches_per_frame, "time")
     got_t = blk.timeattn(xin.cuda(), 'b (f n) d', '(b n) f d', {"n": cfg.patches_per_frame})
-    assert rel_l2(got_t, ref_t) < 1.5e-2
+    check("standalone_forms", "time VarAttention rel-L2 vs oracle", rel_l2(got_t, ref_t), 5.6e-3)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model.visual.blocks[0].mlp(xin)
 
@@ -99,7 +104,49 @@ def test_full_width_t4_vs_oracle():
     with torch.no_grad():
         rc, rx = OE.vision_forward(video, sd, cfg)
     gc, gx = vis.cuda()(video.cuda())
-    assert rel_l2(gx, rx) < 1.5e-2, rel_l2(gx, rx)
+    check("full_width_t4", "feature map rel-L2 vs oracle", rel_l2(gx, rx), 1.06e-2)
+    assert torch.nn.functional.cosine_similarity(gc.cpu(), rc, dim=-1).min() > 0.999
+
+
+def _full_width_tower(cfg, seed):
+    sd = synth.encoder_state(cfg, seed=seed, with_text=False)
+    vis = LaviLa.build_backbone(cfg.with_(text_layers=1, vocab_size=512), None).visual
+    vis.load_state_dict({k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}, strict=True)
+    return sd, vis.cuda()
+
+
+def test_full_width_t16_vs_oracle_c2():
+    """BASELINE config 2's tower itself: full-size TimeSformer-L (24 x 1024, 16 heads), T=16, 224 px, one clip -- the feature map
+    (LaviLa.py:537-573) directly against the oracle, not only through the loss terms."""
+    from helping_hand_for_egocentric_videos_amd import C2
+    cfg = C2
+    sd, vis = _full_width_tower(cfg, 7)
+    video = synth.make_batch(cfg, 1, seed=7)["video"]
+    with torch.no_grad():
+        rc, rx = OE.vision_forward(video, sd, cfg)
+        gc, gx = vis(video.cuda())
+    assert gx.shape == (1, 4097, 1024)
+    check("full_width_t16_c2", "feature map rel-L2 vs oracle", rel_l2(gx, rx), 1.06e-2)
+    check("full_width_t16_c2", "CLS row rel-L2 vs oracle", rel_l2(gx[:, 0], rx[:, 0]), 1.02e-2)
+    assert torch.nn.functional.cosine_similarity(gc.cpu(), rc, dim=-1).min() > 0.999
+
+
+def test_full_width_c4_vs_oracle():
+    """BASELINE config 4 at FULL width: TimeSformer-L (24 x 1024, 16 heads), T=32 frames, 336 px -> n = 576, N = 18 433 tokens, one
+    clip: the n = 576 joint space kernel (space_attnj<3,...>), the T = 32 time kernel and the 24 576-row GEMMs at their real
+    shapes (LaviLa.py:246-283,537-573) against the oracle on the host (~16 TFLOP of fp32 CPU work)."""
+    from helping_hand_for_egocentric_videos_amd import C4
+    cfg = C4
+    sd, vis = _full_width_tower(cfg, 8)
+    video = synth.make_batch(cfg, 1, seed=8)["video"]
+    with torch.no_grad():
+        rc, rx = OE.vision_forward(video, sd, cfg)
+        gc, gx = vis(video.cuda())
+    assert gx.shape == (1, 18433, 1024)
+    check("full_width_c4", "feature map rel-L2 vs oracle", rel_l2(gx, rx), 1.04e-2)
+    check("full_width_c4", "CLS row rel-L2 vs oracle", rel_l2(gx[:, 0], rx[:, 0]), 1.02e-2)
+    per_frame = [(rel_l2(gx[:, 1 + f * 576:1 + (f + 1) * 576], rx[:, 1 + f * 576:1 + (f + 1) * 576])) for f in range(32)]
+    check("full_width_c4", "worst frame rel-L2 vs oracle", max(per_frame), 1.04e-2)
     assert torch.nn.functional.cosine_similarity(gc.cpu(), rc, dim=-1).min() > 0.999
 
 
@@ -115,8 +162,8 @@ def test_long_clip_high_res_shapes_c4():
         rc, rx = OE.vision_forward(video, sd, cfg)
     gc, gx = vis.cuda()(video.cuda())
     assert gx.shape == (1, 1 + 32 * 576, cfg.embed_dim)
-    assert rel_l2(gx, rx) < 1.5e-2, rel_l2(gx, rx)
-    assert rel_l2(gx[:, 0], rx[:, 0]) < 1.5e-2
+    check("c4_shapes_width128", "feature map rel-L2 vs oracle", rel_l2(gx, rx), 4.4e-3)
+    check("c4_shapes_width128", "CLS row rel-L2 vs oracle", rel_l2(gx[:, 0], rx[:, 0]), 5.6e-4)
 
 
 def test_text_tower_on_libhh_matches_oracle_and_stock_path():
@@ -130,5 +177,5 @@ def test_text_tower_on_libhh_matches_oracle_and_stock_path():
         model.text_autocast = None
         sc, sx = model.encode_text(text.cuda())                  # stock fp32 ops
     assert rel_l2(sx, rx) < 1e-4
-    assert rel_l2(gx, rx) < 1.5e-2, rel_l2(gx, rx)
+    check("text_tower", "text feature map rel-L2 vs oracle", rel_l2(gx, rx), 1.1e-2)
     assert torch.nn.functional.cosine_similarity(gc.cpu(), rc, dim=-1).min() > 0.999

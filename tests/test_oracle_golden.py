@@ -59,6 +59,14 @@ def test_step_against_reference_golden(cfg, name):
     np.testing.assert_allclose(res["hs"].detach().numpy(), g["hs"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(res["pred_boxes"].detach().numpy(), g["pred_boxes"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(res["video_embeds"].detach().numpy(), g["video_embeds"], rtol=1e-4, atol=1e-5)
+    # class head (tfm_decoder.py:208,216) and the cardinality metric (box_utils.py:142-154)
+    lg = res["pred_logits"].detach().numpy()
+    np.testing.assert_allclose(lg[:, :, ::173], g["logits_sample"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(lg[:, :, -1], g["logits_last_class"], rtol=1e-4, atol=1e-5)
+    firm = g["logits_top2_margin"] > 1e-4 * float(g["logits_absmax"])
+    assert firm.mean() > 0.95 and np.array_equal(lg.argmax(-1)[firm], g["logits_argmax"][firm])
+    for bt in ("hand_boxes", "obj_boxes"):
+        assert abs(float(res["cardinality_error_" + bt]) - float(g["cardinality_error_" + bt])) < 1e-6
     for key in ("idx_hand", "idx_obj"):
         rows = np.concatenate([a.numpy() for a, _ in res[key]])
         cols = np.concatenate([b.numpy() for _, b in res[key]])

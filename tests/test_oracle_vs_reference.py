@@ -117,7 +117,9 @@ def test_box_ops_matcher_and_losses(R):
             assert torch.equal(a, b["boxes"])
         crit = refglue.build_criterion(R)
         outputs = {"pred_boxes": pred, "pred_logits": torch.zeros(F_, q, 3)}
+        outputs["pred_logits"] = torch.randn(F_, q, 3, generator=g)      # some argmax = last class: cardinality has both outcomes
         rl, ridx = crit(outputs, rt, "hand_boxes", exclude_class=True)
+        _close(OL.cardinality_error(outputs["pred_logits"], mt), rl["cardinality_error_hand_boxes"])      # box_utils.py:142-154
         midx = OL.hungarian_match(pred, mt)
         for (a, b), (c, d) in zip(midx, ridx):
             assert torch.equal(a, c) and torch.equal(b, d) and a.dtype == torch.int64
@@ -219,6 +221,9 @@ def test_full_step_glue(R, cfg, B):
     for key in ("idx_hand", "idx_obj"):
         for (a, b), (c, d) in zip(mine[key], ref[key]):
             assert torch.equal(a, c) and torch.equal(b, d)
+    _close(mine["pred_logits"], ref["pred_logits"])
+    for bt in ("hand_boxes", "obj_boxes"):
+        _close(mine["cardinality_error_" + bt], ref["cardinality_error_" + bt])
     ref["total_loss"].backward()
     mine["total_loss"].backward()
     n_grad = 0

@@ -2,7 +2,9 @@
 
 Asserts: (a) all ranks hold identical parameters after a step, (b) a 2-rank step equals
 a 1-rank step on the concatenated batch, (c) bucketed async all-reduce averages exactly, (d) the packed
-contrastive all-gather is differentiable with the W x local-slice backward.
+contrastive all-gather is differentiable with the W x local-slice backward and carries the normaliser counts, (e) a step issues
+exactly 1 all-gather + #buckets + 1 (flags) all-reduces and nothing else, (f) a parameter unused on one rank only is flagged for
+update on every rank.
 The kernels are not involved (no GPU here): a small torch model stands in for the decoder, with parameter names
 that exercise both AdamW groups, and the oracle's AdamW restatement plays the optimizer.
 """
@@ -14,7 +16,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from helping_hand_for_egocentric_videos_amd.parallel import (BucketedAllReduce, FlatArena, gather_contrastive, no_decay)
+from helping_hand_for_egocentric_videos_amd.parallel import (BucketedAllReduce, FlatArena, gather_contrastive, no_decay, normaliser)
 from oracle import losses as OL, step as OS
 
 
@@ -50,18 +52,41 @@ def make_data(B, seed):
             "tgt": torch.rand(B, 4, generator=g)}
 
 
-def loss_fn(model, d, world):
+def loss_fn(model, d, world, skip_box=False):
     ve, te, boxes = model(d["feats"], d["texts"])
-    gve, gte, pf, vv, nv = gather_contrastive(ve, te, d["pad"], d["verb"], d["noun"])
+    # the local term's count rides in the packed gather (TrainStep does this with the box / word counts): no scalar all-reduce
+    gve, gte, pf, vv, nv, sums = gather_contrastive(ve, te, d["pad"], d["verb"], d["noun"], counts=torch.tensor([float(boxes.shape[0])]))
     Bg = gve.shape[0]
     sim = OL.sim_matrix(gte, gve)
     nce, _ = OL.egonce(sim, OL.sim_matrix(vv, vv), OL.sim_matrix(nv, nv), pf[:, None].repeat(1, Bg))
+    if skip_box:                                   # this rank's graph does not use the `box` head at all
+        return nce
     # local term normalised by the GLOBAL count / world (like num_boxes, box_utils.py:218-222)
-    nb = torch.tensor([float(boxes.shape[0])])
-    if world > 1:
-        dist.all_reduce(nb)
-    box = (boxes - d["tgt"]).abs().sum() / (nb / world).clamp(min=1)[0]
+    box = (boxes - d["tgt"]).abs().sum() / normaliser(sums)[0]
     return nce + box
+
+
+class _Count:
+    """Counts the collectives torch.distributed issues (wraps the module functions for the duration of a step)."""
+    NAMES = ("all_reduce", "all_gather", "all_gather_into_tensor", "broadcast", "reduce_scatter_tensor", "all_to_all_single")
+
+    def __init__(self):
+        self.n = {k: 0 for k in self.NAMES}
+        self._orig = {}
+
+    def __enter__(self):
+        for k in self.NAMES:
+            self._orig[k] = getattr(dist, k)
+
+            def wrapped(*a, _k=k, **kw):
+                self.n[_k] += 1
+                return self._orig[_k](*a, **kw)
+            setattr(dist, k, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for k, f in self._orig.items():
+            setattr(dist, k, f)
 
 
 def _worker(rank, world, port, ret):
@@ -80,18 +105,34 @@ def _worker(rank, world, port, ret):
         state = None
         for it in range(2):
             arena.zero_grad()
-            loss_fn(model, local, world).backward()
-            comm.finish()
+            with _Count() as cnt:
+                loss_fn(model, local, world).backward()
+                comm.finish()
+            # (e) collectives of one step: the packed gather + one all-reduce per bucket + the flags
+            assert cnt.n["all_gather_into_tensor"] == 1 and cnt.n["all_reduce"] == len(arena.buckets) + 1, cnt.n
+            assert sum(cnt.n.values()) == len(arena.buckets) + 2, cnt.n
+            assert float(arena.seg_flag.min()) == world             # every parameter got a gradient on every rank
             grads = {n: p.grad.clone() for n, p in arena.entries}
             params = {n: p.data for n, p in arena.entries}
             state = OS.adamw_update(params, grads, state, lr=1e-2, wd=1e-2)
         flat = arena.params.clone()
+        grads_flat = arena.grads.clone()
         gathered = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(gathered, flat)
         assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged"
+        # (f) a parameter that is unused on rank 1 only: rank 1's backward never touches box.*, but the averaged gradient it
+        # receives is non-zero -- every rank must see the parameter flagged, or the optimizers diverge (torch DDP updates it everywhere)
+        arena.zero_grad()
+        loss_fn(model, local, world, skip_box=(rank == 1)).backward()
+        assert ("box.weight" in arena.touched) == (rank == 0)
+        comm.finish()
+        flags = dict(zip(arena.names, arena.seg_flag.tolist()))
+        assert flags["box.weight"] == 1.0 and flags["box.bias"] == 1.0 and flags["proj.weight"] == float(world), flags
+        o, k = arena.offsets["box.weight"]
+        assert float(arena.grads[o:o + k].abs().max()) > 0           # the other rank's gradient / W arrived here too
         if rank == 0:
             ret["params"] = flat
-            ret["grads"] = arena.grads.clone()
+            ret["grads"] = grads_flat
     finally:
         dist.destroy_process_group()
 
