@@ -1,19 +1,23 @@
 """Benchmark of the hot path: train clips/sec (16-frame 224p, nq=12) -- BASELINE.json's metric -- on N GPUs.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A step = frozen TimeSformer-L forward + text tower + object-query decoder forward/backward + EgoNCE / box /
 word losses (on-device Hungarian) + decoder-gradient all-reduce (RCCL) + fused AdamW over one synthetic batch
-that is resident in HBM.  Weak scaling: the per-GPU batch is fixed.  Prints ONE JSON line on rank 0.
-The same line carries an "mcq" sub-record: the EgoMCQ forward-only path (BASELINE config 5, q = 8 items) timed after the train
-region; --workload mcq times only that path.
+that is resident in HBM (the same batch every step).  Weak scaling: the per-GPU batch is fixed.  Prints ONE JSON line on rank 0:
+`value` (+ per-step mean / std / p50 / p95 from device events), `roofline` (dominant kernel), `attention_roofline`, and on one GPU
+the sub-records `mcq` (EgoMCQ forward, BASELINE config 5), `c4` (BASELINE config 4: 32-frame 336p, the HBM-bound attention
+stress, with its own kernel roofline records) and `cpu_baseline` (the oracle on the host: config 2 on one clip and config 1 --
+T = 4, nq = 4, B = 2 -- exactly).  --config c4|c1 benches that configuration as the main workload instead.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -22,15 +26,28 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from helping_hand_for_egocentric_videos_amd import C2, ops, synth  # noqa: E402
+from helping_hand_for_egocentric_videos_amd import C1, C2, C4, ops, synth  # noqa: E402
 from helping_hand_for_egocentric_videos_amd.model import LaviLa, tfm_decoder  # noqa: E402
 from helping_hand_for_egocentric_videos_amd.step import TrainStep, mcq_forward  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-
+CONFIGS = {"c1": (C1, "C1: 4-frame 224p, nq=4"), "c2": (C2, "C2: 16-frame 224p, nq=12"), "c4": (C4, "C4: 32-frame 336p, nq=12")}
+STRIDE = 5      # every 5th launch of a kernel class is timed (co-prime with the 6 GEMMs / 2 attention calls per block); bracketing every launch costs ~3 % in marker packets
 
 PROF = {"gemm256": 0, "gemm_other": 1, "space_attn": 2, "time_attn": 3, "add_ln": 4, "gemm_tn": 5, "xattn_fwd": 6, "xattn_bwd": 7}
+
+
+def step_tflop_per_clip(cfg, train=True):
+    """Algorithmic work of one clip through the step in TFLOP, BASELINE.md section 3's accounting: encoder = 24*(32*N*D^2 + 4*D*[n*T*(T+1)
+    + T*n*(n+1) + 2N]) + 2*T*n*588*D, text tower 66.5 GFLOP per 5 captions (2.7 GFLOP per clip for EgoMCQ's one query per 5 clips),
+    decoder forward / train from the table (C1 8.7 / 24.7, C2 35.6 / 103, C4 146 / 434 GFLOP; other shapes scale with the memory
+    length).  Config 2: 3.59 train, 3.45 EgoMCQ forward."""
+    N, D, T, n = cfg.tokens, cfg.embed_dim, cfg.num_frames, cfg.patches_per_frame
+    enc = cfg.depth * (32 * N * D * D + 4 * D * (n * T * (T + 1) + T * n * (n + 1) + 2 * N)) + 2 * T * n * 588 * D
+    table = {(4, 224, 4): (8.7e9, 24.7e9), (16, 224, 12): (35.6e9, 103e9), (32, 336, 12): (146e9, 434e9)}
+    dec_f, dec_t = table.get((T, cfg.img_size, cfg.num_queries), (35.6e9 * T * n / 4096, 103e9 * T * n / 4096))
+    return (enc + (66.5e9 + dec_t if train else 2.7e9 + dec_f)) / 1e12
 
 
 def prof_enable(stride):
@@ -53,89 +70,282 @@ def prof_snapshot():
     return {k: prof_read(k) for k in PROF}
 
 
-def pmc_traffic(kernel_substr):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r2_pmc_summary.json, else
-    round 1's: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction);
-    launch-weighted mean over the template instantiations whose name contains `kernel_substr`."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r2_pmc_summary.json", "r1_pmc_summary.json")) if os.path.exists(q)), None)
-    if path is None:
-        return None
-    with open(path) as f:
-        rows = [v for k, v in json.load(f).items() if kernel_substr in k]
-    n = sum(v["launches"] for v in rows)
-    return int(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in rows) / n) if n else None
+def pmc_traffic(kernel_substr, tag_order=("r3", "r2", "r1")):
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/<round>_pmc_summary.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction); launch-weighted mean over the template
+    instantiations whose name contains `kernel_substr`.  Returns (bytes, file) or (None, None)."""
+    for tag in tag_order:
+        path = os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            rows = [v for k, v in json.load(f).items() if kernel_substr in k]
+        n = sum(v["launches"] for v in rows)
+        if n:
+            return int(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in rows) / n), os.path.basename(path)
+    return None, None
 
 
-def sustained_clock(dev):
-    """Shader clock inside the persistent GEMM's main loop under sustained load (s_memtime ticks per s_memrealtime us, read by
-    the kernel itself: hh_debug_gemm_timeline).  MI355X throttles far below its 2.4 GHz nominal clock when the matrix cores are
-    busy, so the 2.5 PFLOP/s datasheet peak is not reachable by ANY bf16 GEMM here; the clock-limited peak is 2.5 * f / 2.4."""
+def _read_timeline():
     import ctypes
     import numpy as np
     from helping_hand_for_egocentric_videos_amd import _lib
-    M, N, K = 32 * 4096, 4096, 1024
-    g = torch.Generator(device=dev).manual_seed(0)
-    a = (torch.randn(M, K, device=dev, generator=g) * 0.5).to(torch.bfloat16)
-    w = (torch.randn(N, K, device=dev, generator=g) * 0.03).to(torch.bfloat16)
-    bias = torch.zeros(N, device=dev)
-    for _ in range(40):                                  # ~35 ms of back-to-back GEMMs: the governor has settled
-        ops.gemm(a, w, bias, act=ops.ACT_QUICKGELU)
-    ops.set_tuning("gemm256_debug_ts", 1)
-    ops.gemm(a, w, bias, act=ops.ACT_QUICKGELU)
-    torch.cuda.synchronize()
-    ops.set_tuning("gemm256_debug_ts", 0)
     buf = np.zeros((256, 8, 7), dtype=np.uint64)
     _lib.check(_lib.lib().hh_debug_gemm_timeline(buf.ctypes.data_as(ctypes.c_void_p), 256), "hh_debug_gemm_timeline")
-    t = buf.astype(np.int64)
+    return buf.astype(np.int64)
+
+
+def in_step_clock(backbone, video, K=4096):
+    """Shader clock inside the persistent GEMM's main loop, measured ON THE STEP'S OWN OPERANDS: the vision tower runs over the bench
+    batch with the kernel's timeline stamps on (hh_set_tuning("gemm256_debug_ts")); the record that survives is the tower's LAST
+    persistent launch -- block 23's fc2 GEMM (K = 4096), the 144th tall GEMM in a row, with the activations and weights of the step.
+    s_memtime ticks per s_memrealtime microsecond, read by the kernel itself.  MI355X throttles below its 2.4 GHz nominal clock when
+    the matrix cores are busy (the step sits at the 1400 W package cap), so the datasheet 2.5 PFLOP/s is not reachable by ANY bf16
+    GEMM here; the clock-limited peak is 2.5 * f / 2.4."""
+    import numpy as np
+    with torch.no_grad():
+        backbone.visual.forward_features(video, out_dtype=torch.bfloat16)          # settle the governor
+        ops.set_tuning("gemm256_debug_ts", 1)
+        backbone.visual.forward_features(video, out_dtype=torch.bfloat16)
+        torch.cuda.synchronize()
+        ops.set_tuning("gemm256_debug_ts", 0)
+    t = _read_timeline()
+    rows = video.shape[0] * (1 + video.shape[1] * (video.shape[3] // 14) ** 2)
+    ntile = max(1, min(8, (rows // 256) * (1024 // 256) // 256))
+    t = t[:, :ntile]
     us = (t[:, :, 2] - t[:, :, 1]) / 100.0               # main loop, 100 MHz real-time counter
     mhz = float(((t[:, :, 6] - t[:, :, 5]) / np.maximum(us, 1e-9)).mean())
     return {"shader_mhz_in_gemm_main_loop": round(mhz, 1), "nominal_mhz": 2400,
+            "where": "last persistent GEMM of a vision-tower forward over the bench batch (block 23 fc2, K = 4096): the step's own activations and weights",
             "main_loop_us_per_ktile": round(float(us.mean()) / (K // 64), 3),
             "clock_limited_peak": round(PEAK_BF16_TFLOPS * mhz / 2400.0, 1)}
 
 
-def cpu_baseline(cfg, enc_sd, dec_sd, seed):
-    """Oracle (CPU restatement, fp32) timed on this host: one full training step on ONE clip of the same workload, with the
-    thread count that is fastest on the 256-thread GPU host (16; more threads run slower) and with 8 threads (the dev container's
-    core count)."""
-    from oracle import step as OS
-    batch = synth.make_batch(cfg, 1, seed=seed)
+class PowerSampler:
+    """Package power / clock samples while the timed region runs, read by a CHILD process (`rocm-smi` every ~0.4 s; this process has
+    initialised the GPU and must not exec anything itself)."""
+    CODE = r"""
+import subprocess, sys, time
+out = open(sys.argv[1], "w")
+while True:
+    try:
+        r = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+    except Exception as e:
+        r = ""
+    p = [l.split(":")[-1].strip() for l in r.splitlines() if "Package Power" in l]
+    s = [l.split("(")[-1].split("Mhz")[0] for l in r.splitlines() if "sclk" in l]
+    out.write("%.2f %s %s\n" % (time.time(), p[0] if p else "nan", s[0] if s else "nan")); out.flush()
+    time.sleep(0.35)
+"""
 
-    def timed(threads, iters):
+    def __init__(self):
+        self.path = tempfile.mktemp(prefix="hh_power_", suffix=".txt")
+        self.proc = None
+
+    def start(self):
+        try:
+            self.proc = subprocess.Popen([sys.executable, "-c", self.CODE, self.path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except OSError:
+            self.proc = None
+
+    def stop(self, t0, t1):
+        if self.proc is None:
+            return None
+        self.proc.terminate()
+        try:
+            self.proc.wait(timeout=5)
+        except subprocess.TimeoutExpired:
+            self.proc.kill()
+        try:
+            rows = [l.split() for l in open(self.path)]
+            os.unlink(self.path)
+        except OSError:
+            return None
+        w = [float(r[1]) for r in rows if t0 <= float(r[0]) <= t1 and r[1] != "nan"]
+        mhz = [float(r[2]) for r in rows if t0 <= float(r[0]) <= t1 and r[2] != "nan"]
+        if not w:
+            return None
+        return {"package_power_w_mean": round(sum(w) / len(w), 1), "package_power_w_max": max(w), "samples": len(w),
+                "sclk_mhz_mean_reported": round(sum(mhz) / len(mhz), 1) if mhz else None,
+                "source": "rocm-smi --showpower --showclocks sampled by a child process during the timed region (cap: 1400 W)"}
+
+
+def cpu_baseline(cfg, enc_sd, dec_sd, seed):
+    """Oracle (CPU restatement, fp32) timed on this host: (a) one full training step on ONE clip of the headline workload (config
+    2), with the thread count that is fastest on the 256-thread GPU host (16; more threads run slower) and with 8 threads (the dev
+    container's core count); (b) BASELINE config 1 exactly -- the reference's own CPU-runnable case,
+    run/train.py:103-203 with T = 4, num_queries = 4, batch = 2."""
+    from oracle import step as OS
+
+    def timed(c, esd, dsd, batch, threads, iters):
         torch.set_num_threads(threads)
-        dsd = {k: v.clone() for k, v in dec_sd.items()}
-        _, _, state = OS.train_step(enc_sd, dsd, batch, cfg, None)       # warm-up (allocator, thread pool)
+        dsd = {k: v.clone() for k, v in dsd.items()}
+        _, _, state = OS.train_step(esd, dsd, batch, c, None)             # warm-up (allocator, thread pool)
         t = time.time()
         for _ in range(iters):
-            _, _, state = OS.train_step(enc_sd, dsd, batch, cfg, state)
+            _, _, state = OS.train_step(esd, dsd, batch, c, state)
         return iters / (time.time() - t), time.time() - t
 
     ncpu = os.cpu_count() or 1
     cores = min(ncpu, int(os.environ.get("HH_CPU_BASELINE_THREADS", 16)))
-    v16, dt16 = timed(cores, 3)
-    v8, dt8 = timed(min(8, ncpu), 2)
-    return {"value": round(v16, 4), "unit": "clips/s", "cores": cores, "kind": "port", "threads_8": round(v8, 4), "host_cpu_count": ncpu,
-            "sample": "1 clip/step (T=%d, %dpx, nq=%d): oracle fp32 full step fwd+bwd+AdamW; %d threads: 1 warm-up + 3 timed steps (%.1f s); "
-                      "8 threads: 1 warm-up + 2 timed steps (%.1f s); more than 16-32 threads run slower on this host" % (
-                          cfg.num_frames, cfg.img_size, cfg.num_queries, cores, dt16, dt8)}
+    batch = synth.make_batch(cfg, 1, seed=seed)
+    v16, dt16 = timed(cfg, enc_sd, dec_sd, batch, cores, 3)
+    v8, dt8 = timed(cfg, enc_sd, dec_sd, batch, min(8, ncpu), 2)
+    rec = {"value": round(v16, 4), "unit": "clips/s", "cores": cores, "kind": "port", "threads_8": round(v8, 4), "host_cpu_count": ncpu,
+           "sample": "1 clip/step (T=%d, %dpx, nq=%d): oracle fp32 full step fwd+bwd+AdamW; %d threads: 1 warm-up + 3 timed steps (%.1f s); "
+                     "8 threads: 1 warm-up + 2 timed steps (%.1f s); more than 16-32 threads run slower on this host" % (
+                         cfg.num_frames, cfg.img_size, cfg.num_queries, cores, dt16, dt8)}
+    c1 = C1
+    esd1 = dict(enc_sd)
+    if cfg.num_frames != c1.num_frames or cfg.img_size != c1.img_size:
+        esd1 = synth.encoder_state(c1, seed=0)
+    dsd1 = synth.decoder_state(c1, seed=0)
+    s1, dt1 = timed(c1, esd1, dsd1, synth.make_batch(c1, 2, seed=seed), cores, 3)
+    rec["c1"] = {"value": round(2 * s1, 4), "unit": "clips/s", "cores": cores, "kind": "port", "ms_per_step": round(1e3 / s1, 1),
+                 "sample": "BASELINE config 1 exactly (4-frame 224p, num_queries=4, batch=2): oracle fp32 full step fwd+bwd+AdamW, %d threads, "
+                           "1 warm-up + 3 timed steps (%.1f s)" % (cores, dt1)}
+    return rec
+
+
+def build(cfg, dev, world=1):
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // max(world, 1))))      # do not oversubscribe the node when N ranks build at once
+    enc_sd = synth.encoder_state(cfg, seed=0)
+    dec_sd = synth.decoder_state(cfg, seed=0)
+    backbone = LaviLa.build_backbone(cfg, enc_sd, device=dev)
+    decoder = tfm_decoder.build_decoder(cfg, dec_sd, device=dev)
+    return enc_sd, dec_sd, backbone, decoder
+
+
+def barrier(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def timed_region(run, steps, warmup, world, timers):
+    """W untimed + EXACTLY K timed calls of run(), bracketed by barrier + synchronize; one device event per step on the main stream.
+    -> (wall seconds, per-step ms list from the events, kernel-timer snapshot, last output)."""
+    for _ in range(warmup):
+        run()
+    barrier(world)
+    if timers:
+        prof_enable(STRIDE)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    out = None
+    for i in range(steps):
+        out = run()
+        ev[i + 1].record()
+    barrier(world)
+    dt = time.perf_counter() - t0
+    per = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    return dt, per, (prof_snapshot() if timers else None), out
+
+
+def step_stats(per):
+    import statistics
+    s = sorted(per)
+    q = lambda f: s[min(len(s) - 1, int(round(f * (len(s) - 1))))]
+    return {"ms_per_step_mean": round(sum(per) / len(per), 3), "ms_per_step_std": round(statistics.pstdev(per), 3) if len(per) > 1 else 0.0,
+            "ms_per_step_p50": round(q(0.5), 3), "ms_per_step_p95": round(q(0.95), 3), "ms_per_step_min": round(s[0], 3),
+            "ms_per_step_max": round(s[-1], 3), "timing": "device events on the main stream after every step (the pipelined encoder of step i+1 overlaps step i, "
+            "so a step's own interval is what the steady state delivers)"}
+
+
+def rate(rec, key, scale):
+    n, seen, ms, work = rec[key]
+    return (work / (ms * 1e-3) / scale, n, seen, ms) if n and ms > 0 else (None, n, seen, ms)
+
+
+def roofline_records(region, iso, dt_ms, pipelined, cfg):
+    """`roofline` (dominant kernel: the persistent GEMM, MFMA-bound) and `attention_roofline` (HBM-bound kernels) from the library's
+    own event timers.  Algorithmic work: 2*M*N*K of the full 256-row tiles per GEMM launch; 8*N*D bytes per clip and attention call
+    (q, k, v read + o written, bf16); bytes read + written for add+LayerNorm."""
+    roof, att = None, {}
+    ach, n, seen, ms = rate(region, "gemm256", 1e12)
+    if ach is not None:
+        traffic, src = pmc_traffic("gemm256d_kernel<true")
+        roof = {"kernel": "gemm256d_kernel (persistent 256x256x64 bf16 MFMA GEMM, continuous k-tile stream, four barriers per k-tile) -- every template instantiation, nothing else",
+                "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "traffic": traffic,
+                "traffic_note": "HBM-side bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/%s, config 2, B=32); algorithmic bytes per launch average 0.99e9" % src,
+                "algorithmic_work": "2*M*N*K of the full 256-row tiles of each launch (DESIGN.md section 5)",
+                "launches_timed": n, "launches_in_region": seen,
+                "timing": "library-side HIP events around the kernel launch alone (hh_prof_enable), every %dth launch, on the launch stream" % STRIDE,
+                "avg_launch_us": round(ms * 1e3 / n, 1), "share_of_step": round(ms * STRIDE / dt_ms, 3),
+                "region": "timed region (pipelined: decoder kernels of the previous step run beside it)" if pipelined else "timed region (un-pipelined)"}
+        if iso is not None:
+            a2, n2, _, ms2 = rate(iso, "gemm256", 1e12)
+            if a2 is not None:
+                roof["isolated"] = {"achieved": round(a2, 1), "frac": round(a2 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms2 * 1e3 / n2, 1),
+                                    "note": "same kernel over 2 un-pipelined steps outside the timed region (alone on the chip); compare with the un-pipelined rocprofv3 summary in profiles/"}
+        o, no, _, mso = rate(region, "gemm_other", 1e12)
+        if o is not None:
+            roof["other_gemm_kernels"] = {"what": "row tails (gemm_tail_kernel), 128x128 kernel, one-tile-per-block 256x256 kernel -- NOT part of `achieved`",
+                                          "achieved": round(o, 1), "unit": "TFLOP/s", "launches_timed": no, "avg_launch_us": round(mso * 1e3 / no, 1),
+                                          "share_of_step": round(mso * STRIDE / dt_ms, 3)}
+    n_ = cfg.patches_per_frame
+    jb = next((b for b in (4, 3, 2) if (n_ // 16) % (4 * b) == 0), None)
+    space_name = "space_attnj_kernel<%d, ...> (joint-block kernel, n = %d keys per frame, head-major q|k|v planes)" % (jb, n_) if jb else "space_attn16_kernel (n = %d)" % n_
+    time_name = "time_attn_mfma_kernel<%d>" % cfg.num_frames
+    for key, kname in (("space_attn", space_name), ("time_attn", time_name), ("add_ln", "add_ln_kernel")):
+        r, n, _, ms = rate(region, key, 1e9)
+        if r is None:
+            continue
+        att[key] = {"kernel": kname, "bound": "hbm", "achieved": round(r, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(r / PEAK_HBM_GBS, 4),
+                    "launches_timed": n, "avg_launch_us": round(ms * 1e3 / n, 1), "share_of_step": round(ms * STRIDE / dt_ms, 3)}
+        if iso is not None:
+            r2, n2, _, ms2 = rate(iso, key, 1e9)
+            if r2 is not None:
+                att[key]["isolated"] = {"achieved": round(r2, 1), "frac": round(r2 / PEAK_HBM_GBS, 4), "avg_launch_us": round(ms2 * 1e3 / n2, 1)}
+    if att:
+        att["note"] = ("algorithmic bytes (8*N*D per attention call and clip, N = %d tokens, D = %d; bytes read + written for add+LayerNorm) / event time of the "
+                       "kernel alone; `isolated` = un-pipelined steps" % (cfg.tokens, cfg.embed_dim))
+    return roof, (att or None)
+
+
+def bench_train(cfg, backbone, decoder, B, steps, warmup, world, rank, dev, args, timers, want_iso=True):
+    batch = {k: v.to(dev) for k, v in synth.make_batch(cfg, B, seed=1000 + rank).items()}
+    ts = TrainStep(cfg, backbone, decoder, enc_cus=args.enc_cus, force_comm=args.force_comm)
+    pipelined = not args.no_pipeline
+    run = lambda: ts.step(batch, next_batch=batch if pipelined else None)
+    dt, per, region, out = timed_region(run, steps, warmup, world, timers)
+    iso = None
+    if timers and pipelined and want_iso:
+        # outside the timed region: two un-pipelined steps, so that every kernel is also timed alone on the chip (no decoder kernels
+        # of the previous step beside the encoder's)
+        prof_enable(STRIDE)
+        for _ in range(2):
+            ts.step(batch)
+        barrier(world)
+        iso = prof_snapshot()
+    if timers:
+        prof_enable(0)
+    return ts, batch, dt, per, region, iso, out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json configuration of the main workload (the metric is quoted on c2)")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default 32; c4: 4; c1: 2)")
     ap.add_argument("--workload", default="train", choices=["train", "mcq"])
+    ap.add_argument("--mcq-items", type=int, default=8, help="EgoMCQ items (5 clips + 1 query each) per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-mcq", action="store_true", help="skip the EgoMCQ forward sub-record (second half of BASELINE.json's metric)")
+    ap.add_argument("--no-c4", action="store_true", help="skip the config-4 sub-record (32-frame 336p)")
+    ap.add_argument("--no-power", action="store_true", help="do not sample package power with a rocm-smi child process")
     ap.add_argument("--enc-cus", type=int, default=None, help="CU budget of the persistent GEMMs on the pipelined encoder stream (multiple of 8; 0 = all)")
     ap.add_argument("--force-comm", action="store_true", help="1 GPU only: run the RCCL collectives of the data-parallel path in a 1-rank group (A/B of the CU reservation)")
     ap.add_argument("--per-op-query-side", action="store_true", help="A/B: per-op autograd query side instead of the fused QueryStack node")
     ap.add_argument("--token-major-qkv", action="store_true", help="A/B: the QKV projections write nn.Linear's token-major [B*N, 3D] instead of head-major planes")
     ap.add_argument("--space-16q", action="store_true", help="A/B: space attention on the 16-query-block kernel instead of the joint-block kernel")
     ap.add_argument("--gemm-tail", type=int, default=None, help="A/B: hh_set_tuning('gemm_tail', v): 1 (default) = row tails of <= 64 rows inside the persistent kernel, 2 = always the separate tail kernel, 0 = the 128x128 kernel; same results")
+    ap.add_argument("--tune", action="append", default=[], metavar="NAME=V", help="A/B: hh_set_tuning(NAME, V) before anything runs (repeatable)")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder forward with this step's decoder")
     args = ap.parse_args()
 
@@ -154,14 +364,10 @@ def main():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     dev = torch.device("cuda", local if world > 1 else 0)
 
-    cfg = C2
+    cfg, cfg_name = CONFIGS[args.config]
+    B = args.batch or {"c2": 32, "c4": 4, "c1": 2}[args.config]
     torch.manual_seed(0)
-    # host threads for the synthetic-weight generation: do not oversubscribe the node when N ranks build models at once
-    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // max(world, 1))))
-    enc_sd = synth.encoder_state(cfg, seed=0)
-    dec_sd = synth.decoder_state(cfg, seed=0)
-    backbone = LaviLa.build_backbone(cfg, enc_sd, device=dev)
-    decoder = tfm_decoder.build_decoder(cfg, dec_sd, device=dev)
+    enc_sd, dec_sd, backbone, decoder = build(cfg, dev, world)
     decoder.transformer.use_query_stack = not args.per_op_query_side
     if args.token_major_qkv:
         from helping_hand_for_egocentric_videos_amd.model import LaviLa as _L
@@ -170,143 +376,145 @@ def main():
         ops.set_tuning("space_joint", 0)
     if args.gemm_tail is not None:
         ops.set_tuning("gemm_tail", args.gemm_tail)
-    B = args.batch
-
-    STRIDE = 5      # every 5th launch of a class is timed (co-prime with the 6 GEMMs / 2 attention calls per block); bracketing every launch costs ~3 % in marker packets
+    for kv in args.tune:
+        k, v = kv.split("=")
+        ops.set_tuning(k, int(v))
     timers = not args.no_kernel_timers
 
+    rccl = None
+    if world > 1:
+        # the collectives really span `world` devices: a sum of ones over the group
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        rccl = {"rccl_ranks": int(one.item()), "backend": dist.get_backend(), "devices_visible": torch.cuda.device_count()}
+        assert rccl["rccl_ranks"] == world
+
+    power = PowerSampler() if (rank == 0 and not args.no_power) else None
+    ts = None
     if args.workload == "train":
-        batch = {k: v.to(dev) for k, v in synth.make_batch(cfg, B, seed=1000 + rank).items()}
-        ts = TrainStep(cfg, backbone, decoder, enc_cus=args.enc_cus, force_comm=args.force_comm)
-        run = lambda: ts.step(batch, next_batch=None if args.no_pipeline else batch)
         clips_per_step = B
-        metric = "train clips/sec (16-frame 224p, nq=12)"
+        metric = "train clips/sec (%d-frame %dp, nq=%d)" % (cfg.num_frames, cfg.img_size, cfg.num_queries)
+        if power:
+            power.start()
+        w0 = time.time()
+        ts, batch, dt, per, region, iso, out = bench_train(cfg, backbone, decoder, B, args.steps, args.warmup, world, rank, dev, args, timers)
+        w1 = time.time()
     else:
-        items = max(1, B // 5)
+        items = args.mcq_items
         mcq = synth.make_mcq_item(cfg, items, seed=1000 + rank)
         video, text = mcq["video"].to(dev), mcq["text"].to(dev)
         decoder.eval()
         run = lambda: mcq_forward(backbone, decoder, video, text, cfg)
         clips_per_step = items * 5
-        metric = "EgoMCQ fwd clips/sec (16-frame 224p)"
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        run()
-    barrier()
-    if timers:
-        prof_enable(STRIDE)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = run()
-    barrier()
-    dt = time.perf_counter() - t0
-    region = prof_snapshot() if timers else None
-    iso = None
-    if timers and args.workload == "train" and not args.no_pipeline:
-        # outside the timed region: two un-pipelined steps, so that every kernel is also timed alone on the chip (no decoder kernels
-        # of the previous step beside the encoder's)
-        prof_enable(STRIDE)
-        for _ in range(2):
-            ts.step(batch)
-        barrier()
-        iso = prof_snapshot()
-    if timers:
-        prof_enable(0)
-    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        metric = "EgoMCQ fwd clips/sec (%d-frame %dp)" % (cfg.num_frames, cfg.img_size)
+        if power:
+            power.start()
+        w0 = time.time()
+        dt, per, region, out = timed_region(run, args.steps, args.warmup, world, timers)
+        w1 = time.time()
+        iso = None
+        if timers:
+            prof_enable(0)
+    power_rec = power.stop(w0 + 0.3 * (w1 - w0), w1) if power else None      # skip the warm-up third of the bracket
+    dts = torch.tensor([dt], device=dev, dtype=torch.float64)
+    per_rank = None
     if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt)
+        allt = torch.empty(world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allt, dts)
+        per_rank = [clips_per_step * args.steps / float(t) for t in allt.tolist()]
+        dist.all_reduce(dts, op=dist.ReduceOp.MAX)
+    dt = float(dts)
     value = clips_per_step * world * args.steps / dt
+
+    # exposed communication at N > 1: the same region again with the gradient collectives switched off (ranks then diverge, which is
+    # fine after the measurement); allreduce_exposed_ms = ms/step with - ms/step without
+    comm_rec = None
+    if world > 1 and args.workload == "train":
+        ts.comm.active = False
+        k2 = max(5, min(args.steps, 20))
+        dt2, _, _, _ = timed_region(lambda: ts.step(batch, next_batch=None if args.no_pipeline else batch), k2, 2, world, False)
+        ts.comm.active = True
+        t2 = torch.tensor([dt2], device=dev, dtype=torch.float64)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        comm_rec = {"ms_per_step_without_gradient_allreduce": round(float(t2) / k2 * 1e3, 2), "steps": k2,
+                    "allreduce_exposed_ms": round(dt / args.steps * 1e3 - float(t2) / k2 * 1e3, 2),
+                    "collectives_per_step": {"all_gather": 1, "all_reduce_gradient_buckets": len(ts.arena.buckets), "all_reduce_flags": 1},
+                    "gradient_bytes_per_step": int(ts.arena.total * 4)}
 
     # second half of BASELINE.json's metric in the same line: EgoMCQ forward clips/s (config 5: q = 8 items = 40 clips + 8 queries)
     mcq_rec = None
-    if args.workload == "train" and not args.no_mcq:
-        q = 8
+    if args.workload == "train" and not args.no_mcq and args.config == "c2":
+        q = args.mcq_items
         item = synth.make_mcq_item(cfg, q, seed=2000 + rank)
         mv, mt = item["video"].to(dev), item["text"].to(dev)
         decoder.eval()
-        for _ in range(2):
-            mcq_forward(backbone, decoder, mv, mt, cfg)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            scores = mcq_forward(backbone, decoder, mv, mt, cfg)
-        barrier()
-        mt_ = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        ksteps = 20
+        mdt, mper, _, scores = timed_region(lambda: mcq_forward(backbone, decoder, mv, mt, cfg), ksteps, 2, world, False)
+        mt_ = torch.tensor([mdt], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(mt_, op=dist.ReduceOp.MAX)
-        mcq_rec = {"metric": "EgoMCQ fwd clips/sec (16-frame 224p)", "value": round(q * 5 * world * 5 / float(mt_), 2), "unit": "clips/s",
-                   "ms_per_step": round(float(mt_) / 5 * 1e3, 2), "steps": 5, "warmup": 2,
+        mcq_rec = {"metric": "EgoMCQ fwd clips/sec (16-frame 224p)", "value": round(q * 5 * world * ksteps / float(mt_), 2), "unit": "clips/s",
+                   "ms_per_step": round(float(mt_) / ksteps * 1e3, 2), "steps": ksteps, "warmup": 2, "step_stats": step_stats(mper),
                    "config": {"workload": "C5: 16-frame EgoMCQ forward, q = %d items (%d clips + %d queries) per step per GPU, replicas only" % (q, 5 * q, q),
-                              "step_tflop_per_clip": 3.45}}
+                              "step_tflop_per_clip": round(step_tflop_per_clip(cfg, train=False), 2)}}
         del mv, mt, scores
 
-    if rank == 0:
-        def rate(rec, key, scale):
-            n, seen, ms, work = rec[key]
-            return (work / (ms * 1e-3) / scale, n, seen, ms) if n and ms > 0 else (None, n, seen, ms)
+    clock = None
+    if rank == 0 and timers and args.workload == "train" and cfg.embed_dim == 1024:
+        clock = in_step_clock(backbone, batch["video"])
 
-        roof = None
-        if region is not None:
-            ach, n, seen, ms = rate(region, "gemm256", 1e12)
-            if ach is not None:
-                roof = {"kernel": "gemm256d_kernel (persistent 256x256x64 bf16 MFMA GEMM, continuous k-tile stream, four barriers per k-tile) -- every template instantiation, nothing else",
-                        "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                        "traffic": pmc_traffic("gemm256d_kernel<true"),
-                        "traffic_note": "HBM-side bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/*_pmc_summary.json, B=32); algorithmic bytes per launch average 0.99e9",
-                        "algorithmic_work": "2*M*N*K of the full 256-row tiles of each launch (DESIGN.md section 5)",
-                        "launches_timed": n, "launches_in_region": seen,
-                        "timing": "library-side HIP events around the kernel launch alone (hh_prof_enable), every %dth launch, on the launch stream" % STRIDE,
-                        "avg_launch_us": round(ms * 1e3 / n, 1), "share_of_step": round(ms * STRIDE / (dt * 1e3), 3),
-                        "region": "timed region (pipelined: decoder kernels of the previous step run beside it)" if not args.no_pipeline else "timed region (un-pipelined)"}
-                if iso is not None:
-                    a2, n2, _, ms2 = rate(iso, "gemm256", 1e12)
-                    if a2 is not None:
-                        roof["isolated"] = {"achieved": round(a2, 1), "frac": round(a2 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms2 * 1e3 / n2, 1),
-                                            "note": "same kernel over 2 un-pipelined steps outside the timed region (alone on the chip); compare with the un-pipelined rocprofv3 summary in profiles/"}
-                o, no, _, mso = rate(region, "gemm_other", 1e12)
-                if o is not None:
-                    roof["other_gemm_kernels"] = {"what": "row tails (gemm_tail_kernel), 128x128 kernel, one-tile-per-block 256x256 kernel -- NOT part of `achieved`",
-                                                  "achieved": round(o, 1), "unit": "TFLOP/s", "launches_timed": no, "avg_launch_us": round(mso * 1e3 / no, 1),
-                                                  "share_of_step": round(mso * STRIDE / (dt * 1e3), 3)}
-                sc = sustained_clock(dev)
-                sc["frac_of_clock_limited_peak"] = round(roof["achieved"] / sc["clock_limited_peak"], 4)
-                roof["sustained_clock"] = sc
+    # config 4 (32-frame 336p: the HBM-bound space-time-attention stress) as a sub-record with its own kernel records
+    c4_rec = None
+    if world == 1 and args.workload == "train" and args.config == "c2" and not args.no_c4:
+        del ts, batch
+        torch.cuda.empty_cache()
+        _, _, bb4, dec4 = build(C4, dev)
+        B4, k4 = 4, 10
+        ts4, batch4, dt4, per4, region4, iso4, out4 = bench_train(C4, bb4, dec4, B4, k4, 3, 1, rank, dev, args, timers)
+        roof4, att4 = roofline_records(region4, iso4, dt4 * 1e3, not args.no_pipeline, C4) if region4 is not None else (None, None)
+        c4_rec = {"metric": "train clips/sec (32-frame 336p, nq=12)", "value": round(B4 * k4 / dt4, 2), "unit": "clips/s", "ms_per_step": round(dt4 / k4 * 1e3, 2),
+                  "steps": k4, "warmup": 3, "step_stats": step_stats(per4),
+                  "config": {"workload": "C4: 32-frame 336p (N = 18 433 tokens / clip), nq=12, frozen TimeSformer-L + object-query decoder train step",
+                             "clips_per_gpu": B4, "step_tflop_per_clip": round(step_tflop_per_clip(C4), 2)},
+                  "roofline": roof4, "attention_roofline": att4, "loss": round(float(out4["total_loss"]), 4)}
+        del ts4, batch4, bb4, dec4
+        torch.cuda.empty_cache()
+
+    if rank == 0:
+        dt_ms = dt * 1e3
+        roof, att = roofline_records(region, iso, dt_ms, not args.no_pipeline, cfg) if region is not None else (None, None)
+        if roof is not None and clock is not None:
+            clock["frac_of_clock_limited_peak"] = round(roof["achieved"] / clock["clock_limited_peak"], 4)
+            roof["sustained_clock"] = clock
+        train = args.workload == "train"
+        tf = step_tflop_per_clip(cfg, train)
         line = {"metric": metric, "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": "C2: 16-frame 224p, nq=12, frozen TimeSformer-L + object-query decoder %s" % (
-                    "train step" if args.workload == "train" else "EgoMCQ forward"), "clips_per_gpu": clips_per_step,
-                    "pipelined_encoder": bool(args.workload == "train" and not args.no_pipeline),
-                    "global_clips": clips_per_step * world, "parallelism": "dp%d" % world,
-                    "step_tflop_per_clip": 3.59 if args.workload == "train" else 3.45},
-                "end_to_end_mfma_frac": round(value * (3.59 if args.workload == "train" else 3.45) / (world * PEAK_BF16_TFLOPS), 4),
+                "config": {"workload": "%s, frozen TimeSformer-L + object-query decoder %s" % (cfg_name, "train step" if train else "EgoMCQ forward"),
+                           "clips_per_gpu": clips_per_step, "pipelined_encoder": bool(train and not args.no_pipeline),
+                           "global_clips": clips_per_step * world, "parallelism": "dp%d" % world,
+                           "resident_batch_reused": True, "materialize_logits": False,
+                           "step_tflop_per_clip": round(tf, 2)},
+                "step_stats": step_stats(per),
+                "end_to_end_mfma_frac": round(value * tf / (world * PEAK_BF16_TFLOPS), 4),
                 "roofline": roof}
-        if region is not None:
-            att = {}
-            for key, kname in (("space_attn", "space_attnj_kernel<4, 2> (joint-block kernel, head-major q|k|v planes)"), ("time_attn", "time_attn_mfma_kernel<16>"), ("add_ln", "add_ln_kernel")):
-                r, n, _, ms = rate(region, key, 1e9)
-                if r is None:
-                    continue
-                att[key] = {"kernel": kname, "bound": "hbm", "achieved": round(r, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(r / PEAK_HBM_GBS, 4),
-                            "launches_timed": n, "avg_launch_us": round(ms * 1e3 / n, 1), "share_of_step": round(ms * STRIDE / (dt * 1e3), 3)}
-                if iso is not None:
-                    r2, n2, _, ms2 = rate(iso, key, 1e9)
-                    if r2 is not None:
-                        att[key]["isolated"] = {"achieved": round(r2, 1), "frac": round(r2 / PEAK_HBM_GBS, 4), "avg_launch_us": round(ms2 * 1e3 / n2, 1)}
-            if att:
-                att["note"] = "algorithmic bytes (8*N*D per attention call and clip; bytes read + written for add+LayerNorm) / event time of the kernel alone; `isolated` = un-pipelined steps"
-                line["attention_roofline"] = att
+        if att:
+            line["attention_roofline"] = att
+        if power_rec:
+            line["power"] = power_rec
+        if rccl:
+            line["rccl"] = rccl
+            line["per_rank_clips_per_s"] = {"min": round(min(per_rank), 2), "max": round(max(per_rank), 2)}
+        if comm_rec:
+            line["comm"] = comm_rec
         if mcq_rec is not None:
             line["mcq"] = mcq_rec
+        if c4_rec is not None:
+            line["c4"] = c4_rec
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, enc_sd, dec_sd, seed=1000)
-        if args.workload == "train":
+        if train:
             line["loss"] = round(float(out["total_loss"]), 4)
         print(json.dumps(line))
     if world > 1 or args.force_comm:

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void adamw_arena_kernel(float* __restrict__ p,
             f32x4 mi = *reinterpret_cast<const f32x4*>(m + i);
             f32x4 vi = *reinterpret_cast<const f32x4*>(v + i);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {            // same operation order as adamw_kernel: bit-identical updates
+            for (int e = 0; e < 4; ++e) {            // same formulas as adamw_kernel
                 float pe = pi[e] * (1.f - lr * wds);
                 const float me = mi[e] * b1 + (1.f - b1) * gi[e];
                 const float ve = vi[e] * b2 + (1.f - b2) * gi[e] * gi[e];

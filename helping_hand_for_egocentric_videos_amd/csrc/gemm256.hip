@@ -576,6 +576,10 @@ static int g_space_dbg = 0;
 int hh_tuning_space_debug() { return g_space_dbg; }
 static int g_space_joint = 1;
 int hh_tuning_space_joint() { return g_space_joint; }
+static int g_space_waves = 0;      // waves per workgroup of the joint space kernel: 0 = automatic, 4 / 8 / 12 = force where the shape divides
+int hh_tuning_space_waves() { return g_space_waves; }
+static int g_space_prog = 1;       // 1 = progressive K / V staging where a specialised kernel exists (n = 576)
+int hh_tuning_space_prog() { return g_space_prog; }
 
 
 extern "C" int hh_set_tuning(const char* name, int value) {
@@ -583,6 +587,8 @@ extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm_tail") && value >= 0 && value <= 2) { g_tail = value; return HH_OK; }
     if (name && !strcmp(name, "space_debug")) { g_space_dbg = value; return HH_OK; }
     if (name && !strcmp(name, "space_joint")) { g_space_joint = value; return HH_OK; }
+    if (name && !strcmp(name, "space_prog") && value >= 0 && value <= 2) { g_space_prog = value; return HH_OK; }
+    if (name && !strcmp(name, "space_waves") && (value == 0 || value == 4 || value == 12)) { g_space_waves = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_skew")) { g_skew = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_pskew") && value >= 0 && value <= 64) { g_pskew = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_debug_nostore")) { g_nostore = value; return HH_OK; }

@@ -145,6 +145,7 @@ class BucketedAllReduce:
         self.pending = []
         self.comm_stream = torch.cuda.Stream() if (self.enabled and arena.params.is_cuda) else None
         self.avg = self.enabled and dist.get_backend(group) == "nccl"
+        self.active = True                                       # False: skip the gradient collectives (bench.py: exposed-communication A/B; ranks diverge)
         self.launched = 0                                        # gradient-bucket collectives issued so far (tests / diagnostics)
         self.flag_reduces = 0
         self._remaining = []
@@ -165,6 +166,8 @@ class BucketedAllReduce:
 
     def _make_hook(self, name):
         def hook(param):
+            if not self.active:
+                return
             o, k = self.arena.offsets[name]
             if param.grad is not None and param.grad.data_ptr() != self.arena.grads.data_ptr() + o * 4:
                 self.arena.grads[o:o + k].copy_(param.grad.reshape(-1))      # autograd produced a fresh tensor
@@ -202,7 +205,7 @@ class BucketedAllReduce:
         torch DDP does; a rank-local decision would let weights, moments and step counts diverge silently)."""
         a = self.arena
         a.seg_flag.copy_(a.local_flags())
-        if not self.enabled:
+        if not self.enabled or not self.active:
             return
         self._remaining = [0] * len(self._remaining)
         self._launch_ready()

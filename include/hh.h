@@ -44,7 +44,11 @@ int hh_version(void);
  *   "gemm256_skew"  -1 auto / 0 off / 1 on: start-time skew of the one-tile-per-block kernel (spreads the epilogue HBM bursts)
  *   "gemm256_pskew" 0..64: start skew quantum of the persistent kernel (default 0)
  *   "space_joint"   1 (default) = space attention on the joint-block kernel where n / 16 divides by 4 waves x {4, 3, 2} blocks,
- *                   0 = always the 16-query-block kernel;  "space_debug" 0 / 1 / 2: full kernel / memory traffic only / no staging
+ *                   0 = always the 16-query-block kernel;  "space_waves" waves per workgroup of the joint kernel: 0 (default) = automatic (12 waves x
+ *                   3 blocks when K / V fill the LDS, i.e. one workgroup per CU, and n / 16 divides by 36 -- config 4's n = 576 --, else 4), 4 / 12 =
+ *                   force where the shape divides;  "space_prog" 1 (default) = K / V staged progressively (compute starts on the first key
+ *                   segment while the rest is in flight) where a specialised kernel exists: n = 576; 0 = off; 2 = also n = 256 (experiment);
+ *                   "space_debug" 0 / 1 / 2: full kernel / memory traffic only / no staging
  *   "gemm256_debug_ts", "gemm256_debug_nostore": diagnostics (timeline recording; skip the epilogue stores) */
 int hh_set_tuning(const char* name, int value);
 const char* hh_last_error_string(void);
@@ -294,7 +298,7 @@ int hh_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * flags so that every rank decides alike); its step counter seg_step[s] (int32, in/out) is then incremented and supplies the bias
  * correction.  seg_decay[s] != 0 selects weight_decay, else 0 (utils/train_utils.py:28-48: the two param groups).  seg_coef: fp32
  * [2*n_seg] scratch.  zero_grads != 0 additionally clears g (the next step's optimizer.zero_grad(), run/train.py:199).  Updates
- * are bit-identical to hh_adamw_step on the same segment and step. */
+ * equal hh_adamw_step's on the same segment and step (same formulas; to fp32 rounding). */
 int hh_adamw_arena_step(float* p, float* g, float* m, float* v, int64_t n, const int64_t* seg_off, const int* seg_decay,
                         int* seg_step, const float* seg_flag, float* seg_coef, int n_seg, float lr, float beta1, float beta2,
                         float eps, float weight_decay, int zero_grads, hh_stream_t stream);

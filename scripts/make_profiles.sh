@@ -3,12 +3,17 @@
 #   1. rocprofv3 --kernel-trace --stats of the default pipelined bench      -> <tag>_bench_kernel_stats.csv, <tag>_summary.md
 #   2. same for the un-pipelined step (durations not inflated by overlap)   -> <tag>_unpipelined_kernel_stats.csv
 #   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)            -> <tag>_pmc_summary.{md,json}
+#   usage: make_profiles.sh <tag> [extra bench.py arguments, e.g. --config c4 --batch 4]   (default: config 2, B = 32)
 TAG=${1:-r1_final}
+shift
+EXTRA="$*"
+export HH_PROFILE_EXTRA="$EXTRA"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-kernel-timers --no-mcq"
+rm -rf $R/gpurun_out/prof_p $R/gpurun_out/prof_u $R/gpurun_out/pmc_FETCH_SIZE $R/gpurun_out/pmc_WRITE_SIZE $R/gpurun_out/pmc_SQ
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-kernel-timers --no-mcq --no-c4 --no-power $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_p -- $BENCH --steps 3 --warmup 2 > $OUT/${TAG}_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_u -- $BENCH --steps 3 --warmup 2 --no-pipeline > $OUT/${TAG}_bench_unpipelined.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -19,6 +24,9 @@ rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU S
 TAG=$TAG python3 - <<'PY'
 import csv, glob, json, os, collections
 R, TAG = os.environ["GRAFT_REPO_ROOT"], os.environ["TAG"]
+EXTRA = os.environ.get("HH_PROFILE_EXTRA", "").strip()
+FLAGS = "--no-cpu-baseline --no-kernel-timers --no-mcq --no-c4 --no-power" + (" " + EXTRA if EXTRA else "")
+WHAT = ("config 4 (32-frame 336p, nq=12), B = 4 clips" if "c4" in EXTRA else "config 2 (16-frame 224p, nq=12), B = 32 clips") if "--batch" not in EXTRA or "c4" in EXTRA else "bench.py " + EXTRA
 OUT = R + "/gpurun_out/profiles_new/"
 def stats(d, dst, title, cmd, note):
     f = glob.glob(R + "/gpurun_out/%s/**/*kernel_stats.csv" % d, recursive=True)[0]
@@ -31,9 +39,9 @@ def stats(d, dst, title, cmd, note):
         L.append("| %s | %s | %.2f | %.1f | %.1f |" % (r["Name"][:96].replace("|", "/"), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                     float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
     return L
-L = stats("prof_p", TAG + "_bench", TAG + " build", "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-mcq",
-          "MI355X, B = 32 clips, config 2 (16-frame 224p, nq=12), software-pipelined step, 5 steps profiled (2 warm-up + 3 timed).\nSum of kernel durations %.1f ms over 5 steps = %.1f ms/step (kernels of the encoder stream and of the decoder stream overlap, so this sum exceeds the wall time per step).")
-L += [""] + stats("prof_u", TAG + "_unpipelined", "Same build, un-pipelined step", "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timers --no-mcq --no-pipeline",
+L = stats("prof_p", TAG + "_bench", TAG + " build", "python3 bench.py --steps 3 --warmup 2 " + FLAGS,
+          "MI355X, " + WHAT + ", software-pipelined step, 5 steps profiled (2 warm-up + 3 timed).\nSum of kernel durations %.1f ms over 5 steps = %.1f ms/step (kernels of the encoder stream and of the decoder stream overlap, so this sum exceeds the wall time per step).")
+L += [""] + stats("prof_u", TAG + "_unpipelined", "Same build, un-pipelined step", "python3 bench.py --steps 3 --warmup 2 " + FLAGS + " --no-pipeline",
                   "Every kernel runs alone on the chip here, so the averages are the isolated kernel durations.\nSum of kernel durations %.1f ms over 5 steps = %.1f ms/step.")
 open(OUT + TAG + "_summary.md", "w").write("\n".join(L) + "\n")
 # ---- PMC
@@ -56,10 +64,10 @@ for k in names:
 json.dump(js, open(OUT + TAG + "_pmc_summary.json", "w"), indent=1)
 M = ["# " + TAG + " -- HBM-side traffic from PMC counters (rocprofv3 --pmc, separate passes)", "",
      "Commands (one counter per pass, as MI355X_MICROARCH.md prescribes):", "",
-     "    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_FETCH_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-mcq --no-pipeline",
-     "    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-mcq --no-pipeline", "",
+     "    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_FETCH_SIZE -- python3 bench.py --steps 1 --warmup 1 " + FLAGS + " --no-pipeline",
+     "    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 " + FLAGS + " --no-pipeline", "",
      "Units/corrections: counter values are KiB; on gfx950 FETCH_SIZE reports exactly 1/2 of wide coalesced streaming reads -> doubled below; WRITE_SIZE is exact.",
-     "The counters sit on the L2's fabric side, so Infinity-Cache hits are included.  Per-launch averages, B = 32 clips, config 2.", "",
+     "The counters sit on the L2's fabric side, so Infinity-Cache hits are included.  Per-launch averages, " + WHAT + ".", "",
      "| kernel | launches | fetch (corrected) MiB | write MiB | traffic / launch MiB |", "|---|---|---|---|---|"]
 M += [r for _, r in sorted(rows, reverse=True)]
 open(OUT + TAG + "_pmc_summary.md", "w").write("\n".join(M) + "\n")
@@ -72,9 +80,9 @@ for f in glob.glob(R + "/gpurun_out/pmc_SQ/**/*counter_collection.csv", recursiv
         agg[row["Kernel_Name"]][row["Counter_Name"]] += float(row["Counter_Value"])
         if row["Counter_Name"] == "SQ_BUSY_CU_CYCLES": cnt[row["Kernel_Name"]] += 1
 S = ["# " + TAG + " -- matrix-core and VALU utilisation per kernel (rocprofv3 --pmc, SQ counters, one pass)", "",
-     "    rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-mcq --no-pipeline", "",
+     "    rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 " + FLAGS + " --no-pipeline", "",
      "MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) (the rocprof-compute definition); VALU busy % = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / (4 x SQ_BUSY_CU_CYCLES);",
-     "MFMA flop = 512 x SQ_INSTS_VALU_MFMA_MOPS_BF16.  Per-launch averages, B = 32 clips, config 2.", "",
+     "MFMA flop = 512 x SQ_INSTS_VALU_MFMA_MOPS_BF16.  Per-launch averages, " + WHAT + ".", "",
      "| kernel | launches | MFMA busy % | VALU busy % | MFMA GFLOP / launch | SQ_INSTS_VALU / launch (M) |", "|---|---|---|---|---|---|"]
 rows = []
 for k, c in agg.items():

@@ -817,7 +817,7 @@ def test_box_ops_vs_oracle_r15():
 
 def test_arena_adamw_decides_on_the_device():
     """hh_adamw_arena_step (the step's optimizer call): per-parameter skip / step count / bias correction from device-side flags.
-    Against hh_adamw_step range by range (bit-identical), torch.optim.AdamW semantics for grad-less parameters (untouched: p, m, v
+    Against hh_adamw_step range by range (to rounding), torch.optim.AdamW semantics for grad-less parameters (untouched: p, m, v
     and the step count stay; no weight decay), parameters with different step counts in one launch, gradient arena cleared."""
     torch.manual_seed(0)
     sizes = [4, 1024, 12, 8192 + 4, 260, 4, 40000, 16]                   # 4-aligned segments, some straddling the 8192-element chunks
@@ -842,7 +842,10 @@ def test_arena_adamw_decides_on_the_device():
         a, b = int(offs[s_]), int(offs[s_ + 1])
         if flags[s_] > 0:
             ops.adamw_step(pr[a:b], g0[a:b].contiguous(), mr[a:b], vr[a:b], lr, b1, b2, eps, wd if decay[s_] else 0.0, steps0[s_] + 1)
-    assert torch.equal(p, pr) and torch.equal(m, mr) and torch.equal(v, vr)
+    # same formulas; the compiler may contract the vectorised and the scalar kernel's multiply-adds differently -> to rounding
+    torch.testing.assert_close(p, pr, rtol=2e-6, atol=1e-9)
+    torch.testing.assert_close(m, mr, rtol=2e-6, atol=1e-8)           # measured 8.7e-10 on moments of magnitude 1e-2
+    torch.testing.assert_close(v, vr, rtol=2e-6, atol=1e-10)
     assert seg_step.tolist() == [t + (1 if f > 0 else 0) for t, f in zip(steps0, flags)]
     assert float(g.abs().max()) == 0.0
     for s_ in (2, 5):                                                    # untouched: nothing moved, not even by weight decay
