@@ -147,6 +147,7 @@ class QueryStack(torch.autograd.Function):
         hs, dmean, drstd = ops.layernorm(tgt_all[1:].reshape(L * R, C), f(dnw), f(dnb), eps, out_dtype=torch.float32, save_stats=True)
         ctx.holder, ctx.dims, ctx.eps, ctx.p = holder, (L, B, Q, C, heads), eps, p
         ctx.P, ctx.saved, ctx.tgt_all, ctx.dec = P, saved, tgt_all, (f(dnw), dmean, drstd)
+        ctx.param_objs = (dnw, dnb) + tuple(params)             # the Parameters themselves: their gradient sinks (parallel._GradSink), if any
         return hs.view(L, B, Q, C)
 
     @staticmethod
@@ -157,10 +158,26 @@ class QueryStack(torch.autograd.Function):
         dhs = dhs.contiguous().view(L, R, C)
         dnw, dmean, drstd = ctx.dec
         F_ = ctx.P[0][14].shape[0]
-        # LayerNorm weight / bias gradients are accumulated with atomics: one zeroed slab for all of them
-        lnbuf = torch.zeros((L * 3 + 1, 2, C), dtype=torch.float32, device=dev)
-        d_wi_c = torch.zeros((L, 3 * C, C), dtype=torch.float32, device=dev)             # key / value rows belong to _MemorySide
-        d_bi_c = torch.zeros((L, 3 * C), dtype=torch.float32, device=dev)
+        # Gradient sinks: inside a TrainStep every parameter of this node owns a zeroed slice of the flat gradient arena
+        # (parallel._GradSink).  When all of them are armed the weight-gradient GEMMs and the LayerNorm reductions write there
+        # directly and this node returns None for them -- no AccumulateGrad `grad += new` kernel per parameter, no temporaries.
+        sinks = [getattr(t, "_hh_sink", None) for t in ctx.param_objs]
+        sunk = all(s is not None and s.armed() for s in sinks)
+        sv = (lambda l, i: sinks[2 + l * NP + i].view) if sunk else None        # arena view of LAYER_PARAMS[i] of layer l
+        if sunk:
+            lnbuf = d_wi_c = d_bi_c = None
+            for s_ in sinks:
+                s_.claim()
+        else:
+            # LayerNorm weight / bias gradients are accumulated with atomics: one zeroed slab for all of them
+            lnbuf = torch.zeros((L * 3 + 1, 2, C), dtype=torch.float32, device=dev)
+            d_wi_c = torch.zeros((L, 3 * C, C), dtype=torch.float32, device=dev)         # key / value rows belong to _MemorySide
+            d_bi_c = torch.zeros((L, 3 * C), dtype=torch.float32, device=dev)
+        # accumulation targets of the LayerNorm weight / bias gradients (zero on entry in both cases)
+        ln_w = lambda l, k: sv(l, (0, 6, 12)[k]) if sunk else lnbuf[l * 3 + k, 0]
+        ln_b = lambda l, k: sv(l, (1, 7, 13)[k]) if sunk else lnbuf[l * 3 + k, 1]
+        dn_w, dn_b = (sinks[0].view, sinks[1].view) if sunk else (lnbuf[L * 3, 0], lnbuf[L * 3, 1])
+        new = lambda l, i, *shape: sv(l, i) if sunk else torch.empty(shape, dtype=torch.float32, device=dev)
         if h.dkv is None:
             h.dkv = torch.empty_like(h.kv)
         M, Lk = h.M, h.L
@@ -176,43 +193,54 @@ class QueryStack(torch.autograd.Function):
             x, tgt3 = ctx.tgt_all[l], ctx.tgt_all[l + 1]
             # decoder.norm of this layer's output (+ the gradient arriving from layer l + 1)
             sl = slice(l * R, (l + 1) * R)
-            g = ops.layernorm_bwd_add(tgt3, dnw, dmean[sl], drstd[sl], dhs[l], g, lnbuf[L * 3, 0], lnbuf[L * 3, 1], out=g)
+            g = ops.layernorm_bwd_add(tgt3, dnw, dmean[sl], drstd[sl], dhs[l], g, dn_w, dn_b, out=g)
             drop = lambda site: dict(a_drop_p=p, a_drop_seed=sd(site), a_drop_ld=C) if p > 0 else {}
             # FFN:  tgt3 = tgt2 + drop3(hid.W2^T + b2),  hid = drop(relu(e.W1^T + b1)),  e = norm3(tgt2)
-            db2 = torch.empty(C, dtype=torch.float32, device=dev)
-            dw2 = ops.qgemm(g, hid, ops.TN, colsum=db2, **drop("d3"))
+            db2 = new(l, 17, C)
+            dw2 = ops.qgemm(g, hid, ops.TN, colsum=db2, out=sv(l, 16) if sunk else None, **drop("d3"))
             dz = ops.qgemm(g, w2, ops.NN, relu_mask=hid, mask_scale=keep, **drop("d3"))
-            db1 = torch.empty(F_, dtype=torch.float32, device=dev)
-            dw1 = ops.qgemm(dz, e, ops.TN, colsum=db1)
+            db1 = new(l, 15, F_)
+            dw1 = ops.qgemm(dz, e, ops.TN, colsum=db1, out=sv(l, 14) if sunk else None)
             de = ops.qgemm(dz, w1, ops.NN)
-            g2 = ops.layernorm_bwd_add(tgt2, n3w, mean3, rstd3, de, g, lnbuf[l * 3 + 2, 0], lnbuf[l * 3 + 2, 1])
+            g2 = ops.layernorm_bwd_add(tgt2, n3w, mean3, rstd3, de, g, ln_w(l, 2), ln_b(l, 2))
             # cross-attention:  tgt2 = tgt1 + drop2(ca.Wo^T + bo),  ca = xattn(q, K_l, V_l),  q = (cq.Wq^T + bq) / 8,  cq = norm2(tgt1) + qpos
-            dbo_c = torch.empty(C, dtype=torch.float32, device=dev)
-            dwo_c = ops.qgemm(g2, ca.view(R, C), ops.TN, colsum=dbo_c, **drop("d2"))
+            dbo_c = new(l, 11, C)
+            dwo_c = ops.qgemm(g2, ca.view(R, C), ops.TN, colsum=dbo_c, out=sv(l, 10) if sunk else None, **drop("d2"))
             dca = ops.qgemm(g2, wo_c, ops.NN, **drop("d2"))
             k, v = kvv[:, :, l * C:(l + 1) * C], kvv[:, :, (Lk + l) * C:(Lk + l + 1) * C]
             dk, dv = dkvv[:, :, l * C:(l + 1) * C], dkvv[:, :, (Lk + l) * C:(Lk + l + 1) * C]
             dq = ops.xattn_bwd(q.view(B, Q, C), k, v, ca, lse, dca.view(B, Q, C), dk, dv, heads, p, sd("x")).view(R, C)
-            ops.qgemm(dq, cq, ops.TN, a_scale=0.125, colsum=d_bi_c[l, :C], out=d_wi_c[l, :C])
+            # query rows of the cross-attention in-projection; its key / value rows are written by _MemorySide (which also reports
+            # the parameter as final when both halves went straight into the arena)
+            ops.qgemm(dq, cq, ops.TN, a_scale=0.125, colsum=(sv(l, 9) if sunk else d_bi_c[l])[:C], out=(sv(l, 8) if sunk else d_wi_c[l])[:C])
             dcq = ops.qgemm(dq, wi_c[:C], ops.NN, a_scale=0.125)
-            g1 = ops.layernorm_bwd_add(tgt1, n2w, mean2, rstd2, dcq, g2, lnbuf[l * 3 + 1, 0], lnbuf[l * 3 + 1, 1])
+            g1 = ops.layernorm_bwd_add(tgt1, n2w, mean2, rstd2, dcq, g2, ln_w(l, 1), ln_b(l, 1))
             # self-attention:  tgt1 = x + drop1(o.Wo^T + bo),  o = attn(q = k = aq.W[:2C], v = a.W[2C:]),  a = norm1(x), aq = a + qpos
-            dbo_s = torch.empty(C, dtype=torch.float32, device=dev)
-            dwo_s = ops.qgemm(g1, o, ops.TN, colsum=dbo_s, **drop("d1"))
+            dbo_s = new(l, 5, C)
+            dwo_s = ops.qgemm(g1, o, ops.TN, colsum=dbo_s, out=sv(l, 4) if sunk else None, **drop("d1"))
             do = ops.qgemm(g1, wo_s, ops.NN, **drop("d1"))
             dqkv = ops.qself_attn_bwd(qkv, do, B, Q, heads, p, sd("sa"))
-            dwi_s = torch.empty((3 * C, C), dtype=torch.float32, device=dev)
-            dbi_s = torch.empty(3 * C, dtype=torch.float32, device=dev)
+            dwi_s = new(l, 2, 3 * C, C)
+            dbi_s = new(l, 3, 3 * C)
             ops.qgemm(dqkv[:, :2 * C], aq, ops.TN, colsum=dbi_s[:2 * C], out=dwi_s[:2 * C])
             ops.qgemm(dqkv[:, 2 * C:], a, ops.TN, colsum=dbi_s[2 * C:], out=dwi_s[2 * C:])
             daq = ops.qgemm(dqkv[:, :2 * C], wi_s[:2 * C], ops.NN)
             da = ops.qgemm(dqkv[:, 2 * C:], wi_s[2 * C:], ops.NN, resid=daq)
-            g = ops.layernorm_bwd_add(x, n1w, mean1, rstd1, da, g1, lnbuf[l * 3, 0], lnbuf[l * 3, 1])
+            g = ops.layernorm_bwd_add(x, n1w, mean1, rstd1, da, g1, ln_w(l, 0), ln_b(l, 0))
             dqpos_parts += [dcq, daq]
-            grads[l * NP:(l + 1) * NP] = [lnbuf[l * 3, 0], lnbuf[l * 3, 1], dwi_s, dbi_s, dwo_s, dbo_s, lnbuf[l * 3 + 1, 0], lnbuf[l * 3 + 1, 1],
-                                          d_wi_c[l], d_bi_c[l], dwo_c, dbo_c, lnbuf[l * 3 + 2, 0], lnbuf[l * 3 + 2, 1], dw1, db1, dw2, db2]
+            if not sunk:
+                grads[l * NP:(l + 1) * NP] = [lnbuf[l * 3, 0], lnbuf[l * 3, 1], dwi_s, dbi_s, dwo_s, dbo_s, lnbuf[l * 3 + 1, 0], lnbuf[l * 3 + 1, 1],
+                                              d_wi_c[l], d_bi_c[l], dwo_c, dbo_c, lnbuf[l * 3 + 2, 0], lnbuf[l * 3 + 2, 1], dw1, db1, dw2, db2]
         dquery = torch.stack(dqpos_parts).sum(0).view(B, Q, C).sum(0)
         ctx.saved = ctx.tgt_all = None
+        if sunk:
+            # everything is in the arena: report the parameters final (bucket all-reduces may start), except the cross-attention
+            # in-projections, whose key / value rows _MemorySide.backward still has to write
+            for i, s_ in enumerate(sinks):
+                if i < 2 or (i - 2) % NP not in (8, 9):
+                    s_.done()
+            h.q_rows_sunk = True
+            return (dquery, torch.zeros(1, dtype=torch.float32, device=dev), None, None, None, None, None, None, None, *grads)
         return (dquery, torch.zeros(1, dtype=torch.float32, device=dev), lnbuf[L * 3, 0], lnbuf[L * 3, 1], None, None, None, None, None, *grads)
 
 

@@ -43,6 +43,7 @@ class _KVHolder:
         self.B = self.M = self.C = self.L = 0
         self.seed = 0
         self.keep, self.kept = False, None
+        self.q_rows_sunk = False         # QueryStack.backward wrote the query rows of every cross-attention in-projection gradient into the arena
 
 
 class _MemorySide(torch.autograd.Function):
@@ -71,6 +72,7 @@ class _MemorySide(torch.autograd.Function):
         holder.kv, holder.dkv = kv, None
         holder.B, holder.M, holder.C, holder.L = B, M, C, L
         ctx.holder, ctx.L, ctx.C = holder, L, C
+        ctx.param_objs = (w_proj, g_pre, b_pre) + tuple(in_wb)   # the Parameters themselves: their gradient sinks (parallel._GradSink), if any
         ctx.save_for_backward(feat_b, mem0, mean, rstd, memory, mem_pos, g_pre, wk, wv)
         return torch.zeros(1, dtype=torch.float32, device=feat_b.device)
 
@@ -98,6 +100,27 @@ class _MemorySide(torch.autograd.Function):
         if h.keep:
             h.kept = (h.kv, h.dkv)                 # test hook (Cross_Attention.debug_keep_kv): K/V and dK/dV outlive the backward
         h.kv = h.dkv = None
+        sinks = [getattr(t, "_hh_sink", None) for t in ctx.param_objs]
+        if h.q_rows_sunk and all(s is not None and s.armed() for s in sinks):
+            # gradient sinks (parallel._GradSink): QueryStack.backward has already written the query rows of every in-projection
+            # gradient into the flat arena; the key / value rows, the memory projection and pre_norm follow in ONE fused multi-tensor
+            # copy, the parameters are reported final and autograd gets None (no per-parameter `grad += new`, no zero-padded temporaries)
+            dst = [sinks[0].view, sinks[1].view, sinks[2].view]
+            src = [dw_proj, dg, db]
+            for l in range(L):
+                vw, vb = sinks[3 + l].view, sinks[3 + L + l].view
+                dst += [vw[C:2 * C], vw[2 * C:], vb[C:2 * C], vb[2 * C:]]
+                src += [dwk[l * C:(l + 1) * C], dwv[l * C:(l + 1) * C], dbk[l * C:(l + 1) * C], dbv[l * C:(l + 1) * C]]
+            for s_ in sinks:
+                s_.claim()
+            torch._foreach_copy_(dst, src)
+            for s_ in sinks:
+                s_.done()
+            return (None, None, None, None, dpos, None, None) + (None,) * (2 * L)
+        if h.q_rows_sunk:                          # the query rows are in the arena, the rest goes through autograd after all: hand the
+            for s_ in sinks[3:]:                   # in-projections back to their post-accumulate hooks (they add into the same slices)
+                if s_ is not None:
+                    s_.unclaim()
         gw, gb = [], []
         for l in range(L):
             w = torch.zeros((3 * C, C), dtype=torch.float32, device=feat_b.device)

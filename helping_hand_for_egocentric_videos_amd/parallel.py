@@ -3,9 +3,10 @@ RCCL on ROCm, over xGMI; "gloo" in CPU tests).
 
 The reference has NO gradient synchronisation (run/train.py:475); the design here is the
 build's own:
-  * parameters and gradients of the trainable decoder live in two flat fp32 arenas (decay group first, no-decay
-    group second -- utils/train_utils.py:28-48) so that AdamW is two fused kernel launches and all-reduce buckets
-    are contiguous slices,
+  * parameters and gradients of the trainable decoder live in two flat fp32 arenas laid out in the order in which backward
+    FINISHES the gradients (heads, query side, memory side last), so that AdamW is one fused launch over per-parameter segments
+    (weight decay is a per-segment flag -- utils/train_utils.py:28-48) and all-reduce buckets are contiguous slices that become
+    ready front to back,
   * buckets are all-reduced asynchronously on a communication stream as soon as every parameter in the bucket has
     its final gradient (post-accumulate hooks) -> overlapped with the rest of backward; mean over ranks,
   * the contrastive batch is gathered with ONE packed all-gather per step (embeddings + pad flags + verb/noun
@@ -34,6 +35,36 @@ def world():
     return 1, 0
 
 
+class _GradSink:
+    """Direct-write target of one parameter's gradient inside the arena (attached to the parameter as `_hh_sink`).
+
+    The decoder's own autograd nodes (model/qside.py QueryStack, model/tfm_decoder.py _MemorySide) own ~120 single-use parameters.
+    Handing their gradients to autograd costs one `grad += new` kernel each (AccumulateGrad into the pre-set arena view) plus the
+    temporaries; instead a node whose parameters all have an ARMED sink writes its weight-gradient GEMMs / LayerNorm reductions
+    straight into `view`, calls done() and returns None for that input.  Armed = FlatArena.zero_grad() has run (the arena is
+    zero, so accumulating kernels may add into it) and this parameter has not received a gradient yet in this step -- a second
+    backward in the same step (gradient accumulation) falls back to autograd's adds."""
+    __slots__ = ("arena", "name", "view")
+
+    def __init__(self, arena, name, view):
+        self.arena, self.name, self.view = arena, name, view
+
+    def armed(self):
+        a = self.arena
+        return a.sink_armed and self.name not in a.touched
+
+    def claim(self):
+        """A node is going to write this gradient itself: from now on only done() reports the parameter (autograd still fires the
+        post-accumulate hooks for the None the node returns -- possibly before another node has written ITS part)."""
+        self.arena.claimed.add(self.name)
+
+    def unclaim(self):
+        self.arena.claimed.discard(self.name)
+
+    def done(self):
+        self.arena._ready(self.name)
+
+
 class FlatArena:
     """Flat fp32 parameter / gradient arenas over the trainable parameters of `module`.
 
@@ -42,16 +73,16 @@ class FlatArena:
 
     SKIP_PREFIXES = ("class_embed.", "vid_proj.")
 
-    def __init__(self, module, bucket_bytes=16 << 20):
+    def __init__(self, module, bucket_bytes=16 << 20, late=None):
+        """late(name) -> True for parameters whose gradient is only final at the very end of backward (the decoder's memory side):
+        they are laid out last, so that the buckets in front of them -- launched strictly in arena order, the same on every rank --
+        can be all-reduced while the memory side is still being differentiated."""
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad and not n.startswith(self.SKIP_PREFIXES)]
-        decay = [(n, p) for n, p in named if not no_decay(n)]
-        nodecay = [(n, p) for n, p in named if no_decay(n)]
-        # reverse registration order ~ order in which backward finishes gradients (heads first, memory side last)
-        self.entries = list(reversed(decay)) + list(reversed(nodecay))
-        self.n_decay = sum(p.numel() for _, p in decay)
+        rev = list(reversed(named))          # reverse registration order ~ order in which backward finishes gradients (heads first)
+        late = late or (lambda n: False)
+        self.entries = [e for e in rev if not late(e[0])] + [e for e in rev if late(e[0])]
         dev = named[0][1].device
         sizes = [(p.numel() + 3) // 4 * 4 for _, p in self.entries]          # keep every view 16-byte aligned
-        self.n_decay_padded = sum(s for s, (n, _) in zip(sizes, self.entries) if not no_decay(n))
         total = sum(sizes)
         self.params = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -93,12 +124,25 @@ class FlatArena:
         self.seg_coef = torch.zeros(2 * len(self.names), dtype=torch.float32, device=dev)
         self._flag_cache = {}
         self.grads_clean = True                                  # the gradient arena is all zero (fresh, or cleared by the last update)
+        self.sink_armed = False                                  # direct gradient writes allowed (between zero_grad() and the update)
+        self.claimed = set()                                     # parameters whose gradient a node writes straight into the arena this step
+        self.ready_callbacks = []                                # called with the parameter name when its gradient is final (comm layer)
+        for n, p in self.entries:
+            o, k = self.offsets[n]
+            p._hh_sink = _GradSink(self, n, self.grads[o:o + k].view_as(p))
         self._touch_hooks = [p.register_post_accumulate_grad_hook(self._make_touch_hook(n)) for n, p in self.entries]
 
     def _make_touch_hook(self, name):
         def hook(param):
-            self.touched.add(name)
+            if name not in self.claimed:
+                self.touched.add(name)
         return hook
+
+    def _ready(self, name):
+        """A node wrote this parameter's gradient straight into the arena (no AccumulateGrad, so no post-accumulate hooks)."""
+        self.touched.add(name)
+        for cb in self.ready_callbacks:
+            cb(name)
 
     @property
     def steps(self):
@@ -122,9 +166,11 @@ class FlatArena:
         """optimizer.zero_grad() (run/train.py:199).  force=False skips the fill when the last hh_adamw_arena_step already cleared
         the arena (TrainStep.step does that)."""
         self.touched.clear()
+        self.claimed.clear()
         if force or not self.grads_clean:
             self.grads.zero_()
         self.grads_clean = False                     # a backward is about to write it
+        self.sink_armed = True
         for n, p in self.entries:                    # autograd may have replaced .grad; re-point it at the arena
             o, k = self.offsets[n]
             if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + o * 4:
@@ -157,24 +203,34 @@ class BucketedAllReduce:
         if self.enabled:
             for n, p in arena.entries:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(n)))
+            arena.ready_callbacks.append(self._param_ready)      # gradients written straight into the arena (no AccumulateGrad)
         self.reset()
 
     def reset(self):
         self._remaining = [len(names) for _, _, names in self.arena.buckets]
         self._next = 0                                           # buckets are launched strictly in arena order on every rank
+        self._seen = set()
         self.pending = []
 
     def _make_hook(self, name):
         def hook(param):
-            if not self.active:
+            if not self.active or name in self.arena.claimed:     # claimed: the writing node reports it (arena._ready)
                 return
             o, k = self.arena.offsets[name]
             if param.grad is not None and param.grad.data_ptr() != self.arena.grads.data_ptr() + o * 4:
                 self.arena.grads[o:o + k].copy_(param.grad.reshape(-1))      # autograd produced a fresh tensor
                 param.grad = self.arena.grads[o:o + k].view_as(param)
-            self._remaining[self._bucket_of[name]] -= 1
-            self._launch_ready()
+            self._param_ready(name)
         return hook
+
+    def _param_ready(self, name):
+        """The gradient of `name` is final for this step.  Idempotent: a parameter whose gradient went straight into the arena
+        (_GradSink.done) is reported again by its post-accumulate hook, which autograd still fires for the None the node returned."""
+        if not self.active or name in self._seen:
+            return
+        self._seen.add(name)
+        self._remaining[self._bucket_of[name]] -= 1
+        self._launch_ready()
 
     def _launch_ready(self):
         """Launch every leading bucket whose gradients are final.  The ORDER of collectives must be identical on all ranks even when

@@ -20,6 +20,13 @@ DP_ENC_CUS = 0                                    # default encoder-stream CU bu
 WEIGHT_DICT = {"loss_bbox_hand_boxes": 5, "loss_bbox_obj_boxes": 5, "loss_giou_hand_boxes": 2, "loss_giou_obj_boxes": 2}
 
 
+def finishes_last(name: str) -> bool:
+    """Decoder parameters whose gradient is written by the memory side's backward (model/tfm_decoder.py _MemorySide), the last node
+    of the step's backward: FlatArena lays them out last so that every earlier all-reduce bucket can overlap it."""
+    return (name == "proj.weight" or name.startswith(("transformer.pre_norm.", "pos_embed", "temporal_embed"))
+            or ".multihead_attn.in_proj_" in name)
+
+
 def build_criterion():
     """run/train.py:459-473."""
     return box_utils.SetCriterion(22047, matcher=box_utils.build_matcher(None), weight_dict=dict(WEIGHT_DICT), eos_coef=0.1,
@@ -34,7 +41,7 @@ class TrainStep:
         self.nce, self.word = EgoNCE(), WordContrastiveLoss()
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         decoder.materialize_logits = not fast_heads
-        self.arena = FlatArena(decoder, bucket_bytes)
+        self.arena = FlatArena(decoder, bucket_bytes, late=finishes_last)
         self.m = torch.zeros_like(self.arena.params)
         self.v = torch.zeros_like(self.arena.params)
         self.force_comm = bool(force_comm)
@@ -178,6 +185,7 @@ class TrainStep:
         ops.adamw_arena_step(a.params, a.grads, self.m, self.v, a.seg_off, a.seg_decay, a.seg_step, a.seg_flag, a.seg_coef,
                              self.lr, *self.betas, self.eps, self.wd, zero_grads=zero_grads)
         a.grads_clean = bool(zero_grads)
+        a.sink_armed = False                                    # until the next zero_grad()
 
 
     # ------------------------------------------------------------------ optimizer state (checkpoint exchange with the reference)

@@ -34,11 +34,7 @@ for it in range(4):
     mark("losses:end")
     out["total_loss"].backward()
     mark("backward:end")
-    ts.comm.finish(); ts.iteration += 1
-    a, nd = ts.arena, ts.arena.n_decay_padded
-    ops.adamw_step(a.params[:nd], a.grads[:nd], ts.m[:nd], ts.v[:nd], ts.lr, *ts.betas, ts.eps, ts.wd, ts.iteration)
-    if a.total > nd:
-        ops.adamw_step(a.params[nd:], a.grads[nd:], ts.m[nd:], ts.v[nd:], ts.lr, *ts.betas, ts.eps, 0.0, ts.iteration)
+    ts.optimizer_step()
     mark("opt:end")
     torch.cuda.synchronize()
     t_sync = time.perf_counter()

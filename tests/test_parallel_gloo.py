@@ -164,10 +164,13 @@ def test_arena_groups_follow_the_reference_optim_policy():
             assert n not in arena.offsets
             continue
         o, k = arena.offsets[n]
-        assert (o < arena.n_decay_padded) == (not no_decay(n))
+        assert bool(arena.seg_decay[arena.names.index(n)]) == (not no_decay(n))
         assert p.data_ptr() == arena.params.data_ptr() + 4 * o and p.grad.data_ptr() == arena.grads.data_ptr() + 4 * o
         assert o % 4 == 0
     assert no_decay("transformer.pre_norm.bias") and not no_decay("transformer.pre_norm.weight")
+    # `late` parameters are laid out behind the others (their buckets are the last to become ready)
+    arena2 = FlatArena(Toy(), late=lambda n: n.startswith("proj."))
+    assert arena2.names[-2:] == ["proj.bias", "proj.weight"] and arena2.offsets["proj.weight"][0] > arena2.offsets["box.weight"][0]
     # no process group: the comm layer is a no-op
     comm = BucketedAllReduce(arena)
     assert not comm.enabled

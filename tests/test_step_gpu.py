@@ -290,12 +290,17 @@ def test_train_step_updates_like_oracle_adamw_and_learns():
     backbone = LaviLa.build_backbone(cfg, esd)
     dec = tfm_decoder.build_decoder(cfg, dsd)
     ts = TrainStep(cfg, backbone, dec, lr=1e-4)
-    # arena bookkeeping: params are views of the flat buffer, grouped decay-first
+    # arena bookkeeping: params are views of the flat buffer; one AdamW segment per parameter with optim_policy's decay flag; the
+    # memory side's parameters (final only at the end of backward) sit behind everything else
+    from helping_hand_for_egocentric_videos_amd.step import finishes_last
+    decay = dict(zip(ts.arena.names, ts.arena.seg_decay.tolist()))
+    first_late = min(o for n_, (o, k) in ts.arena.offsets.items() if finishes_last(n_))
     for n_, p in dec.named_parameters():
         if n_ in ts.arena.offsets:
             o, k = ts.arena.offsets[n_]
             assert p.data_ptr() == ts.arena.params.data_ptr() + 4 * o
-            assert (o < ts.arena.n_decay_padded) == (not OS.no_decay(n_))
+            assert bool(decay[n_]) == (not OS.no_decay(n_))
+            assert (o >= first_late) == finishes_last(n_)
     dec.eval()                                   # deterministic (no dropout) for the comparison
     before = {k: v.detach().clone() for k, v in dec.state_dict().items()}
     # one step by hand in eval mode
@@ -305,9 +310,7 @@ def test_train_step_updates_like_oracle_adamw_and_learns():
     grads = {n_: p.grad.detach().cpu().clone() for n_, p in dec.named_parameters() if n_ in ts.arena.offsets}
     ref_params = {k: v.cpu().clone() for k, v in before.items()}
     OS.adamw_update(ref_params, grads, None, lr=1e-4, wd=1e-5)
-    nd = ts.arena.n_decay_padded
-    ops.adamw_step(ts.arena.params[:nd], ts.arena.grads[:nd], ts.m[:nd], ts.v[:nd], 1e-4, 0.9, 0.999, 1e-8, 1e-5, 1)
-    ops.adamw_step(ts.arena.params[nd:], ts.arena.grads[nd:], ts.m[nd:], ts.v[nd:], 1e-4, 0.9, 0.999, 1e-8, 0.0, 1)
+    ts.optimizer_step(zero_grads=False)          # hh_adamw_arena_step: lr 1e-4, wd 1e-5 on the decay segments, first step
     for n_, p in dec.named_parameters():
         torch.testing.assert_close(p.detach().cpu(), ref_params[n_], rtol=1e-5, atol=1e-7)
     assert torch.equal(dec.class_embed.weight.detach().cpu(), before["class_embed.weight"].cpu())
