@@ -222,8 +222,12 @@ def barrier(world):
     torch.cuda.synchronize()
 
 
-def timed_region(run, steps, warmup, world, timers):
+STATS_STEPS = 50     # per-step statistics are taken over at least this many steps: the K contract steps + extra ones run after the timed region
+
+
+def timed_region(run, steps, warmup, world, timers, stats_steps=0):
     """W untimed + EXACTLY K timed calls of run(), bracketed by barrier + synchronize; one device event per step on the main stream.
+    If K < stats_steps, further steps follow AFTER the timed region (not part of `value`), for the per-step statistics only.
     -> (wall seconds, per-step ms list from the events, kernel-timer snapshot, last output)."""
     for _ in range(warmup):
         run()
@@ -239,18 +243,27 @@ def timed_region(run, steps, warmup, world, timers):
         ev[i + 1].record()
     barrier(world)
     dt = time.perf_counter() - t0
-    per = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
-    return dt, per, (prof_snapshot() if timers else None), out
+    region = prof_snapshot() if timers else None
+    extra = max(0, stats_steps - steps)
+    for i in range(extra):
+        run()
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev.append(e)
+    if extra:
+        barrier(world)
+    per = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps + extra)]
+    return dt, per, region, out
 
 
 def step_stats(per):
     import statistics
     s = sorted(per)
     q = lambda f: s[min(len(s) - 1, int(round(f * (len(s) - 1))))]
-    return {"ms_per_step_mean": round(sum(per) / len(per), 3), "ms_per_step_std": round(statistics.pstdev(per), 3) if len(per) > 1 else 0.0,
+    return {"steps": len(per), "ms_per_step_mean": round(sum(per) / len(per), 3), "ms_per_step_std": round(statistics.pstdev(per), 3) if len(per) > 1 else 0.0,
             "ms_per_step_p50": round(q(0.5), 3), "ms_per_step_p95": round(q(0.95), 3), "ms_per_step_min": round(s[0], 3),
-            "ms_per_step_max": round(s[-1], 3), "timing": "device events on the main stream after every step (the pipelined encoder of step i+1 overlaps step i, "
-            "so a step's own interval is what the steady state delivers)"}
+            "ms_per_step_max": round(s[-1], 3), "timing": "device events on the main stream after every step (the pipelined encoder of step i+1 overlaps step i, so a step's own "
+            "interval is what the steady state delivers); when --steps < 50 the statistics continue past the timed region up to 50 steps"}
 
 
 def rate(rec, key, scale):
@@ -310,7 +323,11 @@ def bench_train(cfg, backbone, decoder, B, steps, warmup, world, rank, dev, args
     ts = TrainStep(cfg, backbone, decoder, enc_cus=args.enc_cus, force_comm=args.force_comm)
     pipelined = not args.no_pipeline
     run = lambda: ts.step(batch, next_batch=batch if pipelined else None)
-    dt, per, region, out = timed_region(run, steps, warmup, world, timers)
+    if timers:
+        prof_enable(0)
+    dt, per, region, out = timed_region(run, steps, warmup, world, timers, stats_steps=STATS_STEPS if want_iso else 0)
+    if timers:
+        prof_enable(0)          # (the extra statistics steps are not part of the kernel-timer region: the snapshot was taken before them)
     iso = None
     if timers and pipelined and want_iso:
         # outside the timed region: two un-pipelined steps, so that every kernel is also timed alone on the chip (no decoder kernels

@@ -68,12 +68,18 @@ SIGNATURES = {
     "hh_lsap_rows": [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
     "hh_box_loss_fwd": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "hh_box_loss_bwd": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "hh_rownorm_fwd": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_float, c_vp],
+    "hh_rownorm_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_int, c_float, c_vp],
+    "hh_workspace_bytes_egonce": [c_int, c_int],
+    "hh_egonce_fwd": [c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_float, c_float, c_vp, c_vp, c_vp, c_vp],
+    "hh_masked_ce_fwd": [c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_float, c_float, c_vp, c_vp, c_vp],
+    "hh_tv_accuracy": [c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp],
     "hh_adamw_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_float, c_float, c_float, c_float, c_float, c_int, c_vp],
     "hh_adamw_arena_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_float, c_float, c_float,
                             c_float, c_int, c_vp],
 }
 _RESTYPES = {"hh_last_error_string": ctypes.c_char_p, "hh_workspace_bytes_gemm_splitk": c_i64, "hh_workspace_bytes_gemm_tn": c_i64,
-             "hh_workspace_bytes_xattn_bwd": c_i64, "hh_workspace_bytes_xattn_fwd": c_i64, "hh_workspace_bytes_attn_cls_partial": c_i64}
+             "hh_workspace_bytes_xattn_bwd": c_i64, "hh_workspace_bytes_xattn_fwd": c_i64, "hh_workspace_bytes_attn_cls_partial": c_i64, "hh_workspace_bytes_egonce": c_i64}
 
 _lib = None
 

@@ -9,7 +9,8 @@ WordContrastiveLoss :72-106) without the reference's host round trips.
     returned value is this rank's share x W -- its MEAN over ranks is the global mean cross-entropy, which is what the mean-reduced
     gradients optimise (as `num_boxes` does for the box losses, box_utils.py:218-222).  The step passes the count it already
     gathered (parallel.gather_contrastive); stand-alone use all-reduces it here.
-Small fp32 reductions (log-softmax over a [5B,B] matrix, CE over 582 nouns) stay on stock PyTorch-ROCm ops.
+The step's call of EgoNCE (a per-row pad flag) and the 582-way masked cross-entropy run on the fused kernels of csrc/loss.hip
+(hh_egonce_fwd, hh_masked_ce_fwd: value and gradient in one pass); the general forms stay on stock PyTorch-ROCm ops.
 """
 import torch
 import torch.distributed as dist
@@ -20,10 +21,59 @@ from .. import ops
 from .metric import sim_matrix
 
 
+class _EgoNCERows(torch.autograd.Function):
+    """EgoNCE for multi_pad_mask = row_pad[:, None].repeat(1, Bg) on hh_egonce_fwd: the loss and d loss / d x come out of the same
+    three launches; the backward is one multiply by the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, x, mask_v, mask_n, row_pad, temperature, thr):
+        xd = x.detach()
+        if xd.stride(-1) != 1 or xd.dtype != torch.float32:
+            xd = xd.float().contiguous()
+        f = lambda t: None if t is None else t.detach().float().contiguous()
+        R = xd.shape[0] // xd.shape[1]
+        loss, grad = ops.egonce_fwd(xd, f(mask_v), f(mask_n), f(row_pad), R, temperature, thr)
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None, None
+
+
+class _MaskedCE(torch.autograd.Function):
+    """Per-row cross-entropy of the word loss (loss.py:95-104) on hh_masked_ce_fwd: ce [rows] (0 on invalid rows) and its Jacobian row
+    d ce[r] / d sim[r, :] in one launch."""
+
+    @staticmethod
+    def forward(ctx, sim, noun_sim, gt, valid, temperature, threshold):
+        sd = sim.detach()
+        if sd.stride(-1) != 1:
+            sd = sd.contiguous()
+        ce, grad = ops.masked_ce_fwd(sd, noun_sim.detach().contiguous(), gt.contiguous(), valid.contiguous(), temperature, threshold)
+        ctx.save_for_backward(grad)
+        return ce
+
+    @staticmethod
+    def backward(ctx, dce):
+        (grad,) = ctx.saved_tensors
+        return grad * dce[:, None], None, None, None, None, None
+
+
 class EgoNCE(nn.Module):
     def __init__(self, temperature=0.07, noun=True, verb=True):
         super().__init__()
         self.noun, self.verb, self.temperature = noun, verb, temperature
+
+    def forward_rows(self, x, mask_v, mask_n, row_pad, vn_threshold=0):
+        """forward(x, mask_v, mask_n, multi_pad_mask=row_pad[:, None].repeat(1, Bg), strict_mask=True) -- the call of
+        run/train.py:144-149, where a caption is either present or absent for all clips -- as one fused node (hh_egonce_fwd).
+        x [R*Bg, Bg], row_pad [R*Bg] -> loss."""
+        if not x.is_cuda:
+            return self.forward(x, mask_v, mask_n, multi_pad_mask=row_pad[:, None].repeat(1, x.shape[1]), strict_mask=True,
+                                vn_threshold=vn_threshold, return_mask=False)[0]
+        return _EgoNCERows.apply(x, mask_v, mask_n, row_pad, self.temperature, float(vn_threshold))
 
     def forward(self, x, mask_v, mask_n, multi_pad_mask=None, strict_mask=False, vn_threshold=0, return_mask=True):
         """x [R*Bg, Bg] (or [Bg,Bg] when multi_pad_mask is None) -> (loss, mask_bool).
@@ -87,11 +137,11 @@ class WordContrastiveLoss(nn.Module):
         cols = ops.lsap_rows(cost.detach().float().contiguous(), valid)            # [B,W] int64, -1 on pad rows
         sel = torch.gather(pred_noun_embeds, 1, cols.clamp(min=0)[..., None].expand(-1, -1, pred_noun_embeds.shape[-1]))
         sim_all = sim_matrix(sel.reshape(Bn * W, -1), noun_embeds)                 # [B*W,V]
-        noun_sim = sim_matrix(noun_embeds, noun_embeds).clone()
-        noun_sim.fill_diagonal_(0)
-        noun_mask = noun_sim.index_select(0, noun_gt_inds.flatten()) > self.noun_threshold
-        ce = F.cross_entropy(sim_all.masked_fill(noun_mask, -1) / self.temperature, noun_gt_inds.flatten(), reduction='none')
         v = valid.flatten()
+        with torch.no_grad():                                                      # (a mask source: loss.py:95-97)
+            noun_sim = sim_matrix(noun_embeds.detach(), noun_embeds.detach())
+        # masked_fill(noun_sim[gt] > threshold with a zeroed diagonal, -1) / T -> cross-entropy, value and gradient in one launch
+        ce = _MaskedCE.apply(sim_all, noun_sim, noun_gt_inds.flatten(), v, self.temperature, self.noun_threshold)
         if count is not None:
             count = count.clamp(min=1)                  # a rank (or the whole global batch) without valid words contributes 0, not NaN
         elif dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -102,5 +152,5 @@ class WordContrastiveLoss(nn.Module):
             count = (count[0] / dist.get_world_size()).clamp(min=1)
         else:
             count = v.sum().float()                     # single process: the reference's plain mean over valid words (loss.py:104)
-        loss = torch.where(v, ce, torch.zeros((), device=ce.device)).sum() / count
+        loss = ce.sum() / count                                                    # (ce is 0 on the padding rows)
         return (loss, cols) if return_assignment else loss

@@ -3,16 +3,42 @@ compute_tv_accuracy, egomcq_accuracy_metrics).  Legacy retrieval metrics of the 
 import torch
 import torch.nn.functional as F
 
+from .. import ops
+
+
+class _RowNorm(torch.autograd.Function):
+    """x / max(||x||_2, eps) along the last dim on hh_rownorm_fwd / hh_rownorm_bwd (one launch each instead of norm + clamp + div
+    and their five-op backward); fixed summation order, so a row-strided view gives the same bits as a dense copy."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        x2 = x.detach().reshape(-1, x.shape[-1]) if x.dim() != 2 else x.detach()
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        y, nrm = ops.rownorm_fwd(x2, eps)
+        ctx.save_for_backward(y, nrm)
+        ctx.eps, ctx.shape = eps, x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, nrm = ctx.saved_tensors
+        return ops.rownorm_bwd(y, nrm, dy.reshape(y.shape), ctx.eps).view(ctx.shape), None
+
+
+def _unit_rows(x, eps):
+    if x.is_cuda and x.dtype == torch.float32:
+        return _RowNorm.apply(x, eps)
+    return x / x.norm(dim=-1, keepdim=True).clamp_min(eps)
+
 
 def sim_matrix(a, b, eps=1e-8, norm=True):
-    """Cosine similarity with eps-clamped norms (metric.py:363-375).  On the GPU the 2-D product runs on hh_qgemm_f32x3 (fp32-grade,
-    differentiable; the contraction is zero-padded to a multiple of 4), the small batched form of the word loss as a broadcast
-    multiply + sum -- no vendor BLAS on the step.  CPU tensors (tests, host-side use) take torch's matmul."""
+    """Cosine similarity with eps-clamped norms (metric.py:363-375).  On the GPU the operands are normalised by hh_rownorm_fwd, the 2-D
+    product runs on hh_qgemm_f32x3 (fp32-grade, differentiable; the contraction is zero-padded to a multiple of 4), the small batched
+    form of the word loss as a broadcast multiply + sum -- no vendor BLAS on the step.  CPU tensors (tests, host-side use) take
+    torch's ops."""
     if norm:
-        if a.is_cuda:                                # torch's row reductions pick their summation order by memory layout: normalise
-            a, b = a.contiguous(), b.contiguous()    # dense copies, so that a strided view (the packed all-gather) gives the same bits
-        a = a / a.norm(dim=-1, keepdim=True).clamp_min(eps)
-        b = b / b.norm(dim=-1, keepdim=True).clamp_min(eps)
+        a, b = _unit_rows(a, eps), _unit_rows(b, eps)
     if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32:
         if a.dim() == 2 and b.dim() == 2:
             from .qside import linear_x3
@@ -30,6 +56,11 @@ def sim_matrix(a, b, eps=1e-8, norm=True):
 def compute_tv_accuracy(similarity, text_embeds, sim_v, sim_n, num_samples, device=None):
     """metric.py:378-392: top-1 text<->video accuracy counting verb/noun-sharing and duplicate-text clips as hits
     (`[::5]` = first of the 5 rephrases).  Stays on device, no host sync."""
+    if similarity.is_cuda and similarity.dtype == torch.float32:
+        # one launch (hh_tv_accuracy) after the text-text cosine matrix: both argmaxes, the positives and the two means
+        acc = ops.tv_accuracy(similarity, sim_matrix(text_embeds[::5], text_embeds[::5]).contiguous(), sim_v.float().contiguous(),
+                              sim_n.float().contiguous())
+        return acc[0], acc[1]
     tv_argmax = similarity.argmax(dim=-1)
     vt_argmax = similarity.argmax(dim=0)
     same = sim_matrix(text_embeds[::5], text_embeds[::5]) > 0.99

@@ -515,3 +515,63 @@ def adamw_arena_step(p, g, m, v, seg_off, seg_decay, seg_step, seg_flag, seg_coe
     _lib.check(_lib.lib().hh_adamw_arena_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(seg_off), _p(seg_decay), _p(seg_step),
                                               _p(seg_flag), _p(seg_coef), n_seg, float(lr), float(beta1), float(beta2), float(eps),
                                               float(weight_decay), int(bool(zero_grads)), _stream()), "hh_adamw_arena_step")
+
+
+# ---- loss tail (csrc/loss.hip)
+def rownorm_fwd(x, eps=1e-8):
+    """x fp32 [rows, cols] (unit inner stride) -> (y = x / max(||x||, eps) dense fp32, norm fp32 [rows])."""
+    _chk(x)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise TypeError("rownorm_fwd: fp32 [rows, cols] with unit inner stride")
+    rows, cols = x.shape
+    y = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    norm = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().hh_rownorm_fwd(_p(x), x.stride(0) if rows > 1 else cols, _p(y), _p(norm), rows, cols, float(eps), _stream()), "hh_rownorm_fwd")
+    return y, norm
+
+
+def rownorm_bwd(y, norm, dy, eps=1e-8):
+    _chk(y, norm)
+    if dy.stride(-1) != 1:
+        dy = dy.contiguous()
+    rows, cols = y.shape
+    dx = torch.empty_like(y)
+    _lib.check(_lib.lib().hh_rownorm_bwd(_p(y), _p(norm), _p(dy), dy.stride(0) if rows > 1 else cols, _p(dx), rows, cols, float(eps), _stream()), "hh_rownorm_bwd")
+    return dx
+
+
+def egonce_fwd(x, sim_v, sim_n, pad, R, temperature, vn_threshold=0.0):
+    """-> (loss fp32 [1], grad fp32 [R*Bg, Bg] = d loss / d x).  x fp32 [R*Bg, Bg] (unit inner stride), pad fp32 [R*Bg]."""
+    _chk(sim_v, sim_n, pad)
+    Rn, Bg = x.shape
+    if x.dtype != torch.float32 or x.stride(1) != 1 or Rn != R * Bg or pad.numel() != Rn:
+        raise TypeError("egonce_fwd: x fp32 [R*Bg, Bg], pad [R*Bg]")
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    grad = torch.empty((Rn, Bg), dtype=torch.float32, device=x.device)
+    scratch = _workspace("egonce", R, Bg, device=x.device)
+    _lib.check(_lib.lib().hh_egonce_fwd(_p(x), x.stride(0), _p(sim_v), _p(sim_n), _p(pad), R, Bg, float(temperature), float(vn_threshold),
+                                        _p(loss), _p(grad), _p(scratch), _stream()), "hh_egonce_fwd")
+    return loss, grad
+
+
+def masked_ce_fwd(sim, noun_sim, gt, valid, temperature, threshold):
+    """-> (ce fp32 [rows], grad fp32 [rows, V]); sim fp32 [rows, V], noun_sim fp32 [V, V], gt int64 [rows], valid bool / uint8 [rows]."""
+    _chk(sim, noun_sim, gt, valid)
+    rows, V = sim.shape
+    ce = torch.empty(rows, dtype=torch.float32, device=sim.device)
+    grad = torch.empty((rows, V), dtype=torch.float32, device=sim.device)
+    v8 = valid.view(torch.uint8) if valid.dtype == torch.bool else valid
+    _lib.check(_lib.lib().hh_masked_ce_fwd(_p(sim), sim.stride(0), _p(noun_sim), _p(gt), _p(v8), rows, V, float(temperature), float(threshold),
+                                           _p(ce), _p(grad), _stream()), "hh_masked_ce_fwd")
+    return ce, grad
+
+
+def tv_accuracy(sim, text_cos, sim_v, sim_n):
+    """compute_tv_accuracy on the device: sim fp32 [Bg, Bg] (row-strided view allowed) -> fp32 [2] = (acc video->text, acc text->video)."""
+    _chk(text_cos, sim_v, sim_n)
+    Bg = sim.shape[0]
+    if sim.stride(1) != 1:
+        sim = sim.contiguous()
+    out = torch.empty(2, dtype=torch.float32, device=sim.device)
+    _lib.check(_lib.lib().hh_tv_accuracy(_p(sim), sim.stride(0), _p(text_cos), _p(sim_v), _p(sim_n), Bg, _p(out), _stream()), "hh_tv_accuracy")
+    return out

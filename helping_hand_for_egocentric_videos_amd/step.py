@@ -144,7 +144,7 @@ class TrainStep:
         Bg = ve.shape[0]
         sim = sim_matrix(te, ve)                                                    # [5Bg, Bg]
         sim_v, sim_n = sim_matrix(vv, vv), sim_matrix(nv, nv)
-        nce, _ = self.nce(sim, sim_v, sim_n, multi_pad_mask=pf[:, None].repeat(1, Bg), strict_mask=True, return_mask=False)
+        nce = self.nce.forward_rows(sim, sim_v, sim_n, pf)                           # multi_pad_mask = pf[:, None].repeat(1, Bg)
         R = te.shape[0] // Bg
         with torch.no_grad():
             acc_vt, acc_tv = compute_tv_accuracy(sim.view(Bg, R, Bg)[:, 0], te, sim_v, sim_n, Bg)

@@ -287,6 +287,30 @@ int hh_box_loss_bwd(const float* pred, int Qtot, int q0, const float* tgt_cxcywh
                     const int64_t* match_pred, const int64_t* match_tgt, const int32_t* match_n,
                     const float* g_l1, const float* g_giou, float* dpred, int64_t F, hh_stream_t stream);
 
+/* ---- loss tail (csrc/loss.hip): the step's small fp32 reductions as a handful of launches instead of ~250 stock elementwise ops.
+ * hh_rownorm_fwd/bwd: y = x / max(||x||_2, eps) per row, the operand normalisation of sim_matrix (model/metric.py:363-375); x fp32
+ * [rows, cols] row stride ldx, y fp32 [rows, cols] dense, norm fp32 [rows] (saved for the backward); dx = d loss / d x.
+ * hh_egonce_fwd: EgoNCE (model/loss.py:8-70) for the call of run/train.py:144-149 -- multi_pad_mask = pad[:, None].repeat(1, Bg),
+ * strict_mask: x fp32 [R*Bg, Bg] (row stride ldx; row i = rephrase i % R of clip i / R), sim_v / sim_n fp32 [Bg, Bg] (either may be
+ * NULL), pad fp32 [R*Bg] (0 = caption absent, row dropped); positives ((sim_v*sim_n)[i/R, j] + [i/R == j]) * pad_i > vn_threshold.
+ * Writes loss[0] and grad fp32 [R*Bg, Bg] = d loss / d x; scratch: hh_workspace_bytes_egonce(R, Bg) bytes.
+ * hh_masked_ce_fwd: the 582-way cross-entropy of WordContrastiveLoss (model/loss.py:95-104): sim fp32 [rows, V] (row stride ld),
+ * noun_sim fp32 [V, V] (cosine similarity of the nouns; its diagonal is ignored), gt int64 [rows], valid uint8 [rows]; logits sim / T
+ * with the columns k != gt of noun_sim[gt, k] > threshold replaced by -1 / T.  ce fp32 [rows] (0 on invalid rows), grad fp32 [rows, V]
+ * = d ce[r] / d sim[r, :].
+ * hh_tv_accuracy: compute_tv_accuracy (model/metric.py:378-392): sim fp32 [Bg, Bg] (row stride ld), text_cos fp32 [Bg, Bg] (cosine
+ * similarity of the first captions), sim_v, sim_n fp32 [Bg, Bg] -> out[0] = video->text, out[1] = text->video top-1 accuracy. */
+int hh_rownorm_fwd(const float* x, int64_t ldx, float* y, float* norm, int rows, int cols, float eps, hh_stream_t stream);
+int hh_rownorm_bwd(const float* y, const float* norm, const float* dy, int64_t lddy, float* dx, int rows, int cols, float eps,
+                   hh_stream_t stream);
+int64_t hh_workspace_bytes_egonce(int R, int Bg);
+int hh_egonce_fwd(const float* x, int64_t ldx, const float* sim_v, const float* sim_n, const float* pad, int R, int Bg,
+                  float temperature, float vn_threshold, float* loss, float* grad, float* scratch, hh_stream_t stream);
+int hh_masked_ce_fwd(const float* sim, int64_t ld, const float* noun_sim, const int64_t* gt, const unsigned char* valid, int rows, int V,
+                     float temperature, float threshold, float* ce, float* grad, hh_stream_t stream);
+int hh_tv_accuracy(const float* sim, int64_t ld, const float* text_cos, const float* sim_v, const float* sim_n, int Bg, float* out,
+                   hh_stream_t stream);
+
 /* ---- fused AdamW over a flat fp32 parameter arena (torch.optim.AdamW semantics; run/train.py:199-203,520)
  * p,g,m,v fp32 [n]; decay_mask uint8 [n] or per-segment handled by caller through two calls.  step >= 1. */
 int hh_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -1,0 +1,33 @@
+#!/bin/bash
+# FETCH_SIZE (L2-side read traffic) of the persistent GEMM for XCD tile-walk shapes: G m-tiles x (32 / G) n-tiles per round and XCD.
+# -> gpurun_out/gemm_group_fetch.md
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/gemm_group_fetch.md
+echo "# Persistent GEMM: XCD tile walk vs L2-side fetch traffic (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction), M = 32 x 4097 rows" > $OUT
+echo "" >> $OUT
+echo "| GEMM | G (m-tiles x n-tiles per round and XCD) | FETCH MiB / launch | x operand bytes | TFLOP/s (same process, timers off) |" >> $OUT
+echo "|---|---|---|---|---|" >> $OUT
+for which in qkv fc1; do
+for G in 4 8 16 32; do
+  rm -rf $R/gpurun_out/pmc_g
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_g -- python3 $R/scripts/gemm_group_fetch.py $G $which > $R/gpurun_out/pmc_g.log 2>&1
+  TF=$(python3 $R/scripts/gemm_group_fetch.py $G $which 2>/dev/null | grep RESULT | sed -e 's/.*call, //')
+  python3 - "$which" "$G" "$TF" >> $OUT <<'PY'
+import csv, glob, os, sys
+which, G, tf = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+R = os.environ["GRAFT_REPO_ROOT"]
+tot, n = 0.0, 0
+for f in glob.glob(R + "/gpurun_out/pmc_g/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if row["Counter_Name"] == "FETCH_SIZE" and "gemm256d_kernel" in row["Kernel_Name"]:
+            tot += float(row["Counter_Value"]); n += 1
+M, K = 32 * 4097, 1024
+N = 3072 if which == "qkv" else 4096
+ops = (M * K + N * K) * 2 / 2**20
+fetch = 2.0 * tot * 1024 / max(n, 1) / 2**20
+print("| %s | %d (%d x %d) | %.0f | %.2f | %s |" % (which, G, G, 32 // G, fetch, fetch / ops, tf))
+PY
+done
+done
+cat $OUT

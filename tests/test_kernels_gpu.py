@@ -717,3 +717,88 @@ def test_layernorm_pos_and_backward_with_residual():
     torch.testing.assert_close(dg.cpu(), 2 * gr.grad, rtol=1e-4, atol=2e-4)
     dx0 = ops.layernorm_bwd_add(x.to(DEV), g.to(DEV), mean, rstd, dy.to(DEV), None, dg, db)
     torch.testing.assert_close(dx0.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------- loss tail (csrc/loss.hip)
+def test_rownorm_fwd_bwd_vs_torch():
+    """hh_rownorm_fwd / bwd = x / clamp(||x||, eps) of sim_matrix (metric.py:370-373) and its gradient, incl. a row under the clamp,
+    a row-strided view (bit-identical to the dense copy) and 3-D operands."""
+    from helping_hand_for_egocentric_videos_amd.model.metric import _RowNorm
+    g = torch.Generator().manual_seed(0)
+    for rows, cols in ((5, 256), (160, 256), (33, 118), (582, 256), (7, 3)):
+        x = torch.randn(rows, cols, generator=g)
+        x[1] = 1e-12                                                     # ||x|| < eps: the clamp is the divisor
+        xr = x.clone().requires_grad_(True)
+        yr = xr / xr.norm(dim=-1, keepdim=True).clamp_min(1e-8)
+        w = torch.randn(rows, cols, generator=g)
+        (yr * w).sum().backward()
+        xg = x.cuda().requires_grad_(True)
+        yg = _RowNorm.apply(xg, 1e-8)
+        (yg * w.cuda()).sum().backward()
+        torch.testing.assert_close(yg.detach().cpu(), yr.detach(), rtol=2e-6, atol=1e-7)
+        torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=2e-5, atol=2e-6)
+    big = torch.randn(40, 300, generator=g).cuda()
+    view = big[::5, :256]                                                # row stride 1500, as the packed all-gather / text[::5] give
+    assert torch.equal(_RowNorm.apply(view, 1e-8), _RowNorm.apply(view.contiguous(), 1e-8))
+    x3 = torch.randn(3, 4, 64, generator=g).cuda()
+    torch.testing.assert_close(_RowNorm.apply(x3, 1e-8), x3 / x3.norm(dim=-1, keepdim=True).clamp_min(1e-8), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("Bg,R", [(2, 5), (6, 5), (32, 5), (100, 5), (256, 5), (7, 3)])
+def test_egonce_rows_kernel_vs_oracle(Bg, R):
+    """hh_egonce_fwd (EgoNCE.forward_rows: the step's call, run/train.py:144-149) vs oracle.losses.egonce: loss and both gradients, with
+    absent captions (dropped rows), verb / noun positives off the diagonal, and global batches that are not multiples of 64."""
+    from helping_hand_for_egocentric_videos_amd.model.loss import EgoNCE
+    from helping_hand_for_egocentric_videos_amd.model.metric import sim_matrix
+    from oracle import losses as OL
+    g = torch.Generator().manual_seed(Bg * 10 + R)
+    te, ve = torch.randn(R * Bg, 64, generator=g), torch.randn(Bg, 64, generator=g)
+    vv, nv = (torch.rand(Bg, 11, generator=g) < 0.3).float(), (torch.rand(Bg, 13, generator=g) < 0.3).float()
+    if Bg > 2:
+        vv[0], nv[0] = vv[1], nv[1]
+        vv[0:2, 3] = 1; nv[0:2, 5] = 1                                   # clips 0 and 1 share verb and noun: mutual positives
+    pf = (torch.rand(R * Bg, generator=g) > 0.3).float()
+    pf[::R] = 1.0                                                        # the first caption of a clip is always there
+    sv, sn = OL.sim_matrix(vv, vv), OL.sim_matrix(nv, nv)
+    ter, ver = te.clone().requires_grad_(True), ve.clone().requires_grad_(True)
+    if R == 5:
+        rl, _ = OL.egonce(OL.sim_matrix(ter, ver), sv, sn, pf[:, None].repeat(1, Bg))
+    else:                                                                # the oracle hard-codes the reference's 5 rephrases: torch module on CPU
+        rl = EgoNCE().forward(OL.sim_matrix(ter, ver), sv, sn, multi_pad_mask=pf[:, None].repeat(1, Bg), strict_mask=True, return_mask=False)[0]
+    rl.backward()
+    tg, vg = te.cuda().requires_grad_(True), ve.cuda().requires_grad_(True)
+    gl = EgoNCE().forward_rows(sim_matrix(tg, vg), sv.cuda(), sn.cuda(), pf.cuda())
+    (3.0 * gl).backward()                                                # a non-unit incoming gradient
+    torch.testing.assert_close(gl.detach().cpu(), rl.detach(), rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(tg.grad.cpu() / 3.0, ter.grad, rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(vg.grad.cpu() / 3.0, ver.grad, rtol=1e-4, atol=2e-6)
+    # the general module path (arbitrary multi_pad_mask, stock ops) gives the same value
+    gen, _ = EgoNCE()(sim_matrix(tg.detach(), vg.detach()), sv.cuda(), sn.cuda(), multi_pad_mask=pf.cuda()[:, None].repeat(1, Bg), strict_mask=True,
+                      return_mask=False)
+    torch.testing.assert_close(gen, gl.detach(), rtol=2e-6, atol=1e-6)
+
+
+def test_masked_ce_kernel_vs_torch():
+    """hh_masked_ce_fwd vs F.cross_entropy(masked_fill(sim, noun_sim[gt] > thr with a zero diagonal, -1) / T) (loss.py:95-104)."""
+    g = torch.Generator().manual_seed(4)
+    rows, V, T, thr = 37, 582, 0.07, 0.6
+    sim = (torch.rand(rows, V, generator=g) * 2 - 1)
+    ne = torch.randn(V, 16, generator=g)
+    ne[5] = ne[9] * 1.01                                                 # nouns 5 and 9 are near-duplicates: masked for each other
+    nsim = torch.nn.functional.normalize(ne, dim=-1) @ torch.nn.functional.normalize(ne, dim=-1).t()
+    gt = torch.randint(0, V, (rows,), generator=g)
+    gt[0], gt[1] = 5, 9
+    valid = torch.rand(rows, generator=g) > 0.25
+    valid[:2] = True
+    ns0 = nsim.clone(); ns0.fill_diagonal_(0)
+    sr = sim.clone().requires_grad_(True)
+    ce_ref = torch.nn.functional.cross_entropy(sr.masked_fill(ns0[gt] > thr, -1) / T, gt, reduction="none")
+    w = torch.randn(rows, generator=g)
+    (torch.where(valid, ce_ref, torch.zeros(())) * w).sum().backward()
+    from helping_hand_for_egocentric_videos_amd.model.loss import _MaskedCE
+    sg = sim.cuda().requires_grad_(True)
+    ce = _MaskedCE.apply(sg, nsim.cuda(), gt.cuda(), valid.cuda(), T, thr)
+    (ce * w.cuda()).sum().backward()
+    torch.testing.assert_close(ce.detach().cpu(), torch.where(valid, ce_ref.detach(), torch.zeros(())), rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(sg.grad.cpu(), sr.grad, rtol=1e-5, atol=1e-6)
+    assert float(sg.grad[0, 9]) == 0.0 and float(sg.grad[~valid.cuda()].abs().max()) == 0.0
