@@ -325,7 +325,8 @@ def bench_train(cfg, backbone, decoder, B, steps, warmup, world, rank, dev, args
     run = lambda: ts.step(batch, next_batch=batch if pipelined else None)
     if timers:
         prof_enable(0)
-    dt, per, region, out = timed_region(run, steps, warmup, world, timers, stats_steps=STATS_STEPS if want_iso else 0)
+    # (profiling runs pass --no-kernel-timers: no extra statistics steps under rocprofv3)
+    dt, per, region, out = timed_region(run, steps, warmup, world, timers, stats_steps=STATS_STEPS if (want_iso and timers) else 0)
     if timers:
         prof_enable(0)          # (the extra statistics steps are not part of the kernel-timer region: the snapshot was taken before them)
     iso = None
@@ -369,10 +370,20 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    # test hooks (tests/test_dp_gpu.py runs the N > 1 code path of this file on a ONE-GPU box): HH_BENCH_BACKEND=gloo with
+    # HH_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 over gloo (RCCL refuses two ranks on one device); the defaults are what the
+    # driver gets: one rank per GPU, backend "nccl" = RCCL over xGMI
+    backend = os.environ.get("HH_BENCH_BACKEND", "nccl")
+    same_device = os.environ.get("HH_BENCH_SAME_DEVICE") == "1"
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        if same_device:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
         if args.force_comm:
@@ -403,7 +414,8 @@ def main():
         # the collectives really span `world` devices: a sum of ones over the group
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)
-        rccl = {"rccl_ranks": int(one.item()), "backend": dist.get_backend(), "devices_visible": torch.cuda.device_count()}
+        rccl = {"rccl_ranks": int(one.item()), "backend": dist.get_backend(), "devices_visible": torch.cuda.device_count(),
+                "ranks_share_one_device": same_device}
         assert rccl["rccl_ranks"] == world
 
     power = PowerSampler() if (rank == 0 and not args.no_power) else None

@@ -518,9 +518,16 @@ def adamw_arena_step(p, g, m, v, seg_off, seg_decay, seg_step, seg_flag, seg_coe
 
 
 # ---- loss tail (csrc/loss.hip)
+def _chk_gpu(*tensors):
+    """Row-strided operands are fine for these kernels (they take a leading dimension): only the device is checked."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libhh ops need GPU tensors (got device %s); there is no CPU fallback" % t.device)
+
+
 def rownorm_fwd(x, eps=1e-8):
     """x fp32 [rows, cols] (unit inner stride) -> (y = x / max(||x||, eps) dense fp32, norm fp32 [rows])."""
-    _chk(x)
+    _chk_gpu(x)
     if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
         raise TypeError("rownorm_fwd: fp32 [rows, cols] with unit inner stride")
     rows, cols = x.shape
@@ -532,8 +539,9 @@ def rownorm_fwd(x, eps=1e-8):
 
 def rownorm_bwd(y, norm, dy, eps=1e-8):
     _chk(y, norm)
-    if dy.stride(-1) != 1:
-        dy = dy.contiguous()
+    _chk_gpu(dy)
+    if dy.stride(-1) != 1 or dy.dtype != torch.float32:
+        dy = dy.float().contiguous()
     rows, cols = y.shape
     dx = torch.empty_like(y)
     _lib.check(_lib.lib().hh_rownorm_bwd(_p(y), _p(norm), _p(dy), dy.stride(0) if rows > 1 else cols, _p(dx), rows, cols, float(eps), _stream()), "hh_rownorm_bwd")
@@ -543,6 +551,7 @@ def rownorm_bwd(y, norm, dy, eps=1e-8):
 def egonce_fwd(x, sim_v, sim_n, pad, R, temperature, vn_threshold=0.0):
     """-> (loss fp32 [1], grad fp32 [R*Bg, Bg] = d loss / d x).  x fp32 [R*Bg, Bg] (unit inner stride), pad fp32 [R*Bg]."""
     _chk(sim_v, sim_n, pad)
+    _chk_gpu(x)
     Rn, Bg = x.shape
     if x.dtype != torch.float32 or x.stride(1) != 1 or Rn != R * Bg or pad.numel() != Rn:
         raise TypeError("egonce_fwd: x fp32 [R*Bg, Bg], pad [R*Bg]")
@@ -556,7 +565,8 @@ def egonce_fwd(x, sim_v, sim_n, pad, R, temperature, vn_threshold=0.0):
 
 def masked_ce_fwd(sim, noun_sim, gt, valid, temperature, threshold):
     """-> (ce fp32 [rows], grad fp32 [rows, V]); sim fp32 [rows, V], noun_sim fp32 [V, V], gt int64 [rows], valid bool / uint8 [rows]."""
-    _chk(sim, noun_sim, gt, valid)
+    _chk(noun_sim, gt, valid)
+    _chk_gpu(sim)
     rows, V = sim.shape
     ce = torch.empty(rows, dtype=torch.float32, device=sim.device)
     grad = torch.empty((rows, V), dtype=torch.float32, device=sim.device)
@@ -569,6 +579,7 @@ def masked_ce_fwd(sim, noun_sim, gt, valid, temperature, threshold):
 def tv_accuracy(sim, text_cos, sim_v, sim_n):
     """compute_tv_accuracy on the device: sim fp32 [Bg, Bg] (row-strided view allowed) -> fp32 [2] = (acc video->text, acc text->video)."""
     _chk(text_cos, sim_v, sim_n)
+    _chk_gpu(sim)
     Bg = sim.shape[0]
     if sim.stride(1) != 1:
         sim = sim.contiguous()

@@ -158,3 +158,28 @@ def test_rccl_collectives_run_on_the_comm_stream_beside_the_pipelined_encoder():
     ret = mgr.dict()
     mp.spawn(_rccl_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
     assert ret["finite"] and ret["loss"] == ret["loss"]
+
+
+def test_bench_multi_rank_code_path_on_one_gpu():
+    """bench.py's N > 1 branch (what the driver runs on an 8-GPU node: rank discovery from the environment, a real collective that
+    proves the group size, barrier + max-over-ranks timing, per-rank rates, the second region without gradient collectives for
+    `allreduce_exposed_ms`, the EgoMCQ sub-record) executed end to end with two ranks sharing cuda:0 over gloo -- RCCL refuses two
+    ranks on one device, so the transport differs from production, the code path does not."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HH_BENCH_BACKEND="gloo", HH_BENCH_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "c1",
+           "--batch", "2", "--no-power"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["config"]["global_clips"] == 4
+    assert line["rccl"]["rccl_ranks"] == 2 and line["rccl"]["ranks_share_one_device"]
+    assert line["value"] > 0 and line["per_rank_clips_per_s"]["min"] <= line["per_rank_clips_per_s"]["max"]
+    comm = line["comm"]
+    assert comm["collectives_per_step"]["all_gather"] == 1 and comm["collectives_per_step"]["all_reduce_flags"] == 1
+    assert comm["ms_per_step_without_gradient_allreduce"] > 0 and "allreduce_exposed_ms" in comm
+    assert "cpu_baseline" not in line and "c4" not in line          # rank-0-at-N=1-only records
