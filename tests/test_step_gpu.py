@@ -8,7 +8,12 @@ Stated tolerances (north_star: "decoder loss within 1e-3 rel of CPU reference, b
     both sides differentiate the same function at the same point: relative L2 per tensor <= 5e-3 (heads <= 1e-2)
     (test_decoder_gradients_on_shared_kv); (2) end to end against the fp32 oracle / the reference golden, where the bf16 rounding
     of K/V flips single ReLU units of the FFN (B*Q ~ 10 rows feed a weight row): per tensor <= 1.5e-1, median <= 5e-2, and the
-    fixture's gradient samples <= 1e-1 relative L2;
+    fixture's gradient samples <= 1e-1 relative L2.  This loose bound is the price of storing K/V in bf16 (half the bytes of the 1.6 GB
+    buffer the cross-attention streams six times per step); measured on MI355X (profiles/r3_parity_measured.json): worst tensor
+    `temporal_embed` 5.7e-2 (T = 4) / `frame_index.weight` 5.5e-2 (T = 16), median 2.4e-2 -- (1) is the real evidence;
+  * class head (R7 / R13): pred_logits values 2e-5 of the logit scale on the GPU's own hs, <= 6.5e-3 end to end (measured 3.2e-3);
+    pred_logits_argmax of the benchmarked fast path == the reference's wherever its top-2 margin exceeds twice the logit bound;
+    cardinality_error_* equal to the reference golden / the oracle on shared hs;
   * matching indices: bit-exact vs the oracle run on the SAME fp32 pred_boxes (index stability across precisions
     is not defined for untrained queries -- SURVEY.md section 8a R12 -- and is reported as a statistic only).
 Parity is defined in eval mode (dropout p=0).
