@@ -62,3 +62,30 @@ def test_load_4_frame_checkpoints_into_16_frame_models(tmp_path):
     assert info["optimizer"] == {"step": 11}
     for (k1, v1), (k2, v2) in zip(dec16.state_dict().items(), dec_b.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_tokenized_text_cache_equals_the_tokenizer():
+    """utils/text_cache.py (run/train.py:66-75): cached token rows == tokenising the batch, only unseen
+    strings reach the tokenizer, the table grows past its initial capacity, duplicates inside a batch are tokenised once."""
+    import torch
+    from helping_hand_for_egocentric_videos_amd.utils.text_cache import TokenizedTextCache
+    calls = []
+
+    def fake_tokenizer(texts):                                        # deterministic stand-in: ids from the characters, eot = max id
+        calls.append(list(texts))
+        out = torch.zeros((len(texts), 77), dtype=torch.int64)
+        for i, t in enumerate(texts):
+            ids = [49406] + [ord(c) + 100 for c in t][:75] + [49407]
+            out[i, :len(ids)] = torch.tensor(ids)
+        return out
+
+    cache = TokenizedTextCache(fake_tokenizer, device="cpu", capacity=4)
+    a = ["#C C opens the door", "", "#C C picks a cup", "#C C opens the door"]
+    got = cache(a)
+    assert torch.equal(got, fake_tokenizer(a)) and len(cache) == 3 and calls[0] == ["#C C opens the door", "", "#C C picks a cup"]
+    n_calls = len(calls)
+    b = ["#C C picks a cup", "#O a man X walks", "", "#C C cuts an onion", "#C C washes the knife", "#C C opens the door"]
+    got = cache(b)
+    assert calls[n_calls] == ["#O a man X walks", "#C C cuts an onion", "#C C washes the knife"]          # only the unseen ones
+    assert torch.equal(got, fake_tokenizer(b)) and len(cache) == 6 and cache.table.shape[0] >= 6
+    assert torch.equal(cache(a), fake_tokenizer(a)) and cache.hits >= 7

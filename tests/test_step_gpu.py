@@ -233,6 +233,7 @@ def test_full_step_vs_reference_golden(cfg, name):
     rows = np.concatenate([a.numpy() for a, _ in res["match_obj"]])
     agree = float((rows == g["idx_obj_rows"]).mean()) if len(rows) == len(g["idx_obj_rows"]) else float("nan")
     print("end-to-end object-index agreement with the fp32 reference:", agree)
+    record("golden_step_" + name, "statistic: end-to-end object-index agreement with the fp32 reference (1 = all frames)", agree, 1.0)
     res["total_loss"].backward()
     norms = dict(zip(g["grad_names"].tolist(), g["grad_norms"].tolist()))
     bad = []
@@ -386,6 +387,7 @@ def test_headline_config_c2_losses_vs_oracle():
             assert torch.equal(a, c) and torch.equal(b, d)
     agree = [torch.equal(a, c) for (a, _), (c, _) in zip(res["match_obj"], ref["idx_obj"])]
     print("C2 end-to-end object-index agreement with the fp32 oracle: %.3f" % (sum(agree) / len(agree)))
+    record("c2_headline_step", "statistic: end-to-end object-index agreement with the fp32 oracle (fraction of frames)", sum(agree) / len(agree), 1.0)
 
 
 def test_c4_full_width_step_losses_vs_oracle():
@@ -420,6 +422,7 @@ def test_c4_full_width_step_losses_vs_oracle():
             assert torch.equal(a, c) and torch.equal(b, d)
     agree = [torch.equal(a, c) for (a, _), (c, _) in zip(res["match_obj"], ref["idx_obj"])]
     print("C4 end-to-end object-index agreement with the fp32 oracle: %.3f" % (sum(agree) / len(agree)))
+    record("c4_full_width_step", "statistic: end-to-end object-index agreement with the fp32 oracle (fraction of frames)", sum(agree) / len(agree), 1.0)
     res["total_loss"].backward()
     for name, p in dec.named_parameters():
         if name in ts.arena.offsets:
