@@ -290,3 +290,68 @@ def mcq_forward(backbone, decoder, video, text, cfg):
         return sim_matrix(te[:, None], ve)[:, 0]
     finally:
         decoder.materialize_logits = was
+
+
+class McqScorer:
+    """EgoMCQ scoring with the same software pipelining as TrainStep: the frozen towers of the NEXT item batch run on an encoder
+    stream while the decoder forward + scoring of the current one runs on the main stream (the decoder's 13-row query side is
+    latency-bound and leaves the chip idle; run/test_EgoMCQ.py:56-83 runs the two back to back).  Same results as mcq_forward.
+
+        scorer = McqScorer(backbone, decoder, cfg)
+        for item, nxt in zip(items, items[1:] + [None]):
+            scores = scorer(item["video"], item["text"], next_item=None if nxt is None else (nxt["video"], nxt["text"]))
+    """
+
+    def __init__(self, backbone, decoder, cfg):
+        self.backbone, self.decoder, self.cfg = backbone, decoder, cfg
+        self.enc_stream = None
+        self._pending = None
+
+    @torch.no_grad()
+    def _encode(self, video, text):
+        cur = torch.cuda.current_stream()
+        side = _mcq_side_stream(video.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            _, tmap = self.backbone.encode_text(text, apply_project=False)
+        _, fmap = self.backbone.visual.forward_features(video.flatten(0, 1), out_dtype=torch.bfloat16)
+        cur.wait_stream(side)
+        tmap.record_stream(cur)
+        return fmap, tmap
+
+    def prefetch(self, video, text):
+        if self.enc_stream is None:
+            self.enc_stream = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        self.enc_stream.wait_stream(main)
+        with torch.cuda.stream(self.enc_stream):
+            fmap, tmap = self._encode(video, text)
+            ev = torch.cuda.Event()
+            ev.record(self.enc_stream)
+        self._pending = (video, text, fmap, tmap, ev)
+
+    @torch.no_grad()
+    def __call__(self, video, text, next_item=None):
+        """video [q,5,T,3,H,W], text [q,77] -> scores [q,5]; next_item = (video, text) of the following call, if known."""
+        cfg, decoder = self.cfg, self.decoder
+        q, T, n = video.shape[0], video.shape[2], cfg.patches_per_frame
+        pend, self._pending = self._pending, None
+        if pend is not None and pend[0] is video and pend[1] is text:
+            fmap, tmap, ev = pend[2], pend[3], pend[4]
+            main = torch.cuda.current_stream()
+            main.wait_event(ev)
+            fmap.record_stream(main)
+            tmap.record_stream(main)
+        else:
+            fmap, tmap = self._encode(video, text)
+        if next_item is not None:
+            self.prefetch(*next_item)
+        was = decoder.materialize_logits
+        decoder.materialize_logits = False
+        try:
+            _, hs, _, _ = decoder(fmap[:, 1:].reshape(q * 5, T, n, fmap.shape[-1]))
+            te = decoder.txt_proj(tmap[torch.arange(q, device=text.device), text.float().argmax(-1)])
+            ve = decoder.obj_proj(hs[-1])[:, -1].view(q, 5, -1)
+            return sim_matrix(te[:, None], ve)[:, 0]
+        finally:
+            decoder.materialize_logits = was

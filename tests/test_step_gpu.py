@@ -28,7 +28,7 @@ from helping_hand_for_egocentric_videos_amd import synth, TINY4, TINY16, ops
 from helping_hand_for_egocentric_videos_amd.model import LaviLa, tfm_decoder, box_utils
 from helping_hand_for_egocentric_videos_amd.model.loss import EgoNCE, WordContrastiveLoss
 from helping_hand_for_egocentric_videos_amd.model.metric import sim_matrix
-from helping_hand_for_egocentric_videos_amd.step import TrainStep, mcq_forward
+from helping_hand_for_egocentric_videos_amd.step import McqScorer, TrainStep, mcq_forward
 from oracle import decoder as OD, losses as OL, step as OS
 from _record import record
 
@@ -948,3 +948,23 @@ def test_linear_x3_accepts_sizes_that_are_not_multiples_of_four():
         assert scale(lin.weight.grad, ref_w.grad) < 2e-5 and scale(lin.bias.grad, ref_b.grad) < 2e-5, (K, N)
         yy = linear_x3(x.detach(), lin.weight.detach(), lin.bias.detach(), relu=True)
         assert scale(yy, torch.relu(yr.detach())) < 2e-5
+
+
+def test_mcq_scorer_pipelined_equals_mcq_forward():
+    """McqScorer (the next item batch's frozen towers prefetched on the encoder stream, bench.py's EgoMCQ leg) returns exactly what
+    the back-to-back mcq_forward (run/test_EgoMCQ.py:56-83) returns, with and without a prefetched batch, for changing batches."""
+    cfg = TINY16
+    backbone = LaviLa.build_backbone(cfg, synth.encoder_state(cfg, seed=4))
+    dec = tfm_decoder.build_decoder(cfg, synth.decoder_state(cfg, seed=4)).eval()
+    items = [synth.make_mcq_item(cfg, 2, seed=s_) for s_ in (1, 2, 3)]
+    items = [(it["video"].cuda(), it["text"].cuda()) for it in items]
+    want = [mcq_forward(backbone, dec, v, t, cfg) for v, t in items]
+    scorer = McqScorer(backbone, dec, cfg)
+    for i, (v, t) in enumerate(items):
+        nxt = items[i + 1] if i + 1 < len(items) else None
+        got = scorer(v, t, next_item=nxt)
+        assert torch.equal(got, want[i]), i
+    assert scorer._pending is None
+    assert torch.equal(scorer(*items[1]), want[1])                       # no prefetch pending: encodes in place
+    scorer.prefetch(*items[0])
+    assert torch.equal(scorer(*items[2]), want[2])                       # a stale prefetch is dropped, not used
