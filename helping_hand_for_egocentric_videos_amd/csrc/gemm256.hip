@@ -583,7 +583,7 @@ int hh_tuning_space_prog() { return g_space_prog; }
 
 
 extern "C" int hh_set_tuning(const char* name, int value) {
-    if (name && !strcmp(name, "gemm256") && value >= 0 && value <= 3) { g_mode = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm256") && value >= 0 && value <= 4) { g_mode = value; return HH_OK; }
     if (name && !strcmp(name, "gemm_tail") && value >= 0 && value <= 2) { g_tail = value; return HH_OK; }
     if (name && !strcmp(name, "space_debug")) { g_space_dbg = value; return HH_OK; }
     if (name && !strcmp(name, "space_joint")) { g_space_joint = value; return HH_OK; }
@@ -605,6 +605,8 @@ bool hh_gemm256_eligible(const GemmParams& p) {
     // measured on the text tower's N = 768 shapes at M = 12320 (147 tiles): 43 vs 65 us (K = 768), 97 vs 152 us (K = 3072)
     return g_mode > 0 && p.N % 256 == 0 && p.M >= 2048 && p.e.splitk <= 1 && (p.M / 256) * (p.N / 256) >= 192;
 }
+
+int hh_gemm256w4_launch(const GemmParams& p, unsigned grid, hipStream_t s);      // gemm256w4.hip (experiment: 4 waves x 128x128)
 
 int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
     if (tail_done) *tail_done = false;
@@ -668,6 +670,7 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
         }
     }
     HHProfScope prof(HH_PROF_GEMM_OTHER, 2.0 * (double)p.M * p.N * p.K, s);
+    if (g_mode == 4 && p.K >= 256 && p.K % 128 == 0 && !g_nostore) return hh_gemm256w4_launch(p, grid, s);
     if (stagger) {
         if (bf) hipLaunchKernelGGL((gemm256_kernel<true, true>), dim3(grid), dim3(512), 2 * BUF_BYTES, s, p);
         else hipLaunchKernelGGL((gemm256_kernel<false, true>), dim3(grid), dim3(512), 2 * BUF_BYTES, s, p);
