@@ -568,7 +568,7 @@ static int g_nostore = 0;          // debug: skip the epilogue stores (timing ex
 static int g_group = 0;            // m-tiles per XCD-local group (weight-panel reuse factor); 0 = per-shape default
 static int g_pskew = 0;            // persistent kernel: start skew quantum (s_sleep(8) units per workgroup index in its XCD)
 static int g_skew = -1;            // start skew of the one-tile-per-block kernel: -1 auto (on with an fp32 residual), 0 off, 1 on
-static int g_mode = 3;             // "gemm256": 0 = 128x128 kernel only, 1 = one tile per block, 2 = + wave-row stagger, 3 = persistent (default)
+static int g_mode = 3;             // "gemm256": 0 = 128x128 kernel only, 1 = one tile per block, 2 = + wave-row stagger, 3 = persistent (default), 4 / 5 = the 4-wave kernels of gemm256w4.hip (one tile per block / persistent)
 static int g_tail = 1;             // "gemm_tail": 1 = row tails of <= 64 rows inside the persistent kernel (in <= 32-row pieces), else the split-K-in-workgroup tail kernel (gemm.hip); 2 = always the tail kernel; 0 = the 128x128 kernel
 
 int hh_tuning_gemm_tail() { return g_tail; }
@@ -583,7 +583,7 @@ int hh_tuning_space_prog() { return g_space_prog; }
 
 
 extern "C" int hh_set_tuning(const char* name, int value) {
-    if (name && !strcmp(name, "gemm256") && value >= 0 && value <= 4) { g_mode = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm256") && value >= 0 && value <= 5) { g_mode = value; return HH_OK; }
     if (name && !strcmp(name, "gemm_tail") && value >= 0 && value <= 2) { g_tail = value; return HH_OK; }
     if (name && !strcmp(name, "space_debug")) { g_space_dbg = value; return HH_OK; }
     if (name && !strcmp(name, "space_joint")) { g_space_joint = value; return HH_OK; }
@@ -606,7 +606,11 @@ bool hh_gemm256_eligible(const GemmParams& p) {
     return g_mode > 0 && p.N % 256 == 0 && p.M >= 2048 && p.e.splitk <= 1 && (p.M / 256) * (p.N / 256) >= 192;
 }
 
-int hh_gemm256w4_launch(const GemmParams& p, unsigned grid, hipStream_t s);      // gemm256w4.hip (experiment: 4 waves x 128x128)
+int hh_gemm256w4_launch(const GemmParams& p, unsigned grid, hipStream_t s);      // gemm256w4.hip (4 waves x 128x128, one tile per workgroup)
+int hh_gemm256w4p_launch(const GemmParams& p, int epi, unsigned pg, hipStream_t s);   // gemm256w4.hip (4 waves x 128x128, persistent)
+int hh_gemm256w4_timeline(unsigned long long* out, int blocks);
+bool hh_gemm256w4_timeline_is_last();
+void hh_gemm256w4_timeline_mark(bool w4);
 
 int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
     if (tail_done) *tail_done = false;
@@ -641,7 +645,7 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
     const int groups = (per_xcd_mt + GROUP - 1) / GROUP;
     const unsigned grid = 8u * (unsigned)groups * GROUP * (unsigned)p.Nt;
     const bool bf = p.e.c_dtype == HH_BF16;
-    if (g_mode >= 3 && p.e.resid == nullptr && p.e.remap_group == 0 && p.K >= 128 && p.M % 256 == 0 && p.N <= 8192 && !g_nostore) {
+    if ((g_mode == 3 || g_mode == 5) && p.e.resid == nullptr && p.e.remap_group == 0 && p.K >= 128 && p.M % 256 == 0 && p.N <= 8192 && !g_nostore) {
         // epilogue flavour; a column scale together with an activation, or a scale boundary inside a 128-column half, take the
         // one-tile-per-block kernel below (generic epilogue)
         const bool scaled = p.e.colscale_cols > 0;
@@ -653,6 +657,12 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
             const unsigned pg = grid < (unsigned)ncu ? grid : (unsigned)ncu;
             p.skew_iters = g_pskew;
             HHProfScope prof(HH_PROF_GEMM256, 2.0 * (double)p.M * p.N * p.K, s);
+            if (g_mode == 5 && p.K >= 256 && p.K % 128 == 0) {
+                int rc = hh_gemm256w4p_launch(p, epi, pg, s);
+                if (tail_done) *tail_done = p.tail_rows > 0;
+                return rc;
+            }
+            hh_gemm256w4_timeline_mark(false);
 #define LAUNCHD(BF, E) hipLaunchKernelGGL((gemm256d_kernel<BF, E>), dim3(pg), dim3(512), P_LDS(p.N), s, p)
             switch (epi * 2 + (bf ? 1 : 0)) {
                 case 0: LAUNCHD(false, 0); break;
@@ -684,6 +694,7 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
 // debug: copy the timeline of the last persistent launch (hh_set_tuning("gemm256_debug_ts", 1)); out[blocks][8 tiles][7]: 5 stamps + shader-clock counter at stamps 1 and 2
 extern "C" int hh_debug_gemm_timeline(unsigned long long* out, int blocks) {
     HH_REQUIRE(out != nullptr && blocks > 0 && blocks <= 512, HH_ERR_SHAPE, "hh_debug_gemm_timeline: bad arguments");
+    if (hh_gemm256w4_timeline_is_last()) return hh_gemm256w4_timeline(out, blocks);
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_ts), sizeof(unsigned long long) * (size_t)blocks * TS_TILES * 7);
     HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_debug_gemm_timeline: %s", hipGetErrorString(e));
     return HH_OK;

@@ -209,6 +209,347 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(GemmParams p) {
 #undef W4_EDGE_T
 }
 
+
+// =====================================================================================================================
+// Persistent form (hh_set_tuning("gemm256", 5)): each workgroup walks its tiles (same XCD-aware virtual grid as gemm256d_kernel) and
+// the half-tile DMA stream runs on ACROSS tile boundaries -- "k-tile nk" of a tile is k-tile 0 of the walk's next tile (K % 128 == 0
+// keeps the ring parity), so there is no per-tile prologue and no drained tail except on the walk's last tile.  The accumulators are
+// not zeroed: the first k-tile's ks = 0 MFMAs take C = 0.  Bias lives in LDS; the epilogue issues exactly STORES store instructions
+// per wave, and the first six quadrant edges of the following tile (whose half-tiles were issued before those stores) wait with
+// vmcnt(24 + STORES) (capped at the 6-bit maximum).
+#define W4_TS_TILES 8
+__device__ unsigned long long g_gemm4_ts[512 * W4_TS_TILES * 7];
+
+template <int BASE>
+__device__ __forceinline__ void w4_mfma0(const bf16x8& w, const bf16x8& a) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0" :: "v"(w), "v"(a), "i"(BASE), "i"(BASE + 3));
+}
+template <int MH, int NH, int I>
+__device__ __forceinline__ void w4_quad0(const bf16x8 (&AF)[4][2], const bf16x8 (&WF)[4][2]) {      // first k-tile of a tile
+    constexpr int ks = I / 16, tn = (I / 4) % 4, tm = I % 4;
+    constexpr int BASE = 4 * (((MH * 4 + tm) * 2 + NH) * 4 + tn);
+    if constexpr (ks == 0) w4_mfma0<BASE>(WF[tn][ks], AF[tm][ks]);
+    else w4_mfma<BASE>(WF[tn][ks], AF[tm][ks]);
+    if constexpr (I + 1 < 32) w4_quad0<MH, NH, I + 1>(AF, WF);
+}
+
+// <= 32 rows x 32 columns of the row tail (see gemm256_tail_piece in gemm256.hip: the same 8 K-slices, summed in the same order; here
+// each of the 4 waves runs slices w and w + 4)
+template <bool OUT_BF16>
+__device__ __forceinline__ void w4_tail_piece(const GemmParams& p, int piece, float* red, int tid) {
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int ncb = p.N / 32;
+    const int n0 = (piece % ncb) * 32, r0 = (piece / ncb) * 32;
+    const int kslice = p.K / 8;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int sl = wave + 4 * half;
+        const int k_begin = sl * kslice;
+        const bf16_t* ap = p.A + (p.tail_m + min(r0 + l31, p.tail_rows - 1)) * p.lda + k_begin + 8 * h;
+        const bf16_t* wp = p.W + (int64_t)(n0 + l31) * p.ldw + k_begin + 8 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int k = 0; k < kslice; k += 64) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { wf[s] = *(const bf16x8*)(wp + k + 16 * s); af[s] = *(const bf16x8*)(ap + k + 16 * s); }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], af[s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(sl * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0 && r0 + l31 < p.tail_rows) {
+        f32x16 t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[(w * 16 + r) * 64 + lane];
+            t[r] = v;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = {t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
+            gemm_store4<OUT_BF16>(p.e, (char*)p.C, p.ldc, p.tail_m + r0 + l31, n0 + 8 * g + 4 * h, v);
+        }
+    }
+    __syncthreads();
+}
+
+// epilogue rows of one (mh, tm) pair: lane owns C[orow][cj .. cj+7] for the four column starts cj = nb + {0, 32, 128, 160}
+template <bool OUT_BF16, int EPI, int IDX>
+__device__ __forceinline__ void w4p_store_rows(const GemmParams& p, int64_t rowbase, int n0, const f32x4 (&bias_v)[4][2], const int64_t (&ccol)[4]) {
+    const hh_gemm_epilogue& e = p.e;
+    const int64_t orow = rowbase + (IDX >> 2) * 128 + (IDX & 3) * 16;
+    char* Cbase = (char*)p.C;
+    f32x4 v0[4], v1[4];
+    v0[0] = w4_acc_read<16 * (IDX * 2 + 0) + 0>();  v1[0] = w4_acc_read<16 * (IDX * 2 + 0) + 4>();
+    v0[1] = w4_acc_read<16 * (IDX * 2 + 0) + 8>();  v1[1] = w4_acc_read<16 * (IDX * 2 + 0) + 12>();
+    v0[2] = w4_acc_read<16 * (IDX * 2 + 1) + 0>();  v1[2] = w4_acc_read<16 * (IDX * 2 + 1) + 4>();
+    v0[3] = w4_acc_read<16 * (IDX * 2 + 1) + 8>();  v1[3] = w4_acc_read<16 * (IDX * 2 + 1) + 12>();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 a = v0[j] + bias_v[j][0], b = v1[j] + bias_v[j][1];
+        if constexpr (EPI == 1) {
+            if (n0 + (j >> 1) * 128 < e.colscale_cols) { a *= e.colscale; b *= e.colscale; }      // uniform: colscale_cols % 128 == 0
+        } else if constexpr (EPI == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a[q] = quick_gelu(a[q]); b[q] = quick_gelu(b[q]); }
+        } else if constexpr (EPI == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a[q] = fmaxf(a[q], 0.f); b[q] = fmaxf(b[q], 0.f); }
+        }
+        if constexpr (OUT_BF16) {
+            u32x4 o = {pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(b[0], b[1]), pack_bf16(b[2], b[3])};
+            *(u32x4*)((bf16_t*)Cbase + orow * p.ldc + ccol[j]) = o;
+        } else {
+            *(f32x4*)((float*)Cbase + orow * p.ldc + ccol[j]) = a;
+            *(f32x4*)((float*)Cbase + orow * p.ldc + ccol[j] + 4) = b;
+        }
+    }
+    if constexpr (IDX + 1 < 8) w4p_store_rows<OUT_BF16, EPI, IDX + 1>(p, rowbase, n0, bias_v, ccol);
+}
+
+template <bool OUT_BF16, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
+    constexpr int STORES = OUT_BF16 ? 32 : 64;                // global_store_dwordx4 per wave and tile in the epilogue (checked in the ISA)
+    constexpr int VM_ST = 24 + STORES > 63 ? 63 : 24 + STORES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int GROUP = p.group_m;
+    const int per = GROUP * p.Nt;
+    const int nk = p.K / 64;                                  // even (K % 128 == 0) and >= 4, checked by the launcher
+    const int vmax = 8 * ((((p.Mt + 7) / 8) + GROUP - 1) / GROUP) * GROUP * p.Nt;
+    auto decode = [&](int v, int64_t& m0, int& n0) -> bool {
+        const int xcd = v & 7, j = v >> 3;
+        const int kg = j / per, r = j % per;
+        const int nt_i = r / GROUP, mi = r % GROUP;
+        const int mt = xcd + 8 * (kg * GROUP + mi);
+        m0 = (int64_t)mt * 256;
+        n0 = nt_i * 256;
+        return mt < p.Mt;
+    };
+    auto next_valid = [&](int v, int64_t& m0, int& n0) -> int {
+        for (; v < vmax; v += gridDim.x)
+            if (decode(v, m0, n0)) return v;
+        return -1;
+    };
+    int64_t m0, nm0 = 0;
+    int n0, nn0 = 0;
+    int v = next_valid(blockIdx.x, m0, n0);
+    if (p.tail_rows > 0)
+        for (int piece = blockIdx.x; piece < (p.N / 32) * ((p.tail_rows + 31) / 32); piece += gridDim.x) w4_tail_piece<OUT_BF16>(p, piece, (float*)smem, tid);
+    if (v < 0) return;
+
+    unsigned aoff[4], woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        aoff[i] = (unsigned)((row * p.lda + c * 8) * 2);
+        const int rl = row & 31, nperm = (row & ~31) + 8 * ((rl & 15) >> 2) + 4 * (rl >> 4) + (rl & 3);
+        woff[i] = (unsigned)((nperm * p.ldw + c * 8) * 2);
+    }
+    const int64_t hiA = 128 * p.lda * 2, hiW = 128 * p.ldw * 2;
+    const char* cA = (const char*)(p.A + m0 * p.lda);
+    const char* cW = (const char*)(p.W + (int64_t)n0 * p.ldw);
+    const char* nA = cA;
+    const char* nW = cW;
+    bool has_next = false;
+    // k-tile kt of the CURRENT tile; kt >= nk continues into the walk's next tile (nothing on the last tile)
+    auto stage = [&](int slot, int kt) {
+        const char* bA = cA;
+        const char* bW = cW;
+        int k = kt;
+        if (kt >= nk) {
+            if (!has_next) return;
+            bA = nA; bW = nW; k = kt - nk;
+        }
+        char* dst = smem + (kt & 1) * W4_BUF + slot * W4_HT + wave * 4096;
+        const bool isA = slot == W4_ALO || slot == W4_AHI;
+        const char* bp = (isA ? bA : bW) + ((slot == W4_AHI) ? hiA : (slot == W4_BHI) ? hiW : 0) + (int64_t)k * 128;
+        asm volatile("" : "+s"(bp));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(bp + (isA ? aoff[i] : woff[i]), dst + i * 1024);
+    };
+
+    float* bias_s = (float*)(smem + 2 * W4_BUF);
+    for (int i = tid * 4; i < p.N; i += 256 * 4)
+        *(f32x4*)(bias_s + i) = p.e.bias ? *(const f32x4*)(p.e.bias + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    W4_BARRIER();
+    if (p.skew_iters > 0) {
+        const int it = p.skew_iters * (int)((blockIdx.x >> 3) & 31);
+        for (int i = 0; i < it; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+
+    int tile_i = 0;
+    auto stamp = [&](int k) {
+        if (p.debug_ts && tid == 0 && tile_i < W4_TS_TILES && blockIdx.x < 512) {
+            unsigned long long* r = g_gemm4_ts + ((int)blockIdx.x * W4_TS_TILES + tile_i) * 7;
+            r[k] = __builtin_amdgcn_s_memrealtime();
+            if (k == 1 || k == 2) r[4 + k] = __builtin_amdgcn_s_memtime();
+        }
+    };
+
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ks * 4 + fq;
+        a_off[ks] = (wr * 64 + frow) * 128 + ((c ^ (frow & 7)) << 4);
+        b_off[ks] = (wc * 64 + frow) * 128 + ((c ^ (frow & 7)) << 4);
+    }
+
+    W4_CLOBBER_AGPRS();
+    bf16x8 fa[4][2], fa2[4][2], fw0[4][2], fw1[4][2];
+
+#define W4_READ(DST, SLOT, KT, OFF) _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
+        DST[t_][ks] = *(const bf16x8*)(smem + ((KT) & 1) * W4_BUF + (SLOT) * W4_HT + OFF[ks] + t_ * 2048);
+#define W4_EDGE(VM) do { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM) : "memory"); W4_BARRIER(); } while (0)
+    // quadrant edge E of k-tile T: on the walk's last tile the stream ends (drain); on a later tile the first six edges still have
+    // the previous epilogue's stores among the younger operations
+#define W4P_EDGE(T, E) do {                                                         \
+        if (!has_next && (T) + 3 >= nk) W4_EDGE(0);                                 \
+        else if (!first && 4 * (T) + (E) < 6) W4_EDGE(VM_ST);                       \
+        else W4_EDGE(24);                                                           \
+    } while (0)
+
+    {   // the walk's first tile needs its successor before the prologue: stage(W4_ALO, 2) may already cross into it (nk >= 4: it does not)
+        has_next = false;
+    }
+    stage(W4_ALO, 0); stage(W4_BLO, 0); stage(W4_BHI, 0); stage(W4_AHI, 0);
+    stage(W4_ALO, 1); stage(W4_BLO, 1); stage(W4_BHI, 1); stage(W4_AHI, 1);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    W4_BARRIER();
+    W4_READ(fa, W4_ALO, 0, a_off)
+    W4_READ(fw0, W4_BLO, 0, b_off)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W4_BARRIER();
+    stage(W4_ALO, 2);                                                   // (nk >= 4: inside this tile)
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                   // W-hi(0)
+    W4_BARRIER();
+
+    bool first = true;
+    for (;;) {
+        stamp(0);
+        const int nv = next_valid(v + gridDim.x, nm0, nn0);
+        has_next = nv >= 0;
+        if (has_next) {
+            nA = (const char*)(p.A + nm0 * p.lda);
+            nW = (const char*)(p.W + (int64_t)nn0 * p.ldw);
+        }
+        stamp(1);
+        for (int t = 0; t < nk; t += 2) {
+            // ================= k-tile t (W sets: fw0 = W-lo, fw1 = W-hi)
+            W4_READ(fw1, W4_BHI, t, b_off)
+            stage(W4_BLO, t + 2);
+            if (t == 0) w4_quad0<0, 0, 0>(fa, fw0); else w4_quad<0, 0, 0>(fa, fw0);
+            W4P_EDGE(t, 0);
+            W4_READ(fa2, W4_AHI, t, a_off)
+            stage(W4_BHI, t + 2);
+            if (t == 0) w4_quad0<0, 1, 0>(fa, fw1); else w4_quad<0, 1, 0>(fa, fw1);
+            W4P_EDGE(t, 1);
+            W4_READ(fa, W4_ALO, t + 1, a_off)
+            stage(W4_AHI, t + 2);
+            if (t == 0) w4_quad0<1, 1, 0>(fa2, fw1); else w4_quad<1, 1, 0>(fa2, fw1);
+            W4P_EDGE(t, 2);
+            W4_READ(fw1, W4_BLO, t + 1, b_off)
+            stage(W4_ALO, t + 3);
+            if (t == 0) w4_quad0<1, 0, 0>(fa2, fw0); else w4_quad<1, 0, 0>(fa2, fw0);
+            W4P_EDGE(t, 3);
+            // ================= k-tile t+1 (W sets swapped: fw1 = W-lo, fw0 = W-hi)
+            W4_READ(fw0, W4_BHI, t + 1, b_off)
+            stage(W4_BLO, t + 3);
+            w4_quad<0, 0, 0>(fa, fw1);
+            W4P_EDGE(t + 1, 0);
+            W4_READ(fa2, W4_AHI, t + 1, a_off)
+            stage(W4_BHI, t + 3);
+            w4_quad<0, 1, 0>(fa, fw0);
+            W4P_EDGE(t + 1, 1);
+            if (t + 2 < nk || has_next) { W4_READ(fa, W4_ALO, t + 2, a_off) }       // (t + 2 == nk: the next tile's k-tile 0)
+            stage(W4_AHI, t + 3);
+            w4_quad<1, 1, 0>(fa2, fw0);
+            W4P_EDGE(t + 1, 2);
+            if (t + 2 < nk || has_next) { W4_READ(fw0, W4_BLO, t + 2, b_off) }
+            stage(W4_ALO, t + 4);
+            w4_quad<1, 0, 0>(fa2, fw1);
+            W4P_EDGE(t + 1, 3);
+        }
+        stamp(2);
+        asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");      // the last MFMAs have written their AGPRs; the next tile's fragments are in registers
+
+        // ---- epilogue of tile (m0, n0): bias from LDS, then exactly STORES store instructions per wave
+        {
+            const hh_gemm_epilogue& e = p.e;
+            const int nb = n0 + wc * 64 + 8 * fq;
+            f32x4 bias_v[4][2];
+            int64_t ccol[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cj = nb + (j & 1) * 32 + (j >> 1) * 128;
+                bias_v[j][0] = *(const f32x4*)(bias_s + cj);
+                bias_v[j][1] = *(const f32x4*)(bias_s + cj + 4);
+                ccol[j] = gemm_ccol(e, cj);
+            }
+            stamp(3);
+            w4p_store_rows<OUT_BF16, EPI, 0>(p, m0 + wr * 64 + frow, n0, bias_v, ccol);
+        }
+        stamp(4);
+        ++tile_i;
+        if (!has_next) break;
+        v = nv; m0 = nm0; n0 = nn0;
+        cA = nA; cW = nW;
+        first = false;
+    }
+#undef W4_READ
+#undef W4_EDGE
+#undef W4P_EDGE
+}
+
+static bool g_w4_ts_last = false;
+bool hh_gemm256w4_timeline_is_last() { return g_w4_ts_last; }
+void hh_gemm256w4_timeline_mark(bool w4) { g_w4_ts_last = w4; }
+int hh_gemm256w4_timeline(unsigned long long* out, int blocks) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm4_ts), sizeof(unsigned long long) * (size_t)blocks * W4_TS_TILES * 7);
+    if (e != hipSuccess) { hh_set_error("hh_debug_gemm_timeline: %s", hipGetErrorString(e)); return HH_ERR_LAUNCH; }
+    return HH_OK;
+}
+
+#define W4P_LDS(N) (2 * W4_BUF + (size_t)(N) * 4)
+int hh_gemm256w4p_launch(const GemmParams& p, int epi, unsigned pg, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+#define ATTRP(BF, E) hipFuncSetAttribute((const void*)gemm256w4p_kernel<BF, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(8192))
+        ATTRP(true, 0); ATTRP(false, 0); ATTRP(true, 1); ATTRP(false, 1); ATTRP(true, 2); ATTRP(false, 2); ATTRP(true, 3); ATTRP(false, 3);
+#undef ATTRP
+        attr_done = true;
+    }
+    const bool bf = p.e.c_dtype == HH_BF16;
+#define LAUNCHP(BF, E) hipLaunchKernelGGL((gemm256w4p_kernel<BF, E>), dim3(pg), dim3(256), W4P_LDS(p.N), s, p)
+    switch (epi * 2 + (bf ? 1 : 0)) {
+        case 0: LAUNCHP(false, 0); break;
+        case 1: LAUNCHP(true, 0); break;
+        case 2: LAUNCHP(false, 1); break;
+        case 3: LAUNCHP(true, 1); break;
+        case 4: LAUNCHP(false, 2); break;
+        case 5: LAUNCHP(true, 2); break;
+        case 6: LAUNCHP(false, 3); break;
+        default: LAUNCHP(true, 3); break;
+    }
+#undef LAUNCHP
+    g_w4_ts_last = true;
+    return hh_check_launch("hh_gemm_bf16(256x256 persistent, 4 waves)");
+}
+
 int hh_gemm256w4_launch(const GemmParams& p, unsigned grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
