@@ -217,6 +217,15 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(GemmParams p) {
 // not zeroed: the first k-tile's ks = 0 MFMAs take C = 0.  Bias lives in LDS; the epilogue issues exactly STORES store instructions
 // per wave, and the first six quadrant edges of the following tile (whose half-tiles were issued before those stores) wait with
 // vmcnt(24 + STORES) (capped at the 6-bit maximum).
+//
+// ONE wave per SIMD issues strictly in order, ~4 cycles per instruction, and an MFMA leaves 8 of its 16 cycles to other instructions
+// (MI355X_MICROARCH.md): everything that is not an MFMA must fit ~2 instructions per MFMA gap or the matrix core waits for the
+// instruction stream itself (the first version of this kernel, with compiler-scheduled reads / address arithmetic / run-time
+// branches on the tile position: 880 cycles per quadrant against 512 of MFMA work -- even with barriers, DMA and reads disabled).
+// So the loop body is specialised at compile time for its place in the tile (first / middle / last iterations, with or without a
+// following tile), every fragment read and LDS-DMA is an asm statement at a fixed place between the MFMAs (8 reads under MFMAs
+// 1..15, 4 DMA pieces under MFMAs 17..23), LDS-DMA sources are scalar running pointers + four loop-invariant lane offsets (saddr
+// form, no vector address arithmetic), and one s_waitcnt + s_barrier closes a quadrant.
 #define W4_TS_TILES 8
 __device__ unsigned long long g_gemm4_ts[512 * W4_TS_TILES * 7];
 
@@ -224,13 +233,102 @@ template <int BASE>
 __device__ __forceinline__ void w4_mfma0(const bf16x8& w, const bf16x8& a) {
     asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0" :: "v"(w), "v"(a), "i"(BASE), "i"(BASE + 3));
 }
-template <int MH, int NH, int I>
-__device__ __forceinline__ void w4_quad0(const bf16x8 (&AF)[4][2], const bf16x8 (&WF)[4][2]) {      // first k-tile of a tile
+__device__ __forceinline__ unsigned w4_lds_u32(const char* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+template <int IMM>
+__device__ __forceinline__ void w4_ldsread(bf16x8& r, unsigned a) {
+    static_assert(IMM >= 0 && IMM < 65536, "ds_read offset field is 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(r) : "v"(a), "n"(IMM));
+}
+// one 16-B-per-lane LDS-DMA piece: global address = scalar base + lane offset, LDS destination = wave base + IMM (through M0)
+template <int IMM>
+__device__ __forceinline__ void w4_dma(unsigned voff, const char* sbase, unsigned wave_lds) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(wave_lds), "n"(IMM) : "memory", "scc");
+}
+// closes a quadrant: the eight fragment registers read under it are valid, the half-tile read in the next quadrant has landed
+// (VM younger DMA / store instructions may stay in flight), every wave is done with the half-tile read in this one
+template <int VM>
+__device__ __forceinline__ void w4_edge(bf16x8 (&F)[4][2]) {
+    asm volatile("s_waitcnt vmcnt(%8) lgkmcnt(0)\n\ts_barrier"
+                 : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[2][0]), "+v"(F[2][1]), "+v"(F[3][0]), "+v"(F[3][1]) : "n"(VM) : "memory");
+}
+// 32 MFMAs AF x WF -> accumulator quadrant (MH, NH); under them the 8 reads of the half-tile at raddr + RIMM into RD and, if DMA_ON,
+// the 4 pieces of the half-tile staged from `src` to LDS offset wave base + DIMM
+template <int MH, int NH, bool ZERO, int RIMM, int DIMM, bool DMA_ON, int I>
+__device__ __forceinline__ void w4q(const bf16x8 (&AF)[4][2], const bf16x8 (&WF)[4][2], bf16x8 (&RD)[4][2], const unsigned (&raddr)[2],
+                                    const unsigned (&voff)[4], const char* src, unsigned wave_lds) {
     constexpr int ks = I / 16, tn = (I / 4) % 4, tm = I % 4;
     constexpr int BASE = 4 * (((MH * 4 + tm) * 2 + NH) * 4 + tn);
-    if constexpr (ks == 0) w4_mfma0<BASE>(WF[tn][ks], AF[tm][ks]);
+    if constexpr (ZERO && ks == 0) w4_mfma0<BASE>(WF[tn][ks], AF[tm][ks]);
     else w4_mfma<BASE>(WF[tn][ks], AF[tm][ks]);
-    if constexpr (I + 1 < 32) w4_quad0<MH, NH, I + 1>(AF, WF);
+    if constexpr (I % 2 == 1 && I < 16) {
+        constexpr int j = I / 2;                                   // read j: fragment tile j >> 1, k-step j & 1
+        w4_ldsread<RIMM + (j >> 1) * 2048>(RD[j >> 1][j & 1], raddr[j & 1]);
+    }
+    if constexpr (DMA_ON && I >= 16 && I < 24 && I % 2 == 1) {
+        constexpr int i = (I - 16) / 2;
+        w4_dma<DIMM + i * 1024>(voff[i], src, wave_lds);
+    }
+    if constexpr (I + 1 < 32) w4q<MH, NH, ZERO, RIMM, DIMM, DMA_ON, I + 1>(AF, WF, RD, raddr, voff, src, wave_lds);
+}
+
+// register-resident state of the k loop
+struct W4State {
+    bf16x8 fa[4][2], fa2[4][2], fw0[4][2], fw1[4][2];     // A (current / next) and the two W fragment sets, [tile][k-step]
+    unsigned ra0[2], ra1[2], rb0[2], rb1[2];              // per-lane LDS addresses of the A / W fragment reads, LDS buffer 0 / 1
+    unsigned aoff[4], woff[4];                            // per-lane global byte offsets of the four DMA pieces of an A / W half-tile
+    const char *pAL, *pAH, *pWL, *pWH;                    // running DMA sources: the next k-tile each half-tile slot stages
+    const char *nAL, *nAH, *nWL, *nWH;                    // k-tile 0 of the walk's next tile
+    unsigned wave_lds;                                    // LDS address of this wave's 4 KB share of half-tile slot 0, buffer 0
+};
+// places of a two-k-tile loop iteration in a tile
+enum { W4V_FIRST0 = 0,        // k-tiles 0, 1 of the walk's first tile
+       W4V_NEXT0,             // k-tiles 0, 1 of a later tile: the previous epilogue's stores are younger than the half-tiles of the first six edges
+       W4V_MID,               // steady state
+       W4V_REBASE,            // k-tiles nk-4, nk-3, another tile follows: the staging pointers cross into it
+       W4V_REBASE_LAST,       // k-tiles nk-4, nk-3 of the walk's last tile: the stream ends, the pipeline starts to drain
+       W4V_TAIL_LAST };       // k-tiles nk-2, nk-1 of the walk's last tile: nothing staged, full waits
+template <int V, int VM_ST>
+__device__ __forceinline__ constexpr int w4_vm(int edge) {
+    return V == W4V_NEXT0 ? (edge < 6 ? VM_ST : 24) : V == W4V_REBASE_LAST ? (edge < 4 ? 24 : 0) : V == W4V_TAIL_LAST ? 0 : 24;
+}
+#define W4_IMM(BUF, SLOT) ((BUF) * W4_BUF + (SLOT) * W4_HT)
+template <int V, int VM_ST>
+__device__ __forceinline__ void w4_iter(W4State& s) {
+    constexpr bool Z = V == W4V_FIRST0 || V == W4V_NEXT0;
+    constexpr bool RB = V == W4V_REBASE || V == W4V_REBASE_LAST;
+    constexpr bool ON = V != W4V_TAIL_LAST;                         // DMA of quadrants 0..6
+    constexpr bool ON7 = V != W4V_TAIL_LAST && V != W4V_REBASE_LAST;
+    // ================= k-tile t (even: LDS buffer 0; W sets: fw0 = W-lo, fw1 = W-hi)
+    // Q0 = A-lo x W-lo   reads W-hi(t)      stages W-lo(t+2)
+    w4q<0, 0, Z, W4_IMM(0, W4_BHI), W4_IMM(0, W4_BLO), ON, 0>(s.fa, s.fw0, s.fw1, s.rb0, s.woff, s.pWL, s.wave_lds);
+    s.pWL += 128;
+    w4_edge<w4_vm<V, VM_ST>(0)>(s.fw1);
+    // Q1 = A-lo x W-hi   reads A-hi(t)      stages W-hi(t+2)
+    w4q<0, 1, Z, W4_IMM(0, W4_AHI), W4_IMM(0, W4_BHI), ON, 0>(s.fa, s.fw1, s.fa2, s.ra0, s.woff, s.pWH, s.wave_lds);
+    s.pWH += 128;
+    w4_edge<w4_vm<V, VM_ST>(1)>(s.fa2);
+    // Q2 = A-hi x W-hi   reads A-lo(t+1)    stages A-hi(t+2)
+    w4q<1, 1, Z, W4_IMM(0, W4_ALO), W4_IMM(0, W4_AHI), ON, 0>(s.fa2, s.fw1, s.fa, s.ra1, s.aoff, s.pAH, s.wave_lds);
+    s.pAH += 128;
+    w4_edge<w4_vm<V, VM_ST>(2)>(s.fa);
+    // Q3 = A-hi x W-lo   reads W-lo(t+1)    stages A-lo(t+3)
+    w4q<1, 0, Z, W4_IMM(0, W4_BLO), W4_IMM(1, W4_ALO), ON, 0>(s.fa2, s.fw0, s.fw1, s.rb1, s.aoff, s.pAL, s.wave_lds);
+    s.pAL = RB ? s.nAL : s.pAL + 128;
+    w4_edge<w4_vm<V, VM_ST>(3)>(s.fw1);
+    // ================= k-tile t+1 (odd: LDS buffer 1; W sets swapped: fw1 = W-lo, fw0 = W-hi)
+    w4q<0, 0, false, W4_IMM(0, W4_BHI), W4_IMM(1, W4_BLO), ON, 0>(s.fa, s.fw1, s.fw0, s.rb1, s.woff, s.pWL, s.wave_lds);
+    s.pWL = RB ? s.nWL : s.pWL + 128;
+    w4_edge<w4_vm<V, VM_ST>(4)>(s.fw0);
+    w4q<0, 1, false, W4_IMM(0, W4_AHI), W4_IMM(1, W4_BHI), ON, 0>(s.fa, s.fw0, s.fa2, s.ra1, s.woff, s.pWH, s.wave_lds);
+    s.pWH = RB ? s.nWH : s.pWH + 128;
+    w4_edge<w4_vm<V, VM_ST>(5)>(s.fa2);
+    // (the reads of k-tile t+2 past the walk's end fetch stale LDS into registers nobody uses)
+    w4q<1, 1, false, W4_IMM(0, W4_ALO), W4_IMM(1, W4_AHI), ON, 0>(s.fa2, s.fw0, s.fa, s.ra0, s.aoff, s.pAH, s.wave_lds);
+    s.pAH = RB ? s.nAH : s.pAH + 128;
+    w4_edge<w4_vm<V, VM_ST>(6)>(s.fa);
+    w4q<1, 0, false, W4_IMM(0, W4_BLO), W4_IMM(0, W4_ALO), ON7, 0>(s.fa2, s.fw1, s.fw0, s.rb0, s.aoff, s.pAL, s.wave_lds);
+    s.pAL += 128;
+    w4_edge<w4_vm<V, VM_ST>(7)>(s.fw0);
 }
 
 // <= 32 rows x 32 columns of the row tail (see gemm256_tail_piece in gemm256.hip: the same 8 K-slices, summed in the same order; here
@@ -326,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
 
     const int GROUP = p.group_m;
     const int per = GROUP * p.Nt;
-    const int nk = p.K / 64;                                  // even (K % 128 == 0) and >= 4, checked by the launcher
+    const int nk = p.K / 64;                                  // even (K % 128 == 0) and >= 6, checked by the launcher
     const int vmax = 8 * ((((p.Mt + 7) / 8) + GROUP - 1) / GROUP) * GROUP * p.Nt;
     auto decode = [&](int v, int64_t& m0, int& n0) -> bool {
         const int xcd = v & 7, j = v >> 3;
@@ -349,37 +447,17 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
         for (int piece = blockIdx.x; piece < (p.N / 32) * ((p.tail_rows + 31) / 32); piece += gridDim.x) w4_tail_piece<OUT_BF16>(p, piece, (float*)smem, tid);
     if (v < 0) return;
 
-    unsigned aoff[4], woff[4];
+    W4State s;
+    // ---- staging: wave w stages pieces 4w .. 4w+3 (8 rows each) of every half-tile
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (row & 7);
-        aoff[i] = (unsigned)((row * p.lda + c * 8) * 2);
+        s.aoff[i] = (unsigned)((row * p.lda + c * 8) * 2);
         const int rl = row & 31, nperm = (row & ~31) + 8 * ((rl & 15) >> 2) + 4 * (rl >> 4) + (rl & 3);
-        woff[i] = (unsigned)((nperm * p.ldw + c * 8) * 2);
+        s.woff[i] = (unsigned)((nperm * p.ldw + c * 8) * 2);
     }
     const int64_t hiA = 128 * p.lda * 2, hiW = 128 * p.ldw * 2;
-    const char* cA = (const char*)(p.A + m0 * p.lda);
-    const char* cW = (const char*)(p.W + (int64_t)n0 * p.ldw);
-    const char* nA = cA;
-    const char* nW = cW;
-    bool has_next = false;
-    // k-tile kt of the CURRENT tile; kt >= nk continues into the walk's next tile (nothing on the last tile)
-    auto stage = [&](int slot, int kt) {
-        const char* bA = cA;
-        const char* bW = cW;
-        int k = kt;
-        if (kt >= nk) {
-            if (!has_next) return;
-            bA = nA; bW = nW; k = kt - nk;
-        }
-        char* dst = smem + (kt & 1) * W4_BUF + slot * W4_HT + wave * 4096;
-        const bool isA = slot == W4_ALO || slot == W4_AHI;
-        const char* bp = (isA ? bA : bW) + ((slot == W4_AHI) ? hiA : (slot == W4_BHI) ? hiW : 0) + (int64_t)k * 128;
-        asm volatile("" : "+s"(bp));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(bp + (isA ? aoff[i] : woff[i]), dst + i * 1024);
-    };
 
     float* bias_s = (float*)(smem + 2 * W4_BUF);
     for (int i = tid * 4; i < p.N; i += 256 * 4)
@@ -400,41 +478,52 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
         }
     };
 
+    // ---- fragment read addresses inside a half-tile: row = base + (lane & 15), chunk = ks*4 + (lane >> 4)
     const int frow = lane & 15, fq = lane >> 4;
-    int a_off[2], b_off[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int c = ks * 4 + fq;
-        a_off[ks] = (wr * 64 + frow) * 128 + ((c ^ (frow & 7)) << 4);
-        b_off[ks] = (wc * 64 + frow) * 128 + ((c ^ (frow & 7)) << 4);
+        s.ra0[ks] = w4_lds_u32(smem) + (wr * 64 + frow) * 128 + ((c ^ (frow & 7)) << 4);
+        s.rb0[ks] = w4_lds_u32(smem) + (wc * 64 + frow) * 128 + ((c ^ (frow & 7)) << 4);
+        s.ra1[ks] = s.ra0[ks] + W4_BUF; s.rb1[ks] = s.rb0[ks] + W4_BUF;
+    }
+    {
+        unsigned wl = w4_lds_u32(smem) + (unsigned)wave * 4096u;
+        asm volatile("" : "+s"(wl));
+        s.wave_lds = wl;
     }
 
-    W4_CLOBBER_AGPRS();
-    bf16x8 fa[4][2], fa2[4][2], fw0[4][2], fw1[4][2];
+    W4_CLOBBER_AGPRS();          // a[0:255] belong to the asm statements
 
-#define W4_READ(DST, SLOT, KT, OFF) _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
-        DST[t_][ks] = *(const bf16x8*)(smem + ((KT) & 1) * W4_BUF + (SLOT) * W4_HT + OFF[ks] + t_ * 2048);
-#define W4_EDGE(VM) do { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM) : "memory"); W4_BARRIER(); } while (0)
-    // quadrant edge E of k-tile T: on the walk's last tile the stream ends (drain); on a later tile the first six edges still have
-    // the previous epilogue's stores among the younger operations
-#define W4P_EDGE(T, E) do {                                                         \
-        if (!has_next && (T) + 3 >= nk) W4_EDGE(0);                                 \
-        else if (!first && 4 * (T) + (E) < 6) W4_EDGE(VM_ST);                       \
-        else W4_EDGE(24);                                                           \
-    } while (0)
-
-    {   // the walk's first tile needs its successor before the prologue: stage(W4_ALO, 2) may already cross into it (nk >= 4: it does not)
-        has_next = false;
+    // ---- prologue of the walk's first tile: k-tiles 0 and 1 (8 half-tiles fill the ring); A-lo(0) / W-lo(0) go to registers, then
+    // A-lo(2) takes A-lo(0)'s place.  Queue at the top of Q0(t), oldest first:
+    // [W-hi(t) landed] A-hi(t), A-lo(t+1), W-lo(t+1), W-hi(t+1), A-hi(t+1), A-lo(t+2)
+    {
+        const char* cA = (const char*)(p.A + m0 * p.lda);
+        const char* cW = (const char*)(p.W + (int64_t)n0 * p.ldw);
+        s.pAL = cA; s.pAH = cA + hiA; s.pWL = cW; s.pWH = cW + hiW;
+        s.nAL = s.nAH = s.nWL = s.nWH = cA;
     }
-    stage(W4_ALO, 0); stage(W4_BLO, 0); stage(W4_BHI, 0); stage(W4_AHI, 0);
-    stage(W4_ALO, 1); stage(W4_BLO, 1); stage(W4_BHI, 1); stage(W4_AHI, 1);
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+#define W4_STAGE(BUF, SLOT, VOFF, PTR) do { w4_dma<W4_IMM(BUF, SLOT)>(s.VOFF[0], s.PTR, s.wave_lds); w4_dma<W4_IMM(BUF, SLOT) + 1024>(s.VOFF[1], s.PTR, s.wave_lds);   \
+        w4_dma<W4_IMM(BUF, SLOT) + 2048>(s.VOFF[2], s.PTR, s.wave_lds); w4_dma<W4_IMM(BUF, SLOT) + 3072>(s.VOFF[3], s.PTR, s.wave_lds); s.PTR += 128; } while (0)
+    W4_STAGE(0, W4_ALO, aoff, pAL); W4_STAGE(0, W4_BLO, woff, pWL); W4_STAGE(0, W4_BHI, woff, pWH); W4_STAGE(0, W4_AHI, aoff, pAH);
+    W4_STAGE(1, W4_ALO, aoff, pAL); W4_STAGE(1, W4_BLO, woff, pWL); W4_STAGE(1, W4_BHI, woff, pWH); W4_STAGE(1, W4_AHI, aoff, pAH);
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                   // A-lo(0), W-lo(0) landed (6 half-tiles younger)
     W4_BARRIER();
-    W4_READ(fa, W4_ALO, 0, a_off)
-    W4_READ(fw0, W4_BLO, 0, b_off)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    W4_BARRIER();
-    stage(W4_ALO, 2);                                                   // (nk >= 4: inside this tile)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j == 0) { w4_ldsread<W4_IMM(0, W4_ALO)>(s.fa[0][0], s.ra0[0]); w4_ldsread<W4_IMM(0, W4_BLO)>(s.fw0[0][0], s.rb0[0]); }
+        if (j == 1) { w4_ldsread<W4_IMM(0, W4_ALO)>(s.fa[0][1], s.ra0[1]); w4_ldsread<W4_IMM(0, W4_BLO)>(s.fw0[0][1], s.rb0[1]); }
+        if (j == 2) { w4_ldsread<W4_IMM(0, W4_ALO) + 2048>(s.fa[1][0], s.ra0[0]); w4_ldsread<W4_IMM(0, W4_BLO) + 2048>(s.fw0[1][0], s.rb0[0]); }
+        if (j == 3) { w4_ldsread<W4_IMM(0, W4_ALO) + 2048>(s.fa[1][1], s.ra0[1]); w4_ldsread<W4_IMM(0, W4_BLO) + 2048>(s.fw0[1][1], s.rb0[1]); }
+        if (j == 4) { w4_ldsread<W4_IMM(0, W4_ALO) + 4096>(s.fa[2][0], s.ra0[0]); w4_ldsread<W4_IMM(0, W4_BLO) + 4096>(s.fw0[2][0], s.rb0[0]); }
+        if (j == 5) { w4_ldsread<W4_IMM(0, W4_ALO) + 4096>(s.fa[2][1], s.ra0[1]); w4_ldsread<W4_IMM(0, W4_BLO) + 4096>(s.fw0[2][1], s.rb0[1]); }
+        if (j == 6) { w4_ldsread<W4_IMM(0, W4_ALO) + 6144>(s.fa[3][0], s.ra0[0]); w4_ldsread<W4_IMM(0, W4_BLO) + 6144>(s.fw0[3][0], s.rb0[0]); }
+        if (j == 7) { w4_ldsread<W4_IMM(0, W4_ALO) + 6144>(s.fa[3][1], s.ra0[1]); w4_ldsread<W4_IMM(0, W4_BLO) + 6144>(s.fw0[3][1], s.rb0[1]); }
+    }
+    w4_edge<63>(s.fa);                                                   // (lgkmcnt(0): both sets are in registers; every wave has read A-lo(0) / W-lo(0))
+    asm volatile("" : "+v"(s.fw0[0][0]), "+v"(s.fw0[0][1]), "+v"(s.fw0[1][0]), "+v"(s.fw0[1][1]), "+v"(s.fw0[2][0]), "+v"(s.fw0[2][1]), "+v"(s.fw0[3][0]), "+v"(s.fw0[3][1]));
+    W4_STAGE(0, W4_ALO, aoff, pAL);                                      // A-lo(2)
     asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                   // W-hi(0)
     W4_BARRIER();
 
@@ -442,50 +531,20 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
     for (;;) {
         stamp(0);
         const int nv = next_valid(v + gridDim.x, nm0, nn0);
-        has_next = nv >= 0;
+        const bool has_next = nv >= 0;
         if (has_next) {
-            nA = (const char*)(p.A + nm0 * p.lda);
-            nW = (const char*)(p.W + (int64_t)nn0 * p.ldw);
+            const char* nA = (const char*)(p.A + nm0 * p.lda);
+            const char* nW = (const char*)(p.W + (int64_t)nn0 * p.ldw);
+            s.nAL = nA; s.nAH = nA + hiA; s.nWL = nW; s.nWH = nW + hiW;
         }
+        asm volatile("" : "+s"(s.nAL), "+s"(s.nAH), "+s"(s.nWL), "+s"(s.nWH));
         stamp(1);
-        for (int t = 0; t < nk; t += 2) {
-            // ================= k-tile t (W sets: fw0 = W-lo, fw1 = W-hi)
-            W4_READ(fw1, W4_BHI, t, b_off)
-            stage(W4_BLO, t + 2);
-            if (t == 0) w4_quad0<0, 0, 0>(fa, fw0); else w4_quad<0, 0, 0>(fa, fw0);
-            W4P_EDGE(t, 0);
-            W4_READ(fa2, W4_AHI, t, a_off)
-            stage(W4_BHI, t + 2);
-            if (t == 0) w4_quad0<0, 1, 0>(fa, fw1); else w4_quad<0, 1, 0>(fa, fw1);
-            W4P_EDGE(t, 1);
-            W4_READ(fa, W4_ALO, t + 1, a_off)
-            stage(W4_AHI, t + 2);
-            if (t == 0) w4_quad0<1, 1, 0>(fa2, fw1); else w4_quad<1, 1, 0>(fa2, fw1);
-            W4P_EDGE(t, 2);
-            W4_READ(fw1, W4_BLO, t + 1, b_off)
-            stage(W4_ALO, t + 3);
-            if (t == 0) w4_quad0<1, 0, 0>(fa2, fw0); else w4_quad<1, 0, 0>(fa2, fw0);
-            W4P_EDGE(t, 3);
-            // ================= k-tile t+1 (W sets swapped: fw1 = W-lo, fw0 = W-hi)
-            W4_READ(fw0, W4_BHI, t + 1, b_off)
-            stage(W4_BLO, t + 3);
-            w4_quad<0, 0, 0>(fa, fw1);
-            W4P_EDGE(t + 1, 0);
-            W4_READ(fa2, W4_AHI, t + 1, a_off)
-            stage(W4_BHI, t + 3);
-            w4_quad<0, 1, 0>(fa, fw0);
-            W4P_EDGE(t + 1, 1);
-            if (t + 2 < nk || has_next) { W4_READ(fa, W4_ALO, t + 2, a_off) }       // (t + 2 == nk: the next tile's k-tile 0)
-            stage(W4_AHI, t + 3);
-            w4_quad<1, 1, 0>(fa2, fw0);
-            W4P_EDGE(t + 1, 2);
-            if (t + 2 < nk || has_next) { W4_READ(fw0, W4_BLO, t + 2, b_off) }
-            stage(W4_ALO, t + 4);
-            w4_quad<1, 0, 0>(fa2, fw1);
-            W4P_EDGE(t + 1, 3);
-        }
+        if (first) w4_iter<W4V_FIRST0, VM_ST>(s); else w4_iter<W4V_NEXT0, VM_ST>(s);
+        for (int t = 2; t < nk - 4; t += 2) w4_iter<W4V_MID, VM_ST>(s);
+        if (has_next) { w4_iter<W4V_REBASE, VM_ST>(s); w4_iter<W4V_MID, VM_ST>(s); }
+        else { w4_iter<W4V_REBASE_LAST, VM_ST>(s); w4_iter<W4V_TAIL_LAST, VM_ST>(s); }
         stamp(2);
-        asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");      // the last MFMAs have written their AGPRs; the next tile's fragments are in registers
+        asm volatile("s_nop 15\n s_nop 15" ::: "memory");      // the last MFMAs have written their AGPRs; the next tile's first fragments are in registers
 
         // ---- epilogue of tile (m0, n0): bias from LDS, then exactly STORES store instructions per wave
         {
@@ -507,12 +566,9 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
         ++tile_i;
         if (!has_next) break;
         v = nv; m0 = nm0; n0 = nn0;
-        cA = nA; cW = nW;
         first = false;
     }
-#undef W4_READ
-#undef W4_EDGE
-#undef W4P_EDGE
+#undef W4_STAGE
 }
 
 static bool g_w4_ts_last = false;
