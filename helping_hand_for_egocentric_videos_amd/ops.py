@@ -49,6 +49,9 @@ def _workspace(fn_name, *dims, device):
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
+GEMM256_DEFAULT = 5          # hh_set_tuning("gemm256", .): the library's default (csrc/gemm256.hip)
+
+
 def set_tuning(name, value):
     """Performance knob for A/B measurements (include/hh.h: hh_set_tuning)."""
     _lib.check(_lib.lib().hh_set_tuning(name.encode(), int(value)), "hh_set_tuning")

@@ -35,7 +35,9 @@ enum hh_qkv_layout { HH_QKV_TOKEN_MAJOR = 0, HH_QKV_HEAD_MAJOR = 1 };
 int hh_version(void);
 /* Performance knobs for A/B measurements (never change results).  Together with the per-stream CU budget below this is the
  * library's ONLY process-global mutable state; no entry point reads the environment.
- *   "gemm256"       0 = 128x128 kernel only, 1 = 256x256 one tile per block, 2 = + wave-row stagger, 3 (default) = persistent
+ *   "gemm256"       0 = 128x128 kernel only, 1 = 256x256 one tile per block, 2 = + wave-row stagger, 3 = persistent 8-wave kernel,
+ *                   4 = 4-wave kernel (128x128 per wave), one tile per block, 5 (default) = persistent 4-wave kernel where K >= 384 and
+ *                   K % 128 == 0, else 3.  All produce bit-identical results.
  *                   256x256: one workgroup per CU walks its tiles in one continuous k-tile stream, four barriers per k-tile
  *   "gemm_tail"     1 (default) = row tails of <= 64 rows (M - 256*floor(M/256), K % 512 == 0) inside the persistent kernel where it
  *                   runs (pieces of <= 32 rows x 32 columns per workgroup), else as 2; 2 = tails of <= 64 rows always on the separate
@@ -72,7 +74,7 @@ int hh_stream_get_cu_budget(hh_stream_t stream, int* out);
  * and the launches' algorithmic work (flops for the GEMM classes, bytes for the others; formulas in DESIGN.md section 5).  It
  * synchronises on the recorded events. */
 enum hh_prof_class {
-    HH_PROF_GEMM256 = 0,      /* persistent 256x256 GEMM kernel (gemm256d_kernel): 2*M*N*K of the full-tile rows */
+    HH_PROF_GEMM256 = 0,      /* persistent 256x256 GEMM kernels (gemm256w4p_kernel, gemm256d_kernel): 2*M*N*K of the full-tile rows */
     HH_PROF_GEMM_OTHER = 1,   /* row tails, 128x128 kernel, one-tile-per-block 256x256 kernel: 2*M*N*K of their rows */
     HH_PROF_SPACE_ATTN = 2,   /* space_attnj_kernel (joint blocks, default) / space_attn16_kernel: 8*B*N*D bytes (q,k,v read + o written, bf16) */
     HH_PROF_TIME_ATTN = 3,    /* time_attn_mfma*_kernel: 8*B*N*D bytes */

@@ -8,7 +8,7 @@ M = 32 * 4096
 g = torch.Generator(device="cuda").manual_seed(0)
 modes = [3, 5]
 dbgs = [0]
-for name, N, K, kw in [("qkv", 3072, 1024, dict(colscale=0.125, colscale_cols=1024)), ("fc2", 1024, 4096, {})]:
+for name, N, K, kw in [("qkv", 3072, 1024, dict(colscale=0.125, colscale_cols=1024)), ("proj", 1024, 1024, {}), ("fc1", 4096, 1024, dict(act=ops.ACT_QUICKGELU)), ("fc2", 1024, 4096, {})]:
     a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
     bias = torch.randn(N, device="cuda", generator=g)
@@ -28,6 +28,8 @@ for name, N, K, kw in [("qkv", 3072, 1024, dict(colscale=0.125, colscale_cols=10
         loop_us = (t[:, :, 2] - t[:, :, 1]) / 100.0
         mhz = (t[:, :, 6] - t[:, :, 5]) / np.maximum(loop_us, 1e-9)
         gap_us = (t[:, 1:, 1] - t[:, :-1, 2]) / 100.0                      # end of a main loop -> start of the next
-        print("%-4s mode %d dbg %2d: cycles / k-tile %.0f (p10 %.0f p90 %.0f)  main loop %.2f us  clock %.0f MHz  between loops %.2f us (%.0f cycles)" % (
-            name, mode, dbg, cyc.mean(), np.percentile(cyc, 10), np.percentile(cyc, 90), loop_us.mean(), mhz.mean(), gap_us.mean(), gap_us.mean() * mhz.mean()), flush=True)
+        epi_us = (t[:, :, 4] - t[:, :, 3]).mean() / 100.0                  # the store part of the epilogue
+        pre_us = (t[:, :, 3] - t[:, :, 2]).mean() / 100.0
+        print("%-4s mode %d dbg %2d: cycles / k-tile %.0f (p10 %.0f p90 %.0f)  main loop %.2f us  clock %.0f MHz  between loops %.2f us (%.0f cycles; bias %.2f, stores %.2f us)" % (
+            name, mode, dbg, cyc.mean(), np.percentile(cyc, 10), np.percentile(cyc, 90), loop_us.mean(), mhz.mean(), gap_us.mean(), gap_us.mean() * mhz.mean(), pre_us, epi_us), flush=True)
 ops.set_tuning("gemm256", 3)

@@ -25,5 +25,5 @@ for name, N, K, kw in [("qkv", 2304, 768, {}), ("proj+res", 768, 768, dict(resid
         ops.set_tuning("gemm256", mode)
         ms = t(f)
         line += f" | mode{mode}: {ms*1e3:7.1f} us {2.0*M*N*K/ms/1e9:7.1f} TF/s"
-    ops.set_tuning("gemm256", 3)
+    ops.set_tuning("gemm256", ops.GEMM256_DEFAULT)
     print(line, flush=True)

@@ -118,7 +118,7 @@ def test_gemm_column_blocked_output(M, N, K, odt):
     assert torch.equal(planes.transpose(0, 1).reshape(M, N), rows)
 
 
-@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("mode", [2, 3, 5])
 @pytest.mark.parametrize("M,N,K", [(256 * 40, 2048, 256), (256 * 24, 3072, 192), (256 * 300, 256, 128), (256 * 20, 4096, 1024),
                                    (256 * 33 + 17, 1024, 512), (256 * 300, 256, 64), (256 * 40, 8192 + 256, 128)])
 def test_gemm_persistent_walks_many_tiles_per_workgroup(mode, M, N, K):
@@ -136,7 +136,7 @@ def test_gemm_persistent_walks_many_tiles_per_workgroup(mode, M, N, K):
         out_f32 = ops.gemm(a, w, bias, out_dtype=torch.float32)
         out_act = ops.gemm(a, w, bias, act=ops.ACT_QUICKGELU)
     finally:
-        ops.set_tuning("gemm256", 3)
+        ops.set_tuning("gemm256", ops.GEMM256_DEFAULT)
     scale = ref.abs().max().item()
     assert (out_f32 - ref).abs().max().item() <= 2e-3 * scale
     assert (out_bf.float() - ref).abs().max().item() <= 8e-3 * scale
@@ -147,14 +147,15 @@ def test_gemm_persistent_walks_many_tiles_per_workgroup(mode, M, N, K):
 @pytest.mark.parametrize("mode", [4, 5])
 @pytest.mark.parametrize("M,N,K,kw", [(256 * 40 + 33, 3072, 1024, dict(colscale=0.125, colscale_cols=1024)), (256 * 64, 1024, 256, dict(act=ops.ACT_RELU)),
                                       (256 * 300, 256, 640, dict(act=ops.ACT_QUICKGELU)), (256 * 20, 4096, 768, {})])
-def test_gemm_four_wave_experiment_matches_the_default_kernel(mode, M, N, K, kw):
+def test_gemm_four_wave_kernels_match_the_eight_wave_kernel(mode, M, N, K, kw):
     """csrc/gemm256w4.hip (hh_set_tuning("gemm256", 4 / 5): the 256x256 tile on 4 waves of 128x128, one tile per workgroup /
-    persistent) accumulates every output in the same order as the default kernel: bit-identical, bf16 and fp32 outputs, head-major
-    planes, row tail inside the persistent walk.  (Measured slower than the default -- DESIGN.md 4.5 -- and kept as a tuning value.)"""
+    persistent -- 5 is the default) accumulates every output in the same order as the 8-wave persistent kernel (3): bit-identical,
+    bf16 and fp32 outputs, head-major planes, row tail inside the persistent walk."""
     g = torch.Generator(device=DEV).manual_seed(M + N + K)
     a = (torch.randn(M, K, device=DEV, generator=g)).to(torch.bfloat16)
     w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
     bias = torch.randn(N, device=DEV, generator=g)
+    ops.set_tuning("gemm256", 3)
     ref = [ops.gemm(a, w, bias, **kw), ops.gemm(a, w, bias, out_dtype=torch.float32, **kw), ops.gemm(a, w, bias, col_blocked=True, **kw)]
     ops.set_tuning("gemm256", mode)
     try:
@@ -163,7 +164,7 @@ def test_gemm_four_wave_experiment_matches_the_default_kernel(mode, M, N, K, kw)
             for r, o in zip(ref, got):
                 assert torch.equal(r, o)
     finally:
-        ops.set_tuning("gemm256", 3)
+        ops.set_tuning("gemm256", ops.GEMM256_DEFAULT)
 
 
 def test_stream_cu_budget_changes_the_grid_not_the_results():
