@@ -264,9 +264,10 @@ __device__ __forceinline__ void w4q(const bf16x8 (&AF)[4][2], const bf16x8 (&WF)
         constexpr int j = I / 2;                                   // read j: fragment tile j >> 1, k-step j & 1
         w4_ldsread<RIMM + (j >> 1) * 2048>(RD[j >> 1][j & 1], raddr[j & 1]);
     }
-    if constexpr (DMA_ON && I >= 16 && I < 24 && I % 2 == 1) {
+    if constexpr (DMA_ON && I >= 16 && I < 24) {                   // M0 in one MFMA gap, the load in the next (the MFMA between them covers the M0 hazard)
         constexpr int i = (I - 16) / 2;
-        w4_dma<DIMM + i * 1024>(voff[i], src, wave_lds);
+        if constexpr (I % 2 == 0) asm volatile("s_add_u32 m0, %0, %1" :: "s"(wave_lds), "n"(DIMM + i * 1024) : "scc");
+        else asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(voff[i]), "s"(src) : "memory");
     }
     if constexpr (I + 1 < 32) w4q<MH, NH, ZERO, RIMM, DIMM, DMA_ON, I + 1>(AF, WF, RD, raddr, voff, src, wave_lds);
 }
@@ -379,9 +380,20 @@ __device__ __forceinline__ void w4_tail_piece(const GemmParams& p, int piece, fl
     __syncthreads();
 }
 
+// quick_gelu (gemm_common.h) on four values with the multiplies / the add as packed fp32 operations (same roundings: bit-identical)
+__device__ __forceinline__ f32x4 w4_quick_gelu4(f32x4 v) {
+    f32x4 t = v * -2.4554669595930157f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_exp2f(t[q]);
+    t = t + 1.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = __builtin_amdgcn_rcpf(t[q]);
+    return v * t;
+}
+
 // epilogue rows of one (mh, tm) pair: lane owns C[orow][cj .. cj+7] for the four column starts cj = nb + {0, 32, 128, 160}
 template <bool OUT_BF16, int EPI, int IDX>
-__device__ __forceinline__ void w4p_store_rows(const GemmParams& p, int64_t rowbase, int n0, const f32x4 (&bias_v)[4][2], const int64_t (&ccol)[4]) {
+__device__ __forceinline__ void w4p_store_rows(const GemmParams& p, int64_t rowbase, const float (&sc)[2], const f32x4 (&bias_v)[4][2], const int64_t (&ccol)[4]) {
     const hh_gemm_epilogue& e = p.e;
     const int64_t orow = rowbase + (IDX >> 2) * 128 + (IDX & 3) * 16;
     char* Cbase = (char*)p.C;
@@ -394,10 +406,9 @@ __device__ __forceinline__ void w4p_store_rows(const GemmParams& p, int64_t rowb
     for (int j = 0; j < 4; ++j) {
         f32x4 a = v0[j] + bias_v[j][0], b = v1[j] + bias_v[j][1];
         if constexpr (EPI == 1) {
-            if (n0 + (j >> 1) * 128 < e.colscale_cols) { a *= e.colscale; b *= e.colscale; }      // uniform: colscale_cols % 128 == 0
+            a *= sc[j >> 1]; b *= sc[j >> 1];                          // colscale_cols % 128 == 0: one factor per 128-column half (1 outside: exact)
         } else if constexpr (EPI == 2) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { a[q] = quick_gelu(a[q]); b[q] = quick_gelu(b[q]); }
+            a = w4_quick_gelu4(a); b = w4_quick_gelu4(b);
         } else if constexpr (EPI == 3) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { a[q] = fmaxf(a[q], 0.f); b[q] = fmaxf(b[q], 0.f); }
@@ -410,7 +421,7 @@ __device__ __forceinline__ void w4p_store_rows(const GemmParams& p, int64_t rowb
             *(f32x4*)((float*)Cbase + orow * p.ldc + ccol[j] + 4) = b;
         }
     }
-    if constexpr (IDX + 1 < 8) w4p_store_rows<OUT_BF16, EPI, IDX + 1>(p, rowbase, n0, bias_v, ccol);
+    if constexpr (IDX + 1 < 8) w4p_store_rows<OUT_BF16, EPI, IDX + 1>(p, rowbase, sc, bias_v, ccol);
 }
 
 template <bool OUT_BF16, int EPI>
@@ -559,8 +570,13 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
                 bias_v[j][1] = *(const f32x4*)(bias_s + cj + 4);
                 ccol[j] = gemm_ccol(e, cj);
             }
+            float sc[2] = {1.f, 1.f};
+            if constexpr (EPI == 1) {
+                if (n0 < e.colscale_cols) sc[0] = e.colscale;
+                if (n0 + 128 < e.colscale_cols) sc[1] = e.colscale;
+            }
             stamp(3);
-            w4p_store_rows<OUT_BF16, EPI, 0>(p, m0 + wr * 64 + frow, n0, bias_v, ccol);
+            w4p_store_rows<OUT_BF16, EPI, 0>(p, m0 + wr * 64 + frow, sc, bias_v, ccol);
         }
         stamp(4);
         ++tile_i;
