@@ -278,8 +278,8 @@ def roofline_records(region, iso, dt_ms, pipelined, cfg):
     roof, att = None, {}
     ach, n, seen, ms = rate(region, "gemm256", 1e12)
     if ach is not None:
-        traffic, src = pmc_traffic("gemm256d_kernel<true")
-        roof = {"kernel": "gemm256d_kernel (persistent 256x256x64 bf16 MFMA GEMM, continuous k-tile stream, four barriers per k-tile) -- every template instantiation, nothing else",
+        traffic, src = pmc_traffic("gemm256w4p_kernel<true")
+        roof = {"kernel": "gemm256w4p_kernel (persistent 256x256x64 bf16 MFMA GEMM: 4 waves x 128x128, one wave per SIMD, continuous half-tile LDS-DMA stream across tiles) -- every template instantiation, nothing else",
                 "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic,
                 "traffic_note": "HBM-side bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/%s, config 2, B=32); algorithmic bytes per launch average 0.99e9" % src,

@@ -20,7 +20,7 @@ R = os.environ["GRAFT_REPO_ROOT"]
 tot, n = 0.0, 0
 for f in glob.glob(R + "/gpurun_out/pmc_g/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if row["Counter_Name"] == "FETCH_SIZE" and "gemm256d_kernel" in row["Kernel_Name"]:
+        if row["Counter_Name"] == "FETCH_SIZE" and ("gemm256d_kernel" in row["Kernel_Name"] or "gemm256w4p_kernel" in row["Kernel_Name"]):
             tot += float(row["Counter_Value"]); n += 1
 M, K = 32 * 4097, 1024
 N = 3072 if which == "qkv" else 4096
