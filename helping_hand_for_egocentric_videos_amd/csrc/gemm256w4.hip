@@ -1,9 +1,11 @@
-// EXPERIMENT (round 3, hh_set_tuning("gemm256", 4)): the 256x256x64 bf16 GEMM tile on FOUR waves of 128x128 instead of eight of
-// 128x64 -- one wave per SIMD with all 512 registers (256 accumulators + three fragment sets).  Motivation: the step sits at the
-// package power cap and a register-only MFMA loop holds twice the rate of the GEMM at that power, so the energy goes into moving
-// operands; with 8 waves every k-tile costs 192 KB of LDS fragment reads per workgroup (each A fragment is read by 4 waves, each W
-// fragment by 2), with 4 waves 128 KB.  Same LDS image, staging and epilogue conventions as gemm256.hip; one tile per workgroup (no
-// persistence / continuity): it is measured against gemm256_kernel (tuning value 2), the 8-wave kernel of the same structure.
+// The 256x256x64 bf16 GEMM tile on FOUR waves of 128x128 instead of eight of 128x64 -- one wave per SIMD with all 512 registers
+// (256 accumulators in AGPRs + four fragment sets).  Replaces nn.Linear on the hot path like gemm256.hip (model/LaviLa.py:249 qkv,
+// :281 proj, :186-189 fc1 / fc2).  Motivation: the step sits at the package power cap, where throughput = power / energy per flop; with 8
+// waves every k-tile costs 192 KB of LDS fragment reads per workgroup (each A fragment is read by 4 waves, each W fragment by 2), with
+// 4 waves 128 KB, and half the waits and barriers.  Same LDS image, staging and epilogue conventions as gemm256.hip, bit-identical
+// results.  Two kernels: gemm256w4_kernel (hh_set_tuning("gemm256", 4)): one tile per workgroup, compiler-scheduled -- the simple
+// form, kept as the readable statement of the pipeline and measured at 770-1090 TFLOP/s; gemm256w4p_kernel (5, the default):
+// persistent, hand-placed instruction stream, 1215-1469 TFLOP/s.
 //
 // Software pipeline of the single wave per SIMD: the four quadrant products of a k-tile run back to back, 32 MFMAs each, and the 8
 // ds_read_b128 of the NEXT quadrant's fresh operand are interleaved with them (two k-tiles per loop iteration, because the roles of
