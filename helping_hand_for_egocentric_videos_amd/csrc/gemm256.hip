@@ -657,7 +657,7 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
             const unsigned pg = grid < (unsigned)ncu ? grid : (unsigned)ncu;
             p.skew_iters = g_pskew;
             HHProfScope prof(HH_PROF_GEMM256, 2.0 * (double)p.M * p.N * p.K, s);
-            if (g_mode == 5 && p.K >= 384 && p.K % 128 == 0) {
+            if (g_mode == 5 && p.K >= 384 && p.K % 128 == 0 && p.N <= 4096) {      // (N: bias vector + epilogue scratch share the 32 KB of LDS the ring leaves)
                 int rc = hh_gemm256w4p_launch(p, epi, pg, s);
                 if (tail_done) *tail_done = p.tail_rows > 0;
                 return rc;

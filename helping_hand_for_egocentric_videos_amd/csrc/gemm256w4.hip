@@ -393,37 +393,72 @@ __device__ __forceinline__ f32x4 w4_quick_gelu4(f32x4 v) {
     return v * t;
 }
 
-// epilogue rows of one (mh, tm) pair: lane owns C[orow][cj .. cj+7] for the four column starts cj = nb + {0, 32, 128, 160}
-template <bool OUT_BF16, int EPI, int IDX>
-__device__ __forceinline__ void w4p_store_rows(const GemmParams& p, int64_t rowbase, const float (&sc)[2], const f32x4 (&bias_v)[4][2], const int64_t (&ccol)[4]) {
-    const hh_gemm_epilogue& e = p.e;
-    const int64_t orow = rowbase + (IDX >> 2) * 128 + (IDX & 3) * 16;
-    char* Cbase = (char*)p.C;
-    f32x4 v0[4], v1[4];
-    v0[0] = w4_acc_read<16 * (IDX * 2 + 0) + 0>();  v1[0] = w4_acc_read<16 * (IDX * 2 + 0) + 4>();
-    v0[1] = w4_acc_read<16 * (IDX * 2 + 0) + 8>();  v1[1] = w4_acc_read<16 * (IDX * 2 + 0) + 12>();
-    v0[2] = w4_acc_read<16 * (IDX * 2 + 1) + 0>();  v1[2] = w4_acc_read<16 * (IDX * 2 + 1) + 4>();
-    v0[3] = w4_acc_read<16 * (IDX * 2 + 1) + 8>();  v1[3] = w4_acc_read<16 * (IDX * 2 + 1) + 12>();
+// ---- epilogue.  Lane (frow, fq) of wave (wr, wc) owns, for each of its 8 row groups IDX = mh*4 + tm (row m0 + mh*128 + wr*64 + tm*16 +
+// frow), the columns n0 + wc*128 + 64 nh + 32 jj + 8 fq + [0, 8) for j = 2 nh + jj = 0..3.
+template <int EPI, int IDX>
+__device__ __forceinline__ void w4p_finish_group(float sc, const f32x4 (&bias_v)[4][2], f32x4 (&a)[4], f32x4 (&b)[4]) {
+    a[0] = w4_acc_read<16 * (IDX * 2 + 0) + 0>();  b[0] = w4_acc_read<16 * (IDX * 2 + 0) + 4>();
+    a[1] = w4_acc_read<16 * (IDX * 2 + 0) + 8>();  b[1] = w4_acc_read<16 * (IDX * 2 + 0) + 12>();
+    a[2] = w4_acc_read<16 * (IDX * 2 + 1) + 0>();  b[2] = w4_acc_read<16 * (IDX * 2 + 1) + 4>();
+    a[3] = w4_acc_read<16 * (IDX * 2 + 1) + 8>();  b[3] = w4_acc_read<16 * (IDX * 2 + 1) + 12>();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        f32x4 a = v0[j] + bias_v[j][0], b = v1[j] + bias_v[j][1];
+        a[j] += bias_v[j][0]; b[j] += bias_v[j][1];
         if constexpr (EPI == 1) {
-            a *= sc[j >> 1]; b *= sc[j >> 1];                          // colscale_cols % 128 == 0: one factor per 128-column half (1 outside: exact)
+            a[j] *= sc; b[j] *= sc;                                    // (1 outside the scaled columns: exact)
         } else if constexpr (EPI == 2) {
-            a = w4_quick_gelu4(a); b = w4_quick_gelu4(b);
+            a[j] = w4_quick_gelu4(a[j]); b[j] = w4_quick_gelu4(b[j]);
         } else if constexpr (EPI == 3) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { a[q] = fmaxf(a[q], 0.f); b[q] = fmaxf(b[q], 0.f); }
-        }
-        if constexpr (OUT_BF16) {
-            u32x4 o = {pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]), pack_bf16(b[0], b[1]), pack_bf16(b[2], b[3])};
-            *(u32x4*)((bf16_t*)Cbase + orow * p.ldc + ccol[j]) = o;
-        } else {
-            *(f32x4*)((float*)Cbase + orow * p.ldc + ccol[j]) = a;
-            *(f32x4*)((float*)Cbase + orow * p.ldc + ccol[j] + 4) = b;
+            for (int q = 0; q < 4; ++q) { a[j][q] = fmaxf(a[j][q], 0.f); b[j][q] = fmaxf(b[j][q], 0.f); }
         }
     }
-    if constexpr (IDX + 1 < 8) w4p_store_rows<OUT_BF16, EPI, IDX + 1>(p, rowbase, sc, bias_v, ccol);
+}
+// bf16 output: group IDX goes through the wave's LDS scratch (16 rows x 256 B, 16-B chunks XOR-swizzled with the row: conflict-free both
+// ways) and leaves as 4 stores of 4 rows x 256 B; the stores of group IDX - 1 are issued behind the arithmetic of group IDX.
+template <int EPI, int IDX>
+__device__ __forceinline__ void w4p_store_tile(const GemmParams& p, bf16_t* cptr, int64_t rowbase, char* scr, int frow, int fq, int l15, int l4,
+                                               float sc, const f32x4 (&bias_v)[4][2], u32x4 (*prev)[4] = nullptr) {
+    f32x4 a[4], b[4];
+    w4p_finish_group<EPI, IDX>(sc, bias_v, a, b);
+    u32x4 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (u32x4){pack_bf16(a[j][0], a[j][1]), pack_bf16(a[j][2], a[j][3]), pack_bf16(b[j][0], b[j][1]), pack_bf16(b[j][2], b[j][3])};
+    if constexpr (IDX > 0) {                                           // the previous group's rows (its LDS reads were issued before this group's arithmetic)
+        const int64_t r0 = rowbase + ((IDX - 1) >> 2) * 128 + ((IDX - 1) & 3) * 16 + l4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(u32x4*)(cptr + (r0 + 4 * q) * p.ldc) = (*prev)[q];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(u32x4*)(scr + frow * 256 + (((j * 4 + fq) ^ frow) << 4)) = o[j];      // chunk = 8 nh + 4 jj + fq = 4 j + fq
+    u32x4 rd[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int r = 4 * q + l4; rd[q] = *(const u32x4*)(scr + r * 256 + ((l15 ^ r) << 4)); }
+    if constexpr (IDX + 1 < 8) w4p_store_tile<EPI, IDX + 1>(p, cptr, rowbase, scr, frow, fq, l15, l4, sc, bias_v, &rd);
+    else {
+        const int64_t r0 = rowbase + (IDX >> 2) * 128 + (IDX & 3) * 16 + l4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(u32x4*)(cptr + (r0 + 4 * q) * p.ldc) = rd[q];
+    }
+}
+// straight from the MFMA layout (a store instruction covers 16 rows x 64 B of bf16): fp32 output, and the QuickGELU epilogue, whose
+// arithmetic (two transcendentals per value) is longer than even these slow stores -- the LDS round trip only adds to it
+template <bool OUT_BF16, int EPI, int IDX>
+__device__ __forceinline__ void w4p_store_rows_direct(const GemmParams& p, int64_t rowbase, float sc, const f32x4 (&bias_v)[4][2], const int64_t (&ccol)[4]) {
+    const int64_t orow = rowbase + (IDX >> 2) * 128 + (IDX & 3) * 16;
+    f32x4 a[4], b[4];
+    w4p_finish_group<EPI, IDX>(sc, bias_v, a, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (OUT_BF16) {
+            u32x4 o = {pack_bf16(a[j][0], a[j][1]), pack_bf16(a[j][2], a[j][3]), pack_bf16(b[j][0], b[j][1]), pack_bf16(b[j][2], b[j][3])};
+            *(u32x4*)((bf16_t*)p.C + orow * p.ldc + ccol[j]) = o;
+        } else {
+            *(f32x4*)((float*)p.C + orow * p.ldc + ccol[j]) = a[j];
+            *(f32x4*)((float*)p.C + orow * p.ldc + ccol[j] + 4) = b[j];
+        }
+    }
+    if constexpr (IDX + 1 < 8) w4p_store_rows_direct<OUT_BF16, EPI, IDX + 1>(p, rowbase, sc, bias_v, ccol);
 }
 
 template <bool OUT_BF16, int EPI>
@@ -467,10 +502,12 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
         const int row = (wave * 4 + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (row & 7);
         s.aoff[i] = (unsigned)((row * p.lda + c * 8) * 2);
-        const int rl = row & 31, nperm = (row & ~31) + 8 * ((rl & 15) >> 2) + 4 * (rl >> 4) + (rl & 3);
+        // W half-tile row R (its 64-row halves belong to wave columns wc = 0 / 1) holds column 128 wc + 64 NH + perm(R & 63) of the
+        // tile: a wave owns 128 CONTIGUOUS columns, so that the epilogue can write 256-byte row segments
+        const int rl = row & 31, nperm = (row >> 6) * 128 + (row & 32) + 8 * ((rl & 15) >> 2) + 4 * (rl >> 4) + (rl & 3);
         s.woff[i] = (unsigned)((nperm * p.ldw + c * 8) * 2);
     }
-    const int64_t hiA = 128 * p.lda * 2, hiW = 128 * p.ldw * 2;
+    const int64_t hiA = 128 * p.lda * 2, hiW = 64 * p.ldw * 2;
 
     float* bias_s = (float*)(smem + 2 * W4_BUF);
     for (int i = tid * 4; i < p.N; i += 256 * 4)
@@ -562,23 +599,34 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
         // ---- epilogue of tile (m0, n0): bias from LDS, then exactly STORES store instructions per wave
         {
             const hh_gemm_epilogue& e = p.e;
-            const int nb = n0 + wc * 64 + 8 * fq;
+            const int nb = n0 + wc * 128 + 8 * fq;                     // lane's columns: nb + 64 nh + 32 jj + [0, 8)
             f32x4 bias_v[4][2];
-            int64_t ccol[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int cj = nb + (j & 1) * 32 + (j >> 1) * 128;
+                const int cj = nb + (j & 1) * 32 + (j >> 1) * 64;
                 bias_v[j][0] = *(const f32x4*)(bias_s + cj);
                 bias_v[j][1] = *(const f32x4*)(bias_s + cj + 4);
-                ccol[j] = gemm_ccol(e, cj);
             }
-            float sc[2] = {1.f, 1.f};
+            float sc = 1.f;
             if constexpr (EPI == 1) {
-                if (n0 < e.colscale_cols) sc[0] = e.colscale;
-                if (n0 + 128 < e.colscale_cols) sc[1] = e.colscale;
+                if (n0 + wc * 128 < e.colscale_cols) sc = e.colscale;  // colscale_cols % 128 == 0: the wave's 128 columns are all in or all out
             }
             stamp(3);
-            w4p_store_rows<OUT_BF16, EPI, 0>(p, m0 + wr * 64 + frow, sc, bias_v, ccol);
+            if constexpr (OUT_BF16 && EPI != 2) {
+                // through this wave's 4 KB of LDS: a lane finishes 4 x 16 B of one row (MFMA layout), the wave then stores 4 rows x 256 B
+                // per instruction.  A store instruction covering 16 rows x 64 B takes ~270 cycles on the CU's store path, 4 rows x 256 B
+                // 66 (scripts/store_probe.hip) -- the epilogue was bound by exactly that.
+                char* scr = smem + 2 * W4_BUF + p.N * 4 + wave * 4096;
+                const int l15 = lane & 15, l4 = lane >> 4;
+                const int ncol = n0 + wc * 128 + l15 * 8;              // this lane's 8 columns in the store phase
+                bf16_t* cptr = (bf16_t*)p.C + gemm_ccol(e, ncol);
+                w4p_store_tile<EPI, 0>(p, cptr, m0 + wr * 64, scr, frow, fq, l15, l4, sc, bias_v);
+            } else {
+                int64_t ccol[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ccol[j] = gemm_ccol(e, nb + (j & 1) * 32 + (j >> 1) * 64);
+                w4p_store_rows_direct<OUT_BF16, EPI, 0>(p, m0 + wr * 64 + frow, sc, bias_v, ccol);
+            }
         }
         stamp(4);
         ++tile_i;
@@ -598,11 +646,11 @@ int hh_gemm256w4_timeline(unsigned long long* out, int blocks) {
     return HH_OK;
 }
 
-#define W4P_LDS(N) (2 * W4_BUF + (size_t)(N) * 4)
+#define W4P_LDS(N) (2 * W4_BUF + (size_t)(N) * 4 + 4 * 4096)      // staging ring + bias vector + 4 KB of epilogue scratch per wave
 int hh_gemm256w4p_launch(const GemmParams& p, int epi, unsigned pg, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-#define ATTRP(BF, E) hipFuncSetAttribute((const void*)gemm256w4p_kernel<BF, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(8192))
+#define ATTRP(BF, E) hipFuncSetAttribute((const void*)gemm256w4p_kernel<BF, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096))
         ATTRP(true, 0); ATTRP(false, 0); ATTRP(true, 1); ATTRP(false, 1); ATTRP(true, 2); ATTRP(false, 2); ATTRP(true, 3); ATTRP(false, 3);
 #undef ATTRP
         attr_done = true;
