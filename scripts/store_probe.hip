@@ -1,7 +1,8 @@
 // Probe: store throughput of the GEMM epilogue's access pattern.  One workgroup of 4 waves per CU (128 KB of LDS claimed), each wave
 // issues 32 global_store_dwordx4 per "tile" (1 KB per instruction), 16 tiles, on 1 / 8 / 64 / 256 CUs.  Pattern A = the MFMA-layout
 // epilogue (a store covers 16 rows x 64 B, row stride ldc), B = 4 rows x 256 B (what an LDS transpose would give), C = 2 rows x 512 B;
-// V = pattern A with ~18 dependent-free VALU instructions between two stores (the real epilogue's arithmetic).
+// V = pattern A with ~18 dependent-free VALU instructions between two stores (the real epilogue's arithmetic); D = 8 rows x 128 B;
+// H = the attention kernels' output pattern (16 rows, each lane 16 B at a 32-B pitch, the holes filled by the next instruction).
 // build: hipcc --offload-arch=gfx950 -O3 -o scripts/_bin/store_probe scripts/store_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -30,9 +31,15 @@ __global__ __launch_bounds__(256, 1) void probe(char* C, long ldc_bytes, unsigne
             } else if (PAT == 1) {
                 const long row = wr * 128 + i * 4 + (lane >> 4);
                 off = row * ldc_bytes + (wc * 128) * 2 + (lane & 15) * 16;
-            } else {
+            } else if (PAT == 2) {
                 const long row = wave * 64 + i * 2 + (lane >> 5);
                 off = row * ldc_bytes + (lane & 31) * 16;
+            } else if (PAT == 4) {   // D: 8 rows x 128 B (one head's slice of 8 token rows)
+                const long row = wave * 64 + (i >> 2) * 8 + (lane >> 3);
+                off = row * ldc_bytes + (i & 3) * 128 + (lane & 7) * 16;
+            } else {                 // H: the attention kernels' pattern: 16 rows, lane g writes 16 B at 32 g (+16 in the second store)
+                const long row = wave * 64 + (i >> 3) * 16 + (lane & 15);
+                off = row * ldc_bytes + ((i >> 1) & 3) * 128 + (lane >> 4) * 32 + (i & 1) * 16;
             }
             if (PAT == 3) {
 #pragma unroll
@@ -70,6 +77,8 @@ int main() {
         run<1>("B: 4 rows x 256 B", C, ldc, out, tiles, grid);
         run<2>("C: 2 rows x 512 B", C, ldc, out, tiles, grid);
         run<3>("V: A + 16 VALU per store", C, ldc, out, tiles, grid);
+        run<4>("D: 8 rows x 128 B", C, ldc, out, tiles, grid);
+        run<5>("H: 16 rows x 4 x 16 B, holes", C, ldc, out, tiles, grid);
     }
     return 0;
 }
