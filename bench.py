@@ -334,8 +334,10 @@ def bench_train(cfg, backbone, decoder, B, steps, warmup, world, rank, dev, args
         # outside the timed region: two un-pipelined steps, so that every kernel is also timed alone on the chip (no decoder kernels
         # of the previous step beside the encoder's)
         prof_enable(STRIDE)
+        ts.text_on_side_stream = False      # (the text tower normally runs beside the vision tower's first blocks)
         for _ in range(2):
             ts.step(batch)
+        ts.text_on_side_stream = True
         barrier(world)
         iso = prof_snapshot()
     if timers:

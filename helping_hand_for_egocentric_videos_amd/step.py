@@ -58,6 +58,7 @@ class TrainStep:
         self.enc_cus = (DP_ENC_CUS if self.comm.enabled else 0) if enc_cus is None else int(enc_cus)
         self._pending = None
         self._zeroed_idx = None
+        self.text_on_side_stream = True               # False: both towers on one stream (bench.py's kernel-alone timing steps)
         backbone.eval()                               # run/train.py:89
 
     # ------------------------------------------------------------------ forward
@@ -71,7 +72,7 @@ class TrainStep:
         cur = torch.cuda.current_stream()
         if self._text_stream is None:
             self._text_stream = torch.cuda.Stream()
-        side = self._text_stream
+        side = self._text_stream if self.text_on_side_stream else cur
         side.wait_stream(cur)
         with torch.no_grad():
             with torch.cuda.stream(side):
