@@ -521,14 +521,19 @@ __device__ __forceinline__ void spacej_chunk(const char* kc0, const char* kc1, c
     }
 }
 
-__device__ __forceinline__ void space_store_block(const f32x4 (&o)[4], float l, bf16_t* op) {
+// op: this lane's 16 columns of query row c (out + row * D + head * 64 + 16 g); the block leaves as two stores of 8 full 128-B lines
+// (common.h: hh_fullline_swap) -- called with all 64 lanes active
+__device__ __forceinline__ void space_store_block(const f32x4 (&o)[4], float l, bf16_t* op, int c, int64_t D) {
     const float inv = 1.f / l;
     const u32x4 w0 = {pack_bf16(o[0][0] * inv, o[0][1] * inv), pack_bf16(o[0][2] * inv, o[0][3] * inv),
                       pack_bf16(o[1][0] * inv, o[1][1] * inv), pack_bf16(o[1][2] * inv, o[1][3] * inv)};
     const u32x4 w1 = {pack_bf16(o[2][0] * inv, o[2][1] * inv), pack_bf16(o[2][2] * inv, o[2][3] * inv),
                       pack_bf16(o[3][0] * inv, o[3][1] * inv), pack_bf16(o[3][2] * inv, o[3][3] * inv)};
-    *(u32x4*)(op) = w0;
-    *(u32x4*)(op + 8) = w1;
+    u32x4 x, y;
+    hh_fullline_swap(w0, w1, x, y);
+    bf16_t* p0 = op - (int64_t)(c >> 3) * 8 * D + 8 * (c >> 3);       // row c & 7, piece 2 g + (c >> 3)
+    *(u32x4*)(p0) = x;
+    *(u32x4*)(p0 + 8 * D) = y;
 }
 
 template <int JB, int NTJ, bool DBG, int NWV = NWJ, int WPS = 2>
@@ -630,9 +635,9 @@ __global__ __launch_bounds__(64 * NWV, WPS) void space_attnj_kernel(const bf16_t
                 l_run = 0.f;
                 for (int t = 0; t + 1 < nt; ++t) space16_chunk<1, false>(Ks, Vs, q[j], t, lane, o2, m_run, l_run);
                 space16_chunk<1, true>(Ks, Vs, q[j], nt - 1, lane, o2, m_run, l_run);
-                space_store_block(o2, l_run, op);
+                space_store_block(o2, l_run, op, c, D);
             } else {
-                space_store_block(o[j], l_run, op);
+                space_store_block(o[j], l_run, op, c, D);
             }
         }
     }
@@ -889,9 +894,9 @@ __global__ __launch_bounds__(64 * NWV, WPS) void space_attnp_kernel(const bf16_t
             l_run = 0.f;
             for (int t = 0; t + 1 < nt; ++t) space16_chunk<1, false>(Ks, Vs, q[j], t, lane, o2, m_run, l_run);
             space16_chunk<1, true>(Ks, Vs, q[j], nt - 1, lane, o2, m_run, l_run);
-            space_store_block(o2, l_run, op);
+            space_store_block(o2, l_run, op, c, D);
         } else {
-            space_store_block(o[j], l_run, op);
+            space_store_block(o[j], l_run, op, c, D);
         }
     }
     if (cls_partial == nullptr) return;

@@ -163,10 +163,20 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
             af[dt] = (bf16x8){tr[0], tr[1], tr[2], tr[3], vcls[dt], 0, 0, 0};
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dt], pf, z4, 0, 0, 0);
         }
-        if (p0 + t * PT + c / T < n) {
+        const u32x4 w0 = {pack_bf16(o[0][0], o[0][1]), pack_bf16(o[0][2], o[0][3]), pack_bf16(o[1][0], o[1][1]), pack_bf16(o[1][2], o[1][3])};
+        const u32x4 w1 = {pack_bf16(o[2][0], o[2][1]), pack_bf16(o[2][2], o[2][3]), pack_bf16(o[3][0], o[3][1]), pack_bf16(o[3][2], o[3][3])};
+        if constexpr (T == 16) {
+            // a tile is one patch x 16 frames: the guard is wave-uniform and the 16 rows are 16 separate 128-B lines; lanes c and c ^ 8
+            // swap one piece so that each store writes 8 FULL lines (common.h: hh_fullline_swap)
+            u32x4 x, y;
+            hh_fullline_swap(w0, w1, x, y);
+            if (p0 + t * PT < n) {
+                const int64_t col = head * 64 + 16 * g + 8 * (c >> 3);
+                *(u32x4*)(out + ((int64_t)b * N + tokrow(t, c & 7)) * D + col) = x;
+                *(u32x4*)(out + ((int64_t)b * N + tokrow(t, 8 + (c & 7))) * D + col) = y;
+            }
+        } else if (p0 + t * PT + c / T < n) {
             bf16_t* op = out + ((int64_t)b * N + tokrow(t, c)) * D + head * 64 + 16 * g;
-            const u32x4 w0 = {pack_bf16(o[0][0], o[0][1]), pack_bf16(o[0][2], o[0][3]), pack_bf16(o[1][0], o[1][1]), pack_bf16(o[1][2], o[1][3])};
-            const u32x4 w1 = {pack_bf16(o[2][0], o[2][1]), pack_bf16(o[2][2], o[2][3]), pack_bf16(o[3][0], o[3][1]), pack_bf16(o[3][2], o[3][3])};
             *(u32x4*)(op) = w0;
             *(u32x4*)(op + 8) = w1;
         }
@@ -363,11 +373,13 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afk[dt], pf, z4, 0, 0, 0);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afc[dt], pfc, o[dt], 0, 0, 0);
             }
-            bf16_t* op = out + ((int64_t)b * N + tok(u, 16 * qt + c)) * D + head * 64 + 16 * g;
             const u32x4 w0 = {pack_bf16(o[0][0], o[0][1]), pack_bf16(o[0][2], o[0][3]), pack_bf16(o[1][0], o[1][1]), pack_bf16(o[1][2], o[1][3])};
             const u32x4 w1 = {pack_bf16(o[2][0], o[2][1]), pack_bf16(o[2][2], o[2][3]), pack_bf16(o[3][0], o[3][1]), pack_bf16(o[3][2], o[3][3])};
-            *(u32x4*)(op) = w0;
-            *(u32x4*)(op + 8) = w1;
+            u32x4 x, y;                                                  // 8 full 128-B lines per store (common.h: hh_fullline_swap)
+            hh_fullline_swap(w0, w1, x, y);
+            const int64_t col = head * 64 + 16 * g + 8 * (c >> 3);
+            *(u32x4*)(out + ((int64_t)b * N + tok(u, 16 * qt + (c & 7))) * D + col) = x;
+            *(u32x4*)(out + ((int64_t)b * N + tok(u, 16 * qt + 8 + (c & 7))) * D + col) = y;
         }
         if (cls_partial == nullptr) return;
         const f32x4 y0 = r.y0, y1 = r.y1;

@@ -56,3 +56,16 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// Full-line output stores for the 16-query MFMA output layout (lane (c = lane & 15, g = lane >> 4) holds 32 B of row c: w0 = bytes
+// [32 g, 32 g + 16), w1 = the next 16).  Stored as they are, one instruction covers 16 rows x four 16-B pieces -- 16 partial lines,
+// ~270 cycles on the CU's store path against ~77 for 8 rows x 128 B (scripts/store_probe.hip).  Here lanes c and c ^ 8 swap one piece
+// (DPP row_ror:8, two bank-masked moves per dword): `x` then holds, for row c & 7, piece 2 g + (c >> 3) of that row's 128 B, `y` the same
+// for row 8 + (c & 7): two instructions of 8 full 128-B lines each.  All 64 lanes must be active.
+__device__ __forceinline__ void hh_fullline_swap(const u32x4& w0, const u32x4& w1, u32x4& x, u32x4& y) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[i] = (unsigned)__builtin_amdgcn_update_dpp((int)w0[i], (int)w1[i], 0x128, 0xF, 0xC, false);     // lanes 8..15 of a row: w1 of lane c - 8
+        y[i] = (unsigned)__builtin_amdgcn_update_dpp((int)w1[i], (int)w0[i], 0x128, 0xF, 0x3, false);     // lanes 0..7: w0 of lane c + 8
+    }
+}
