@@ -18,7 +18,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 void hh_set_error(const char* fmt, ...);
 int hh_check_launch(const char* what);
-int hh_stream_cu_count(hipStream_t s);      // CUs the stream may use (runtime.cpp)
+int hh_stream_cu_count(hipStream_t s);
+int hh_stream_slot(hipStream_t s);          // 0..31, or -1 when more than 32 streams have launched persistent GEMMs      // CUs the stream may use (runtime.cpp)
 
 // device timing of one kernel launch (runtime.cpp: hh_prof_enable / hh_prof_read); `work` = algorithmic flops or bytes of the launch
 struct HHProfScope {

@@ -247,6 +247,8 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
     p.M = M; p.N = N; p.K = K; p.e = *epi;
     p.m_start = 0;
     p.skew_iters = 0;
+    p.dynamic = 0;
+    p.tile_slot = 0;
     p.group_m = 4;
     p.debug_nostore = 0;
     p.debug_ts = 0;

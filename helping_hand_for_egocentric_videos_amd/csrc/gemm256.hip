@@ -563,12 +563,14 @@ __global__ __launch_bounds__(512, 2) void gemm256d_kernel(GemmParams p) {
 
 // ---- tuning state.  hh_set_tuning() is the library's ONLY process-global mutable state besides the per-stream CU budget table
 // (runtime.cpp); no entry point reads the environment.  The knobs select between kernels that compute the same result.
-static int g_debug_ts = 0;         // debug: record the per-tile timeline of the persistent kernel
+static int g_debug_ts = 0;         // debug: record the per-tile timeline of the persistent kernel (1: every launch, last one wins; n > 1: only the n-th launch after the knob was set)
+static int g_ts_count = 0;
 static int g_nostore = 0;          // debug: skip the epilogue stores (timing experiments only)
 static int g_group = 0;            // m-tiles per XCD-local group (weight-panel reuse factor); 0 = per-shape default
 static int g_pskew = 0;            // persistent kernel: start skew quantum (s_sleep(8) units per workgroup index in its XCD)
 static int g_skew = -1;            // start skew of the one-tile-per-block kernel: -1 auto (on with an fp32 residual), 0 off, 1 on
 static int g_mode = 5;             // "gemm256": 0 = 128x128 kernel only, 1 = one tile per block, 2 = + wave-row stagger, 3 = persistent 8-wave kernel, 4 = 4-wave kernel of gemm256w4.hip, one tile per block, 5 = persistent 4-wave kernel where K allows, else 3 (default)
+static int g_dynamic = 1;           // "gemm256_dynamic": 4-wave persistent kernel takes its tiles from per-XCD atomic counters (1, default) or by static stride (0)
 static int g_tail = 1;             // "gemm_tail": 1 = row tails of <= 64 rows inside the persistent kernel (in <= 32-row pieces), else the split-K-in-workgroup tail kernel (gemm.hip); 2 = always the tail kernel; 0 = the 128x128 kernel
 
 int hh_tuning_gemm_tail() { return g_tail; }
@@ -592,7 +594,8 @@ extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm256_skew")) { g_skew = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_pskew") && value >= 0 && value <= 64) { g_pskew = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_debug_nostore")) { g_nostore = value; return HH_OK; }
-    if (name && !strcmp(name, "gemm256_debug_ts")) { g_debug_ts = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm256_debug_ts")) { g_debug_ts = value; g_ts_count = 0; return HH_OK; }
+    if (name && !strcmp(name, "gemm256_dynamic") && (value == 0 || value == 1)) { g_dynamic = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_group") && value >= 0 && value <= 64) { g_group = value; return HH_OK; }
     hh_set_error("hh_set_tuning: unknown knob '%s' or value %d out of range", name ? name : "(null)", value);
     return HH_ERR_UNSUPPORTED;
@@ -640,7 +643,7 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
     const int GROUP = g_group > 0 ? g_group : ((p.N / 256 <= 12 && p.K <= 1024) ? 16 : 8);
     p.group_m = GROUP;
     p.debug_nostore = g_nostore;
-    p.debug_ts = g_debug_ts;
+    p.debug_ts = g_debug_ts == 1;
     const int per_xcd_mt = (p.Mt + 7) / 8;
     const int groups = (per_xcd_mt + GROUP - 1) / GROUP;
     const unsigned grid = 8u * (unsigned)groups * GROUP * (unsigned)p.Nt;
@@ -657,7 +660,11 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
             const unsigned pg = grid < (unsigned)ncu ? grid : (unsigned)ncu;
             p.skew_iters = g_pskew;
             HHProfScope prof(HH_PROF_GEMM256, 2.0 * (double)p.M * p.N * p.K, s);
-            if (g_mode == 5 && p.K >= 384 && p.K % 128 == 0 && p.N <= 4096) {      // (N: bias vector + epilogue scratch share the 32 KB of LDS the ring leaves)
+            if (g_debug_ts > 1) p.debug_ts = (++g_ts_count == g_debug_ts);
+            if (g_mode == 5 && p.K >= 384 && p.K % 128 == 0 && p.N <= 4096) {
+                const int slot = g_dynamic ? hh_stream_slot(s) : -1;
+                p.dynamic = slot >= 0;
+                p.tile_slot = slot >= 0 ? slot : 0;      // (N: bias vector + epilogue scratch share the 32 KB of LDS the ring leaves)
                 int rc = hh_gemm256w4p_launch(p, epi, pg, s);
                 if (tail_done) *tail_done = p.tail_rows > 0;
                 return rc;

@@ -461,6 +461,10 @@ __device__ __forceinline__ void w4p_store_rows_direct(const GemmParams& p, int64
     if constexpr (IDX + 1 < 8) w4p_store_rows_direct<OUT_BF16, EPI, IDX + 1>(p, rowbase, sc, bias_v, ccol);
 }
 
+// Dynamic tile walk: per stream slot (runtime.cpp: hh_stream_slot) 8 per-XCD tile counters + the count of finished workgroups; the last
+// workgroup of a launch zeroes them again (kernels of one stream never overlap).  Zero-initialised device memory, no allocation.
+__device__ unsigned g_w4_tile_cnt[32][16];
+
 template <bool OUT_BF16, int EPI>
 __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
     constexpr int STORES = OUT_BF16 ? 32 : 64;                // global_store_dwordx4 per wave and tile in the epilogue (checked in the ISA)
@@ -473,27 +477,42 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
     const int GROUP = p.group_m;
     const int per = GROUP * p.Nt;
     const int nk = p.K / 64;                                  // even (K % 128 == 0) and >= 6, checked by the launcher
-    const int vmax = 8 * ((((p.Mt + 7) / 8) + GROUP - 1) / GROUP) * GROUP * p.Nt;
-    auto decode = [&](int v, int64_t& m0, int& n0) -> bool {
-        const int xcd = v & 7, j = v >> 3;
-        const int kg = j / per, r = j % per;
-        const int nt_i = r / GROUP, mi = r % GROUP;
-        const int mt = xcd + 8 * (kg * GROUP + mi);
-        m0 = (int64_t)mt * 256;
+    // ---- tile walk.  XCD x (= blockIdx & 7) owns the m-tiles x, x + 8, ... and walks them in groups of GROUP m-tiles x all n-tiles
+    // (n-major inside a group: GROUP workgroups share a W panel, consecutive ones an A panel); its tiles have the dense indices
+    // 0 .. tiles_x - 1.  A workgroup's first tile is static (index blockIdx >> 3); every further one comes from the XCD's atomic counter
+    // (p.dynamic), fetched one tile ahead: a workgroup that starts late or runs beside another stream's kernels simply takes fewer
+    // tiles -- with equal static shares every delayed workgroup delayed the whole launch (the step's first GEMMs, which run beside the
+    // text tower and the previous step's decoder, spanned up to 5x their own work).
+    const int xcd = blockIdx.x & 7, nwx = gridDim.x >> 3;
+    const int mtx = p.Mt > xcd ? (p.Mt - xcd + 7) / 8 : 0;    // m-tiles of this XCD
+    const int tiles_x = mtx * p.Nt;
+    const int gfull = mtx / GROUP, grem = mtx % GROUP;
+    auto decode = [&](int d, int64_t& m0, int& n0) {
+        int kg, nt_i, mi;
+        if (d < gfull * per) { kg = d / per; const int r = d % per; nt_i = r / GROUP; mi = r % GROUP; }
+        else { const int r = d - gfull * per; kg = gfull; nt_i = r / grem; mi = r % grem; }
+        m0 = (int64_t)(xcd + 8 * (kg * GROUP + mi)) * 256;
         n0 = nt_i * 256;
-        return mt < p.Mt;
     };
-    auto next_valid = [&](int v, int64_t& m0, int& n0) -> int {
-        for (; v < vmax; v += gridDim.x)
-            if (decode(v, m0, n0)) return v;
-        return -1;
+    unsigned* tcnt = g_w4_tile_cnt[p.tile_slot];
+    // a workgroup is done with the counters once its last fetch has returned; the last one to say so resets them for the next launch
+    auto finish = [&]() {
+        if (p.dynamic && tid == 0) {
+            const unsigned done = atomicAdd(tcnt + 8, 1u);
+            if (done == gridDim.x - 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) atomicExch(tcnt + i, 0u);
+            }
+        }
     };
-    int64_t m0, nm0 = 0;
-    int n0, nn0 = 0;
-    int v = next_valid(blockIdx.x, m0, n0);
+    int64_t m0 = 0, nm0 = 0;
+    int n0 = 0, nn0 = 0;
+    int d = blockIdx.x >> 3;                                  // dense index of the current tile
+    const bool any = d < tiles_x;
+    if (any) decode(d, m0, n0);
     if (p.tail_rows > 0)
         for (int piece = blockIdx.x; piece < (p.N / 32) * ((p.tail_rows + 31) / 32); piece += gridDim.x) w4_tail_piece<OUT_BF16>(p, piece, (float*)smem, tid);
-    if (v < 0) return;
+    if (!any) { finish(); return; }
 
     W4State s;
     // ---- staging: wave w stages pieces 4w .. 4w+3 (8 rows each) of every half-tile
@@ -580,17 +599,33 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
     bool first = true;
     for (;;) {
         stamp(0);
-        const int nv = next_valid(v + gridDim.x, nm0, nn0);
-        const bool has_next = nv >= 0;
+        // the walk's next tile: static stride, or (dynamic) one atomic fetch by lane 0 of wave 0 -- issued here, older than every DMA of
+        // this tile, so the counted waits of the first iteration's last edges (whose half-tiles are younger) have retired it
+        unsigned tk = 0;
+        if (p.dynamic && tid == 0) {
+            const unsigned zero = 0, one = 1;
+            asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk) : "v"(zero), "v"(one), "s"(tcnt + xcd) : "memory");
+        }
+        stamp(1);
+        if (first) w4_iter<W4V_FIRST0, VM_ST>(s); else w4_iter<W4V_NEXT0, VM_ST>(s);
+        for (int t = 2; t < nk - 4; t += 2) w4_iter<W4V_MID, VM_ST>(s);
+        int nd = d + nwx;
+        if (p.dynamic) {                                       // publish the fetched index to the four waves (one barrier per tile)
+            volatile __attribute__((address_space(3))) unsigned* slot = (volatile __attribute__((address_space(3))) unsigned*)(smem + 2 * W4_BUF + p.N * 4 + 4 * 4096 - 16);      // (the end of the epilogue scratch, idle between epilogues)
+            if (tid == 0) { asm volatile("" : "+v"(tk)); *slot = tk; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W4_BARRIER();
+            nd = __builtin_amdgcn_readfirstlane((int)*slot) + nwx;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const bool has_next = nd < tiles_x;
         if (has_next) {
+            decode(nd, nm0, nn0);
             const char* nA = (const char*)(p.A + nm0 * p.lda);
             const char* nW = (const char*)(p.W + (int64_t)nn0 * p.ldw);
             s.nAL = nA; s.nAH = nA + hiA; s.nWL = nW; s.nWH = nW + hiW;
         }
         asm volatile("" : "+s"(s.nAL), "+s"(s.nAH), "+s"(s.nWL), "+s"(s.nWH));
-        stamp(1);
-        if (first) w4_iter<W4V_FIRST0, VM_ST>(s); else w4_iter<W4V_NEXT0, VM_ST>(s);
-        for (int t = 2; t < nk - 4; t += 2) w4_iter<W4V_MID, VM_ST>(s);
         if (has_next) { w4_iter<W4V_REBASE, VM_ST>(s); w4_iter<W4V_MID, VM_ST>(s); }
         else { w4_iter<W4V_REBASE_LAST, VM_ST>(s); w4_iter<W4V_TAIL_LAST, VM_ST>(s); }
         stamp(2);
@@ -631,9 +666,10 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
         stamp(4);
         ++tile_i;
         if (!has_next) break;
-        v = nv; m0 = nm0; n0 = nn0;
+        d = nd; m0 = nm0; n0 = nn0;
         first = false;
     }
+    finish();
 #undef W4_STAGE
 }
 

@@ -56,6 +56,19 @@ int hh_stream_cu_count(hipStream_t s) {
     return device_cus();
 }
 
+// Slot (0 .. 31) of a stream in the library's per-stream device state (the dynamic tile counters of the persistent GEMM): kernels on one
+// stream run one after the other, so one slot per stream is never shared by two running kernels.  -1: table full (callers fall back).
+static hipStream_t g_slot_stream[32];
+static int g_slot_n = 0;
+int hh_stream_slot(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_budget_mu);
+    for (int i = 0; i < g_slot_n; ++i)
+        if (g_slot_stream[i] == s) return i;
+    if (g_slot_n == 32) return -1;
+    g_slot_stream[g_slot_n] = s;
+    return g_slot_n++;
+}
+
 extern "C" int hh_stream_set_cu_budget(hh_stream_t stream, int n_cus) {
     const int ncu = device_cus();
     if (n_cus == 0) n_cus = ncu;
@@ -65,7 +78,15 @@ extern "C" int hh_stream_set_cu_budget(hh_stream_t stream, int n_cus) {
     }
     std::lock_guard<std::mutex> lk(g_budget_mu);
     for (int i = 0; i < g_budget_n; ++i)
-        if (g_budget_stream[i] == (hipStream_t)stream) { g_budget_cus[i] = n_cus; return HH_OK; }
+        if (g_budget_stream[i] == (hipStream_t)stream) {
+            if (n_cus == ncu) {                                  // back to the default: the entry leaves the table
+                --g_budget_n;
+                g_budget_stream[i] = g_budget_stream[g_budget_n];
+                g_budget_cus[i] = g_budget_cus[g_budget_n];
+            } else g_budget_cus[i] = n_cus;
+            return HH_OK;
+        }
+    if (n_cus == ncu) return HH_OK;
     if (g_budget_n == 16) { hh_set_error("hh_stream_set_cu_budget: more than 16 budgeted streams"); return HH_ERR_UNSUPPORTED; }
     g_budget_stream[g_budget_n] = (hipStream_t)stream;
     g_budget_cus[g_budget_n++] = n_cus;

@@ -28,13 +28,18 @@ def report(tag, t):
         tag, np.percentile(s0, 50), np.percentile(s0, 90), np.percentile(s0, 99), s0.max(), end.max() - start.min(), np.median(end - start), (end - start).max()), flush=True)
 for _ in range(3): ts.step(batch, next_batch=batch)
 torch.cuda.synchronize()
-ops.set_tuning("gemm256_debug_ts", 1)
-for rep in range(1):
-    ts.step(batch, next_batch=batch); torch.cuda.synchronize()
-    report("pipelined step", timeline())
-for tail in (1, 2):
-    ops.set_tuning("gemm_tail", tail)
-    ts.encode(batch["video"], batch["text"]); torch.cuda.synchronize()
-    report("towers only, gemm_tail=%d" % tail, timeline())
-ops.set_tuning("gemm_tail", 1)
-ops.set_tuning("gemm256_debug_ts", 0)
+def busy(tag, t, tiles):
+    t = t[:, :tiles]
+    start = t[:, 0, 0] / 100.0
+    end = t[:, tiles - 1, 4] / 100.0
+    b = end - start
+    print("%-34s span %.1f us | per-workgroup busy over its first %d tiles: p10 %.1f p50 %.1f p90 %.1f max %.1f us | start spread p90 %.1f max %.1f" % (
+        tag, end.max() - start.min(), tiles, np.percentile(b, 10), np.median(b), np.percentile(b, 90), b.max(), np.percentile(start - start.min(), 90), (start - start.min()).max()), flush=True)
+# persistent launches of a step in order: per vision block qkv_t, proj_t, qkv_s, proj_s, fc1, fc2 (+ text tower / decoder launches beside them)
+for nth in (26, 28, 30, 32, 34, 36, 38):
+    for mode, run in (("pipelined", lambda: ts.step(batch, next_batch=batch)), ("towers only", lambda: ts.encode(batch["video"], batch["text"]))):
+        torch.cuda.synchronize()
+        ops.set_tuning("gemm256_debug_ts", nth)
+        run(); torch.cuda.synchronize()
+        ops.set_tuning("gemm256_debug_ts", 0)
+        busy("launch %3d %s" % (nth, mode), timeline(), 8)

@@ -18,6 +18,11 @@ def timed(f, n=8, w=3):
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
 for rnd in range(2):
+    ts.text_on_side_stream = False
+    e1 = timed(lambda: ts.encode(batch["video"], batch["text"]))
+    p1 = timed(lambda: ts.step(batch, next_batch=batch))
+    ts.text_on_side_stream = True
+    print(f"text tower on the SAME stream: both towers {e1:7.2f} ms | pipelined step {p1:7.2f} ms", flush=True)
     e = timed(lambda: ts.encode(batch["video"], batch["text"]))
     v = timed(lambda: bb.visual.forward_features(batch["video"], out_dtype=torch.bfloat16))
     p = timed(lambda: ts.step(batch, next_batch=batch))

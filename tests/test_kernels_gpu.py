@@ -167,6 +167,36 @@ def test_gemm_four_wave_kernels_match_the_eight_wave_kernel(mode, M, N, K, kw):
         ops.set_tuning("gemm256", ops.GEMM256_DEFAULT)
 
 
+@pytest.mark.parametrize("M,N,K", [(256 * 37 + 20, 1024, 1024), (256 * 300, 256, 512), (256 * 20, 4096, 768), (256 * 77, 3072, 384)])
+def test_gemm_dynamic_tile_walk_matches_the_static_one(M, N, K):
+    """hh_set_tuning("gemm256_dynamic", 1) (default): a workgroup of the persistent 4-wave kernel takes every tile after its first from
+    its XCD's atomic counter; the counters are per stream and zeroed again by the launch's last workgroup.  Same tiles, same results
+    as the static stride, launch after launch, on two streams at once, with a CU budget, with ragged m-tile counts per XCD."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = (torch.randn(M, K, device=DEV, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    ops.set_tuning("gemm256_dynamic", 0)
+    try:
+        ref = ops.gemm(a, w, bias)
+    finally:
+        ops.set_tuning("gemm256_dynamic", 1)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ops.set_stream_cu_budget(s2, 64)
+    for s_ in (s1, s2):
+        s_.wait_stream(torch.cuda.current_stream())
+    outs = []
+    for rep in range(4):
+        for s_ in (s1, s2):
+            with torch.cuda.stream(s_):
+                outs.append(ops.gemm(a, w, bias))
+        outs.append(ops.gemm(a, w, bias))
+    torch.cuda.synchronize()
+    ops.set_stream_cu_budget(s2, 0)
+    for o in outs:
+        assert torch.equal(o, ref)
+
+
 def test_stream_cu_budget_changes_the_grid_not_the_results():
     """hh_stream_set_cu_budget: persistent GEMMs launched on a budgeted stream walk their tiles with fewer workgroups."""
     g = torch.Generator(device=DEV).manual_seed(5)
