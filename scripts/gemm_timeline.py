@@ -14,7 +14,6 @@ for name, N, K, kw in [("qkv", 3072, 1024, dict(colscale=0.125, colscale_cols=10
     bias = torch.randn(N, device="cuda", generator=g)
     for mode, dbg in [(3, 0)] + [(5, d) for d in dbgs]:
         ops.set_tuning("gemm256", mode)
-        ops.set_tuning("gemm256_debug_nostore", dbg)
         for _ in range(3): ops.gemm(a, w, bias, **kw)
         ops.set_tuning("gemm256_debug_ts", 1)
         ops.gemm(a, w, bias, **kw); torch.cuda.synchronize()
@@ -33,4 +32,4 @@ for name, N, K, kw in [("qkv", 3072, 1024, dict(colscale=0.125, colscale_cols=10
         pre_us = (t[:, :, 3] - t[:, :, 2]).mean() / 100.0
         print("%-4s mode %d dbg %2d: cycles / k-tile %.0f (p10 %.0f p90 %.0f)  main loop %.2f us  clock %.0f MHz  between loops %.2f us (%.0f cycles; bias %.2f, stores %.2f us)" % (
             name, mode, dbg, cyc.mean(), np.percentile(cyc, 10), np.percentile(cyc, 90), loop_us.mean(), mhz.mean(), gap_us.mean(), gap_us.mean() * mhz.mean(), pre_us, epi_us), flush=True)
-ops.set_tuning("gemm256", ops.GEMM256_DEFAULT); ops.set_tuning("gemm256_debug_nostore", 0)
+ops.set_tuning("gemm256", ops.GEMM256_DEFAULT)
