@@ -571,6 +571,7 @@ static int g_pskew = 0;            // persistent kernel: start skew quantum (s_s
 static int g_skew = -1;            // start skew of the one-tile-per-block kernel: -1 auto (on with an fp32 residual), 0 off, 1 on
 static int g_mode = 5;             // "gemm256": 0 = 128x128 kernel only, 1 = one tile per block, 2 = + wave-row stagger, 3 = persistent 8-wave kernel, 4 = 4-wave kernel of gemm256w4.hip, one tile per block, 5 = persistent 4-wave kernel where K allows, else 3 (default)
 static int g_dynamic = 1;           // "gemm256_dynamic": 4-wave persistent kernel takes its tiles from per-XCD atomic counters (1, default) or by static stride (0)
+static int g_min_tiles = 192;       // "gemm256_min_tiles": fewest 256x256 tiles for which the 256x256 kernels are used
 static int g_tail = 1;             // "gemm_tail": 1 = row tails of <= 64 rows inside the persistent kernel (in <= 32-row pieces), else the split-K-in-workgroup tail kernel (gemm.hip); 2 = always the tail kernel; 0 = the 128x128 kernel
 
 int hh_tuning_gemm_tail() { return g_tail; }
@@ -596,6 +597,7 @@ extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm256_debug_nostore")) { g_nostore = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_debug_ts")) { g_debug_ts = value; g_ts_count = 0; return HH_OK; }
     if (name && !strcmp(name, "gemm256_dynamic") && (value == 0 || value == 1)) { g_dynamic = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm256_min_tiles") && value >= 1 && value <= 4096) { g_min_tiles = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_group") && value >= 0 && value <= 64) { g_group = value; return HH_OK; }
     hh_set_error("hh_set_tuning: unknown knob '%s' or value %d out of range", name ? name : "(null)", value);
     return HH_ERR_UNSUPPORTED;
@@ -604,9 +606,14 @@ extern "C" int hh_set_tuning(const char* name, int value) {
 #define P_LDS(N) (2 * BUF_BYTES + (size_t)(N) * 4)       // persistent kernel: two staging buffers + the bias vector
 
 bool hh_gemm256_eligible(const GemmParams& p) {
-    // at least ~3/4 of the CUs must get a 256x256 tile: below that the 128x128 kernel (4x the tiles, two workgroups per CU) wins --
-    // measured on the text tower's N = 768 shapes at M = 12320 (147 tiles): 43 vs 65 us (K = 768), 97 vs 152 us (K = 3072)
-    return g_mode > 0 && p.N % 256 == 0 && p.M >= 2048 && p.e.splitk <= 1 && (p.M / 256) * (p.N / 256) >= 192;
+    // at least ~3/4 of the CUs must get a 256x256 tile for the 8-wave kernels: below that the 128x128 kernel (4x the tiles, two workgroups
+    // per CU) wins -- measured on the text tower's N = 768 shapes at M = 12320 (147 tiles): 43 vs 65 us (K = 768), 97 vs 152 us (K = 3072).
+    // The persistent 4-wave kernel wins from half the CUs on (same shapes, 144 tiles: 30.4 vs 34.4 us and 75 vs 91 us alone, and it
+    // holds 144 CUs instead of all of them beside the vision tower): "gemm256_min_tiles" / 128 for the shapes it takes
+    const bool w4 = g_mode == 5 && p.K >= 384 && p.K % 128 == 0 && p.N <= 4096 && p.e.resid == nullptr && p.e.remap_group == 0 &&
+                    (p.e.colscale_cols == 0 || (p.e.act == HH_ACT_NONE && p.e.colscale_cols % 128 == 0));
+    const int min_tiles = (w4 && g_min_tiles == 192) ? 128 : g_min_tiles;
+    return g_mode > 0 && p.N % 256 == 0 && p.M >= 2048 && p.e.splitk <= 1 && (p.M / 256) * (p.N / 256) >= min_tiles;
 }
 
 int hh_gemm256w4_launch(const GemmParams& p, unsigned grid, hipStream_t s);      // gemm256w4.hip (4 waves x 128x128, one tile per workgroup)

@@ -44,6 +44,8 @@ int hh_version(void);
  *                   split-K-in-workgroup kernel; 0 = on the 128x128 kernel.  Same results in all three.
  *   "gemm256_dynamic" 1 (default) = the persistent 4-wave kernel takes every tile after a workgroup's first from per-XCD atomic counters
  *                   (per launch stream, zeroed again by the launch's last workgroup), 0 = static stride
+ *   "gemm256_min_tiles" fewest 256x256 tiles for which the 256x256 kernels are used (default 192; the persistent 4-wave kernel takes
+ *                   its shapes from 128 tiles on); smaller GEMMs run on the 128x128 kernel
  *   "gemm256_group" m-tiles per XCD-local group of the tile walk (0 = per-shape default)
  *   "gemm256_skew"  -1 auto / 0 off / 1 on: start-time skew of the one-tile-per-block kernel (spreads the epilogue HBM bursts)
  *   "gemm256_pskew" 0..64: start skew quantum of the persistent kernel (default 0)
