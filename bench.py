@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 from helping_hand_for_egocentric_videos_amd import C1, C2, C4, ops, synth  # noqa: E402
 from helping_hand_for_egocentric_videos_amd.model import LaviLa, tfm_decoder  # noqa: E402
-from helping_hand_for_egocentric_videos_amd.step import McqScorer, TrainStep, mcq_forward  # noqa: E402
+from helping_hand_for_egocentric_videos_amd.step import McqScorer, TrainStep, first_clips_check, mcq_forward  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
@@ -66,16 +66,25 @@ def prof_read(name):
     return n.value, seen.value, ms.value, work.value
 
 
+def prof_kernel_name(name):
+    """The kernel (template instantiation as rocprofv3 prints it) the library dispatched for the class's last launch (hh_prof_kernel_name)."""
+    from helping_hand_for_egocentric_videos_amd import _lib
+    r = _lib.lib().hh_prof_kernel_name(PROF[name])
+    return r.decode() if r else ""
+
+
 def prof_snapshot():
-    return {k: prof_read(k) for k in PROF}
+    snap = {k: prof_read(k) for k in PROF}
+    snap["names"] = {k: prof_kernel_name(k) for k in PROF}
+    return snap
 
 
-def pmc_traffic(kernel_substr, tag_order=("r3", "r2", "r1")):
-    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/<round>_pmc_summary.json: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction); launch-weighted mean over the template
-    instantiations whose name contains `kernel_substr`.  Returns (bytes, file) or (None, None)."""
+def pmc_traffic(kernel_substr, cfg_tag="", tag_order=("r4", "r3", "r2", "r1")):
+    """HBM-side bytes per launch of a kernel from the COMMITTED PMC passes of the same configuration (profiles/<round>_[c4_]pmc_summary.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction); launch-weighted mean over the
+    template instantiations whose name contains `kernel_substr`.  NOT measured in this run.  Returns (bytes, file) or (None, None)."""
     for tag in tag_order:
-        path = os.path.join(ROOT, "profiles", tag + "_pmc_summary.json")
+        path = os.path.join(ROOT, "profiles", tag + "_" + cfg_tag + "pmc_summary.json")
         if not os.path.exists(path):
             continue
         with open(path) as f:
@@ -84,6 +93,32 @@ def pmc_traffic(kernel_substr, tag_order=("r3", "r2", "r1")):
         if n:
             return int(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in rows) / n), os.path.basename(path)
     return None, None
+
+
+def rocprof_committed(kernel_substr, cfg_tag="", pipelined=True, tag_order=("r4", "r3")):
+    """Average duration per launch (us) and launch count of the kernels whose name contains `kernel_substr` in the committed rocprofv3
+    --kernel-trace --stats CSV of the same bench command (profiles/<round>_[c4_]{bench,unpipelined}_kernel_stats.csv).  -> dict or None."""
+    import csv
+    for tag in tag_order:
+        path = os.path.join(ROOT, "profiles", "%s_%s%s_kernel_stats.csv" % (tag, cfg_tag, "bench" if pipelined else "unpipelined"))
+        if not os.path.exists(path):
+            continue
+        calls, total_ns = 0, 0.0
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if kernel_substr in row.get("Name", ""):
+                    calls += int(row["Calls"]); total_ns += float(row["TotalDurationNs"])
+        if calls:
+            return {"avg_launch_us": round(total_ns / calls / 1e3, 1), "launches": calls, "total_ms": round(total_ns / 1e6, 2), "file": os.path.basename(path)}
+    return None
+
+
+def gemm_algorithmic_bytes(cfg, B):
+    """Operand + result bytes of the vision tower's six GEMMs per block (bf16: A [M,K] and W [N,K] read once, C [M,N] written once),
+    launch-weighted mean per launch -- what the PMC traffic of the persistent GEMM is compared with."""
+    M, D = B * cfg.tokens, cfg.embed_dim
+    shapes = [(3 * D, D)] * 2 + [(D, D)] * 2 + [(4 * D, D), (D, 4 * D)]          # (N, K): qkv x2, proj x2, fc1, fc2
+    return int(sum(2 * (M * K + N * K + M * N) for N, K in shapes) / len(shapes))
 
 
 def _read_timeline():
@@ -174,7 +209,7 @@ def cpu_baseline(cfg, enc_sd, dec_sd, seed):
     """Oracle (CPU restatement, fp32) timed on this host: (a) one full training step on ONE clip of the headline workload (config
     2), with the thread count that is fastest on the 256-thread GPU host (16; more threads run slower) and with 8 threads (the dev
     container's core count); (b) BASELINE config 1 exactly -- the reference's own CPU-runnable case,
-    run/train.py:103-203 with T = 4, num_queries = 4, batch = 2."""
+    run/train.py:103-203 with T = 4, num_queries = 4, batch = 2; (c) BASELINE config 5 -- one EgoMCQ item forward."""
     from oracle import step as OS
 
     def timed(c, esd, dsd, batch, threads, iters):
@@ -204,6 +239,15 @@ def cpu_baseline(cfg, enc_sd, dec_sd, seed):
     rec["c1"] = {"value": round(2 * s1, 4), "unit": "clips/s", "cores": cores, "kind": "port", "ms_per_step": round(1e3 / s1, 1),
                  "sample": "BASELINE config 1 exactly (4-frame 224p, num_queries=4, batch=2): oracle fp32 full step fwd+bwd+AdamW, %d threads, "
                            "1 warm-up + 3 timed steps (%.1f s)" % (cores, dt1)}
+    # (c) BASELINE config 5: one EgoMCQ item (5 candidate clips + 1 query text), forward only -- run/test_EgoMCQ.py:56-83
+    torch.set_num_threads(cores)
+    item = synth.make_mcq_item(cfg, 1, seed=seed)
+    t = time.time()
+    OS.mcq_forward(enc_sd, dec_sd, item["video"], item["text"], cfg)
+    dt5 = time.time() - t
+    rec["c5"] = {"value": round(5 / dt5, 4), "unit": "clips/s", "cores": cores, "kind": "port", "s_per_item": round(dt5, 2),
+                 "sample": "BASELINE config 5: ONE EgoMCQ item (5 clips of T=%d %dpx + 1 query), oracle fp32 forward + scoring, %d threads, 1 timed call "
+                           "(%.1f s; thread pool warm from the legs above)" % (cfg.num_frames, cfg.img_size, cores, dt5)}
     return rec
 
 
@@ -256,14 +300,19 @@ def timed_region(run, steps, warmup, world, timers, stats_steps=0):
     return dt, per, region, out
 
 
-def step_stats(per):
+def step_stats(per, drop_first=False):
+    """drop_first: in a pipelined region the first step's frozen towers already ran during the warm-up step before it (the step is
+    ~half as long as a steady-state one): it is left out of the statistics (it IS part of `value`, whose K steps are the contract)."""
     import statistics
+    if drop_first and len(per) > 2:
+        per = per[1:]
     s = sorted(per)
     q = lambda f: s[min(len(s) - 1, int(round(f * (len(s) - 1))))]
     return {"steps": len(per), "ms_per_step_mean": round(sum(per) / len(per), 3), "ms_per_step_std": round(statistics.pstdev(per), 3) if len(per) > 1 else 0.0,
             "ms_per_step_p50": round(q(0.5), 3), "ms_per_step_p95": round(q(0.95), 3), "ms_per_step_min": round(s[0], 3),
             "ms_per_step_max": round(s[-1], 3), "timing": "device events on the main stream after every step (the pipelined encoder of step i+1 overlaps step i, so a step's own "
-            "interval is what the steady state delivers); when --steps < 50 the statistics continue past the timed region up to 50 steps"}
+            "interval is what the steady state delivers); when --steps < 50 the statistics continue past the timed region up to 50 steps"
+            + ("; the region's first step (towers prefetched during warm-up) is left out" if drop_first else "")}
 
 
 def rate(rec, key, scale):
@@ -271,23 +320,38 @@ def rate(rec, key, scale):
     return (work / (ms * 1e-3) / scale, n, seen, ms) if n and ms > 0 else (None, n, seen, ms)
 
 
-def roofline_records(region, iso, dt_ms, pipelined, cfg):
-    """`roofline` (dominant kernel: the persistent GEMM, MFMA-bound) and `attention_roofline` (HBM-bound kernels) from the library's
+def roofline_records(region, iso, dt_ms, pipelined, cfg, B):
+    """dt_ms: wall time of the whole timed region.  `roofline` (dominant kernel: the persistent GEMM, MFMA-bound) and `attention_roofline` (HBM-bound kernels) from the library's
     own event timers.  Algorithmic work: 2*M*N*K of the full 256-row tiles per GEMM launch; 8*N*D bytes per clip and attention call
-    (q, k, v read + o written, bf16); bytes read + written for add+LayerNorm."""
+    (q, k, v read + o written, bf16); bytes read + written for add+LayerNorm.  Kernel labels are what the
+    library dispatched (hh_prof_kernel_name), not names composed here."""
     roof, att = None, {}
+    names = region.get("names", {})
+    cfg_tag = "c4_" if (cfg.num_frames == 32 and cfg.img_size == 336) else ""
+    have_profile = cfg_tag == "c4_" or (cfg.num_frames == 16 and cfg.img_size == 224)
     ach, n, seen, ms = rate(region, "gemm256", 1e12)
     if ach is not None:
-        traffic, src = pmc_traffic("gemm256w4p_kernel<true")
+        traffic, src = pmc_traffic("gemm256w4p_kernel<true", cfg_tag) if have_profile else (None, None)
+        alg_bytes = gemm_algorithmic_bytes(cfg, B)
         roof = {"kernel": "gemm256w4p_kernel (persistent 256x256x64 bf16 MFMA GEMM: 4 waves x 128x128, one wave per SIMD, continuous half-tile LDS-DMA stream across tiles) -- every template instantiation, nothing else",
+                "last_dispatched": names.get("gemm256", ""),
                 "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": traffic,
-                "traffic_note": "HBM-side bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/%s, config 2, B=32); algorithmic bytes per launch average 0.99e9" % src,
+                "traffic": traffic, "traffic_from_committed_pmc": traffic,
+                "traffic_note": ("HBM-side bytes per launch, NOT measured in this run: launch-weighted mean over gemm256w4p_kernel<true, *> in the committed "
+                                 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration (profiles/%s; FETCH_SIZE doubled per the gfx950 correction)" % src) if src else None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "algorithmic_bytes_note": "A [M,K] + W [N,K] read once + C [M,N] written once, bf16, mean over the vision tower's six GEMMs per block (qkv x2, proj x2, fc1, fc2) at M = %d" % (B * cfg.tokens),
+                "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
                 "algorithmic_work": "2*M*N*K of the full 256-row tiles of each launch (DESIGN.md section 5)",
                 "launches_timed": n, "launches_in_region": seen,
-                "timing": "library-side HIP events around the kernel launch alone (hh_prof_enable), every %dth launch, on the launch stream" % STRIDE,
-                "avg_launch_us": round(ms * 1e3 / n, 1), "share_of_step": round(ms * STRIDE / dt_ms, 3),
+                "timing": "library-side HIP events recorded on the launch stream right before and right after the kernel launch (hh_prof_enable), every %dth launch; in a pipelined "
+                          "region the bracket also holds the time the dispatch waits for CUs held by the other streams' kernels, which rocprofv3's per-dispatch duration does "
+                          "not -- `rocprofv3_committed` is that figure from the committed profile of the same command" % STRIDE,
+                "avg_launch_us": round(ms * 1e3 / n, 1), "stream_time_over_step": round(ms * STRIDE / dt_ms, 3),
                 "region": "timed region (pipelined: decoder kernels of the previous step run beside it)" if pipelined else "timed region (un-pipelined)"}
+        rp = rocprof_committed("gemm256w4p_kernel", cfg_tag, pipelined) if have_profile else None
+        if rp is not None:
+            roof["rocprofv3_committed"] = rp
         if iso is not None:
             a2, n2, _, ms2 = rate(iso, "gemm256", 1e12)
             if a2 is not None:
@@ -297,24 +361,21 @@ def roofline_records(region, iso, dt_ms, pipelined, cfg):
         if o is not None:
             roof["other_gemm_kernels"] = {"what": "row tails (gemm_tail_kernel), 128x128 kernel, one-tile-per-block 256x256 kernel -- NOT part of `achieved`",
                                           "achieved": round(o, 1), "unit": "TFLOP/s", "launches_timed": no, "avg_launch_us": round(mso * 1e3 / no, 1),
-                                          "share_of_step": round(mso * STRIDE / dt_ms, 3)}
-    n_ = cfg.patches_per_frame
-    jb = next((b for b in (4, 3, 2) if (n_ // 16) % (4 * b) == 0), None)
-    space_name = "space_attnj_kernel<%d, ...> (joint-block kernel, n = %d keys per frame, head-major q|k|v planes)" % (jb, n_) if jb else "space_attn16_kernel (n = %d)" % n_
-    time_name = "time_attn_mfma_kernel<%d>" % cfg.num_frames
-    for key, kname in (("space_attn", space_name), ("time_attn", time_name), ("add_ln", "add_ln_kernel")):
+                                          "stream_time_over_step": round(mso * STRIDE / dt_ms, 3)}
+    for key in ("space_attn", "time_attn", "add_ln"):
         r, n, _, ms = rate(region, key, 1e9)
         if r is None:
             continue
-        att[key] = {"kernel": kname, "bound": "hbm", "achieved": round(r, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(r / PEAK_HBM_GBS, 4),
-                    "launches_timed": n, "avg_launch_us": round(ms * 1e3 / n, 1), "share_of_step": round(ms * STRIDE / dt_ms, 3)}
+        att[key] = {"kernel": names.get(key, "") or key, "bound": "hbm", "achieved": round(r, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(r / PEAK_HBM_GBS, 4),
+                    "launches_timed": n, "avg_launch_us": round(ms * 1e3 / n, 1), "stream_time_over_step": round(ms * STRIDE / dt_ms, 3)}
         if iso is not None:
             r2, n2, _, ms2 = rate(iso, key, 1e9)
             if r2 is not None:
                 att[key]["isolated"] = {"achieved": round(r2, 1), "frac": round(r2 / PEAK_HBM_GBS, 4), "avg_launch_us": round(ms2 * 1e3 / n2, 1)}
     if att:
         att["note"] = ("algorithmic bytes (8*N*D per attention call and clip, N = %d tokens, D = %d; bytes read + written for add+LayerNorm) / event time of the "
-                       "kernel alone; `isolated` = un-pipelined steps" % (cfg.tokens, cfg.embed_dim))
+                       "kernel alone; `isolated` = un-pipelined steps; `kernel` = the instantiation the library dispatched last (hh_prof_kernel_name); "
+                       "`stream_time_over_step` = the class's time on its stream / wall time of a step (three streams run concurrently: these do not sum to 1)" % (cfg.tokens, cfg.embed_dim))
     return roof, (att or None)
 
 
@@ -473,6 +534,14 @@ def main():
                     "collectives_per_step": {"all_gather": 1, "all_reduce_gradient_buckets": len(ts.arena.buckets), "all_reduce_flags": 1},
                     "gradient_bytes_per_step": int(ts.arena.total * 4)}
 
+    # the line's own parity bit: clips 0-1 of the benchmarked batch against the same two clips run as a batch of 2 (after the timed region)
+    selfcheck = None
+    if world == 1 and args.workload == "train":
+        selfcheck = first_clips_check(ts, batch, k=2)
+        selfcheck["what"] = ("eval-mode forward (towers, decoder, hand-box matching) of the bench batch vs its first 2 clips alone; clip 0 must be bit-identical through "
+                             "the encoder; the small batch's last clip holds its GEMM row tail (different K summation order: bf16 roundings); hs / boxes differ by the "
+                             "cross-attention's key-slice count (fp32 re-association)")
+
     # second half of BASELINE.json's metric in the same line: EgoMCQ forward clips/s (config 5: q = 8 items = 40 clips + 8 queries)
     mcq_rec = None
     if args.workload == "train" and not args.no_mcq and args.config == "c2":
@@ -488,7 +557,7 @@ def main():
         if world > 1:
             dist.all_reduce(mt_, op=dist.ReduceOp.MAX)
         mcq_rec = {"metric": "EgoMCQ fwd clips/sec (16-frame 224p)", "value": round(q * 5 * world * ksteps / float(mt_), 2), "unit": "clips/s",
-                   "ms_per_step": round(float(mt_) / ksteps * 1e3, 2), "steps": ksteps, "warmup": 2, "step_stats": step_stats(mper),
+                   "ms_per_step": round(float(mt_) / ksteps * 1e3, 2), "steps": ksteps, "warmup": 2, "step_stats": step_stats(mper, drop_first=not args.no_pipeline),
                    "config": {"workload": "C5: 16-frame EgoMCQ forward, q = %d items (%d clips + %d queries) per step per GPU, replicas only" % (q, 5 * q, q),
                               "pipelined_encoder": not args.no_pipeline, "resident_batch_reused": True,
                               "step_tflop_per_clip": round(step_tflop_per_clip(cfg, train=False), 2)}}
@@ -506,9 +575,9 @@ def main():
         _, _, bb4, dec4 = build(C4, dev)
         B4, k4 = 4, 10
         ts4, batch4, dt4, per4, region4, iso4, out4 = bench_train(C4, bb4, dec4, B4, k4, 3, 1, rank, dev, args, timers)
-        roof4, att4 = roofline_records(region4, iso4, dt4 * 1e3, not args.no_pipeline, C4) if region4 is not None else (None, None)
+        roof4, att4 = roofline_records(region4, iso4, dt4 * 1e3, not args.no_pipeline, C4, B4) if region4 is not None else (None, None)
         c4_rec = {"metric": "train clips/sec (32-frame 336p, nq=12)", "value": round(B4 * k4 / dt4, 2), "unit": "clips/s", "ms_per_step": round(dt4 / k4 * 1e3, 2),
-                  "steps": k4, "warmup": 3, "step_stats": step_stats(per4),
+                  "steps": k4, "warmup": 3, "step_stats": step_stats(per4, drop_first=not args.no_pipeline),
                   "config": {"workload": "C4: 32-frame 336p (N = 18 433 tokens / clip), nq=12, frozen TimeSformer-L + object-query decoder train step",
                              "clips_per_gpu": B4, "step_tflop_per_clip": round(step_tflop_per_clip(C4), 2)},
                   "roofline": roof4, "attention_roofline": att4, "loss": round(float(out4["total_loss"]), 4)}
@@ -517,7 +586,7 @@ def main():
 
     if rank == 0:
         dt_ms = dt * 1e3
-        roof, att = roofline_records(region, iso, dt_ms, not args.no_pipeline, cfg) if region is not None else (None, None)
+        roof, att = roofline_records(region, iso, dt_ms, not args.no_pipeline, cfg, clips_per_step) if region is not None else (None, None)
         if roof is not None and clock is not None:
             clock["frac_of_clock_limited_peak"] = round(roof["achieved"] / clock["clock_limited_peak"], 4)
             roof["sustained_clock"] = clock
@@ -531,7 +600,7 @@ def main():
                            "global_clips": clips_per_step * world, "parallelism": "dp%d" % world,
                            "resident_batch_reused": True, "materialize_logits": False,
                            "step_tflop_per_clip": round(tf, 2)},
-                "step_stats": step_stats(per),
+                "step_stats": step_stats(per, drop_first=bool(train and not args.no_pipeline)),
                 "end_to_end_mfma_frac": round(value * tf / (world * PEAK_BF16_TFLOPS), 4),
                 "roofline": roof}
         if att:
@@ -551,6 +620,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, enc_sd, dec_sd, seed=1000)
         if train:
             line["loss"] = round(float(out["total_loss"]), 4)
+        if selfcheck is not None:
+            line["selfcheck"] = selfcheck
         print(json.dumps(line))
     if world > 1 or args.force_comm:
         dist.destroy_process_group()

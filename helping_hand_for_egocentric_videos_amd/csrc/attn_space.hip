@@ -986,6 +986,7 @@ extern "C" int hh_space_attn_fwd(const void* qkv, int qkv_layout, void* out, flo
                 HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds16);
                 attrp = lds16;
             }
+            hh_prof_note_kernel(HH_PROF_SPACE_ATTN, "space_attnp_kernel<3, 12, 3, 36, 12, 24, 24, 16>");
             hipLaunchKernelGGL(kp, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * 12), lds16, (hipStream_t)stream,
                                (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, heads, qkv_layout);
             return hh_check_launch("hh_space_attn_fwd");
@@ -1000,6 +1001,7 @@ extern "C" int hh_space_attn_fwd(const void* qkv, int qkv_layout, void* out, flo
                 HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds16);
                 attrp2 = lds16;
             }
+            hh_prof_note_kernel(HH_PROF_SPACE_ATTN, "space_attnp_kernel<4, 4, 2, 16, 12, 12, 12, 0>");
             hipLaunchKernelGGL(kp, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * 4), lds16, (hipStream_t)stream,
                                (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, heads, qkv_layout);
             return hh_check_launch("hh_space_attn_fwd");
@@ -1014,10 +1016,13 @@ extern "C" int hh_space_attn_fwd(const void* qkv, int qkv_layout, void* out, flo
             HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds16);
             attrj[slot] = lds16;
         }
+        hh_prof_note_kernel(HH_PROF_SPACE_ATTN, nw == 12 ? "space_attnj_kernel<3, 2, false, 12, 3>" : jb == 4 ? (dbg ? "space_attnj_kernel<4, 2, true, 4, 2> (debug)" : "space_attnj_kernel<4, 2, false, 4, 2>")
+                                                : jb == 3 ? "space_attnj_kernel<3, 2, false, 4, 2>" : "space_attnj_kernel<2, 6, false, 4, 2>");
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * nw), lds16, (hipStream_t)stream,
                            (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP, dbg, qkv_layout);
         return hh_check_launch("hh_space_attn_fwd");
     }
+    hh_prof_note_kernel(HH_PROF_SPACE_ATTN, "space_attn16_kernel");
     hipLaunchKernelGGL(space_attn16_kernel, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW16), lds16, (hipStream_t)stream,
                        (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP, hh_tuning_space_debug(), qkv_layout);
     return hh_check_launch("hh_space_attn_fwd");

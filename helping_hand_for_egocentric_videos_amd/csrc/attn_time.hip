@@ -463,11 +463,13 @@ extern "C" int hh_time_attn_fwd(const void* qkv, int qkv_layout, void* out, floa
     bf16_t* o = (bf16_t*)out;
     HHProfScope prof(HH_PROF_TIME_ATTN, 8.0 * B * (1.0 + (double)T * n) * heads * 64, s);
     if (T == 32) {
+        hh_prof_note_kernel(HH_PROF_TIME_ATTN, "time_attn_mfma32_kernel");
         hipLaunchKernelGGL(time_attn_mfma32_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout);
         return hh_check_launch("hh_time_attn_fwd(T=32)");
     }
     const unsigned wg = (unsigned)((blocks + 3) / 4);           // one wave per record, four waves per workgroup
-#define LAUNCHM(TT) hipLaunchKernelGGL(time_attn_mfma_kernel<TT>, dim3(wg), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout)
+#define LAUNCHM(TT) do { hh_prof_note_kernel(HH_PROF_TIME_ATTN, "time_attn_mfma_kernel<" #TT ">"); \
+                         hipLaunchKernelGGL(time_attn_mfma_kernel<TT>, dim3(wg), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout); } while (0)
     switch (T) {
         case 1: LAUNCHM(1); break;
         case 2: LAUNCHM(2); break;

@@ -29,6 +29,8 @@ struct HHProfScope {
     hipStream_t stream_;
 };
 
+void hh_prof_note_kernel(int klass, const char* name);    // runtime.cpp: the kernel a launch site dispatched for a profiled class (hh_prof_kernel_name)
+
 #define HH_REQUIRE(cond, code, ...)                 \
     do {                                            \
         if (!(cond)) {                              \

@@ -672,11 +672,15 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
                 const int slot = g_dynamic ? hh_stream_slot(s) : -1;
                 p.dynamic = slot >= 0;
                 p.tile_slot = slot >= 0 ? slot : 0;      // (N: bias vector + epilogue scratch share the 32 KB of LDS the ring leaves)
+                static const char* const w4p_names[8] = {"gemm256w4p_kernel<false, 0>", "gemm256w4p_kernel<true, 0>", "gemm256w4p_kernel<false, 1>", "gemm256w4p_kernel<true, 1>",
+                                                         "gemm256w4p_kernel<false, 2>", "gemm256w4p_kernel<true, 2>", "gemm256w4p_kernel<false, 3>", "gemm256w4p_kernel<true, 3>"};
+                hh_prof_note_kernel(HH_PROF_GEMM256, w4p_names[epi * 2 + (bf ? 1 : 0)]);
                 int rc = hh_gemm256w4p_launch(p, epi, pg, s);
                 if (tail_done) *tail_done = p.tail_rows > 0;
                 return rc;
             }
             hh_gemm256w4_timeline_mark(false);
+            hh_prof_note_kernel(HH_PROF_GEMM256, "gemm256d_kernel (8-wave persistent)");
 #define LAUNCHD(BF, E) hipLaunchKernelGGL((gemm256d_kernel<BF, E>), dim3(pg), dim3(512), P_LDS(p.N), s, p)
             switch (epi * 2 + (bf ? 1 : 0)) {
                 case 0: LAUNCHD(false, 0); break;

@@ -304,7 +304,8 @@ extern "C" int hh_add_layernorm_fwd(float* x, const void* delta, const void* del
     const int nv = (cols + 255) / 256;
     // algorithmic bytes per element: x read (4) [+ written (4)] + delta (2) [+ delta2 (2)] + y (2 or 4)
     HHProfScope prof(HH_PROF_ADD_LN, (double)rows * cols * (4 + (write_x ? 4 : 0) + 2 + (delta2 ? 2 : 0) + (y_dtype == HH_BF16 ? 2 : 4)), s);
-#define LA(NV, T, W) hipLaunchKernelGGL((add_ln_kernel<NV, T, W>), grid, block, 0, s, x, d, (const bf16_t*)delta2, gamma, beta, (T*)y, rows, cols, eps)
+#define LA(NV, T, W) do { hh_prof_note_kernel(HH_PROF_ADD_LN, "add_ln_kernel<" #NV ", " #T ", " #W ">"); \
+                          hipLaunchKernelGGL((add_ln_kernel<NV, T, W>), grid, block, 0, s, x, d, (const bf16_t*)delta2, gamma, beta, (T*)y, rows, cols, eps); } while (0)
 #define LB(NV) do { if (y_dtype == HH_BF16) { if (write_x) LA(NV, bf16_t, true); else LA(NV, bf16_t, false); } \
                     else { if (write_x) LA(NV, float, true); else LA(NV, float, false); } } while (0)
     if (nv <= 2) LB(2); else if (nv <= 4) LB(4); else LB(8);

@@ -211,6 +211,11 @@ __global__ __launch_bounds__(256) void masked_ce_kernel(const float* __restrict_
         return;
     }
     const int64_t g = gt[row];
+    if (g < 0 || g >= V) {                                  // F.cross_entropy raises on such a target; no host round trip here: the row turns NaN
+        for (int k = lane; k < V; k += 64) gr[k] = __builtin_nanf("");
+        if (lane == 0) ce[row] = __builtin_nanf("");
+        return;
+    }
     const float* sr = sim + (int64_t)row * lds_;
     const float* nr = noun_sim + g * V;
     float m = -INFINITY;

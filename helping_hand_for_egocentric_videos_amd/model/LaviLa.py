@@ -327,7 +327,6 @@ class CLIP(nn.Module):
         self.image_projection = nn.Parameter(torch.empty(vision_width, embed_dim))
         self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / tempearture_init))
-        self.text_autocast = torch.bfloat16          # compute dtype of the stock-op text tower on the GPU
         self.initialize_parameters()
 
     def initialize_parameters(self):
@@ -356,27 +355,23 @@ class CLIP(nn.Module):
 
     def encode_text(self, text, use_checkpoint=False, apply_project=True):
         """LaviLa.py:660-670 (apply_project=False, as encode_image has it, skips the EOT-token projection: the training step only
-        uses the feature map).  Frozen weights on the GPU (the training / MCQ path): Linears and LayerNorms of the 12 text
-        blocks on libhh kernels (`Transformer.forward_frozen`); otherwise stock PyTorch ops (bf16 autocast on the GPU)."""
-        frozen = text.is_cuda and not torch.is_grad_enabled() or (text.is_cuda and not any(p.requires_grad for p in self.transformer.parameters()))
-        if frozen and self.text_autocast is not None:
-            with torch.no_grad():
-                x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]
-                x = self.transformer.forward_frozen(x)
-                x = ops.layernorm(x, self.ln_final.weight.detach().float(), self.ln_final.bias.detach().float(), self.ln_final.eps,
-                                  out_dtype=torch.float32)
-        else:
-            with torch.autocast("cuda", dtype=self.text_autocast, enabled=text.is_cuda and self.text_autocast is not None):
-                x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]
-                x = self.transformer(x.permute(1, 0, 2), use_checkpoint=use_checkpoint).permute(1, 0, 2)
-                x = self.ln_final(x)
-            x = x.float()
+        uses the feature map).  The backbone is frozen on this path (run/train.py:89,109-116; run/test_EgoMCQ.py:60 under no_grad):
+        Linears and LayerNorms of the 12 text blocks run on libhh kernels (`Transformer.forward_frozen`), the 77 x 77 causal core on
+        hh_text_attn_fwd.  There is no stock-op branch: a text tower that wants gradients is not part of this path and raises."""
+        _require_gpu(text, "CLIP.encode_text")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.transformer.parameters()):
+            raise NotImplementedError("CLIP.encode_text: the text tower is frozen on the hot path (run/train.py:89 freezes the backbone; optim_policy, "
+                                      "utils/train_utils.py:42-43, gives it no optimizer group); a trainable text tower has no libhh backward and there is "
+                                      "no stock-op fallback -- call under torch.no_grad() or freeze the parameters")
+        with torch.no_grad():
+            x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]
+            x = self.transformer.forward_frozen(x)
+            x = ops.layernorm(x, self.ln_final.weight.detach().float(), self.ln_final.bias.detach().float(), self.ln_final.eps,
+                              out_dtype=torch.float32)
         x_cls = x[torch.arange(x.shape[0], device=x.device), text.float().argmax(dim=-1)]      # (ids < 2^24: exact; the int64 ArgMax reduce is 20x slower)
         if not apply_project:
             return x_cls, x
-        if frozen and x_cls.dtype == torch.float32:
-            return ops.qgemm(x_cls.contiguous(), self.text_projection.detach().float().contiguous(), ops.NN), x
-        return x_cls @ self.text_projection, x
+        return ops.qgemm(x_cls.contiguous(), self.text_projection.detach().float().contiguous(), ops.NN), x
 
     def forward(self, image, text, use_checkpoint=False, norm_embed=True, return_feature_map=False):
         image_embed, image_fmap = self.encode_image(image, use_checkpoint=use_checkpoint)

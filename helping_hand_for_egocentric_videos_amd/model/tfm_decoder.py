@@ -541,6 +541,14 @@ class ObjDecoder(nn.Module):
             cond = (base[:, :, None] + fr[None, None, :, None, :]).flatten(1, 2)                             # [l,B*T,Q,C]
         else:
             cond = hs if full else hs[-1:]
+            if self.pred_traj and torch.is_grad_enabled():
+                # the trajectory branch is skipped for this clip length (on every rank alike: the shape decides): tell the gradient
+                # buckets now, or frame_index / frame_proj would hold back every all-reduce until the end of backward (parallel.py)
+                for prm, nm in ((self.frame_index.weight, "frame_index.weight"), (self.frame_proj.weight, "frame_proj.weight"),
+                                (self.frame_proj.bias, "frame_proj.bias")):
+                    sink = getattr(prm, "_hh_sink", None)
+                    if sink is not None:
+                        sink.arena.declare_unused([sink.name])
         outputs_coord = self.bbox_embed(cond).sigmoid()
         out = {'pred_boxes': outputs_coord[-1]}
         expand_t = self.pred_traj and T == self.num_frames

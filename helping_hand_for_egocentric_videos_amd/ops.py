@@ -568,9 +568,20 @@ def egonce_fwd(x, sim_v, sim_n, pad, R, temperature, vn_threshold=0.0):
 
 def masked_ce_fwd(sim, noun_sim, gt, valid, temperature, threshold):
     """-> (ce fp32 [rows], grad fp32 [rows, V]); sim fp32 [rows, V], noun_sim fp32 [V, V], gt int64 [rows], valid bool / uint8 [rows]."""
-    _chk(noun_sim, gt, valid)
-    _chk_gpu(sim)
+    _chk_gpu(sim, noun_sim, gt, valid)
+    if sim.dim() != 2 or noun_sim.dim() != 2 or noun_sim.shape != (sim.shape[1], sim.shape[1]):
+        raise ValueError("masked_ce_fwd: sim [rows, V] and noun_sim [V, V] expected, got %s / %s" % (tuple(sim.shape), tuple(noun_sim.shape)))
+    if gt.dtype.is_floating_point or gt.dtype == torch.bool or valid.dtype not in (torch.bool, torch.uint8):
+        raise TypeError("masked_ce_fwd: gt must be an integer tensor, valid bool / uint8")
+    # the kernel reads fp32 / int64 through raw pointers: a bf16 similarity (autocast) or int32 ids must be converted, not reinterpreted
+    if sim.dtype != torch.float32 or sim.stride(1) != 1:
+        sim = sim.float().contiguous()
+    noun_sim = noun_sim.float().contiguous()
+    gt = gt.to(torch.int64).contiguous()
+    valid = valid.contiguous()
     rows, V = sim.shape
+    if gt.numel() != rows or valid.numel() != rows:
+        raise ValueError("masked_ce_fwd: gt / valid must have one entry per row of sim")
     ce = torch.empty(rows, dtype=torch.float32, device=sim.device)
     grad = torch.empty((rows, V), dtype=torch.float32, device=sim.device)
     v8 = valid.view(torch.uint8) if valid.dtype == torch.bool else valid

@@ -43,7 +43,12 @@ class _GradSink:
     temporaries; instead a node whose parameters all have an ARMED sink writes its weight-gradient GEMMs / LayerNorm reductions
     straight into `view`, calls done() and returns None for that input.  Armed = FlatArena.zero_grad() has run (the arena is
     zero, so accumulating kernels may add into it) and this parameter has not received a gradient yet in this step -- a second
-    backward in the same step (gradient accumulation) falls back to autograd's adds."""
+    backward in the same step (gradient accumulation) falls back to autograd's adds.
+
+    PRECONDITION: a sunk parameter has exactly ONE consumer node per step (true for every parameter the decoder's nodes own: each
+    nn.Parameter enters one QueryStack / _MemorySide).  done() reports the gradient FINAL -- under data parallelism its bucket may
+    be all-reduced right away -- so a second direct write in the same step would land after / beside the collective and let ranks
+    diverge silently; FlatArena._ready raises on it instead."""
     __slots__ = ("arena", "name", "view")
 
     def __init__(self, arena, name, view):
@@ -126,6 +131,7 @@ class FlatArena:
         self.grads_clean = True                                  # the gradient arena is all zero (fresh, or cleared by the last update)
         self.sink_armed = False                                  # direct gradient writes allowed (between zero_grad() and the update)
         self.claimed = set()                                     # parameters whose gradient a node writes straight into the arena this step
+        self._sunk = set()                                       # ... and whose write has been reported final (_ready): at most once per step
         self.ready_callbacks = []                                # called with the parameter name when its gradient is final (comm layer)
         for n, p in self.entries:
             o, k = self.offsets[n]
@@ -134,15 +140,31 @@ class FlatArena:
 
     def _make_touch_hook(self, name):
         def hook(param):
+            self.grads_clean = False                 # a gradient landed (also from a diagnostic backward between two steps)
             if name not in self.claimed:
                 self.touched.add(name)
         return hook
 
     def _ready(self, name):
         """A node wrote this parameter's gradient straight into the arena (no AccumulateGrad, so no post-accumulate hooks)."""
+        if name in self._sunk:
+            raise RuntimeError("FlatArena: the gradient of '%s' was written straight into the arena twice in one step; a sunk parameter must have "
+                               "exactly one consumer node per step (_GradSink precondition) -- its bucket may already be in an all-reduce" % name)
+        self._sunk.add(name)
+        self.grads_clean = False
         self.touched.add(name)
         for cb in self.ready_callbacks:
             cb(name)
+
+    def declare_unused(self, names):
+        """The forward pass knows that these parameters get no gradient in this step ON ANY RANK (a shape-dependent branch every rank
+        takes alike, e.g. the trajectory branch when the clip length differs from num_frames): report them to the communication layer
+        now, so that their bucket -- and every later one, buckets launch strictly in arena order -- is not held back until finish().
+        They stay un-`touched`: AdamW skips them as torch does."""
+        for name in names:
+            if name in self.offsets and name not in self.touched:
+                for cb in self.ready_callbacks:
+                    cb(name)
 
     @property
     def steps(self):
@@ -167,6 +189,7 @@ class FlatArena:
         the arena (TrainStep.step does that)."""
         self.touched.clear()
         self.claimed.clear()
+        self._sunk.clear()
         if force or not self.grads_clean:
             self.grads.zero_()
         self.grads_clean = False                     # a backward is about to write it

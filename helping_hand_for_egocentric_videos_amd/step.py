@@ -258,6 +258,60 @@ class TrainStep:
         self.decoder.transformer._seed = None if seed is None else (int(seed) ^ (40503 * rank)) & 0x7FFFFFFF
 
 
+def batch_slice(batch, k, captions_per_clip):
+    """The first k clips of a batch dict (synth.make_batch contract: `text` holds captions_per_clip rows per clip, `all_nouns` is shared)."""
+    out = {}
+    for name, v in batch.items():
+        out[name] = v if name == "all_nouns" else (v[:k * captions_per_clip] if name == "text" else v[:k])
+    return out
+
+
+@torch.no_grad()
+def first_clips_check(ts, batch, k=2):
+    """Does clip i of a large batch get the result it gets in a batch of k clips?  Eval-mode forward (no dropout) of the frozen towers +
+    decoder + hand-box matching on `batch` and on its first k clips; returns what differs.  Per clip every kernel of the path computes
+    the same function at any batch size; the SUMMATION ORDER differs in two places only -- (1) the <= 64 token rows behind the last
+    full 256-row GEMM tile (rows of the batch's LAST clip: the in-kernel row tail sums 8 K-slices, the tiles sum k-tiles in order), so
+    the last clip of the small batch may differ from its large-batch result by bf16 roundings; every earlier clip must be
+    BIT-IDENTICAL through the encoder; (2) the cross-attention's key slices (`ops.xattn_fwd` cuts the keys into more slices when
+    B * heads cannot fill the chip), fp32 re-association ~1e-6 of `hs`.  bench.py prints this as `selfcheck`; tests/test_step_gpu.py
+    asserts it at the benchmarked batch."""
+    dec, cfg = ts.decoder, ts.cfg
+    was_training = dec.training
+    dec.eval()
+    try:
+        def fwd(b):
+            grid, _ = ts.encode(b["video"], b["text"])
+            det, hs, _, _ = dec(grid)
+            hand = b["boxes"][:, :, :2].flatten(0, 1)
+            mh = ts.criterion.matcher.match_raw(det["pred_boxes"], 0, 2, hand)
+            return grid, hs, det["pred_boxes"], mh
+        nq = cfg.num_queries if cfg.num_queries != 0 else 10
+        T = batch["video"].shape[1]
+        gb, hb, pb, mb = fwd(batch)
+        small = batch_slice(batch, k, cfg.captions_per_clip)
+        gs, hs_, ps, ms = fwd(small)
+        # the k clips' own hand-box loss (box_utils.py:445-461 on the k clips alone), from the large batch's boxes and from the small batch's
+        hand = small["boxes"][:, :, :2].flatten(0, 1)
+        def hand_loss(pred):
+            det = {"pred_boxes": pred.contiguous(), "pred_logits": None, "aux_outputs": []}
+            return box_utils.compute_box_loss("hand_boxes", ts.criterion, det, hand, None, None, n_queries=nq)[0]
+        lb, ls = hand_loss(pb[:k * T]), hand_loss(ps)
+        f = lambda t: t.float()
+        scale = lambda t: float(f(t).abs().max().clamp_min(1e-30))
+        idx_equal = all(bool(torch.equal(mb[key][:k * T], ms[key])) for key in ("pred_idx", "tgt_idx", "n", "count"))
+        rec = {"clips_compared": k, "batch": int(batch["video"].shape[0]),
+               "encoder_bit_identical_clips_before_last": bool(k < 2 or torch.equal(gb[:k - 1], gs[:k - 1])),
+               "encoder_last_clip_max_abs_diff_over_scale": float((f(gb[k - 1]) - f(gs[k - 1])).abs().max()) / scale(gs[k - 1]),
+               "hs_max_abs_diff_over_scale": float((f(hb[:, :k]) - f(hs_)).abs().max()) / scale(hs_),
+               "pred_boxes_max_abs_diff": float((pb[:k * T] - ps).abs().max()),
+               "matched_indices_equal": idx_equal,
+               "hand_box_loss_first_clips_rel_diff": abs(float(lb) - float(ls)) / max(abs(float(ls)), 1e-30)}
+        return rec
+    finally:
+        dec.train(was_training)
+
+
 _MCQ_STREAMS = {}
 
 

@@ -9,11 +9,17 @@ import torch
 
 
 class TokenizedTextCache:
-    def __init__(self, tokenizer, context_length=77, device="cuda", capacity=1 << 16):
+    """Rows are stored as int32 (CLIP's vocabulary is 49 408 ids; 308 B per caption) and widened to int64 in the gather.  `max_rows`
+    bounds the table (default 2^21 rows = 0.65 GB; EgoClip has ~3.8 M narrations x 5 rephrases, which unbounded would pin > 10 GB of
+    HBM beside a step that sizes its batch to memory): once it is full, captions that are not in it are tokenised and uploaded for
+    the call only (a bypass, no eviction -- the epoch's first 2 M distinct captions keep hitting)."""
+
+    def __init__(self, tokenizer, context_length=77, device="cuda", capacity=1 << 16, max_rows=1 << 21):
         self.tokenizer, self.context_length, self.device = tokenizer, context_length, torch.device(device)
         self.index = {}                                               # caption -> row of the table
-        self.table = torch.zeros((capacity, context_length), dtype=torch.int64, device=self.device)
-        self.hits = self.misses = 0
+        self.max_rows = int(max_rows)
+        self.table = torch.zeros((min(capacity, self.max_rows), context_length), dtype=torch.int32, device=self.device)
+        self.hits = self.misses = self.bypassed = 0
 
     def __len__(self):
         return len(self.index)
@@ -21,21 +27,30 @@ class TokenizedTextCache:
     def __call__(self, texts):
         """list[str] -> int64 [len(texts), context_length] on the cache's device."""
         new = [t for t in dict.fromkeys(texts) if t not in self.index]
+        extra = {}                                                    # captions beyond the cap: rows of this call only
+        rows_extra = None
         if new:
             rows = self.tokenizer(new)
             if rows.shape != (len(new), self.context_length):
                 raise ValueError("TokenizedTextCache: tokenizer returned %s for %d strings" % (tuple(rows.shape), len(new)))
             start = len(self.index)
-            if start + len(new) > self.table.shape[0]:                # grow geometrically (a reallocation, not per step)
-                grown = torch.zeros((max(2 * self.table.shape[0], start + len(new)), self.context_length), dtype=torch.int64, device=self.device)
+            keep = max(0, min(len(new), self.max_rows - start))      # how many of the new captions still fit under the cap
+            if keep and start + keep > self.table.shape[0]:           # grow geometrically up to the cap (a reallocation, not per step)
+                grown = torch.zeros((min(self.max_rows, max(2 * self.table.shape[0], start + keep)), self.context_length), dtype=torch.int32, device=self.device)
                 grown[:start] = self.table[:start]
                 self.table = grown
-            self.table[start:start + len(new)] = rows.to(device=self.device, dtype=torch.int64, non_blocking=True)
-            for i, t in enumerate(new):
-                self.index[t] = start + i
+            if keep:
+                self.table[start:start + keep] = rows[:keep].to(device=self.device, dtype=torch.int32, non_blocking=True)
+                for i, t in enumerate(new[:keep]):
+                    self.index[t] = start + i
+            if keep < len(new):
+                rows_extra = rows[keep:].to(device=self.device, dtype=torch.int32, non_blocking=True)
+                extra = {t: self.table.shape[0] + i for i, t in enumerate(new[keep:])}      # indices past the table: rows of `rows_extra`
+                self.bypassed += len(new) - keep
         self.misses += len(new)
         self.hits += len(texts) - len(new)
-        idx = torch.tensor([self.index[t] for t in texts], dtype=torch.int64)
+        idx = torch.tensor([self.index[t] if t in self.index else extra[t] for t in texts], dtype=torch.int64)
         if self.device.type == "cuda":
             idx = idx.pin_memory().to(self.device, non_blocking=True)
-        return self.table.index_select(0, idx)
+        src = self.table if rows_extra is None else torch.cat([self.table, rows_extra], dim=0)
+        return src.index_select(0, idx).to(torch.int64)

@@ -80,7 +80,8 @@ int hh_stream_get_cu_budget(hh_stream_t stream, int* out);
 enum hh_prof_class {
     HH_PROF_GEMM256 = 0,      /* persistent 256x256 GEMM kernels (gemm256w4p_kernel, gemm256d_kernel): 2*M*N*K of the full-tile rows */
     HH_PROF_GEMM_OTHER = 1,   /* row tails, 128x128 kernel, one-tile-per-block 256x256 kernel: 2*M*N*K of their rows */
-    HH_PROF_SPACE_ATTN = 2,   /* space_attnj_kernel (joint blocks, default) / space_attn16_kernel: 8*B*N*D bytes (q,k,v read + o written, bf16) */
+    HH_PROF_SPACE_ATTN = 2,   /* space_attnj_kernel (joint blocks; n = 256) / space_attnp_kernel (progressive staging; n = 576) / space_attn16_kernel:
+                                 8*B*N*D bytes (q,k,v read + o written, bf16) */
     HH_PROF_TIME_ATTN = 3,    /* time_attn_mfma*_kernel: 8*B*N*D bytes */
     HH_PROF_ADD_LN = 4,       /* fused residual add + LayerNorm: bytes read + written */
     HH_PROF_GEMM_TN = 5,      /* weight-gradient GEMM: 2*M*N*K */
@@ -90,6 +91,9 @@ enum hh_prof_class {
 };
 int hh_prof_enable(int stride);
 int hh_prof_read(int klass, int64_t* launches_timed, int64_t* launches_seen, double* total_ms, double* total_work);
+/* the kernel (template instantiation, spelled as rocprofv3 --kernel-trace prints it) that the LAST launch of the class dispatched since
+ * hh_prof_enable(stride > 0); "" if none.  A static string owned by the library. */
+const char* hh_prof_kernel_name(int klass);
 
 /* ---- caller-owned workspaces.  No entry point allocates; these return the size in BYTES of the scratch buffer an entry point
  * takes (negative = bad arguments):
@@ -303,7 +307,7 @@ int hh_box_loss_bwd(const float* pred, int Qtot, int q0, const float* tgt_cxcywh
  * hh_masked_ce_fwd: the 582-way cross-entropy of WordContrastiveLoss (model/loss.py:95-104): sim fp32 [rows, V] (row stride ld),
  * noun_sim fp32 [V, V] (cosine similarity of the nouns; its diagonal is ignored), gt int64 [rows], valid uint8 [rows]; logits sim / T
  * with the columns k != gt of noun_sim[gt, k] > threshold replaced by -1 / T.  ce fp32 [rows] (0 on invalid rows), grad fp32 [rows, V]
- * = d ce[r] / d sim[r, :].
+ * = d ce[r] / d sim[r, :].  A valid row whose gt is outside [0, V) gets ce = NaN and a NaN gradient row (F.cross_entropy raises there).
  * hh_tv_accuracy: compute_tv_accuracy (model/metric.py:378-392): sim fp32 [Bg, Bg] (row stride ld), text_cos fp32 [Bg, Bg] (cosine
  * similarity of the first captions), sim_v, sim_n fp32 [Bg, Bg] -> out[0] = video->text, out[1] = text->video top-1 accuracy. */
 int hh_rownorm_fwd(const float* x, int64_t ldx, float* y, float* norm, int rows, int cols, float eps, hh_stream_t stream);

@@ -10,7 +10,8 @@ g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(B * N, 3 * D, device="cuda", generator=g)
 qkv[:, :D] *= 0.5
 qkv = qkv.to(torch.bfloat16)
-out = torch.empty(B * N, D, dtype=torch.bfloat16, device="cuda")
+out = torch.zeros(B * N, D, dtype=torch.bfloat16, device="cuda")          # (zeroed: the CLS rows, row b*N, are written by hh_cls_combine, not by this kernel)
+patch = (torch.arange(B * N, device="cuda") % N) != 0                           # rows the space kernel writes
 planes = qkv.view(B * N, 3 * heads, 64).transpose(0, 1).contiguous()          # head-major planes [3*heads, B*N, 64]
 L = _lib.lib()
 LAYOUT = 0
@@ -24,9 +25,9 @@ def t(reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 ops.set_tuning("space_joint", 1); a = t(); ref = out.clone()
 ops.set_tuning("space_joint", 0); b = t()
-print("joint-block kernel %7.1f us   16-query kernel %7.1f us   max |diff| %.3e" % (a, b, (out.float() - ref.float()).abs().max().item()))
+print("joint-block kernel %7.1f us   16-query kernel %7.1f us   max |diff| %.3e" % (a, b, (out[patch].float() - ref[patch].float()).abs().max().item()))
 ops.set_tuning("space_joint", 1); print("joint again        %7.1f us" % t())
-LAYOUT = 1; c = t(); print("joint, head-major qkv planes %7.1f us   max |diff| vs token-major %.3e" % (c, (out[1:].float() - ref[1:].float()).abs().max().item()))
+LAYOUT = 1; c = t(); print("joint, head-major qkv planes %7.1f us   max |diff| vs token-major %.3e" % (c, (out[patch].float() - ref[patch].float()).abs().max().item()))
 ops.set_tuning("space_debug", 1); print("joint, head-major, memory only %7.1f us" % t()); ops.set_tuning("space_debug", 0)
 LAYOUT = 0
 for dbg, name in ((1, "memory only (stage K/V, read Q, write O)"), (2, "compute only (no K/V staging)")):

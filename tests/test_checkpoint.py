@@ -89,3 +89,9 @@ def test_tokenized_text_cache_equals_the_tokenizer():
     assert calls[n_calls] == ["#O a man X walks", "#C C cuts an onion", "#C C washes the knife"]          # only the unseen ones
     assert torch.equal(got, fake_tokenizer(b)) and len(cache) == 6 and cache.table.shape[0] >= 6
     assert torch.equal(cache(a), fake_tokenizer(a)) and cache.hits >= 7
+    assert got.dtype == torch.int64 and cache.table.dtype == torch.int32          # stored narrow, returned as the tokenizer returns them
+    # bounded: beyond max_rows unseen captions bypass the table (tokenised + uploaded for the call only), results unchanged
+    small = TokenizedTextCache(fake_tokenizer, device="cpu", capacity=2, max_rows=3)
+    c = ["a b", "c d", "e f", "g h", "a b", "i j"]
+    assert torch.equal(small(c), fake_tokenizer(c)) and len(small) == 3 and small.table.shape[0] == 3 and small.bypassed == 2
+    assert torch.equal(small(c), fake_tokenizer(c)) and len(small) == 3 and small.bypassed == 4

@@ -174,8 +174,48 @@ def test_text_tower_on_libhh_matches_oracle_and_stock_path():
     with torch.no_grad():
         rc, rx = OE.encode_text(text, sd, cfg)
         gc, gx = model.encode_text(text.cuda())                  # libhh GEMM / LayerNorm path (frozen weights)
-        model.text_autocast = None
-        sc, sx = model.encode_text(text.cuda())                  # stock fp32 ops
+        # the same modules through their stock nn.Module forwards (fp32; composed HERE -- the product has no such branch): the
+        # state dict landed in the right modules and the oracle restates them
+        t = text.cuda()
+        sx = model.token_embedding(t) + model.positional_embedding[:t.shape[1]]
+        sx = model.ln_final(model.transformer(sx.permute(1, 0, 2)).permute(1, 0, 2)).float()
     assert rel_l2(sx, rx) < 1e-4
+    # a text tower that wants gradients is not on the path: it raises instead of falling back to stock ops
+    for p in model.transformer.parameters():
+        p.requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        model.encode_text(text.cuda())
+    for p in model.transformer.parameters():
+        p.requires_grad_(False)
     check("text_tower", "text feature map rel-L2 vs oracle", rel_l2(gx, rx), 1.1e-2)
     assert torch.nn.functional.cosine_similarity(gc.cpu(), rc, dim=-1).min() > 0.999
+
+
+def test_inflated_4_frame_checkpoint_through_the_16_frame_tower_f2():
+    """SURVEY 8f row 2 on the GPU (run/test_egtea.py:46-96,115): a 4-frame LaViLa state ('module.'-prefixed, as the checkpoints are)
+    is loaded into a T = 16 tower -- `visual.temporal_embed` inflated bilinearly by utils/checkpoint.py -- and the GPU feature map is
+    compared with the oracle fed the SAME inflated state, so the inflated embedding really is what the kernels add."""
+    from helping_hand_for_egocentric_videos_amd.utils import checkpoint as ck
+    sd4 = synth.encoder_state(TINY4, seed=11)
+    ckpt = {"state_dict": {"module." + k: v.clone() for k, v in sd4.items()}}
+    model = LaviLa.build_backbone(TINY16, None, device="cpu")
+    ck.load_backbone_checkpoint(model, ckpt)
+    assert model.visual.temporal_embed.shape == (1, 16, TINY16.embed_dim)
+    # the oracle's state: the 4-frame tensors with the temporal embedding inflated by the same (reference-equal) function
+    sd16 = {k: v.clone() for k, v in sd4.items()}
+    sd16 = ck.inflate_positional_embeds({"visual.temporal_embed": torch.zeros(1, 16, TINY16.embed_dim)}, sd16, num_frames=16)
+    assert torch.equal(model.visual.temporal_embed.data, sd16["visual.temporal_embed"])
+    want = torch.nn.functional.interpolate(sd4["visual.temporal_embed"].unsqueeze(0), (16, TINY16.embed_dim), mode="bilinear").squeeze(0)
+    assert torch.equal(sd16["visual.temporal_embed"], want)
+    video = synth.make_batch(TINY16, 2, seed=11)["video"]
+    with torch.no_grad():
+        rc, rx = OE.vision_forward(video, sd16, TINY16)
+    model = model.cuda().eval()
+    gc, gx = model.visual(video.cuda())
+    check("f2_inflated_4_to_16", "feature map rel-L2 vs oracle on the inflated state", rel_l2(gx, rx), 4.4e-3)
+    # and the inflation matters: the un-inflated first 4 frames' embedding tiled would not pass
+    sd_bad = dict(sd16)
+    sd_bad["visual.temporal_embed"] = sd4["visual.temporal_embed"].repeat(1, 4, 1)
+    with torch.no_grad():
+        _, bx = OE.vision_forward(video, sd_bad, TINY16)
+    assert rel_l2(gx, bx) > 2 * rel_l2(gx, rx)
