@@ -424,6 +424,7 @@ def main():
     ap.add_argument("--force-comm", action="store_true", help="1 GPU only: run the RCCL collectives of the data-parallel path in a 1-rank group (A/B of the CU reservation)")
     ap.add_argument("--per-op-query-side", action="store_true", help="A/B: per-op autograd query side instead of the fused QueryStack node")
     ap.add_argument("--token-major-qkv", action="store_true", help="A/B: the QKV projections write nn.Linear's token-major [B*N, 3D] instead of head-major planes")
+    ap.add_argument("--no-ln-fold", action="store_true", help="A/B: norm1 / norm2 as stand-alone fused add+LayerNorm kernels instead of folded into the GEMMs around them")
     ap.add_argument("--space-16q", action="store_true", help="A/B: space attention on the 16-query-block kernel instead of the joint-block kernel")
     ap.add_argument("--gemm-tail", type=int, default=None, help="A/B: hh_set_tuning('gemm_tail', v): 1 (default) = row tails of <= 64 rows inside the persistent kernel, 2 = always the separate tail kernel, 0 = the 128x128 kernel; same results")
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=V", help="A/B: hh_set_tuning(NAME, V) before anything runs (repeatable)")
@@ -455,6 +456,8 @@ def main():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     dev = torch.device("cuda", local if world > 1 else 0)
 
+    if args.no_ln_fold:
+        LaviLa.LN_FOLD = False
     cfg, cfg_name = CONFIGS[args.config]
     B = args.batch or {"c2": 32, "c4": 4, "c1": 2}[args.config]
     torch.manual_seed(0)

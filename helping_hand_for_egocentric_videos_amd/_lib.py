@@ -14,7 +14,9 @@ c_i64, c_int, c_float, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctyp
 class GemmEpilogue(ctypes.Structure):
     _fields_ = [("bias", c_vp), ("resid", c_vp), ("ldr", c_i64), ("colscale", c_float), ("colscale_cols", c_int),
                 ("act", c_int), ("c_dtype", c_int), ("remap_group", c_i64), ("remap_skip", c_i64),
-                ("remap_offset", c_i64), ("splitk", c_int), ("split_stride", c_i64), ("c_block_stride", c_i64)]
+                ("remap_offset", c_i64), ("splitk", c_int), ("split_stride", c_i64), ("c_block_stride", c_i64),
+                ("ln_stats", c_vp), ("ln_colsum", c_vp), ("z_resid", c_vp), ("z_ldr", c_i64), ("z_out", c_vp), ("z_ldc", c_i64),
+                ("z_stats", c_vp), ("z_partials", c_vp), ("z_eps", c_float), ("skip_c", c_int)]
 
 
 class QGemmOpts(ctypes.Structure):
@@ -37,6 +39,8 @@ SIGNATURES = {
     "hh_prof_read": [c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
     "hh_workspace_bytes_gemm_splitk": [c_i64, c_int, c_int],
     "hh_workspace_bytes_gemm_tn": [c_int, c_int, c_int],
+    "hh_workspace_bytes_gemm_zstats": [c_i64, c_int],
+    "hh_ln_rowstats": [c_vp, c_i64, c_vp, c_i64, c_int, c_float, c_vp],
     "hh_workspace_bytes_xattn_bwd": [c_int, c_int, c_int, c_int],
     "hh_workspace_bytes_xattn_fwd": [c_int, c_int, c_int, c_int],
     "hh_workspace_bytes_attn_cls_partial": [c_int, c_int, c_int, c_int, c_int],
@@ -79,7 +83,7 @@ SIGNATURES = {
     "hh_adamw_arena_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_float, c_float, c_float,
                             c_float, c_int, c_vp],
 }
-_RESTYPES = {"hh_last_error_string": ctypes.c_char_p, "hh_prof_kernel_name": ctypes.c_char_p, "hh_workspace_bytes_gemm_splitk": c_i64, "hh_workspace_bytes_gemm_tn": c_i64,
+_RESTYPES = {"hh_last_error_string": ctypes.c_char_p, "hh_prof_kernel_name": ctypes.c_char_p, "hh_workspace_bytes_gemm_splitk": c_i64, "hh_workspace_bytes_gemm_tn": c_i64, "hh_workspace_bytes_gemm_zstats": c_i64,
              "hh_workspace_bytes_xattn_bwd": c_i64, "hh_workspace_bytes_xattn_fwd": c_i64, "hh_workspace_bytes_attn_cls_partial": c_i64, "hh_workspace_bytes_egonce": c_i64}
 
 _lib = None

@@ -227,8 +227,24 @@ __global__ __launch_bounds__(64 * NWT) void gemm_tail_kernel(GemmParams p) {
 
 int hh_tuning_gemm_tail();                  // gemm256.hip: hh_set_tuning("gemm_tail", 0) routes row tails back to the 128x128 kernel (A/B measurements)
 
+int hh_ln_fold_stats_launch(const float* partials, int slices, float* stats, int64_t rows_part, const void* z, int64_t ldz, int64_t rows, int cols, float eps,
+                            hipStream_t s);        // ln.hip
+static int gemm_bf16_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                          int64_t M, int N, int K, const hh_gemm_epilogue* epi, hh_stream_t stream, int64_t* stats_done_rows);
+
 extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                             int64_t M, int N, int K, const hh_gemm_epilogue* epi, hh_stream_t stream) {
+    int64_t stats_done = 0;                 // rows [0, stats_done) got per-slice row sums of z inside the GEMM kernel
+    int rc = gemm_bf16_impl(A, lda, W, ldw, C, ldc, M, N, K, epi, stream, &stats_done);
+    if (rc != HH_OK || epi->z_out == nullptr || M == 0) return rc;
+    // producer side of the LayerNorm fold: rows [0, stats_done) have per-slice (sum, sum of squares) in z_partials (persistent kernel) ->
+    // (rstd, -rstd * mean); the other rows (row tails, GEMMs on the generic kernels) get theirs from z itself -- one launch for both
+    HH_REQUIRE(stats_done == 0 || epi->z_partials != nullptr, HH_ERR_SHAPE, "hh_gemm_bf16: z_partials workspace is NULL (hh_workspace_bytes_gemm_zstats)");
+    return hh_ln_fold_stats_launch(epi->z_partials, N / 128, epi->z_stats, stats_done, epi->z_out, epi->z_ldc, M, N, epi->z_eps, (hipStream_t)stream);
+}
+
+static int gemm_bf16_impl(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                          int64_t M, int N, int K, const hh_gemm_epilogue* epi, hh_stream_t stream, int64_t* stats_done_rows) {
     HH_REQUIRE(epi != nullptr, HH_ERR_SHAPE, "hh_gemm_bf16: epilogue descriptor is NULL");
     HH_REQUIRE(M >= 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0, HH_ERR_SHAPE,
                "hh_gemm_bf16: need N %% 128 == 0 and K %% 64 == 0 (M=%lld N=%d K=%d)", (long long)M, N, K);
@@ -241,6 +257,21 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
                HH_ERR_ALIGN, "hh_gemm_bf16: pointers must be 16-byte aligned");
     HH_REQUIRE(epi->c_dtype == HH_F32 || epi->c_dtype == HH_BF16, HH_ERR_DTYPE, "hh_gemm_bf16: bad output dtype");
     HH_REQUIRE(epi->resid == nullptr || epi->ldr % 4 == 0, HH_ERR_SHAPE, "hh_gemm_bf16: ldr must be a multiple of 4");
+    if (gemm_ln_ext(*epi)) {                 // LayerNorm fold (include/hh.h)
+        HH_REQUIRE(epi->resid == nullptr && epi->remap_group == 0 && epi->splitk <= 1, HH_ERR_UNSUPPORTED,
+                   "hh_gemm_bf16: the LayerNorm fold takes no fp32 residual / row remap / split-K");
+        if (epi->ln_stats)
+            HH_REQUIRE(epi->ln_colsum != nullptr && epi->bias != nullptr && HH_ALIGNED16(epi->ln_colsum) && (((uintptr_t)epi->ln_stats) & 7) == 0, HH_ERR_SHAPE,
+                       "hh_gemm_bf16: ln_stats needs ln_colsum and bias (16-byte aligned; ln_stats 8-byte aligned)");
+        if (epi->z_out) {
+            HH_REQUIRE(epi->z_resid != nullptr && epi->z_stats != nullptr && epi->act == HH_ACT_NONE && epi->colscale_cols == 0 && !cblk &&
+                       epi->ln_stats == nullptr && epi->c_dtype == HH_BF16, HH_ERR_UNSUPPORTED,
+                       "hh_gemm_bf16: z_out needs z_resid and z_stats, a bf16 row-major C, and no activation / column scale / ln_stats");
+            HH_REQUIRE(epi->z_ldr >= N && epi->z_ldc >= N && epi->z_ldr % 4 == 0 && epi->z_ldc % 8 == 0 && N <= 2048 && HH_ALIGNED16(epi->z_resid) &&
+                       HH_ALIGNED16(epi->z_out) && (((uintptr_t)epi->z_stats) & 7) == 0 && epi->z_eps > 0.f, HH_ERR_SHAPE,
+                       "hh_gemm_bf16: bad z_resid / z_out / z_stats (N <= 2048, z_ldr %% 4 == 0, z_ldc %% 8 == 0, eps > 0)");
+        }
+    }
     if (M == 0) return HH_OK;
     GemmParams p;
     p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.C = C; p.ldc = cblk ? 64 : ldc;
@@ -267,6 +298,7 @@ extern "C" int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t l
         pm.tail_rows = fold ? (int)(M - pm.M) : 0;
         bool folded = false;
         int rc = hh_gemm256_launch(pm, (hipStream_t)stream, &folded);
+        if (rc == HH_OK && epi->z_out != nullptr) *stats_done_rows = pm.M;      // (the persistent kernel left per-slice row sums in z_partials)
         if (rc != HH_OK || pm.M == M || folded) return rc;
         p.m_start = pm.M;
     }

@@ -569,6 +569,9 @@ static int g_nostore = 0;          // debug: skip the epilogue stores (timing ex
 static int g_group = 0;            // m-tiles per XCD-local group (weight-panel reuse factor); 0 = per-shape default
 static int g_pskew = 0;            // persistent kernel: start skew quantum (s_sleep(8) units per workgroup index in its XCD)
 static int g_skew = -1;            // start skew of the one-tile-per-block kernel: -1 auto (on with an fp32 residual), 0 off, 1 on
+bool hh_gemm256w4p_ln_ext_ok(const GemmParams& p, bool w4);      // gemm256w4.hip: the 4-wave persistent kernel implements this LayerNorm-fold epilogue
+int hh_gemm256w4p_ln_epi(const hh_gemm_epilogue& e);
+void hh_gemm256w4p_set_ln_ext(int v);
 static int g_mode = 5;             // "gemm256": 0 = 128x128 kernel only, 1 = one tile per block, 2 = + wave-row stagger, 3 = persistent 8-wave kernel, 4 = 4-wave kernel of gemm256w4.hip, one tile per block, 5 = persistent 4-wave kernel where K allows, else 3 (default)
 static int g_dynamic = 1;           // "gemm256_dynamic": 4-wave persistent kernel takes its tiles from per-XCD atomic counters (1, default) or by static stride (0)
 static int g_min_tiles = 192;       // "gemm256_min_tiles": fewest 256x256 tiles for which the 256x256 kernels are used
@@ -598,12 +601,14 @@ extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm256_debug_ts")) { g_debug_ts = value; g_ts_count = 0; return HH_OK; }
     if (name && !strcmp(name, "gemm256_dynamic") && (value == 0 || value == 1)) { g_dynamic = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_min_tiles") && value >= 1 && value <= 4096) { g_min_tiles = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm_ln_w4") && (value == 0 || value == 1)) { hh_gemm256w4p_set_ln_ext(value); return HH_OK; }
     if (name && !strcmp(name, "gemm256_group") && value >= 0 && value <= 64) { g_group = value; return HH_OK; }
     hh_set_error("hh_set_tuning: unknown knob '%s' or value %d out of range", name ? name : "(null)", value);
     return HH_ERR_UNSUPPORTED;
 }
 
 #define P_LDS(N) (2 * BUF_BYTES + (size_t)(N) * 4)       // persistent kernel: two staging buffers + the bias vector
+
 
 bool hh_gemm256_eligible(const GemmParams& p) {
     // at least ~3/4 of the CUs must get a 256x256 tile for the 8-wave kernels: below that the 128x128 kernel (4x the tiles, two workgroups
@@ -613,6 +618,7 @@ bool hh_gemm256_eligible(const GemmParams& p) {
     const bool w4 = g_mode == 5 && p.K >= 384 && p.K % 128 == 0 && p.N <= 4096 && p.e.resid == nullptr && p.e.remap_group == 0 &&
                     (p.e.colscale_cols == 0 || (p.e.act == HH_ACT_NONE && p.e.colscale_cols % 128 == 0));
     const int min_tiles = (w4 && g_min_tiles == 192) ? 128 : g_min_tiles;
+    if (gemm_ln_ext(p.e) && !hh_gemm256w4p_ln_ext_ok(p, w4)) return false;      // the LayerNorm fold: persistent 4-wave kernel or the generic 128x128 one
     return g_mode > 0 && p.N % 256 == 0 && p.M >= 2048 && p.e.splitk <= 1 && (p.M / 256) * (p.N / 256) >= min_tiles;
 }
 
@@ -660,7 +666,8 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
         // one-tile-per-block kernel below (generic epilogue)
         const bool scaled = p.e.colscale_cols > 0;
         int epi = -1;
-        if (p.e.act == HH_ACT_NONE) epi = scaled ? (p.e.colscale_cols % 128 == 0 ? 1 : -1) : 0;
+        if (gemm_ln_ext(p.e)) epi = hh_gemm256w4p_ln_epi(p.e);      // (eligible only on the 4-wave kernel: hh_gemm256w4p_ln_ext_ok)
+        else if (p.e.act == HH_ACT_NONE) epi = scaled ? (p.e.colscale_cols % 128 == 0 ? 1 : -1) : 0;
         else if (!scaled) epi = p.e.act == HH_ACT_QUICKGELU ? 2 : p.e.act == HH_ACT_RELU ? 3 : -1;
         if (epi >= 0) {
             const int ncu = hh_stream_cu_count(s) & ~7;      // CU budget of this stream; the stride of the tile walk must keep blockIdx & 7 == XCD
@@ -672,13 +679,15 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
                 const int slot = g_dynamic ? hh_stream_slot(s) : -1;
                 p.dynamic = slot >= 0;
                 p.tile_slot = slot >= 0 ? slot : 0;      // (N: bias vector + epilogue scratch share the 32 KB of LDS the ring leaves)
-                static const char* const w4p_names[8] = {"gemm256w4p_kernel<false, 0>", "gemm256w4p_kernel<true, 0>", "gemm256w4p_kernel<false, 1>", "gemm256w4p_kernel<true, 1>",
-                                                         "gemm256w4p_kernel<false, 2>", "gemm256w4p_kernel<true, 2>", "gemm256w4p_kernel<false, 3>", "gemm256w4p_kernel<true, 3>"};
+                static const char* const w4p_names[14] = {"gemm256w4p_kernel<false, 0>", "gemm256w4p_kernel<true, 0>", "gemm256w4p_kernel<false, 1>", "gemm256w4p_kernel<true, 1>",
+                                                          "gemm256w4p_kernel<false, 2>", "gemm256w4p_kernel<true, 2>", "gemm256w4p_kernel<false, 3>", "gemm256w4p_kernel<true, 3>",
+                                                          "", "gemm256w4p_kernel<true, 4>", "", "gemm256w4p_kernel<true, 5>", "", "gemm256w4p_kernel<true, 6>"};
                 hh_prof_note_kernel(HH_PROF_GEMM256, w4p_names[epi * 2 + (bf ? 1 : 0)]);
                 int rc = hh_gemm256w4p_launch(p, epi, pg, s);
                 if (tail_done) *tail_done = p.tail_rows > 0;
                 return rc;
             }
+            if (epi >= 4) { hh_set_error("hh_gemm_bf16: internal: LayerNorm-fold epilogue on the 8-wave kernel"); return HH_ERR_UNSUPPORTED; }
             hh_gemm256w4_timeline_mark(false);
             hh_prof_note_kernel(HH_PROF_GEMM256, "gemm256d_kernel (8-wave persistent)");
 #define LAUNCHD(BF, E) hipLaunchKernelGGL((gemm256d_kernel<BF, E>), dim3(pg), dim3(512), P_LDS(p.N), s, p)
@@ -696,6 +705,10 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
             if (tail_done) *tail_done = p.tail_rows > 0;
             return hh_check_launch("hh_gemm_bf16(256x256 persistent)");
         }
+    }
+    if (gemm_ln_ext(p.e)) {                  // (hh_gemm256_eligible admits the fold only where the persistent 4-wave kernel takes it)
+        hh_set_error("hh_gemm_bf16: internal: LayerNorm-fold epilogue reached a 256x256 kernel that does not implement it");
+        return HH_ERR_UNSUPPORTED;
     }
     HHProfScope prof(HH_PROF_GEMM_OTHER, 2.0 * (double)p.M * p.N * p.K, s);
     if (g_mode == 4 && p.K >= 256 && p.K % 128 == 0 && !g_nostore) return hh_gemm256w4_launch(p, grid, s);

@@ -395,12 +395,19 @@ __device__ __forceinline__ f32x4 w4_quick_gelu4(f32x4 v) {
 
 // ---- epilogue.  Lane (frow, fq) of wave (wr, wc) owns, for each of its 8 row groups IDX = mh*4 + tm (row m0 + mh*128 + wr*64 + tm*16 +
 // frow), the columns n0 + wc*128 + 64 nh + 32 jj + 8 fq + [0, 8) for j = 2 nh + jj = 0..3.
+// EPI: 0 bias, 1 bias + column scale, 2 bias + QuickGELU, 3 bias + ReLU, 4 bias + the producer side of the LayerNorm fold (include/hh.h:
+// z = z_resid + value, bf16, + row statistics), 5 / 6 = 1 / 2 with the consumer side of the fold in front:
+// value = rstd[row] * acc - rstd[row] * mean[row] * colsum[n] + bias[n].
+template <int BASE16>
+__device__ __forceinline__ void w4p_acc_group(f32x4 (&a)[4], f32x4 (&b)[4]) {
+    a[0] = w4_acc_read<BASE16 + 0>();       b[0] = w4_acc_read<BASE16 + 4>();
+    a[1] = w4_acc_read<BASE16 + 8>();       b[1] = w4_acc_read<BASE16 + 12>();
+    a[2] = w4_acc_read<BASE16 + 16 + 0>();  b[2] = w4_acc_read<BASE16 + 16 + 4>();
+    a[3] = w4_acc_read<BASE16 + 16 + 8>();  b[3] = w4_acc_read<BASE16 + 16 + 12>();
+}
 template <int EPI, int IDX>
 __device__ __forceinline__ void w4p_finish_group(float sc, const f32x4 (&bias_v)[4][2], f32x4 (&a)[4], f32x4 (&b)[4]) {
-    a[0] = w4_acc_read<16 * (IDX * 2 + 0) + 0>();  b[0] = w4_acc_read<16 * (IDX * 2 + 0) + 4>();
-    a[1] = w4_acc_read<16 * (IDX * 2 + 0) + 8>();  b[1] = w4_acc_read<16 * (IDX * 2 + 0) + 12>();
-    a[2] = w4_acc_read<16 * (IDX * 2 + 1) + 0>();  b[2] = w4_acc_read<16 * (IDX * 2 + 1) + 4>();
-    a[3] = w4_acc_read<16 * (IDX * 2 + 1) + 8>();  b[3] = w4_acc_read<16 * (IDX * 2 + 1) + 12>();
+    w4p_acc_group<16 * (IDX * 2)>(a, b);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         a[j] += bias_v[j][0]; b[j] += bias_v[j][1];
@@ -414,18 +421,47 @@ __device__ __forceinline__ void w4p_finish_group(float sc, const f32x4 (&bias_v)
         }
     }
 }
+// consumer side of the LayerNorm fold: st = (rstd, -rstd * mean) of this lane's row; the column sums stay in registers, the bias is re-read
+// from LDS per group (the two vectors together would not fit the register file beside the next tile's first fragments)
+template <int EPI, int IDX>
+__device__ __forceinline__ void w4p_finish_group_ln(float sc, const float* bias_l, const f32x4 (&cs_v)[4][2], f32x2 st, f32x4 (&a)[4], f32x4 (&b)[4]) {
+    w4p_acc_group<16 * (IDX * 2)>(a, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 b0 = *(const f32x4*)(bias_l + (j & 1) * 32 + (j >> 1) * 64), b1 = *(const f32x4*)(bias_l + (j & 1) * 32 + (j >> 1) * 64 + 4);
+        a[j] = a[j] * st[0] + (cs_v[j][0] * st[1] + b0);
+        b[j] = b[j] * st[0] + (cs_v[j][1] * st[1] + b1);
+        if constexpr (EPI == 5) {
+            a[j] *= sc; b[j] *= sc;
+        } else {
+            a[j] = w4_quick_gelu4(a[j]); b[j] = w4_quick_gelu4(b[j]);
+        }
+    }
+}
+// per-tile constants of the LayerNorm-fold epilogues
+struct W4Ln {
+    const float* bias_l;          // LDS: bias + this lane's first column
+    const float* stats;           // consumer: ln_stats + 2 * (first row of this lane); row group IDX adds 2 * rowoff(IDX)
+    f32x4 cs_v[4][2];             // consumer: column sums of this lane's 32 columns
+};
+__device__ __forceinline__ constexpr int w4_rowoff(int IDX) { return (IDX >> 2) * 128 + (IDX & 3) * 16; }
+
 // bf16 output: group IDX goes through the wave's LDS scratch (16 rows x 256 B, 16-B chunks XOR-swizzled with the row: conflict-free both
 // ways) and leaves as 4 stores of 4 rows x 256 B; the stores of group IDX - 1 are issued behind the arithmetic of group IDX.
 template <int EPI, int IDX>
 __device__ __forceinline__ void w4p_store_tile(const GemmParams& p, bf16_t* cptr, int64_t rowbase, char* scr, int frow, int fq, int l15, int l4,
-                                               float sc, const f32x4 (&bias_v)[4][2], u32x4 (*prev)[4] = nullptr) {
+                                               float sc, const f32x4 (&bias_v)[4][2], const W4Ln& ln, f32x2 st, u32x4 (*prev)[4] = nullptr) {
     f32x4 a[4], b[4];
-    w4p_finish_group<EPI, IDX>(sc, bias_v, a, b);
+    f32x2 st_next = st;
+    if constexpr (EPI == 5) {
+        if constexpr (IDX + 1 < 8) st_next = *(const f32x2*)(ln.stats + 2 * w4_rowoff(IDX + 1));      // one group ahead
+        w4p_finish_group_ln<EPI, IDX>(sc, ln.bias_l, ln.cs_v, st, a, b);
+    } else w4p_finish_group<EPI, IDX>(sc, bias_v, a, b);
     u32x4 o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = (u32x4){pack_bf16(a[j][0], a[j][1]), pack_bf16(a[j][2], a[j][3]), pack_bf16(b[j][0], b[j][1]), pack_bf16(b[j][2], b[j][3])};
     if constexpr (IDX > 0) {                                           // the previous group's rows (its LDS reads were issued before this group's arithmetic)
-        const int64_t r0 = rowbase + ((IDX - 1) >> 2) * 128 + ((IDX - 1) & 3) * 16 + l4;
+        const int64_t r0 = rowbase + w4_rowoff(IDX - 1) + l4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(u32x4*)(cptr + (r0 + 4 * q) * p.ldc) = (*prev)[q];
     }
@@ -434,9 +470,9 @@ __device__ __forceinline__ void w4p_store_tile(const GemmParams& p, bf16_t* cptr
     u32x4 rd[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int r = 4 * q + l4; rd[q] = *(const u32x4*)(scr + r * 256 + ((l15 ^ r) << 4)); }
-    if constexpr (IDX + 1 < 8) w4p_store_tile<EPI, IDX + 1>(p, cptr, rowbase, scr, frow, fq, l15, l4, sc, bias_v, &rd);
+    if constexpr (IDX + 1 < 8) w4p_store_tile<EPI, IDX + 1>(p, cptr, rowbase, scr, frow, fq, l15, l4, sc, bias_v, ln, st_next, &rd);
     else {
-        const int64_t r0 = rowbase + (IDX >> 2) * 128 + (IDX & 3) * 16 + l4;
+        const int64_t r0 = rowbase + w4_rowoff(IDX) + l4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(u32x4*)(cptr + (r0 + 4 * q) * p.ldc) = rd[q];
     }
@@ -444,10 +480,15 @@ __device__ __forceinline__ void w4p_store_tile(const GemmParams& p, bf16_t* cptr
 // straight from the MFMA layout (a store instruction covers 16 rows x 64 B of bf16): fp32 output, and the QuickGELU epilogue, whose
 // arithmetic (two transcendentals per value) is longer than even these slow stores -- the LDS round trip only adds to it
 template <bool OUT_BF16, int EPI, int IDX>
-__device__ __forceinline__ void w4p_store_rows_direct(const GemmParams& p, int64_t rowbase, float sc, const f32x4 (&bias_v)[4][2], const int64_t (&ccol)[4]) {
-    const int64_t orow = rowbase + (IDX >> 2) * 128 + (IDX & 3) * 16;
+__device__ __forceinline__ void w4p_store_rows_direct(const GemmParams& p, int64_t rowbase, float sc, const f32x4 (&bias_v)[4][2], const int64_t (&ccol)[4],
+                                                      const W4Ln& ln, f32x2 st) {
+    const int64_t orow = rowbase + w4_rowoff(IDX);
     f32x4 a[4], b[4];
-    w4p_finish_group<EPI, IDX>(sc, bias_v, a, b);
+    f32x2 st_next = st;
+    if constexpr (EPI == 6) {
+        if constexpr (IDX + 1 < 8) st_next = *(const f32x2*)(ln.stats + 2 * w4_rowoff(IDX + 1));
+        w4p_finish_group_ln<EPI, IDX>(sc, ln.bias_l, ln.cs_v, st, a, b);
+    } else w4p_finish_group<EPI, IDX>(sc, bias_v, a, b);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if constexpr (OUT_BF16) {
@@ -458,7 +499,66 @@ __device__ __forceinline__ void w4p_store_rows_direct(const GemmParams& p, int64
             *(f32x4*)((float*)p.C + orow * p.ldc + ccol[j] + 4) = b[j];
         }
     }
-    if constexpr (IDX + 1 < 8) w4p_store_rows_direct<OUT_BF16, EPI, IDX + 1>(p, rowbase, sc, bias_v, ccol);
+    if constexpr (IDX + 1 < 8) w4p_store_rows_direct<OUT_BF16, EPI, IDX + 1>(p, rowbase, sc, bias_v, ccol, ln, st_next);
+}
+
+// ---- producer side of the LayerNorm fold (EPI 4; the attention output projections, model/LaviLa.py:281 -> :372,388).  For row group IDX the
+// lane adds, in the MFMA layout, the fp32 residual row (z_resid: 8 loads per group, issued ONE GROUP AHEAD) to value = acc + bias, sums
+// z and z^2 over its 32 columns (the four lanes of a row are 16 apart: two cross-lane adds), and sends z -- and C = bf16(value), unless
+// skip_c -- through the wave's LDS scratch to 4-rows-x-256-B stores.  The (sum, sum of squares) of the wave's 128 columns go to
+// z_partials[row][n0 / 128 + wc]; gemm.hip's finalize pass adds the N / 128 slices in a fixed order.
+template <int IDX>
+__device__ __forceinline__ void w4p_zload(const float* xrow, f32x4 (&xa)[4], f32x4 (&xb)[4], int64_t ldx) {
+    const float* r = xrow + (int64_t)w4_rowoff(IDX) * ldx;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        xa[j] = *(const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64);
+        xb[j] = *(const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64 + 4);
+    }
+}
+__device__ __forceinline__ void w4p_lds_rows(char* scr, int frow, int fq, int l15, int l4, const f32x4 (&a)[4], const f32x4 (&b)[4], u32x4 (&rd)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32x4 o = {pack_bf16(a[j][0], a[j][1]), pack_bf16(a[j][2], a[j][3]), pack_bf16(b[j][0], b[j][1]), pack_bf16(b[j][2], b[j][3])};
+        *(u32x4*)(scr + frow * 256 + (((j * 4 + fq) ^ frow) << 4)) = o;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int r = 4 * q + l4; rd[q] = *(const u32x4*)(scr + r * 256 + ((l15 ^ r) << 4)); }
+}
+template <int IDX>
+__device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cptr, bf16_t* zptr, const float* xrow, float* part, int64_t rowbase, char* scr,
+                                                 int frow, int fq, int l15, int l4, const float* bias_l, f32x4 (&xa)[4], f32x4 (&xb)[4]) {
+    f32x4 xna[4], xnb[4];
+    if constexpr (IDX + 1 < 8) w4p_zload<IDX + 1>(xrow, xna, xnb, p.e.z_ldr);
+    f32x4 a[4], b[4];
+    w4p_acc_group<16 * (IDX * 2)>(a, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] += *(const f32x4*)(bias_l + (j & 1) * 32 + (j >> 1) * 64);
+        b[j] += *(const f32x4*)(bias_l + (j & 1) * 32 + (j >> 1) * 64 + 4);
+    }
+    const int64_t r0 = rowbase + w4_rowoff(IDX) + l4;
+    u32x4 rd[4];
+    if (!p.e.skip_c) {
+        w4p_lds_rows(scr, frow, fq, l15, l4, a, b, rd);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(u32x4*)(cptr + (r0 + 4 * q) * p.ldc) = rd[q];
+    }
+    f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] += xa[j]; b[j] += xb[j];
+        s4 += a[j]; s4 += b[j];
+        q4 += a[j] * a[j]; q4 += b[j] * b[j];
+    }
+    float sm = (s4[0] + s4[1]) + (s4[2] + s4[3]), sq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+    sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+    sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+    if (fq == 0) { const f32x2 o = {sm, sq}; *(f32x2*)(part + (int64_t)w4_rowoff(IDX) * 2 * (p.N >> 7)) = o; }
+    w4p_lds_rows(scr, frow, fq, l15, l4, a, b, rd);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(u32x4*)(zptr + (r0 + 4 * q) * p.e.z_ldc) = rd[q];
+    if constexpr (IDX + 1 < 8) w4p_store_tile_z<IDX + 1>(p, cptr, zptr, xrow, part, rowbase, scr, frow, fq, l15, l4, bias_l, xna, xnb);
 }
 
 // Dynamic tile walk: per stream slot (runtime.cpp: hh_stream_slot) 8 per-XCD tile counters + the count of finished workgroups; the last
@@ -467,7 +567,9 @@ __device__ unsigned g_w4_tile_cnt[32][16];
 
 template <bool OUT_BF16, int EPI>
 __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
-    constexpr int STORES = OUT_BF16 ? 32 : 64;                // global_store_dwordx4 per wave and tile in the epilogue (checked in the ISA)
+    // global_store_dwordx4 per wave and tile in the epilogue that are younger than every load of it (checked in the ISA); the producer
+    // side of the LayerNorm fold (EPI 4) waits for its residual loads group by group: only the last group's z stores are certain to trail
+    constexpr int STORES = EPI == 4 ? 4 : OUT_BF16 ? 32 : 64;
     constexpr int VM_ST = 24 + STORES > 63 ? 63 : 24 + STORES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -604,7 +706,9 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
         unsigned tk = 0;
         if (p.dynamic && tid == 0) {
             const unsigned zero = 0, one = 1;
-            asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk) : "v"(zero), "v"(one), "s"(tcnt + xcd) : "memory");
+            // (s_nop 4: the address SGPRs may have just come back from a VGPR spill lane -- v_readlane -> VMEM SGPR read needs 5 wait states, and
+            // the hazard recogniser does not look inside inline asm: without it the LayerNorm-fold instantiation faulted on a stale pointer)
+            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk) : "v"(zero), "v"(one), "s"(tcnt + xcd) : "memory");
         }
         stamp(1);
         if (first) w4_iter<W4V_FIRST0, VM_ST>(s); else w4_iter<W4V_NEXT0, VM_ST>(s);
@@ -636,18 +740,42 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
             const hh_gemm_epilogue& e = p.e;
             const int nb = n0 + wc * 128 + 8 * fq;                     // lane's columns: nb + 64 nh + 32 jj + [0, 8)
             f32x4 bias_v[4][2];
+            if constexpr (EPI < 4) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int cj = nb + (j & 1) * 32 + (j >> 1) * 64;
-                bias_v[j][0] = *(const f32x4*)(bias_s + cj);
-                bias_v[j][1] = *(const f32x4*)(bias_s + cj + 4);
+                for (int j = 0; j < 4; ++j) {
+                    const int cj = nb + (j & 1) * 32 + (j >> 1) * 64;
+                    bias_v[j][0] = *(const f32x4*)(bias_s + cj);
+                    bias_v[j][1] = *(const f32x4*)(bias_s + cj + 4);
+                }
             }
             float sc = 1.f;
-            if constexpr (EPI == 1) {
+            if constexpr (EPI == 1 || EPI == 5) {
                 if (n0 + wc * 128 < e.colscale_cols) sc = e.colscale;  // colscale_cols % 128 == 0: the wave's 128 columns are all in or all out
             }
             stamp(3);
-            if constexpr (OUT_BF16 && EPI != 2) {
+            W4Ln ln;
+            f32x2 st0 = {1.f, 0.f};
+            if constexpr (EPI >= 4) ln.bias_l = bias_s + nb;
+            if constexpr (EPI >= 5) {
+                ln.stats = e.ln_stats + 2 * (m0 + wr * 64 + frow);
+                st0 = *(const f32x2*)(ln.stats);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cj = nb + (j & 1) * 32 + (j >> 1) * 64;
+                    ln.cs_v[j][0] = *(const f32x4*)(e.ln_colsum + cj);
+                    ln.cs_v[j][1] = *(const f32x4*)(e.ln_colsum + cj + 4);
+                }
+            }
+            if constexpr (EPI == 4) {
+                char* scr = smem + 2 * W4_BUF + p.N * 4 + wave * 4096;
+                const int l15 = lane & 15, l4 = lane >> 4;
+                const int ncol = n0 + wc * 128 + l15 * 8;              // this lane's 8 columns in the store phase
+                const float* xrow = e.z_resid + (m0 + wr * 64 + frow) * e.z_ldr + nb;
+                float* part = e.z_partials + ((m0 + wr * 64 + frow) * (int64_t)(p.N >> 7) + ((n0 >> 7) + wc)) * 2;
+                f32x4 xa[4], xb[4];
+                w4p_zload<0>(xrow, xa, xb, e.z_ldr);
+                w4p_store_tile_z<0>(p, (bf16_t*)p.C + ncol, (bf16_t*)e.z_out + ncol, xrow, part, m0 + wr * 64, scr, frow, fq, l15, l4, ln.bias_l, xa, xb);
+            } else if constexpr (OUT_BF16 && EPI != 2 && EPI != 6) {
                 // through this wave's 4 KB of LDS: a lane finishes 4 x 16 B of one row (MFMA layout), the wave then stores 4 rows x 256 B
                 // per instruction.  A store instruction covering 16 rows x 64 B takes ~270 cycles on the CU's store path, 4 rows x 256 B
                 // 66 (scripts/store_probe.hip) -- the epilogue was bound by exactly that.
@@ -655,12 +783,12 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
                 const int l15 = lane & 15, l4 = lane >> 4;
                 const int ncol = n0 + wc * 128 + l15 * 8;              // this lane's 8 columns in the store phase
                 bf16_t* cptr = (bf16_t*)p.C + gemm_ccol(e, ncol);
-                w4p_store_tile<EPI, 0>(p, cptr, m0 + wr * 64, scr, frow, fq, l15, l4, sc, bias_v);
+                w4p_store_tile<EPI, 0>(p, cptr, m0 + wr * 64, scr, frow, fq, l15, l4, sc, bias_v, ln, st0);
             } else {
                 int64_t ccol[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ccol[j] = gemm_ccol(e, nb + (j & 1) * 32 + (j >> 1) * 64);
-                w4p_store_rows_direct<OUT_BF16, EPI, 0>(p, m0 + wr * 64 + frow, sc, bias_v, ccol);
+                w4p_store_rows_direct<OUT_BF16, EPI, 0>(p, m0 + wr * 64 + frow, sc, bias_v, ccol, ln, st0);
             }
         }
         stamp(4);
@@ -672,6 +800,21 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
     finish();
 #undef W4_STAGE
 }
+
+// LayerNorm fold (include/hh.h) on this kernel: bf16 outputs; producer = bias only (EPI 4), consumer = with the q column scale on whole
+// 128-column halves (EPI 5) or QuickGELU (EPI 6).  Everything else with the fold runs on the generic 128x128 kernel.
+static int g_w4_ln_ext = 1;         // hh_set_tuning("gemm_ln_w4", 0): keep LayerNorm-fold GEMMs off this kernel (A/B, debugging)
+void hh_gemm256w4p_set_ln_ext(int v) { g_w4_ln_ext = v; }
+int hh_gemm256w4p_ln_epi(const hh_gemm_epilogue& e) {
+    if (e.c_dtype != HH_BF16) return -1;
+    if (e.z_out) return (e.ln_stats == nullptr && e.act == HH_ACT_NONE && e.colscale_cols == 0 && e.c_block_stride == 0) ? 4 : -1;
+    if (e.ln_stats) {
+        if (e.act == HH_ACT_NONE && e.colscale_cols > 0 && e.colscale_cols % 128 == 0) return 5;
+        if (e.act == HH_ACT_QUICKGELU && e.colscale_cols == 0) return 6;
+    }
+    return -1;
+}
+bool hh_gemm256w4p_ln_ext_ok(const GemmParams& p, bool w4) { return g_w4_ln_ext && w4 && p.M >= 256 && hh_gemm256w4p_ln_epi(p.e) >= 0; }
 
 static bool g_w4_ts_last = false;
 bool hh_gemm256w4_timeline_is_last() { return g_w4_ts_last; }
@@ -688,11 +831,18 @@ int hh_gemm256w4p_launch(const GemmParams& p, int epi, unsigned pg, hipStream_t 
     if (!attr_done) {
 #define ATTRP(BF, E) hipFuncSetAttribute((const void*)gemm256w4p_kernel<BF, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096))
         ATTRP(true, 0); ATTRP(false, 0); ATTRP(true, 1); ATTRP(false, 1); ATTRP(true, 2); ATTRP(false, 2); ATTRP(true, 3); ATTRP(false, 3);
+        ATTRP(true, 4); ATTRP(true, 5); ATTRP(true, 6);
 #undef ATTRP
         attr_done = true;
     }
     const bool bf = p.e.c_dtype == HH_BF16;
 #define LAUNCHP(BF, E) hipLaunchKernelGGL((gemm256w4p_kernel<BF, E>), dim3(pg), dim3(256), W4P_LDS(p.N), s, p)
+    if (epi >= 4) {
+        if (!bf) { hh_set_error("hh_gemm_bf16: the LayerNorm-fold epilogues of the persistent kernel write bf16"); return HH_ERR_UNSUPPORTED; }
+        if (epi == 4) LAUNCHP(true, 4); else if (epi == 5) LAUNCHP(true, 5); else LAUNCHP(true, 6);
+        g_w4_ts_last = true;
+        return hh_check_launch("hh_gemm_bf16(256x256 persistent, 4 waves, LayerNorm fold)");
+    }
     switch (epi * 2 + (bf ? 1 : 0)) {
         case 0: LAUNCHP(false, 0); break;
         case 1: LAUNCHP(true, 0); break;

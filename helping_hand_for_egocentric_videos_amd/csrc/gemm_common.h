@@ -35,9 +35,15 @@ __device__ __forceinline__ int64_t gemm_ccol(const hh_gemm_epilogue& e, int n) {
 }
 
 // Epilogue for one accumulator tile in the swapped (C^T) layout: lane owns C[orow][n .. n+3].
+// LayerNorm fold (include/hh.h): consumer side -- v <- rstd[m] * v - rstd[m] * mean[m] * colsum[n] + bias[n] (orow == m: no remap with it);
+// producer side -- z = z_resid + (acc + bias) stored as bf16 beside C (its row statistics come from hh_ln_rowstats-style passes
+// of the caller: gemm.hip).
 template <bool OUT_BF16>
 __device__ __forceinline__ void gemm_store4(const hh_gemm_epilogue& e, char* Cbase, int64_t ldc, int64_t orow, int n, f32x4 v) {
-    if (e.bias) v += *(const f32x4*)(e.bias + n);
+    if (e.ln_stats) {
+        const f32x2 st = *(const f32x2*)(e.ln_stats + 2 * orow);
+        v = v * st[0] + (*(const f32x4*)(e.ln_colsum + n) * st[1] + *(const f32x4*)(e.bias + n));
+    } else if (e.bias) v += *(const f32x4*)(e.bias + n);
     if (n < e.colscale_cols) v *= e.colscale;
     if (e.act == HH_ACT_QUICKGELU) {
 #pragma unroll
@@ -47,6 +53,12 @@ __device__ __forceinline__ void gemm_store4(const hh_gemm_epilogue& e, char* Cba
         for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
     }
     if (e.resid) v += *(const f32x4*)(e.resid + orow * e.ldr + n);
+    if (e.z_out) {
+        const f32x4 z = *(const f32x4*)(e.z_resid + orow * e.z_ldr + n) + v;
+        u32x2 o = {pack_bf16(z[0], z[1]), pack_bf16(z[2], z[3])};
+        *(u32x2*)((bf16_t*)e.z_out + orow * e.z_ldc + n) = o;
+        if (e.skip_c) return;
+    }
     if constexpr (OUT_BF16) {
         u32x2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
         *(u32x2*)((bf16_t*)Cbase + orow * ldc + gemm_ccol(e, n)) = o;
@@ -76,6 +88,9 @@ __device__ __forceinline__ void gemm_store8(const hh_gemm_epilogue& e, char* Cba
         *(f32x4*)((float*)Cbase + orow * ldc + gemm_ccol(e, n) + 4) = v1;
     }
 }
+
+// include/hh.h: LayerNorm-fold fields of the epilogue in use (only gemm_store4 and the persistent 4-wave kernel implement them)
+__host__ __device__ __forceinline__ bool gemm_ln_ext(const hh_gemm_epilogue& e) { return e.ln_stats != nullptr || e.z_out != nullptr; }
 
 int hh_gemm256_launch(const GemmParams& p, hipStream_t s, bool* tail_done);   // gemm256.hip; returns HH_OK or an error; *tail_done: p.tail_rows were computed
 bool hh_gemm256_eligible(const GemmParams& p);

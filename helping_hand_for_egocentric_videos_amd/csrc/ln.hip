@@ -83,6 +83,103 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
     }
 }
 
+// Row statistics of a bf16 matrix for the LayerNorm fold of the GEMMs (include/hh.h, hh_gemm_epilogue.ln_stats): stats[row] = (rstd,
+// -rstd * mean), two-pass in registers.  Rows [row0, rows).
+template <int NV>
+__global__ __launch_bounds__(256) void ln_rowstats_kernel(const bf16_t* __restrict__ z, int64_t ldz, float* __restrict__ stats, int64_t row0,
+                                                          int64_t rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NV][4];
+    load_row<NV, bf16_t>(z + row * ldz, cols, lane, v);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (lane == 0) { f32x2 o = {rstd, -rstd * mean}; *(f32x2*)(stats + 2 * row) = o; }
+}
+
+// rows [row0, rows) of z -> stats (library-internal: the producer side of the fold calls it for the rows whose statistics did not come
+// out of the GEMM's own epilogue)
+int hh_ln_rowstats_launch(const void* z, int64_t ldz, float* stats, int64_t row0, int64_t rows, int cols, float eps, hipStream_t s) {
+    if (rows <= row0) return HH_OK;
+    dim3 grid((unsigned)((rows - row0 + 3) / 4)), block(256);
+    const int nv = (cols + 255) / 256;
+#define LR(NV) hipLaunchKernelGGL((ln_rowstats_kernel<NV>), grid, block, 0, s, (const bf16_t*)z, ldz, stats, row0, rows, cols, eps)
+    if (nv <= 2) LR(2); else if (nv <= 4) LR(4); else LR(8);
+#undef LR
+    return hh_check_launch("hh_ln_rowstats");
+}
+
+// Statistics of the producer side of the LayerNorm fold in ONE launch: rows [0, rows_part) have per-slice (sum, sum of squares) written by
+// the persistent GEMM's epilogue (gemm256w4.hip, EPI 4) -- one thread per row, slices added in index order (deterministic); rows
+// [rows_part, rows) (the GEMM's row tail) are read back from z itself, one wave per row, two-pass (the last blocks of the grid).
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fold_stats_kernel(const float* __restrict__ partials, int slices, float* __restrict__ stats, int64_t rows_part,
+                                                            const bf16_t* __restrict__ z, int64_t ldz, int64_t rows, int cols, float eps, int part_blocks) {
+    if ((int)blockIdx.x < part_blocks) {
+        const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (row >= rows_part) return;
+        const f32x2* p = (const f32x2*)partials + row * slices;
+        float s = 0.f, q = 0.f;
+        for (int i = 0; i < slices; ++i) { const f32x2 v = p[i]; s += v[0]; q += v[1]; }
+        const float inv_cols = 1.f / (float)cols;
+        const float mean = s * inv_cols;
+        const float rstd = rsqrtf(fmaxf(q * inv_cols - mean * mean, 0.f) + eps);
+        const f32x2 o = {rstd, -rstd * mean};
+        *(f32x2*)(stats + 2 * row) = o;
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t row = rows_part + (int64_t)((int)blockIdx.x - part_blocks) * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NV][4];
+    load_row<NV, bf16_t>(z + row * ldz, cols, lane, v);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < cols) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (lane == 0) { f32x2 o = {rstd, -rstd * mean}; *(f32x2*)(stats + 2 * row) = o; }
+}
+int hh_ln_fold_stats_launch(const float* partials, int slices, float* stats, int64_t rows_part, const void* z, int64_t ldz, int64_t rows, int cols, float eps,
+                            hipStream_t s) {
+    if (rows <= 0) return HH_OK;
+    const int part_blocks = (int)((rows_part + 255) / 256);
+    const unsigned grid = (unsigned)(part_blocks + (rows - rows_part + 3) / 4);
+    const int nv = (cols + 255) / 256;
+#define LF(NV) hipLaunchKernelGGL((ln_fold_stats_kernel<NV>), dim3(grid), dim3(256), 0, s, partials, slices, stats, rows_part, (const bf16_t*)z, ldz, rows, cols, eps, part_blocks)
+    if (nv <= 2) LF(2); else if (nv <= 4) LF(4); else LF(8);
+#undef LF
+    return hh_check_launch("hh_gemm_bf16(LayerNorm statistics)");
+}
+
+extern "C" int hh_ln_rowstats(const void* z, int64_t ldz, float* stats, int64_t rows, int cols, float eps, hh_stream_t stream) {
+    HH_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 2048 && ldz >= cols && ldz % 4 == 0, HH_ERR_SHAPE, "hh_ln_rowstats: cols=%d must be a multiple of 8 and <= 2048", cols);
+    HH_REQUIRE(z != nullptr && stats != nullptr && HH_ALIGNED16(z) && (((uintptr_t)stats) & 7) == 0, HH_ERR_ALIGN, "hh_ln_rowstats: bad pointers");
+    return hh_ln_rowstats_launch(z, ldz, stats, 0, rows, cols, eps, (hipStream_t)stream);
+}
+
 // fused residual add + LayerNorm:  x (fp32, in place) += delta (bf16)  ;  y = LN(x)
 // Keeps the fp32 residual read-modify-write out of the GEMM epilogues (where it is limited by per-CU memory throughput and
 // cannot overlap the MFMA main loop) and does it here at streaming HBM rate; x is written back only when WRITE_X.

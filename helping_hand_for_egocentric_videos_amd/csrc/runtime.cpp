@@ -104,6 +104,9 @@ extern "C" int hh_stream_get_cu_budget(hh_stream_t stream, int* out) {
 extern "C" int64_t hh_workspace_bytes_gemm_splitk(int64_t M, int N, int splitk) {
     return (M < 0 || N <= 0 || splitk < 1) ? -1 : (int64_t)splitk * M * N * 4;                 // fp32 partial slabs [splitk, M, N]
 }
+extern "C" int64_t hh_workspace_bytes_gemm_zstats(int64_t M, int N) {
+    return (M < 0 || N <= 0 || N % 128) ? -1 : M * (int64_t)(N / 128) * 2 * 4;                 // fp32 [M, N / 128, (sum, sum of squares)]
+}
 extern "C" int64_t hh_workspace_bytes_gemm_tn(int M, int N, int splits) {
     return (M <= 0 || N <= 0 || splits < 1) ? -1 : (int64_t)splits * M * N * 4;                // fp32 partial tiles [splits, M, N]
 }

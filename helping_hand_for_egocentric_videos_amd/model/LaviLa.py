@@ -90,6 +90,11 @@ class VideoPatchEmbed(nn.Module):
 
 
 QKV_HEAD_MAJOR_PLANES = True       # False: the QKV projection writes nn.Linear's token-major [B*N, 3D] (A/B measurements)
+# norm1 / norm2 (LaviLa.py:372,388) folded into the GEMMs around them: the attention output projections add the fp32 residual stream in
+# their epilogue and emit z = bf16(x + branch) with its row statistics, the space qkv / fc1 GEMMs apply rstd / mean / gamma / beta
+# algebraically (include/hh.h, hh_gemm_epilogue.ln_stats / z_out): two of the three add+LayerNorm passes per block disappear.
+# False: the stand-alone fused add+LayerNorm kernels (A/B measurements).
+LN_FOLD = True
 
 
 class VarAttention(nn.Module):
@@ -124,13 +129,18 @@ class VarAttention(nn.Module):
     def _mode(einops_to):
         return "space" if einops_to.replace(" ", "") == "(bf)nd" else "time"
 
-    def core(self, xn, pk, B, T, n, mode):
-        """xn bf16 [B*N, D] (already normalised) -> attention output bf16 [B*N, D] (before proj)."""
+    def core(self, xn, pk, B, T, n, mode, ln=None):
+        """xn bf16 [B*N, D] (already normalised) -> attention output bf16 [B*N, D] (before proj).
+        ln=(stats, folded operands): xn holds UN-normalised rows z and the LayerNorm is applied inside the qkv GEMM."""
         D = xn.shape[1]
         # q *= d^-1/2 (LaviLa.py:252) in the GEMM epilogue; the space kernel takes base-2 logits (x log2 e, ops.attention_q_scale)
         qscale = self.scale * (ops.LOG2E if mode == "space" else 1.0)
         # head-major planes [3*heads, B*N, 64]: a head's rows are contiguous 128-byte lines for the attention kernels (ops.gemm col_blocked)
-        qkv = ops.gemm(xn, pk["wqkv"], pk["bqkv"], colscale=qscale, colscale_cols=D, col_blocked=QKV_HEAD_MAJOR_PLANES)
+        if ln is None:
+            qkv = ops.gemm(xn, pk["wqkv"], pk["bqkv"], colscale=qscale, colscale_cols=D, col_blocked=QKV_HEAD_MAJOR_PLANES)
+        else:
+            stats, (wf, cs, bf) = ln
+            qkv = ops.gemm(xn, wf, bf, colscale=qscale, colscale_cols=D, col_blocked=QKV_HEAD_MAJOR_PLANES, ln=(stats, cs))
         return ops.divided_attention(qkv, B, T, n, self.num_heads, mode)
 
     def forward(self, x, einops_from, einops_to, einops_dims):
@@ -179,6 +189,10 @@ class SpaceTimeBlock(nn.Module):
                           "space": self.attn.packed(), "w1": ops.to_bf16(self.mlp.fc1.weight.detach()),
                           "b1": self.mlp.fc1.bias.detach().float(), "w2": ops.to_bf16(self.mlp.fc2.weight.detach()),
                           "b2": self.mlp.fc2.bias.detach().float()}
+            if LN_FOLD:
+                # norm1 -> space qkv, norm2 -> fc1: (bf16(gamma o W), its row sums, beta W^T + b)
+                self._pack["qkv_n1"] = ops.fold_layernorm_into_linear(self.attn.qkv.weight, self.attn.qkv.bias, self.norm1.weight, self.norm1.bias)
+                self._pack["fc1_n2"] = ops.fold_layernorm_into_linear(self.mlp.fc1.weight, self.mlp.fc1.bias, self.norm2.weight, self.norm2.bias)
         return self._pack
 
     def fused(self, x, B, T, n, pending=None):
@@ -194,6 +208,15 @@ class SpaceTimeBlock(nn.Module):
         else:
             xn = ops.add_layernorm(x, pending[0], *pk["n3"], write_x=True, delta2=pending[1])          # x = (x + s_prev) + m_prev
         a = self.timeattn.core(xn, pk["time"], B, T, n, "time")
+        if "qkv_n1" in pk:
+            # the projections add x in their epilogue and hand z = bf16(x + branch) + its row statistics to the next GEMM, which applies
+            # norm1 / norm2 algebraically: no stand-alone add+LayerNorm pass, the time branch itself is never written
+            _, z1, st1 = ops.gemm(a, pk["time"]["wproj"], pk["time"]["bproj"], z=(x, pk["n1"][2], False))      # z1 = x + t
+            a = self.attn.core(z1, pk["space"], B, T, n, "space", ln=(st1, pk["qkv_n1"]))                        # qkv(LN1(x + t))
+            sp, z2, st2 = ops.gemm(a, pk["space"]["wproj"], pk["space"]["bproj"], z=(x, pk["n2"][2], True))    # s, z2 = x + s
+            wf, cs, bf = pk["fc1_n2"]
+            h = ops.gemm(z2, wf, bf, act=ops.ACT_QUICKGELU, ln=(st2, cs))                                        # fc1(LN2(x + s))
+            return sp, ops.gemm(h, pk["w2"], pk["b2"])
         t = ops.gemm(a, pk["time"]["wproj"], pk["time"]["bproj"])                                             # time branch
         a = self.attn.core(ops.add_layernorm(x, t, *pk["n1"], write_x=False), pk["space"], B, T, n, "space")   # LN1(x + t)
         sp = ops.gemm(a, pk["space"]["wproj"], pk["space"]["bproj"])

@@ -205,9 +205,37 @@ def qself_attn_bwd(qkv, dout, B, Q, heads, dropout_p=0.0, seed=0):
     return dqkv
 
 
+def ln_rowstats(z, eps):
+    """(rstd, -rstd * mean) per row of z bf16 [rows, cols] -> fp32 [rows, 2]: the `ln=` operand of gemm() for a z that did not come
+    out of gemm(..., z=...) (include/hh.h: hh_ln_rowstats)."""
+    _chk(z)
+    if z.dtype != torch.bfloat16 or z.dim() != 2:
+        raise TypeError("ln_rowstats: z must be bf16 [rows, cols]")
+    st = torch.empty((z.shape[0], 2), dtype=torch.float32, device=z.device)
+    _lib.check(_lib.lib().hh_ln_rowstats(_p(z), z.stride(0), _p(st), z.shape[0], z.shape[1], float(eps), _stream()), "hh_ln_rowstats")
+    return st
+
+
+def fold_layernorm_into_linear(weight, bias, gamma, beta):
+    """Operands of the consumer side of the LayerNorm fold for y = Linear(LayerNorm(z)) (include/hh.h): the bf16 weight gamma o W, its
+    row sums over K (of the ROUNDED operand, so that rstd * (z W'^T - mean * colsum) cancels exactly what the matrix core summed), and
+    the bias beta W^T + b in fp32.  Once per weight (cached by the modules)."""
+    w = weight.detach().float()
+    wp = to_bf16((w * gamma.detach().float()[None, :]).contiguous())
+    colsum = wp.float().sum(dim=1).contiguous()
+    b = (w.double() @ beta.detach().double()).float()
+    if bias is not None:
+        b = b + bias.detach().float()
+    return wp, colsum, b.contiguous()
+
+
 def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, resid=None, colscale=1.0,
-         colscale_cols=0, remap=None, out_rows=None, splitk=1, col_blocked=False):
+         colscale_cols=0, remap=None, out_rows=None, splitk=1, col_blocked=False, ln=None, z=None):
     """C = epilogue(A @ W^T).  a bf16 [M,K], w bf16 [N,K] (nn.Linear weight layout), bias fp32 [N].
+
+    LayerNorm fold (include/hh.h):  ln=(stats fp32 [M,2], colsum fp32 [N]) -- consumer side: `a` holds un-normalised rows, `w` / `bias`
+    come from fold_layernorm_into_linear;  z=(x fp32 [M,N], eps, keep_c) -- producer side: returns (C or None, z = bf16(x + A W^T + bias),
+    stats of z) instead of C.
 
     resid fp32 [rows,N] is added after the activation; `out` may alias `resid` (in-place residual update).
     remap=(group, skip, offset) scatters output row m to m + (m//group)*skip + offset (token-major scatter).
@@ -228,6 +256,9 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
     N = w.shape[0]
     if w.shape[1] != K:
         raise ValueError("gemm: K mismatch %s vs %s" % (tuple(a.shape), tuple(w.shape)))
+    if ln is not None or z is not None:
+        if splitk > 1 or resid is not None or remap is not None or out is not None or out_rows is not None or (z is not None and (col_blocked or ln is not None)):
+            raise ValueError("gemm: the LayerNorm fold takes no split-K / residual / remap / preallocated output (and z= no col_blocked / ln=)")
     if splitk > 1:
         if bias is not None or resid is not None or out is not None or act != ACT_NONE:
             raise ValueError("gemm: split-K takes no bias / residual / activation / preallocated output")
@@ -244,12 +275,34 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
         e = GemmEpilogue()
         e.bias = bias.data_ptr() if bias is not None else None
         e.colscale, e.colscale_cols, e.act, e.c_dtype, e.c_block_stride = float(colscale), int(colscale_cols), int(act), _dt(planes), M * 64
+        if ln is not None:
+            _set_ln(e, ln, M, N, bias)
         _lib.check(_lib.lib().hh_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(planes), 64, M, N, K, ctypes.byref(e), _stream()),
                    "hh_gemm_bf16")
         return planes
+    zt = st = None
+    keep_c = True
+    if z is not None:
+        x, eps, keep_c = z
+        _chk(x)
+        if x.dtype != torch.float32 or tuple(x.shape) != (M, N) or out_dtype != torch.bfloat16:
+            raise TypeError("gemm: z=(x, eps, keep_c) needs x fp32 [M, N] and a bf16 output")
+        zt = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+        st = torch.empty((M, 2), dtype=torch.float32, device=a.device)
     if out is None:
-        out = torch.empty((out_rows if out_rows is not None else M, N), dtype=out_dtype, device=a.device)
+        out = torch.empty((out_rows if out_rows is not None else M, N), dtype=out_dtype, device=a.device) if keep_c else None
     e = GemmEpilogue()
+    if ln is not None:
+        _set_ln(e, ln, M, N, bias)
+    if z is not None:
+        part = _workspace("gemm_zstats", M, N, device=a.device)
+        e.z_resid, e.z_ldr, e.z_out, e.z_ldc, e.z_stats, e.z_partials = x.data_ptr(), N, zt.data_ptr(), N, st.data_ptr(), part.data_ptr()
+        e.z_eps, e.skip_c = float(eps), int(not keep_c)
+        e.bias = bias.data_ptr() if bias is not None else None
+        e.colscale, e.c_dtype = 1.0, BF16
+        cbuf = out if keep_c else zt                               # (a valid pointer even when C is skipped)
+        _lib.check(_lib.lib().hh_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(cbuf), N, M, N, K, ctypes.byref(e), _stream()), "hh_gemm_bf16")
+        return out, zt, st
     e.bias = bias.data_ptr() if bias is not None else None
     e.resid = resid.data_ptr() if resid is not None else None
     e.ldr = resid.stride(0) if resid is not None else 0
@@ -259,6 +312,14 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
     _lib.check(L.hh_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K, ctypes.byref(e),
                               _stream()), "hh_gemm_bf16")
     return out
+
+
+def _set_ln(e, ln, M, N, bias):
+    stats, colsum = ln
+    _chk(stats, colsum)
+    if stats.dtype != torch.float32 or tuple(stats.shape) != (M, 2) or colsum.dtype != torch.float32 or colsum.numel() != N or bias is None:
+        raise TypeError("gemm: ln=(stats fp32 [M,2], colsum fp32 [N]) and a bias are required for the LayerNorm fold")
+    e.ln_stats, e.ln_colsum = stats.data_ptr(), colsum.data_ptr()
 
 
 def to_bf16(x):

@@ -99,10 +99,12 @@ const char* hh_prof_kernel_name(int klass);
  * takes (negative = bad arguments):
  *   gemm_splitk      : C of hh_gemm_bf16 with epi->splitk = S  (fp32 [S, M, N], split_stride = M*N)
  *   gemm_tn          : `partials` of hh_gemm_tn_bf16           (fp32 [splits, M, N])
+ *   gemm_zstats      : epi->z_partials of hh_gemm_bf16             (fp32 [M, N / 128, 2] per-slice row sums)
  *   xattn_bwd        : `dq` of hh_xattn_bwd                    (fp32 [dq_splits, B, Q, heads*64])
  *   attn_cls_partial : `cls_partial` of hh_space_attn_fwd (time_mode 0) / hh_time_attn_fwd (1) and input of hh_cls_combine
  *                      (fp32 [B, heads, G, 68]) */
 int64_t hh_workspace_bytes_gemm_splitk(int64_t M, int N, int splitk);
+int64_t hh_workspace_bytes_gemm_zstats(int64_t M, int N);      /* `z_partials` of hh_gemm_bf16's producer-side LayerNorm fold */
 int64_t hh_workspace_bytes_gemm_tn(int M, int N, int splits);
 int64_t hh_workspace_bytes_xattn_bwd(int B, int Q, int heads, int dq_splits);
 int64_t hh_workspace_bytes_xattn_fwd(int B, int Q, int heads, int splits);
@@ -149,10 +151,33 @@ typedef struct hh_gemm_epilogue {
     int64_t c_block_stride;   /* 0: C is row-major [M, ldc].  S > 0: C is column-blocked -- N / 64 planes of [M, 64], plane j at
                                  C + j * S (S >= 64 * M): element (m, n) at (n / 64) * S + m * 64 + n % 64; ldc is ignored.  With
                                  N = 3 * heads * 64 this is the HH_QKV_HEAD_MAJOR layout of the attention kernels */
+    /* ---- LayerNorm folded into the GEMMs on either side of it (model/LaviLa.py:372-388: norm1 / norm2 sit between the attention
+     * output projection and the next qkv / fc1 Linear).  Algebra:  LN(z) W^T + b = rstd * (z (gamma o W)^T) - rstd*mean * colsum(gamma o W) + (beta W^T + b).
+     * PRODUCER side (z_out != NULL; the projection GEMM): with v = acc + bias (fp32, before the bf16 rounding of C),
+     *     z[m,n] = z_resid[m,n] + v[m,n]   ->  z_out (bf16);   z_stats[m] = (rstd, -rstd * mean) of row m of z over all N columns;
+     *   C is still written (the branch output the residual stream adds later) unless skip_c.  No act / colscale / resid / remap / split-K
+     *   / column-blocked C with it.  z_partials: workspace of hh_workspace_bytes_gemm_zstats(M, N) bytes.
+     * CONSUMER side (ln_stats != NULL; the qkv / fc1 GEMM): A holds the rows z, W holds bf16(gamma o W), bias holds beta W^T + b, and
+     *     acc <- ln_stats[m][0] * acc + ln_stats[m][1] * ln_colsum[n] + bias[n]   before colscale / act (bias must be non-NULL).
+     *   No resid / remap / split-K with it. */
+    const float* ln_stats;    /* fp32 [M, 2] = (rstd, -rstd * mean) per row of A, or NULL */
+    const float* ln_colsum;   /* fp32 [N]: sum_k float(W[n, k]) of the bf16 operand actually multiplied */
+    const float* z_resid;     /* fp32 [M, z_ldr] */
+    int64_t z_ldr;
+    void* z_out;              /* bf16 [M, z_ldc], or NULL (producer side off) */
+    int64_t z_ldc;
+    float* z_stats;           /* fp32 [M, 2] out */
+    float* z_partials;        /* workspace */
+    float z_eps;              /* LayerNorm eps of the statistics */
+    int skip_c;               /* != 0 with z_out: C is not written (a branch nobody adds to the residual stream: the time branch, LaviLa.py:372-384) */
 } hh_gemm_epilogue;
 
 int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                  int64_t M, int N, int K, const hh_gemm_epilogue* epi, hh_stream_t stream);
+
+/* Row statistics for the consumer side of the LayerNorm fold when z does not come out of hh_gemm_bf16 (tests, other producers):
+ * stats[m] = (rstd, -rstd * mean) of row m of z (bf16 [rows, ldz], cols <= 2048, cols % 8 == 0), two-pass in fp32. */
+int hh_ln_rowstats(const void* z, int64_t ldz, float* stats, int64_t rows, int cols, float eps, hh_stream_t stream);
 
 /* ---- casts / transposes (host-side plumbing for weights and wgrad operands) */
 int hh_cast_f32_to_bf16(const float* x, void* y, int64_t n, hh_stream_t stream);

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from helping_hand_for_egocentric_videos_amd import ops
+from _record import record
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -855,3 +856,75 @@ def test_masked_ce_kernel_vs_torch():
     torch.testing.assert_close(ce.detach().cpu(), torch.where(valid, ce_ref.detach(), torch.zeros(())), rtol=2e-6, atol=2e-6)
     torch.testing.assert_close(sg.grad.cpu(), sr.grad, rtol=1e-5, atol=1e-6)
     assert float(sg.grad[0, 9]) == 0.0 and float(sg.grad[~valid.cuda()].abs().max()) == 0.0
+
+
+# ---- LayerNorm folded into the GEMMs around it (include/hh.h: hh_gemm_epilogue.ln_stats / z_out; model/LaviLa.py:372-388)
+LN_FOLD_SHAPES = [(4097, 1024, 1024), (300, 128, 128), (33, 256, 512),               # generic kernels / row-tail kernel
+                  (256 * 40 + 32, 1024, 1024), (256 * 36, 1024, 512),                # persistent kernel + in-kernel row tail
+                  (2 * 4097, 1024, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K", LN_FOLD_SHAPES)
+@pytest.mark.parametrize("keep_c", [True, False])
+def test_gemm_ln_fold_producer(M, N, K, keep_c):
+    """Producer side: z = bf16(x + A W^T + b) beside C = bf16(A W^T + b), and (rstd, -rstd * mean) of the rows of z."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    x = torch.randn(M, N, device=DEV, generator=g) * 2.0 + 0.3
+    x0 = x.clone()
+    eps = 1e-6
+    c, z, st = ops.gemm(a, w, bias, z=(x, eps, keep_c))
+    assert torch.equal(x, x0)                                                    # the residual stream is only read
+    v = a.float() @ w.float().t() + bias
+    zr = x + v
+    scale = v.abs().max().item()
+    if keep_c:
+        assert (c.float() - v).abs().max().item() <= 8e-3 * scale
+        assert torch.equal(c, ops.gemm(a, w, bias))                              # the branch output is the plain GEMM's, bit for bit
+    else:
+        assert c is None
+    assert (z.float() - zr).abs().max().item() <= 8e-3 * zr.abs().max().item()
+    mean, var = zr.mean(1), zr.var(1, unbiased=False)
+    rstd = (var + eps).rsqrt()
+    # the statistics are those of z up to its bf16 rounding (rows of 128 ... 1024 values: ~2^-9 / sqrt(N) on the moments)
+    assert ((st[:, 0] - rstd) / rstd).abs().max().item() <= 2e-3
+    assert (st[:, 1] + rstd * mean).abs().max().item() <= 4e-3 * (1.0 + (rstd * mean).abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(4097, 3072, 1024), (300, 384, 128), (33, 256, 512), (256 * 40 + 32, 3072, 1024), (256 * 20, 4096, 1024),
+                                   (2 * 4097, 3072, 1024)])
+@pytest.mark.parametrize("variant", ["qkv", "qkv_planes", "gelu"])
+def test_gemm_ln_fold_consumer(M, N, K, variant):
+    """Consumer side: Linear(LayerNorm(z)) with the LayerNorm applied algebraically inside the GEMM (gamma folded into the bf16 weight,
+    beta into the bias, rstd / mean through the row statistics) vs fp32 torch; and vs the stand-alone LayerNorm -> GEMM route."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K + 1)
+    zf = torch.randn(M, K, device=DEV, generator=g) * torch.exp(0.5 * torch.randn(K, device=DEV, generator=g)) + 0.2
+    z = zf.to(torch.bfloat16)
+    gamma = 1.0 + 0.2 * torch.randn(K, device=DEV, generator=g)
+    beta = 0.1 * torch.randn(K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) * K ** -0.5
+    b = 0.02 * torch.randn(N, device=DEV, generator=g)
+    eps = 1e-6
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(z.float(), (K,), gamma, beta, eps), w, b)
+    wf, cs, bf_ = ops.fold_layernorm_into_linear(w, b, gamma, beta)
+    st = ops.ln_rowstats(z, eps)
+    cols = N // 3 // 128 * 128
+    if variant == "gelu":
+        out = ops.gemm(z, wf, bf_, act=ops.ACT_QUICKGELU, ln=(st, cs)).float()
+        ref = ref * torch.sigmoid(1.702 * ref)
+        old = ops.gemm(ops.layernorm(z, gamma, beta, eps), ops.to_bf16(w), b, act=ops.ACT_QUICKGELU).float()
+    else:
+        ref[:, :cols] *= 0.125
+        out = ops.gemm(z, wf, bf_, colscale=0.125, colscale_cols=cols, ln=(st, cs), col_blocked=variant == "qkv_planes")
+        if variant == "qkv_planes":
+            out = out.transpose(0, 1).reshape(M, N)
+        out = out.float()
+        old = ops.gemm(ops.layernorm(z, gamma, beta, eps), ops.to_bf16(w), b, colscale=0.125, colscale_cols=cols).float()
+    scale = ref.abs().max().item()
+    e_new, e_old = (out - ref).abs().max().item() / scale, (old - ref).abs().max().item() / scale
+    l_new, l_old = float((out - ref).norm() / ref.norm()), float((old - ref).norm() / ref.norm())
+    record("gemm_ln_fold_consumer[%s,%d,%d,%d]" % (variant, M, N, K), "rel-L2 vs fp32 (stand-alone LN -> GEMM route: %.2e)" % l_old, l_new, 8e-3)
+    assert e_new <= 1.6e-2 and l_new <= 8e-3, (e_new, l_new)
+    assert l_new <= 1.5 * l_old + 1e-4, (l_new, l_old)                           # the fold is as accurate as the route it replaces
