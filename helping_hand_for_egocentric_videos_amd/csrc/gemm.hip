@@ -278,6 +278,7 @@ static int gemm_bf16_impl(const void* A, int64_t lda, const void* W, int64_t ldw
     p.M = M; p.N = N; p.K = K; p.e = *epi;
     p.m_start = 0;
     p.skew_iters = 0;
+    p.skew_phases = 0;
     p.dynamic = 0;
     p.tile_slot = 0;
     p.group_m = 4;

@@ -572,6 +572,7 @@ static int g_skew = -1;            // start skew of the one-tile-per-block kerne
 bool hh_gemm256w4p_ln_ext_ok(const GemmParams& p, bool w4);      // gemm256w4.hip: the 4-wave persistent kernel implements this LayerNorm-fold epilogue
 int hh_gemm256w4p_ln_epi(const hh_gemm_epilogue& e);
 void hh_gemm256w4p_set_ln_ext(int v);
+static int g_ln_pskew = 0, g_ln_phases = 4;      // "gemm_ln_pskew" / "gemm_ln_phases": start skew of the LayerNorm-fold producer GEMMs (EPI 4)
 static int g_mode = 5;             // "gemm256": 0 = 128x128 kernel only, 1 = one tile per block, 2 = + wave-row stagger, 3 = persistent 8-wave kernel, 4 = 4-wave kernel of gemm256w4.hip, one tile per block, 5 = persistent 4-wave kernel where K allows, else 3 (default)
 static int g_dynamic = 1;           // "gemm256_dynamic": 4-wave persistent kernel takes its tiles from per-XCD atomic counters (1, default) or by static stride (0)
 static int g_min_tiles = 192;       // "gemm256_min_tiles": fewest 256x256 tiles for which the 256x256 kernels are used
@@ -601,6 +602,8 @@ extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm256_debug_ts")) { g_debug_ts = value; g_ts_count = 0; return HH_OK; }
     if (name && !strcmp(name, "gemm256_dynamic") && (value == 0 || value == 1)) { g_dynamic = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_min_tiles") && value >= 1 && value <= 4096) { g_min_tiles = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm_ln_pskew") && value >= 0 && value <= 256) { g_ln_pskew = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm_ln_phases") && value >= 0 && value <= 32) { g_ln_phases = value; return HH_OK; }
     if (name && !strcmp(name, "gemm_ln_w4") && (value == 0 || value == 1)) { hh_gemm256w4p_set_ln_ext(value); return HH_OK; }
     if (name && !strcmp(name, "gemm256_group") && value >= 0 && value <= 64) { g_group = value; return HH_OK; }
     hh_set_error("hh_set_tuning: unknown knob '%s' or value %d out of range", name ? name : "(null)", value);
@@ -673,6 +676,8 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
             const int ncu = hh_stream_cu_count(s) & ~7;      // CU budget of this stream; the stride of the tile walk must keep blockIdx & 7 == XCD
             const unsigned pg = grid < (unsigned)ncu ? grid : (unsigned)ncu;
             p.skew_iters = g_pskew;
+            p.skew_phases = 0;
+            if (epi == 4 && g_ln_pskew > 0) { p.skew_iters = g_ln_pskew; p.skew_phases = g_ln_phases; }
             HHProfScope prof(HH_PROF_GEMM256, 2.0 * (double)p.M * p.N * p.K, s);
             if (g_debug_ts > 1) p.debug_ts = (++g_ts_count == g_debug_ts);
             if (g_mode == 5 && p.K >= 384 && p.K % 128 == 0 && p.N <= 4096) {

@@ -441,9 +441,14 @@ __device__ __forceinline__ void w4p_finish_group_ln(float sc, const float* bias_
 // per-tile constants of the LayerNorm-fold epilogues
 struct W4Ln {
     const float* bias_l;          // LDS: bias + this lane's first column
-    const float* stats;           // consumer: ln_stats + 2 * (first row of this lane); row group IDX adds 2 * rowoff(IDX)
+    const float* stats;           // consumer: LDS, (rstd, -rstd * mean) of this lane's first row; row group IDX adds 2 * rowoff(IDX)
     f32x4 cs_v[4][2];             // consumer: column sums of this lane's 32 columns
 };
+// Consumer side: what a tile's epilogue needs from memory -- bias and column sums of its 256 columns, the statistics of its 256 rows: 4 KB --
+// is fetched by LDS-DMA one tile AHEAD (one 1-KB piece per wave, issued when the walk's next tile is known, i.e. a whole main loop
+// before its epilogue) into a double-buffered record in the LDS the full-length bias vector occupies in the other instantiations.
+// With global loads at the start of the epilogue instead, every tile waited a memory latency for them (fc1: +92 us per launch).
+#define W4_LNREC 4096          // [bias 256 f32 | colsum 256 f32 | stats 256 x (rstd, -rstd * mean)]
 __device__ __forceinline__ constexpr int w4_rowoff(int IDX) { return (IDX >> 2) * 128 + (IDX & 3) * 16; }
 
 // bf16 output: group IDX goes through the wave's LDS scratch (16 rows x 256 B, 16-B chunks XOR-swizzled with the row: conflict-free both
@@ -631,12 +636,27 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
     const int64_t hiA = 128 * p.lda * 2, hiW = 64 * p.ldw * 2;
 
     float* bias_s = (float*)(smem + 2 * W4_BUF);
-    for (int i = tid * 4; i < p.N; i += 256 * 4)
-        *(f32x4*)(bias_s + i) = p.e.bias ? *(const f32x4*)(p.e.bias + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI < 5) {
+        for (int i = tid * 4; i < p.N; i += 256 * 4)
+            *(f32x4*)(bias_s + i) = p.e.bias ? *(const f32x4*)(p.e.bias + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     W4_BARRIER();
+    // consumer side of the LayerNorm fold: the epilogue record of tile (tm0, tn0) -> LDS record `par` (W4_LNREC), one 1-KB LDS-DMA piece per
+    // wave: bias / column sums of the tile's 256 columns, statistics of its rows 0..127 / 128..255.  (s_nop 4: see the tile-counter atomic.)
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto ln_prefetch = [&](int par, int64_t tm0, int tn0) {
+        const char* src = wave == 0 ? (const char*)(p.e.bias + tn0) : wave == 1 ? (const char*)(p.e.ln_colsum + tn0)
+                                    : (const char*)(p.e.ln_stats + 2 * tm0) + (wave - 2) * 1024;
+        unsigned dst = w4_lds_u32(smem + 2 * W4_BUF) + (unsigned)par * W4_LNREC + (unsigned)wave * 1024u;
+        asm volatile("" : "+s"(src), "+s"(dst));
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane16), "s"(src), "s"(dst) : "memory");
+    };
     if (p.skew_iters > 0) {
-        const int it = p.skew_iters * (int)((blockIdx.x >> 3) & 31);
+        // start skew: workgroups of an XCD begin `skew_iters` sleeps apart (P phases, or a 32-step ramp).  The tiles of a launch take equal
+        // time, so without it every CU reaches its epilogue together; for the producer side of the LayerNorm fold (EPI 4: 256 KB of fp32
+        // residual rows per tile) that is a 64 MB read burst per round during which no matrix core works
+        const int it = p.skew_iters * (int)(p.skew_phases > 0 ? (blockIdx.x >> 3) % p.skew_phases : (blockIdx.x >> 3) & 31);
         for (int i = 0; i < it; ++i) __builtin_amdgcn_s_sleep(8);
     }
 
@@ -677,6 +697,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
     }
 #define W4_STAGE(BUF, SLOT, VOFF, PTR) do { w4_dma<W4_IMM(BUF, SLOT)>(s.VOFF[0], s.PTR, s.wave_lds); w4_dma<W4_IMM(BUF, SLOT) + 1024>(s.VOFF[1], s.PTR, s.wave_lds);   \
         w4_dma<W4_IMM(BUF, SLOT) + 2048>(s.VOFF[2], s.PTR, s.wave_lds); w4_dma<W4_IMM(BUF, SLOT) + 3072>(s.VOFF[3], s.PTR, s.wave_lds); s.PTR += 128; } while (0)
+    if constexpr (EPI >= 5) ln_prefetch(0, m0, n0);                      // (older than every DMA of the ring: the prologue's waits cover it)
     W4_STAGE(0, W4_ALO, aoff, pAL); W4_STAGE(0, W4_BLO, woff, pWL); W4_STAGE(0, W4_BHI, woff, pWH); W4_STAGE(0, W4_AHI, aoff, pAH);
     W4_STAGE(1, W4_ALO, aoff, pAL); W4_STAGE(1, W4_BLO, woff, pWL); W4_STAGE(1, W4_BHI, woff, pWH); W4_STAGE(1, W4_AHI, aoff, pAH);
     asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                   // A-lo(0), W-lo(0) landed (6 half-tiles younger)
@@ -728,6 +749,9 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
             const char* nA = (const char*)(p.A + nm0 * p.lda);
             const char* nW = (const char*)(p.W + (int64_t)nn0 * p.ldw);
             s.nAL = nA; s.nAH = nA + hiA; s.nWL = nW; s.nWH = nW + hiW;
+            // its epilogue record, into the other LDS record (this tile's is read in the epilogue below); it lands -- and every wave's
+            // counted wait + barrier of the next edges publishes it -- a whole main loop before it is read
+            if constexpr (EPI >= 5) ln_prefetch((tile_i + 1) & 1, nm0, nn0);
         }
         asm volatile("" : "+s"(s.nAL), "+s"(s.nAH), "+s"(s.nWL), "+s"(s.nWH));
         if (has_next) { w4_iter<W4V_REBASE, VM_ST>(s); w4_iter<W4V_MID, VM_ST>(s); }
@@ -755,15 +779,18 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
             stamp(3);
             W4Ln ln;
             f32x2 st0 = {1.f, 0.f};
-            if constexpr (EPI >= 4) ln.bias_l = bias_s + nb;
+            if constexpr (EPI == 4) ln.bias_l = bias_s + nb;
             if constexpr (EPI >= 5) {
-                ln.stats = e.ln_stats + 2 * (m0 + wr * 64 + frow);
+                const float* rec = (const float*)(smem + 2 * W4_BUF + (tile_i & 1) * W4_LNREC);     // this tile's record (LDS)
+                const int cl = wc * 128 + 8 * fq;                                   // the lane's first column inside the tile
+                ln.bias_l = rec + cl;
+                ln.stats = rec + 512 + 2 * (wr * 64 + frow);
                 st0 = *(const f32x2*)(ln.stats);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int cj = nb + (j & 1) * 32 + (j >> 1) * 64;
-                    ln.cs_v[j][0] = *(const f32x4*)(e.ln_colsum + cj);
-                    ln.cs_v[j][1] = *(const f32x4*)(e.ln_colsum + cj + 4);
+                    const int cj = cl + (j & 1) * 32 + (j >> 1) * 64;
+                    ln.cs_v[j][0] = *(const f32x4*)(rec + 256 + cj);
+                    ln.cs_v[j][1] = *(const f32x4*)(rec + 256 + cj + 4);
                 }
             }
             if constexpr (EPI == 4) {
@@ -808,13 +835,15 @@ void hh_gemm256w4p_set_ln_ext(int v) { g_w4_ln_ext = v; }
 int hh_gemm256w4p_ln_epi(const hh_gemm_epilogue& e) {
     if (e.c_dtype != HH_BF16) return -1;
     if (e.z_out) return (e.ln_stats == nullptr && e.act == HH_ACT_NONE && e.colscale_cols == 0 && e.c_block_stride == 0) ? 4 : -1;
-    if (e.ln_stats) {
+    if (e.ln_stats) {                        // (callers check N >= 2048: the two epilogue records live where the N-float bias vector is)
         if (e.act == HH_ACT_NONE && e.colscale_cols > 0 && e.colscale_cols % 128 == 0) return 5;
         if (e.act == HH_ACT_QUICKGELU && e.colscale_cols == 0) return 6;
     }
     return -1;
 }
-bool hh_gemm256w4p_ln_ext_ok(const GemmParams& p, bool w4) { return g_w4_ln_ext && w4 && p.M >= 256 && hh_gemm256w4p_ln_epi(p.e) >= 0; }
+bool hh_gemm256w4p_ln_ext_ok(const GemmParams& p, bool w4) {
+    return g_w4_ln_ext && w4 && p.M >= 256 && hh_gemm256w4p_ln_epi(p.e) >= 0 && (p.e.ln_stats == nullptr || p.N * 4 >= 2 * W4_LNREC);
+}
 
 static bool g_w4_ts_last = false;
 bool hh_gemm256w4_timeline_is_last() { return g_w4_ts_last; }

@@ -37,6 +37,13 @@ def scan(path):
             continue
         insts.append((i + 1, t, in_asm, func))
     bad = []
+    # (2) kernels whose inline asm OWNS the accumulator file (gemm256w4p_kernel: a[0:255] hold the tile across asm statements; the compiler
+    # only sees a clobber list) must not have compiler-generated traffic into AGPRs: under register pressure hipcc spills VGPRs into
+    # "free" AGPRs (v_accvgpr_write_b32 aN, vM / loads with an a[..] destination) -- which silently corrupts the accumulators
+    for ln, t, in_asm, func in insts:
+        if "gemm256w4p_kernel" in func and not in_asm:
+            if re.match(r"v_accvgpr_write_b32 a\d+, v\d+", t) or re.match(r"(global|buffer|ds)_(load|read)\S* a\[", t) or re.match(r"v_accvgpr_mov", t):
+                bad.append((func, ln, t, ln, "compiler-generated write into the asm-owned accumulator registers (VGPR spill to AGPR)", 0))
     for k, (ln, t, _, func) in enumerate(insts):
         m = re.match(r"v_(readlane|readfirstlane)_b32 (s\d+)", t)
         if not m:

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Regenerates the committed profile summaries on the GPU box (run through gpurun; copy gpurun_out/profiles_new/* to profiles/):
 #   1. rocprofv3 --kernel-trace --stats of the default pipelined bench      -> <tag>_bench_kernel_stats.csv, <tag>_summary.md
+#      (round 4: 8 warm-up + 12 timed steps instead of 2 + 3 -- a 5-step run ends before the chip reaches its steady power / clock state and
+#       reads the GEMMs ~8 % faster than the bench's own 20-step region: 468 vs 504-511 us per launch in the same session)
 #   2. same for the un-pipelined step (durations not inflated by overlap)   -> <tag>_unpipelined_kernel_stats.csv
 #   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)            -> <tag>_pmc_summary.{md,json}
 #   usage: make_profiles.sh <tag> [extra bench.py arguments, e.g. --config c4 --batch 4]   (default: config 2, B = 32)
@@ -14,8 +16,8 @@ OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
 rm -rf $R/gpurun_out/prof_p $R/gpurun_out/prof_u $R/gpurun_out/pmc_FETCH_SIZE $R/gpurun_out/pmc_WRITE_SIZE $R/gpurun_out/pmc_SQ
 BENCH="python3 $R/bench.py --no-cpu-baseline --no-kernel-timers --no-mcq --no-c4 --no-power $EXTRA"
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_p -- $BENCH --steps 3 --warmup 2 > $OUT/${TAG}_bench.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_u -- $BENCH --steps 3 --warmup 2 --no-pipeline > $OUT/${TAG}_bench_unpipelined.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_p -- $BENCH --steps 12 --warmup 8 > $OUT/${TAG}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_u -- $BENCH --steps 12 --warmup 8 --no-pipeline > $OUT/${TAG}_bench_unpipelined.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- $BENCH --steps 1 --warmup 1 --no-pipeline > $OUT/${TAG}_pmc_$c.log 2>&1
 done
@@ -28,21 +30,22 @@ EXTRA = os.environ.get("HH_PROFILE_EXTRA", "").strip()
 FLAGS = "--no-cpu-baseline --no-kernel-timers --no-mcq --no-c4 --no-power" + (" " + EXTRA if EXTRA else "")
 WHAT = ("config 4 (32-frame 336p, nq=12), B = 4 clips" if "c4" in EXTRA else "config 2 (16-frame 224p, nq=12), B = 32 clips") if "--batch" not in EXTRA or "c4" in EXTRA else "bench.py " + EXTRA
 OUT = R + "/gpurun_out/profiles_new/"
+STEPS = 20
 def stats(d, dst, title, cmd, note):
     f = glob.glob(R + "/gpurun_out/%s/**/*kernel_stats.csv" % d, recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     open(OUT + dst + "_kernel_stats.csv", "w").write(open(f).read())
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    L = ["# %s -- rocprofv3 --kernel-trace --stats of `%s`" % (title, cmd), "", note % (tot / 1e6, tot / 5e6), "",
+    L = ["# %s -- rocprofv3 --kernel-trace --stats of `%s`" % (title, cmd), "", note % (tot / 1e6, tot / (STEPS * 1e6)), "",
          "| kernel | calls | total ms | avg us | % of kernel time |", "|---|---|---|---|---|"]
     for r in rows[:24]:
         L.append("| %s | %s | %.2f | %.1f | %.1f |" % (r["Name"][:96].replace("|", "/"), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                     float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
     return L
-L = stats("prof_p", TAG + "_bench", TAG + " build", "python3 bench.py --steps 3 --warmup 2 " + FLAGS,
-          "MI355X, " + WHAT + ", software-pipelined step, 5 steps profiled (2 warm-up + 3 timed).\nSum of kernel durations %.1f ms over 5 steps = %.1f ms/step (kernels of the encoder stream and of the decoder stream overlap, so this sum exceeds the wall time per step).")
-L += [""] + stats("prof_u", TAG + "_unpipelined", "Same build, un-pipelined step", "python3 bench.py --steps 3 --warmup 2 " + FLAGS + " --no-pipeline",
-                  "Every kernel runs alone on the chip here, so the averages are the isolated kernel durations.\nSum of kernel durations %.1f ms over 5 steps = %.1f ms/step.")
+L = stats("prof_p", TAG + "_bench", TAG + " build", "python3 bench.py --steps 12 --warmup 8 " + FLAGS,
+          "MI355X, " + WHAT + ", software-pipelined step, 20 steps profiled (8 warm-up + 12 timed).\nSum of kernel durations %.1f ms over 20 steps = %.1f ms/step (kernels of the encoder stream and of the decoder stream overlap, so this sum exceeds the wall time per step).")
+L += [""] + stats("prof_u", TAG + "_unpipelined", "Same build, un-pipelined step", "python3 bench.py --steps 12 --warmup 8 " + FLAGS + " --no-pipeline",
+                  "Every kernel runs alone on the chip here, so the averages are the isolated kernel durations.\nSum of kernel durations %.1f ms over 20 steps = %.1f ms/step.")
 open(OUT + TAG + "_summary.md", "w").write("\n".join(L) + "\n")
 # ---- PMC
 val = {}

@@ -1,0 +1,24 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r4e
+python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "ln_fold or gemm" 2>&1 | tail -6 > gpurun_out/r4e/tests_kernels.log
+python -m pytest tests/test_encoder_gpu.py tests/test_batch_pin_gpu.py -x -q -m gpu 2>&1 | tail -8 > gpurun_out/r4e/tests_enc.log
+cat gpurun_out/r4e/tests_kernels.log gpurun_out/r4e/tests_enc.log | tail -14
+B="python bench.py --steps 20 --warmup 5 --no-mcq --no-c4 --no-cpu-baseline --no-power"
+for rep in 1 2; do
+for cfg in "0:4" "16:4" "32:2" "8:8"; do
+  sk=${cfg%%:*}; ph=${cfg##*:}
+  $B --tune gemm_ln_pskew=$sk --tune gemm_ln_phases=$ph 2>&1 | tail -1 > gpurun_out/r4e/bench_sk${sk}_ph${ph}_$rep.log
+done
+$B --no-ln-fold 2>&1 | tail -1 > gpurun_out/r4e/bench_nofold_$rep.log
+done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r4e/bench_*.log')):
+    try:
+        d=json.loads(open(f).read()); r=d['roofline']
+        print(f, d['value'], d['ms_per_step'], 'gemm', r['achieved'], r['avg_launch_us'], r['stream_time_over_step'])
+    except Exception as e: print(f, 'ERR', e, open(f).read()[-300:])
+PY
+python scripts/launch_census.py > gpurun_out/r4e/launch_census.txt 2>&1
+python scripts/copy_census.py > gpurun_out/r4e/copy_census.txt 2>&1
