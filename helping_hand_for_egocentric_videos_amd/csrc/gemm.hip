@@ -263,6 +263,7 @@ static int gemm_bf16_impl(const void* A, int64_t lda, const void* W, int64_t ldw
         if (epi->ln_stats)
             HH_REQUIRE(epi->ln_colsum != nullptr && epi->bias != nullptr && HH_ALIGNED16(epi->ln_colsum) && (((uintptr_t)epi->ln_stats) & 7) == 0, HH_ERR_SHAPE,
                        "hh_gemm_bf16: ln_stats needs ln_colsum and bias (16-byte aligned; ln_stats 8-byte aligned)");
+        HH_REQUIRE(epi->z_out != nullptr || (epi->z_update == 0 && epi->skip_c == 0), HH_ERR_UNSUPPORTED, "hh_gemm_bf16: z_update / skip_c need z_out");
         if (epi->z_out) {
             HH_REQUIRE(epi->z_resid != nullptr && epi->z_stats != nullptr && epi->act == HH_ACT_NONE && epi->colscale_cols == 0 && !cblk &&
                        epi->ln_stats == nullptr && epi->c_dtype == HH_BF16, HH_ERR_UNSUPPORTED,

@@ -532,7 +532,7 @@ __device__ __forceinline__ void w4p_lds_rows(char* scr, int frow, int fq, int l1
 }
 template <int IDX>
 __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cptr, bf16_t* zptr, const float* xrow, float* part, int64_t rowbase, char* scr,
-                                                 int frow, int fq, int l15, int l4, const float* bias_l, f32x4 (&xa)[4], f32x4 (&xb)[4]) {
+                                                 int frow, int fq, int l15, int l4, const float* bias_l, float* xw0, unsigned xoff, f32x4 (&xa)[4], f32x4 (&xb)[4]) {
     f32x4 xna[4], xnb[4];
     if constexpr (IDX + 1 < 8) w4p_zload<IDX + 1>(xrow, xna, xnb, p.e.z_ldr);
     f32x4 a[4], b[4];
@@ -556,6 +556,29 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cp
         s4 += a[j]; s4 += b[j];
         q4 += a[j] * a[j]; q4 += b[j] * b[j];
     }
+    if (p.e.z_update) {
+        // x <- x + branch in place (the rows this lane loaded xa / xb from).  Straight from the MFMA layout a store instruction would
+        // cover 16 rows x 4 pieces of 16 B at a 32-B stride (measured: fc2 + 228 us per launch, most of it these 64 stores per tile);
+        // through the wave's LDS scratch -- one 64-column half (16 rows x 256 B, the bf16 image's geometry and swizzle) at a time -- the
+        // rows leave as 4-rows-x-256-B stores of whole lines.
+        // (wave-uniform base + ONE lane-invariant 32-bit offset: per-lane 64-bit row pointers would be hoisted out of the tile loop and,
+        // live across the main loop, push the register allocator into the asm-owned AGPRs -- scripts/check_isa_hazards.py)
+        float* xw = xw0 + (int64_t)w4_rowoff(IDX) * p.e.z_ldr;          // row 0 of the group, the wave's column 0 (uniform)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                *(f32x4*)(scr + frow * 256 + (((jj * 8 + 2 * fq) ^ frow) << 4)) = a[2 * h + jj];
+                *(f32x4*)(scr + frow * 256 + (((jj * 8 + 2 * fq + 1) ^ frow) << 4)) = b[2 * h + jj];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * q + l4;
+                const f32x4 v = *(const f32x4*)(scr + r * 256 + ((l15 ^ r) << 4));
+                *(f32x4*)(xw + (int64_t)(4 * q) * p.e.z_ldr + h * 64 + xoff) = v;
+            }
+        }
+    }
     float sm = (s4[0] + s4[1]) + (s4[2] + s4[3]), sq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
     sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
     sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
@@ -563,7 +586,7 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cp
     w4p_lds_rows(scr, frow, fq, l15, l4, a, b, rd);
 #pragma unroll
     for (int q = 0; q < 4; ++q) *(u32x4*)(zptr + (r0 + 4 * q) * p.e.z_ldc) = rd[q];
-    if constexpr (IDX + 1 < 8) w4p_store_tile_z<IDX + 1>(p, cptr, zptr, xrow, part, rowbase, scr, frow, fq, l15, l4, bias_l, xna, xnb);
+    if constexpr (IDX + 1 < 8) w4p_store_tile_z<IDX + 1>(p, cptr, zptr, xrow, part, rowbase, scr, frow, fq, l15, l4, bias_l, xw0, xoff, xna, xnb);
 }
 
 // Dynamic tile walk: per stream slot (runtime.cpp: hh_stream_slot) 8 per-XCD tile counters + the count of finished workgroups; the last
@@ -801,7 +824,11 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
                 float* part = e.z_partials + ((m0 + wr * 64 + frow) * (int64_t)(p.N >> 7) + ((n0 >> 7) + wc)) * 2;
                 f32x4 xa[4], xb[4];
                 w4p_zload<0>(xrow, xa, xb, e.z_ldr);
-                w4p_store_tile_z<0>(p, (bf16_t*)p.C + ncol, (bf16_t*)e.z_out + ncol, xrow, part, m0 + wr * 64, scr, frow, fq, l15, l4, ln.bias_l, xa, xb);
+                float* xw0 = (float*)e.z_resid + (m0 + wr * 64) * e.z_ldr + n0 + wc * 128;      // wave-uniform
+                int lo = lane;
+                asm volatile("" : "+v"(lo));                            // (recomputed per tile: not a value to keep live across the main loop)
+                const unsigned xoff = (unsigned)(lo >> 4) * (unsigned)e.z_ldr + 4u * (unsigned)(lo & 15);
+                w4p_store_tile_z<0>(p, (bf16_t*)p.C + ncol, (bf16_t*)e.z_out + ncol, xrow, part, m0 + wr * 64, scr, frow, fq, l15, l4, ln.bias_l, xw0, xoff, xa, xb);
             } else if constexpr (OUT_BF16 && EPI != 2 && EPI != 6) {
                 // through this wave's 4 KB of LDS: a lane finishes 4 x 16 B of one row (MFMA layout), the wave then stores 4 rows x 256 B
                 // per instruction.  A store instruction covering 16 rows x 64 B takes ~270 cycles on the CU's store path, 4 rows x 256 B

@@ -90,10 +90,10 @@ class VideoPatchEmbed(nn.Module):
 
 
 QKV_HEAD_MAJOR_PLANES = True       # False: the QKV projection writes nn.Linear's token-major [B*N, 3D] (A/B measurements)
-# norm1 / norm2 (LaviLa.py:372,388) folded into the GEMMs around them: the attention output projections add the fp32 residual stream in
-# their epilogue and emit z = bf16(x + branch) with its row statistics, the space qkv / fc1 GEMMs apply rstd / mean / gamma / beta
-# algebraically (include/hh.h, hh_gemm_epilogue.ln_stats / z_out): two of the three add+LayerNorm passes per block disappear.
-# False: the stand-alone fused add+LayerNorm kernels (A/B measurements).
+# norm3 / norm1 / norm2 (LaviLa.py:353,372,388) folded into the GEMMs around them: the GEMMs that end a branch (time proj, space proj, fc2)
+# add the fp32 residual stream in their epilogue, emit z = bf16(x + branch) with its row statistics and (space proj, fc2) write the fp32
+# sum back; the time qkv / space qkv / fc1 GEMMs apply rstd / mean / gamma / beta algebraically (include/hh.h, hh_gemm_epilogue.ln_stats /
+# z_out / z_update): no stand-alone add+LayerNorm pass is left inside the tower.  False: the fused add+LayerNorm kernels (A/B measurements).
 LN_FOLD = True
 
 
@@ -190,33 +190,44 @@ class SpaceTimeBlock(nn.Module):
                           "b1": self.mlp.fc1.bias.detach().float(), "w2": ops.to_bf16(self.mlp.fc2.weight.detach()),
                           "b2": self.mlp.fc2.bias.detach().float()}
             if LN_FOLD:
-                # norm1 -> space qkv, norm2 -> fc1: (bf16(gamma o W), its row sums, beta W^T + b)
+                # norm3 -> time qkv, norm1 -> space qkv, norm2 -> fc1: (bf16(gamma o W), its row sums, beta W^T + b)
+                self._pack["qkv_n3"] = ops.fold_layernorm_into_linear(self.timeattn.qkv.weight, self.timeattn.qkv.bias, self.norm3.weight, self.norm3.bias)
                 self._pack["qkv_n1"] = ops.fold_layernorm_into_linear(self.attn.qkv.weight, self.attn.qkv.bias, self.norm1.weight, self.norm1.bias)
                 self._pack["fc1_n2"] = ops.fold_layernorm_into_linear(self.mlp.fc1.weight, self.mlp.fc1.bias, self.norm2.weight, self.norm2.bias)
         return self._pack
 
     def fused(self, x, B, T, n, pending=None):
-        """x fp32 [B*N, D] residual stream (updated IN PLACE); `pending` = the previous block's (space branch, MLP branch) bf16
-        outputs that have not been added to x yet.  Returns this block's (space branch, MLP branch), to be added by the next
-        add+LayerNorm: x = (x + space) + mlp is written once per block instead of twice.
+        """x fp32 [B*N, D] residual stream, updated IN PLACE.
 
-        The GEMM epilogues only write bf16 branch outputs; every fp32 residual read-modify-write happens inside the
-        fused add+LayerNorm kernel (streaming HBM rate) instead of the GEMM epilogue (per-CU store-rate bound)."""
+        LN_FOLD (default): no stand-alone LayerNorm pass.  Every GEMM that ends a branch (time proj, space proj, fc2) reads the fp32
+        residual rows in its epilogue, adds its result, and emits z = bf16(sum) with the row statistics for the LayerNorm that follows;
+        space proj and fc2 also write the fp32 sum back (x <- x + s, x <- x + m: LaviLa.py:384,388 -- the time branch only feeds norm1,
+        :372-384).  The GEMM that follows (time qkv, space qkv, fc1) applies norm3 / norm1 / norm2 algebraically (include/hh.h).
+        `pending` = (z3, stats3) of THIS block's norm3 input, produced by the previous block's fc2 (None: first block, computed here);
+        returns the pair for the next block.
+        LN_FOLD False: the fused add+LayerNorm kernels; `pending` / the result are then the (space branch, MLP branch) bf16 outputs
+        that the next add+LayerNorm adds to x (x = (x + space) + mlp written once per block)."""
         pk = self.packed()
+        if "qkv_n1" in pk:
+            eps3, eps1, eps2 = pk["n3"][2], pk["n1"][2], pk["n2"][2]
+            if pending is None:
+                z3 = ops.to_bf16(x)
+                st3 = ops.ln_rowstats(z3, eps3)
+            else:
+                z3, st3 = pending
+            a = self.timeattn.core(z3, pk["time"], B, T, n, "time", ln=(st3, pk["qkv_n3"]))                     # qkv(LN3(x))
+            _, z1, st1 = ops.gemm(a, pk["time"]["wproj"], pk["time"]["bproj"], z=(x, eps1, False))              # z1 = x + t
+            a = self.attn.core(z1, pk["space"], B, T, n, "space", ln=(st1, pk["qkv_n1"]))                        # qkv(LN1(x + t))
+            _, z2, st2 = ops.gemm(a, pk["space"]["wproj"], pk["space"]["bproj"], z=(x, eps2, False, True))      # x <- x + s; z2
+            wf, cs, bf = pk["fc1_n2"]
+            h = ops.gemm(z2, wf, bf, act=ops.ACT_QUICKGELU, ln=(st2, cs))                                        # fc1(LN2(x))
+            _, z3n, st3n = ops.gemm(h, pk["w2"], pk["b2"], z=(x, eps3, False, True))                             # x <- x + m; next z3
+            return z3n, st3n
         if pending is None:
             xn = ops.layernorm(x, *pk["n3"])
         else:
             xn = ops.add_layernorm(x, pending[0], *pk["n3"], write_x=True, delta2=pending[1])          # x = (x + s_prev) + m_prev
         a = self.timeattn.core(xn, pk["time"], B, T, n, "time")
-        if "qkv_n1" in pk:
-            # the projections add x in their epilogue and hand z = bf16(x + branch) + its row statistics to the next GEMM, which applies
-            # norm1 / norm2 algebraically: no stand-alone add+LayerNorm pass, the time branch itself is never written
-            _, z1, st1 = ops.gemm(a, pk["time"]["wproj"], pk["time"]["bproj"], z=(x, pk["n1"][2], False))      # z1 = x + t
-            a = self.attn.core(z1, pk["space"], B, T, n, "space", ln=(st1, pk["qkv_n1"]))                        # qkv(LN1(x + t))
-            sp, z2, st2 = ops.gemm(a, pk["space"]["wproj"], pk["space"]["bproj"], z=(x, pk["n2"][2], True))    # s, z2 = x + s
-            wf, cs, bf = pk["fc1_n2"]
-            h = ops.gemm(z2, wf, bf, act=ops.ACT_QUICKGELU, ln=(st2, cs))                                        # fc1(LN2(x + s))
-            return sp, ops.gemm(h, pk["w2"], pk["b2"])
         t = ops.gemm(a, pk["time"]["wproj"], pk["time"]["bproj"])                                             # time branch
         a = self.attn.core(ops.add_layernorm(x, t, *pk["n1"], write_x=False), pk["space"], B, T, n, "space")   # LN1(x + t)
         sp = ops.gemm(a, pk["space"]["wproj"], pk["space"]["bproj"])
@@ -228,8 +239,10 @@ class SpaceTimeBlock(nn.Module):
         _require_gpu(x, "SpaceTimeBlock")
         B, N, D = x.shape
         y = x.float().reshape(B * N, D).clone()
-        sp, m = self.fused(y, B, space_f, time_n)
-        return ((y + sp.float()) + m.float()).view(B, N, D)
+        r = self.fused(y, B, space_f, time_n)
+        if "qkv_n1" in self.packed():
+            return y.view(B, N, D)                       # (the fold updates the residual stream inside the GEMM epilogues)
+        return ((y + r[0].float()) + r[1].float()).view(B, N, D)
 
 
 class SpaceTimeTransformer(nn.Module):
@@ -320,7 +333,7 @@ class SpaceTimeTransformer(nn.Module):
         pending = None
         for blk in self.blocks:
             pending = blk.fused(xs, B, T, n, pending)
-        if pending is None:
+        if pending is None or "qkv_n1" in self.blocks[0].packed():       # (with the fold xs already holds the full residual stream)
             out = ops.layernorm(xs, *pk["norm"], out_dtype=out_dtype)
         else:
             out = ops.add_layernorm(xs, pending[0], *pk["norm"], write_x=False, out_dtype=out_dtype, delta2=pending[1])

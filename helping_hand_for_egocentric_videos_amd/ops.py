@@ -234,8 +234,8 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
     """C = epilogue(A @ W^T).  a bf16 [M,K], w bf16 [N,K] (nn.Linear weight layout), bias fp32 [N].
 
     LayerNorm fold (include/hh.h):  ln=(stats fp32 [M,2], colsum fp32 [N]) -- consumer side: `a` holds un-normalised rows, `w` / `bias`
-    come from fold_layernorm_into_linear;  z=(x fp32 [M,N], eps, keep_c) -- producer side: returns (C or None, z = bf16(x + A W^T + bias),
-    stats of z) instead of C.
+    come from fold_layernorm_into_linear;  z=(x fp32 [M,N], eps, keep_c[, update]) -- producer side: returns (C or None, z = bf16(x + A W^T + bias),
+    stats of z) instead of C; update=True also writes the fp32 sum back into x (the residual-stream update in the GEMM's epilogue).
 
     resid fp32 [rows,N] is added after the activation; `out` may alias `resid` (in-place residual update).
     remap=(group, skip, offset) scatters output row m to m + (m//group)*skip + offset (token-major scatter).
@@ -282,8 +282,10 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
         return planes
     zt = st = None
     keep_c = True
+    update = False
     if z is not None:
-        x, eps, keep_c = z
+        x, eps, keep_c = z[:3]
+        update = bool(z[3]) if len(z) > 3 else False
         _chk(x)
         if x.dtype != torch.float32 or tuple(x.shape) != (M, N) or out_dtype != torch.bfloat16:
             raise TypeError("gemm: z=(x, eps, keep_c) needs x fp32 [M, N] and a bf16 output")
@@ -297,7 +299,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
     if z is not None:
         part = _workspace("gemm_zstats", M, N, device=a.device)
         e.z_resid, e.z_ldr, e.z_out, e.z_ldc, e.z_stats, e.z_partials = x.data_ptr(), N, zt.data_ptr(), N, st.data_ptr(), part.data_ptr()
-        e.z_eps, e.skip_c = float(eps), int(not keep_c)
+        e.z_eps, e.skip_c, e.z_update = float(eps), int(not keep_c), int(update)
         e.bias = bias.data_ptr() if bias is not None else None
         e.colscale, e.c_dtype = 1.0, BF16
         cbuf = out if keep_c else zt                               # (a valid pointer even when C is skipped)

@@ -155,7 +155,7 @@ typedef struct hh_gemm_epilogue {
      * output projection and the next qkv / fc1 Linear).  Algebra:  LN(z) W^T + b = rstd * (z (gamma o W)^T) - rstd*mean * colsum(gamma o W) + (beta W^T + b).
      * PRODUCER side (z_out != NULL; the projection GEMM): with v = acc + bias (fp32, before the bf16 rounding of C),
      *     z[m,n] = z_resid[m,n] + v[m,n]   ->  z_out (bf16);   z_stats[m] = (rstd, -rstd * mean) of row m of z over all N columns;
-     *   C is still written (the branch output the residual stream adds later) unless skip_c.  No act / colscale / resid / remap / split-K
+     *   C is still written (the branch output the residual stream adds later) unless skip_c; with z_update the fp32 z also replaces z_resid.  No act / colscale / resid / remap / split-K
      *   / column-blocked C with it.  z_partials: workspace of hh_workspace_bytes_gemm_zstats(M, N) bytes.
      * CONSUMER side (ln_stats != NULL; the qkv / fc1 GEMM): A holds the rows z, W holds bf16(gamma o W), bias holds beta W^T + b, and
      *     acc <- ln_stats[m][0] * acc + ln_stats[m][1] * ln_colsum[n] + bias[n]   before colscale / act (bias must be non-NULL).
@@ -170,6 +170,8 @@ typedef struct hh_gemm_epilogue {
     float* z_partials;        /* workspace */
     float z_eps;              /* LayerNorm eps of the statistics */
     int skip_c;               /* != 0 with z_out: C is not written (a branch nobody adds to the residual stream: the time branch, LaviLa.py:372-384) */
+    int z_update;             /* != 0 with z_out: z (fp32, before its bf16 rounding) is also written back to z_resid IN PLACE -- the residual
+                                 stream update x <- x + branch (LaviLa.py:384,388) happens in the producing GEMM's epilogue */
 } hh_gemm_epilogue;
 
 int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,

@@ -67,8 +67,37 @@ def test_block_by_block_drift_is_bounded():
     pending = None
     for i, blk in enumerate(vis.blocks):
         pending = blk.fused(xs, B, T, n, pending)
-        check("block_drift", f"residual stream after block {i} rel-L2",
-              rel_l2(((xs + pending[0].float()) + pending[1].float()).view(1, -1, D), inter[i + 1]), 4.4e-3)
+        # LayerNorm fold (default): the GEMM epilogues have already updated xs; otherwise the block's two branch outputs are still pending
+        full = xs if LaviLa.LN_FOLD else (xs + pending[0].float()) + pending[1].float()
+        check("block_drift", f"residual stream after block {i} rel-L2", rel_l2(full.view(1, -1, D), inter[i + 1]), 4.4e-3)
+        if LaviLa.LN_FOLD:                        # the hand-off to the next block: z3 is the bf16 rounding of the stream, its statistics match
+            z3, st3 = pending
+            assert torch.equal(z3, xs.to(torch.bfloat16))
+            rstd = (xs.var(1, unbiased=False) + 1e-6).rsqrt()
+            assert ((st3[:, 0] - rstd) / rstd).abs().max().item() <= 2e-3
+
+
+def test_layernorm_fold_equals_the_standalone_layernorm_route():
+    """The same tower with norm3 / norm1 / norm2 folded into the GEMMs (default) and with the stand-alone fused add+LayerNorm kernels:
+    both within the oracle bound, and within bf16-operand distance of each other (two valid roundings of the same function)."""
+    cfg = TINY16
+    sd = synth.encoder_state(cfg, seed=5, with_text=False)
+    video = synth.make_batch(cfg, 2, seed=5)["video"]
+    with torch.no_grad():
+        _, rx = OE.vision_forward(video, sd, cfg)
+    outs = {}
+    was = LaviLa.LN_FOLD
+    try:
+        for fold in (True, False):
+            LaviLa.LN_FOLD = fold
+            vis = LaviLa.build_backbone(cfg, None).visual
+            vis.load_state_dict({k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}, strict=True)
+            _, gx = vis.cuda()(video.cuda())
+            outs[fold] = gx
+            check("ln_fold_vs_standalone", "feature map rel-L2 vs oracle (fold=%s)" % fold, rel_l2(gx, rx), 4.4e-3)
+    finally:
+        LaviLa.LN_FOLD = was
+    check("ln_fold_vs_standalone", "fold vs stand-alone route rel-L2", rel_l2(outs[True], outs[False]), 4.4e-3)
 
 
 def test_module_api_shapes_and_standalone_forms():

@@ -864,6 +864,25 @@ LN_FOLD_SHAPES = [(4097, 1024, 1024), (300, 128, 128), (33, 256, 512),          
                   (2 * 4097, 1024, 1024)]
 
 
+@pytest.mark.parametrize("M,N,K", LN_FOLD_SHAPES + [(256 * 33 + 7, 1024, 4096)])
+def test_gemm_ln_fold_producer_updates_the_residual_stream_in_place(M, N, K):
+    """z_update: the fp32 sum x + A W^T + b replaces x (the residual-stream update of LaviLa.py:384,388 in the GEMM's epilogue), z is its
+    bf16 rounding, C is not written."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K + 7)
+    a = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    x = torch.randn(M, N, device=DEV, generator=g) * 2.0 + 0.3
+    want = x + (a.float() @ w.float().t() + bias)
+    c, z, st = ops.gemm(a, w, bias, z=(x, 1e-6, False, True))
+    assert c is None
+    scale = want.abs().max().item()
+    assert (x - want).abs().max().item() <= 2e-3 * scale                        # fp32 accumulation order only
+    assert torch.equal(z, x.to(torch.bfloat16))                                 # z is the rounding of what was written back
+    rstd = (want.var(1, unbiased=False) + 1e-6).rsqrt()
+    assert ((st[:, 0] - rstd) / rstd).abs().max().item() <= 2e-3
+
+
 @pytest.mark.parametrize("M,N,K", LN_FOLD_SHAPES)
 @pytest.mark.parametrize("keep_c", [True, False])
 def test_gemm_ln_fold_producer(M, N, K, keep_c):
