@@ -199,10 +199,11 @@ __global__ __launch_bounds__(64) void box_loss_bwd_kernel(const float* __restric
                                                           const float* __restrict__ tgt, int k,
                                                           const int64_t* __restrict__ mp, const int64_t* __restrict__ mt,
                                                           const int* __restrict__ mn, const float* __restrict__ g_l1,
-                                                          const float* __restrict__ g_giou, float* __restrict__ dpred, int64_t F) {
+                                                          const float* __restrict__ g_giou, float* __restrict__ dpred, int64_t F,
+                                                          const float* __restrict__ c_l1, const float* __restrict__ c_giou) {
     const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (f >= F) return;
-    const float gl = *g_l1, gg = *g_giou;
+    const float gl = *g_l1 * (c_l1 ? *c_l1 : 1.f), gg = *g_giou * (c_giou ? *c_giou : 1.f);
     const int nm = mn[f];
     for (int i = 0; i < nm; ++i) {
         const int64_t pi = (f * Qtot + q0 + mp[f * k + i]) * 4;
@@ -275,6 +276,65 @@ extern "C" int hh_box_loss_bwd(const float* pred, int Qtot, int q0, const float*
     HH_REQUIRE(F >= 0 && k > 0 && k <= MAXK, HH_ERR_SHAPE, "hh_box_loss_bwd: bad shape");
     if (F == 0) return HH_OK;
     hipLaunchKernelGGL(box_loss_bwd_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pred, Qtot, q0,
-                       tgt_cxcywh, k, match_pred, match_tgt, match_n, g_l1, g_giou, dpred, F);
+                       tgt_cxcywh, k, match_pred, match_tgt, match_n, g_l1, g_giou, dpred, F, nullptr, nullptr);
     return hh_check_launch("hh_box_loss_bwd");
+}
+
+// ---- the scalar tail of the step's two box losses (box_utils.py:156-173,142-154,445-461; run/train.py:161-183) in ONE launch instead of
+// ~35 scalar / [F]-sized stock ops: per box type t in {hand, object}
+//   loss_bbox_t = sums_t[0] / nb_t, loss_giou_t = sums_t[1] / nb_t, total_t = (w_l1 * loss_bbox_t + w_giou * loss_giou_t) / denom,
+//   cardinality_error_t = mean_f | #(argmax[f, q0_t .. q0_t + q_t) != no_object) - count_t[f] |      (argmax may be NULL: skipped, 0)
+// out[8] = total_h, total_o, loss_bbox_h, loss_giou_h, loss_bbox_o, loss_giou_o, card_h, card_o; coef[4] = d total_h / d sums_h[0], d total_h
+// / d sums_h[1], d total_o / d sums_o[0], d total_o / d sums_o[1] (the backward's constants).  One workgroup.
+__global__ __launch_bounds__(256) void box_tail_kernel(const float* __restrict__ sums_h, const float* __restrict__ sums_o, const float* __restrict__ nb,
+                                                       const int* __restrict__ count_h, const int* __restrict__ count_o,
+                                                       const int64_t* __restrict__ argmax, int Q, int q0_h, int q_h, int q0_o, int q_o, int64_t no_object,
+                                                       int64_t F, float w_l1, float w_giou, float denom, float* __restrict__ out, float* __restrict__ coef) {
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float ch = 0.f, co = 0.f;
+    if (argmax != nullptr) {
+        for (int64_t f = tid; f < F; f += 256) {
+            int nh = 0, no = 0;
+            for (int j = 0; j < q_h; ++j) nh += argmax[f * Q + q0_h + j] != no_object;
+            for (int j = 0; j < q_o; ++j) no += argmax[f * Q + q0_o + j] != no_object;
+            ch += fabsf((float)nh - (float)count_h[f]);
+            co += fabsf((float)no - (float)count_o[f]);
+        }
+    }
+    ch = wave_sum(ch); co = wave_sum(co);
+    if (lane == 0) { red[0][wave] = ch; red[1][wave] = co; }
+    __syncthreads();
+    if (tid == 0) {
+        const float nh = nb[0], no = nb[1];
+        const float lbh = sums_h[0] / nh, lgh = sums_h[1] / nh, lbo = sums_o[0] / no, lgo = sums_o[1] / no;
+        out[0] = (w_l1 * lbh + w_giou * lgh) / denom;
+        out[1] = (w_l1 * lbo + w_giou * lgo) / denom;
+        out[2] = lbh; out[3] = lgh; out[4] = lbo; out[5] = lgo;
+        out[6] = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)F;
+        out[7] = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)F;
+        coef[0] = w_l1 / nh / denom; coef[1] = w_giou / nh / denom; coef[2] = w_l1 / no / denom; coef[3] = w_giou / no / denom;
+    }
+}
+
+extern "C" int hh_box_tail_fwd(const float* sums_h, const float* sums_o, const float* num_boxes, const int32_t* count_h, const int32_t* count_o,
+                               const int64_t* argmax, int Q, int q0_h, int q_h, int q0_o, int q_o, int64_t no_object, int64_t F, float w_l1, float w_giou,
+                               float denom, float* out, float* coef, hh_stream_t stream) {
+    HH_REQUIRE(sums_h && sums_o && num_boxes && count_h && count_o && out && coef && F > 0 && denom > 0.f, HH_ERR_SHAPE, "hh_box_tail_fwd: bad arguments");
+    HH_REQUIRE(argmax == nullptr || (Q > 0 && q0_h >= 0 && q0_h + q_h <= Q && q0_o >= 0 && q0_o + q_o <= Q), HH_ERR_SHAPE, "hh_box_tail_fwd: query slices outside Q");
+    hipLaunchKernelGGL(box_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums_h, sums_o, num_boxes, count_h, count_o, argmax, Q, q0_h, q_h, q0_o,
+                       q_o, no_object, F, w_l1, w_giou, denom, out, coef);
+    return hh_check_launch("hh_box_tail_fwd");
+}
+
+// hh_box_loss_bwd with the upstream gradient given as g[0] * coef_l1[0] / g[0] * coef_giou[0] (the constants hh_box_tail_fwd left on the
+// device): dpred is ADDED to, so the two box types -- disjoint query slices -- share one zero-initialised buffer
+extern "C" int hh_box_loss_bwd_scaled(const float* pred, int Qtot, int q0, const float* tgt_cxcywh, int k, const int64_t* match_pred,
+                                      const int64_t* match_tgt, const int32_t* match_n, const float* g, const float* coef_l1, const float* coef_giou,
+                                      float* dpred, int64_t F, hh_stream_t stream) {
+    HH_REQUIRE(F >= 0 && k > 0 && k <= MAXK && g && coef_l1 && coef_giou, HH_ERR_SHAPE, "hh_box_loss_bwd_scaled: bad arguments");
+    if (F == 0) return HH_OK;
+    hipLaunchKernelGGL(box_loss_bwd_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pred, Qtot, q0,
+                       tgt_cxcywh, k, match_pred, match_tgt, match_n, g, g, dpred, F, coef_l1, coef_giou);
+    return hh_check_launch("hh_box_loss_bwd_scaled");
 }

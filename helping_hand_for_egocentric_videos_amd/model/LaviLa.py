@@ -389,7 +389,7 @@ class CLIP(nn.Module):
             return x_cls, x
         return x_cls @ self.image_projection, x
 
-    def encode_text(self, text, use_checkpoint=False, apply_project=True):
+    def encode_text(self, text, use_checkpoint=False, apply_project=True, want_cls=True):
         """LaviLa.py:660-670 (apply_project=False, as encode_image has it, skips the EOT-token projection: the training step only
         uses the feature map).  The backbone is frozen on this path (run/train.py:89,109-116; run/test_EgoMCQ.py:60 under no_grad):
         Linears and LayerNorms of the 12 text blocks run on libhh kernels (`Transformer.forward_frozen`), the 77 x 77 causal core on
@@ -404,6 +404,8 @@ class CLIP(nn.Module):
             x = self.transformer.forward_frozen(x)
             x = ops.layernorm(x, self.ln_final.weight.detach().float(), self.ln_final.bias.detach().float(), self.ln_final.eps,
                               out_dtype=torch.float32)
+        if not want_cls and not apply_project:          # (the training step gathers the EOT rows itself, run/train.py:124: four launches saved)
+            return None, x
         x_cls = x[torch.arange(x.shape[0], device=x.device), text.float().argmax(dim=-1)]      # (ids < 2^24: exact; the int64 ArgMax reduce is 20x slower)
         if not apply_project:
             return x_cls, x

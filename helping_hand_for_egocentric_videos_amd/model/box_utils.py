@@ -222,6 +222,48 @@ def split_detr_out(detr_out, start=0, end=2):
     return o
 
 
+class _BoxTail(torch.autograd.Function):
+    """Both box losses of the training step as one node: hh_box_loss_fwd per box type + ONE hh_box_tail_fwd launch for every scalar that
+    follows (loss_bbox / loss_giou per type, the weighted totals of compute_box_loss, both cardinality errors), instead of ~35 scalar
+    and [frames]-sized stock ops and their autograd; backward = two hh_box_loss_bwd_scaled launches into one zeroed buffer."""
+
+    @staticmethod
+    def forward(ctx, pred, mh, mo, nq, num_boxes, argmax, no_object, w_l1, w_giou, denom):
+        p = pred.detach().float().contiguous()
+        out, coef = ops.box_tail_fwd(p, mh, mo, 0, 2, 2, nq - 2, num_boxes, argmax, no_object, w_l1, w_giou, denom)
+        ctx.mh, ctx.mo = mh, mo
+        ctx.save_for_backward(p, coef)
+        rest = out[2:]                                   # (loss_bbox_h, loss_giou_h, loss_bbox_o, loss_giou_o, card_h, card_o): logged, no gradient
+        ctx.mark_non_differentiable(rest)
+        return out[0], out[1], rest
+
+    @staticmethod
+    def backward(ctx, g_h, g_o, _):
+        p, coef = ctx.saved_tensors
+        f = lambda g: g.reshape(1).float().contiguous()
+        return ops.box_tail_bwd(p, ctx.mh, ctx.mo, 0, 2, f(g_h), f(g_o), coef), None, None, None, None, None, None, None, None, None
+
+
+def step_box_losses(criterion, detr_out, hand_boxes, obj_boxes, n_queries, num_boxes, match_hand, match_obj):
+    """compute_box_loss('hand_boxes', ...) + compute_box_loss('obj_boxes', ...) of run/train.py:161-183 for the training step's fast path
+    (raw xyxy targets, matching already done, `num_boxes` fp32 [>= 2] = the world-averaged, clamped normalisers of both box types,
+    class head returning `pred_logits_argmax`): -> (loss_hand, loss_obj, MatchResult hand, MatchResult obj, dict of the criterion's
+    unweighted terms).  Same values as the two compute_box_loss calls (tests/test_step_gpu.py)."""
+    wd = criterion.weight_dict
+    w_l1, w_giou = wd["loss_bbox_hand_boxes"], wd["loss_giou_hand_boxes"]
+    assert wd["loss_bbox_obj_boxes"] == w_l1 and wd["loss_giou_obj_boxes"] == w_giou, "one weight pair for both box types"
+    argmax = detr_out.get("pred_logits_argmax") if "cardinality" in criterion.losses else None
+    if argmax is not None:
+        argmax = argmax.contiguous()
+    no_object = (detr_out.get("num_classes") or 0) - 1
+    lh, lo, out = _BoxTail.apply(detr_out["pred_boxes"], match_hand, match_obj, n_queries, num_boxes.float().contiguous(), argmax, no_object,
+                                 float(w_l1), float(w_giou), len(wd) / 3)
+    terms = {"loss_bbox_hand_boxes": out[0], "loss_giou_hand_boxes": out[1], "loss_bbox_obj_boxes": out[2], "loss_giou_obj_boxes": out[3]}
+    if argmax is not None:
+        terms["cardinality_error_hand_boxes"], terms["cardinality_error_obj_boxes"] = out[4], out[5]
+    return lh, lo, MatchResult(match_hand), MatchResult(match_obj), terms
+
+
 def compute_box_loss(box_type, criterion, detr_out, target_boxes, target_classes, all_image_size, n_queries=10, *, num_boxes=None,
                      match=None, return_loss_dict=False):
     """box_utils.py:445-461: ((5*L1 + 2*GIoU)/num_boxes summed) / (len(weight_dict)/3), plus the matching.

@@ -566,6 +566,38 @@ def box_loss_bwd(pred, q0, m, g_l1, g_giou, dpred):
     return dpred
 
 
+def box_tail_fwd(pred, m_h, m_o, q0_h, q_h, q0_o, q_o, num_boxes, argmax, no_object, w_l1, w_giou, denom):
+    """Both box types of the step at once (include/hh.h: hh_box_loss_fwd x 2 + hh_box_tail_fwd): -> (out fp32 [8], coef fp32 [4])."""
+    _chk(pred, num_boxes, argmax)
+    F_, Qtot, _ = pred.shape
+    sums = torch.zeros(4, dtype=torch.float32, device=pred.device)
+    L = _lib.lib()
+    for m, q0, off in ((m_h, q0_h, 0), (m_o, q0_o, 2)):
+        _lib.check(L.hh_box_loss_fwd(_p(pred), Qtot, q0, _p(m["tgt"]), m["tgt"].shape[1], _p(m["pred_idx"]), _p(m["tgt_idx"]), _p(m["n"]),
+                                     ctypes.c_void_p(sums.data_ptr() + 4 * off), F_, _stream()), "hh_box_loss_fwd")
+    out = torch.empty(8, dtype=torch.float32, device=pred.device)
+    coef = torch.empty(4, dtype=torch.float32, device=pred.device)
+    if num_boxes.dtype != torch.float32 or num_boxes.numel() < 2 or (argmax is not None and (argmax.dtype != torch.int64 or argmax.shape[0] != F_)):
+        raise TypeError("box_tail_fwd: num_boxes fp32 [>= 2], argmax int64 [F, Q]")
+    _lib.check(L.hh_box_tail_fwd(_p(sums), ctypes.c_void_p(sums.data_ptr() + 8), _p(num_boxes), _p(m_h["count"]), _p(m_o["count"]), _p(argmax),
+                                 0 if argmax is None else argmax.shape[1], q0_h, q_h, q0_o, q_o, int(no_object), F_, float(w_l1), float(w_giou),
+                                 float(denom), _p(out), _p(coef), _stream()), "hh_box_tail_fwd")
+    return out, coef
+
+
+def box_tail_bwd(pred, m_h, m_o, q0_h, q0_o, g_h, g_o, coef):
+    """d (g_h * total_h + g_o * total_o) / d pred: two launches into one zeroed buffer (the box types own disjoint query slices)."""
+    _chk(pred, g_h, g_o, coef)
+    F_, Qtot, _ = pred.shape
+    dpred = torch.zeros_like(pred)
+    L = _lib.lib()
+    for m, q0, g, off in ((m_h, q0_h, g_h, 0), (m_o, q0_o, g_o, 2)):
+        _lib.check(L.hh_box_loss_bwd_scaled(_p(pred), Qtot, q0, _p(m["tgt"]), m["tgt"].shape[1], _p(m["pred_idx"]), _p(m["tgt_idx"]), _p(m["n"]), _p(g),
+                                            ctypes.c_void_p(coef.data_ptr() + 4 * off), ctypes.c_void_p(coef.data_ptr() + 4 * off + 4), _p(dpred), F_,
+                                            _stream()), "hh_box_loss_bwd_scaled")
+    return dpred
+
+
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
     _chk(p, g, m, v)
     _lib.check(_lib.lib().hh_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),

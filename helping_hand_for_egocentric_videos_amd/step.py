@@ -76,7 +76,7 @@ class TrainStep:
         side.wait_stream(cur)
         with torch.no_grad():
             with torch.cuda.stream(side):
-                _, tmap = self.backbone.encode_text(text, apply_project=False)
+                _, tmap = self.backbone.encode_text(text, apply_project=False, want_cls=False)
             _, fmap = self.backbone.visual.forward_features(video, out_dtype=torch.bfloat16)
         cur.wait_stream(side)
         tmap.record_stream(cur)
@@ -149,10 +149,15 @@ class TrainStep:
         R = te.shape[0] // Bg
         with torch.no_grad():
             acc_vt, acc_tv = compute_tv_accuracy(sim.view(Bg, R, Bg)[:, 0], te, sim_v, sim_n, Bg)
-        lh, mh, dh = box_utils.compute_box_loss("hand_boxes", self.criterion, det, hand, None, None, n_queries=nq, num_boxes=norm[0],
-                                                match=mh, return_loss_dict=True)
-        lo, mo, do = box_utils.compute_box_loss("obj_boxes", self.criterion, det, objb, None, None, n_queries=nq, num_boxes=norm[1],
-                                                match=mo, return_loss_dict=True)
+        if det.get("pred_logits") is None and "boxes" in self.criterion.losses:
+            # both box types, every scalar of box_utils.py:142-173,445-461 and both cardinality metrics: one fused node (3 launches)
+            lh, lo, mh, mo, dh = box_utils.step_box_losses(self.criterion, det, hand, objb, nq, norm, mh, mo)
+            do = dh
+        else:                                           # materialised class logits (fast_heads=False): the per-type module functions
+            lh, mh, dh = box_utils.compute_box_loss("hand_boxes", self.criterion, det, hand, None, None, n_queries=nq, num_boxes=norm[0],
+                                                    match=mh, return_loss_dict=True)
+            lo, mo, do = box_utils.compute_box_loss("obj_boxes", self.criterion, det, objb, None, None, n_queries=nq, num_boxes=norm[1],
+                                                    match=mo, return_loss_dict=True)
         noun_embeds = self.decoder.txt_proj(batch["all_nouns"])
         word = self.word(noun_embeds, obj[:, :-1], batch["nouns"], count=sums[2] / W if W > 1 else None)
         total = nce + lh + lo + 0.5 * word                                          # run/train.py:149,183,191

@@ -324,6 +324,20 @@ int hh_box_loss_bwd(const float* pred, int Qtot, int q0, const float* tgt_cxcywh
                     const int64_t* match_pred, const int64_t* match_tgt, const int32_t* match_n,
                     const float* g_l1, const float* g_giou, float* dpred, int64_t F, hh_stream_t stream);
 
+/* The scalar tail of the step's two box losses in one launch (box_utils.py:142-173,445-461; run/train.py:161-183): per box type t in
+ * {hand, object}, from sums_t = hh_box_loss_fwd's (sum L1, sum (1 - GIoU)) and num_boxes[t] (the clamped, world-averaged normaliser):
+ *   loss_bbox_t = sums_t[0] / nb_t;  loss_giou_t = sums_t[1] / nb_t;  total_t = (w_l1 * loss_bbox_t + w_giou * loss_giou_t) / denom;
+ *   cardinality_error_t = mean over frames of | #(argmax[f, q0_t .. q0_t + q_t) != no_object) - count_t[f] |   (argmax int64 [F, Q] or NULL).
+ * out fp32 [8] = total_h, total_o, loss_bbox_h, loss_giou_h, loss_bbox_o, loss_giou_o, card_h, card_o;  coef fp32 [4] = d total_h / d sums_h[0],
+ * d total_h / d sums_h[1], d total_o / d sums_o[0], d total_o / d sums_o[1].  hh_box_loss_bwd_scaled = hh_box_loss_bwd with upstream gradients
+ * g[0] * coef_l1[0] and g[0] * coef_giou[0]; it ADDS into dpred (both box types write disjoint query slices of one zeroed buffer). */
+int hh_box_tail_fwd(const float* sums_h, const float* sums_o, const float* num_boxes, const int32_t* count_h, const int32_t* count_o,
+                    const int64_t* argmax, int Q, int q0_h, int q_h, int q0_o, int q_o, int64_t no_object, int64_t F, float w_l1, float w_giou,
+                    float denom, float* out, float* coef, hh_stream_t stream);
+int hh_box_loss_bwd_scaled(const float* pred, int Qtot, int q0, const float* tgt_cxcywh, int k, const int64_t* match_pred,
+                           const int64_t* match_tgt, const int32_t* match_n, const float* g, const float* coef_l1, const float* coef_giou,
+                           float* dpred, int64_t F, hh_stream_t stream);
+
 /* ---- loss tail (csrc/loss.hip): the step's small fp32 reductions as a handful of launches instead of ~250 stock elementwise ops.
  * hh_rownorm_fwd/bwd: y = x / max(||x||_2, eps) per row, the operand normalisation of sim_matrix (model/metric.py:363-375); x fp32
  * [rows, cols] row stride ldx, y fp32 [rows, cols] dense, norm fp32 [rows] (saved for the backward); dx = d loss / d x.

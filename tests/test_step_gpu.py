@@ -968,3 +968,41 @@ def test_mcq_scorer_pipelined_equals_mcq_forward():
     assert torch.equal(scorer(*items[1]), want[1])                       # no prefetch pending: encodes in place
     scorer.prefetch(*items[0])
     assert torch.equal(scorer(*items[2]), want[2])                       # a stale prefetch is dropped, not used
+
+
+def test_fused_box_tail_equals_the_two_compute_box_loss_calls():
+    """box_utils.step_box_losses (the step's fast path: hh_box_loss_fwd x 2 + ONE hh_box_tail_fwd launch for every scalar of
+    box_utils.py:142-173,445-461) == compute_box_loss('hand_boxes') + compute_box_loss('obj_boxes'): totals, the criterion's unweighted
+    terms, both cardinality errors, and d(lh + 0.7 lo) / d pred_boxes."""
+    g = torch.Generator().manual_seed(11)
+    F_, Q, nq = 96, 13, 12
+    crit = box_utils.SetCriterion(22047, box_utils.build_matcher(None), {"loss_bbox_hand_boxes": 5, "loss_bbox_obj_boxes": 5,
+                                  "loss_giou_hand_boxes": 2, "loss_giou_obj_boxes": 2}, 0.1, ["boxes", "cardinality"]).cuda()
+    batch = synth.make_batch(TINY16.with_(num_queries=nq), F_ // 16, seed=3)
+    hand = batch["boxes"][:, :, :2].flatten(0, 1).cuda()
+    objb = batch["boxes"][:, :, 2:].flatten(0, 1).cuda()
+    base = (torch.rand(F_, Q, 4, generator=g) * 0.5 + 0.2).cuda()
+    am = torch.randint(22040, 22048, (F_, Q), generator=g).cuda()                      # some queries predict the no-object class 22047
+    res = {}
+    for fused in (True, False):
+        pred = base.clone().requires_grad_(True)
+        det = {"pred_boxes": pred, "pred_logits": None, "pred_logits_argmax": am, "num_classes": 22048, "aux_outputs": []}
+        mh = crit.matcher.match_raw(pred, 0, 2, hand)
+        mo = crit.matcher.match_raw(pred, 2, nq - 2, objb)
+        nb = torch.stack([mh["count"].sum(), mo["count"].sum()]).float().clamp(min=1)
+        if fused:
+            lh, lo, _, _, terms = box_utils.step_box_losses(crit, det, hand, objb, nq, nb, mh, mo)
+        else:
+            lh, _, dh = box_utils.compute_box_loss("hand_boxes", crit, det, hand, None, None, n_queries=nq, num_boxes=nb[0], match=mh, return_loss_dict=True)
+            lo, _, do = box_utils.compute_box_loss("obj_boxes", crit, det, objb, None, None, n_queries=nq, num_boxes=nb[1], match=mo, return_loss_dict=True)
+            terms = dict(dh, **do)
+        (lh + 0.7 * lo).backward()
+        res[fused] = (lh.detach(), lo.detach(), {k: v.detach() for k, v in terms.items()}, pred.grad.clone())
+    a, b = res[True], res[False]
+    torch.testing.assert_close(a[0], b[0], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(a[1], b[1], rtol=1e-6, atol=1e-7)
+    assert set(a[2]) == set(b[2]) and len(a[2]) == 6
+    for k in a[2]:
+        torch.testing.assert_close(a[2][k].float(), b[2][k].float(), rtol=1e-6, atol=1e-7, msg=k)
+    torch.testing.assert_close(a[3], b[3], rtol=1e-5, atol=1e-8)
+    assert float(a[2]["cardinality_error_hand_boxes"]) > 0 and float(a[3].abs().max()) > 0
