@@ -75,6 +75,7 @@ SIGNATURES = {
     "hh_box_loss_bwd": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "hh_box_tail_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_float, c_float, c_float, c_vp, c_vp, c_vp],
     "hh_box_loss_bwd_scaled": [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "hh_text_flags": [c_vp, c_int, c_int, c_vp, c_vp, c_vp],
     "hh_rownorm_fwd": [c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_float, c_vp],
     "hh_rownorm_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_int, c_float, c_vp],
     "hh_workspace_bytes_egonce": [c_int, c_int],

@@ -248,6 +248,37 @@ extern "C" int hh_masked_ce_fwd(const float* sim, int64_t ld, const float* noun_
     return hh_check_launch("hh_masked_ce_fwd");
 }
 
+// ---- per-caption token statistics of the step (run/train.py:124,144): eot[r] = argmax_l text[r, l] (the EOT token has the largest id of the
+// vocabulary; first index on ties, as torch.argmax) and pad[r] = (#(text[r, :] != 0) != 2) as fp32 (0 = an empty rephrase slot [SOT, EOT]).
+// One wave per row; replaces ne / sum / ne / cast + float / argmax (7 stock launches, two of them int64 reductions).
+__global__ __launch_bounds__(256) void text_flags_kernel(const int64_t* __restrict__ text, int rows, int L, int64_t* __restrict__ eot, float* __restrict__ pad) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int64_t* t = text + (int64_t)row * L;
+    int64_t best = INT64_MIN;
+    int bi = 0x7fffffff, nz = 0;
+    for (int l = lane; l < L; l += 64) {
+        const int64_t v = t[l];
+        nz += v != 0;
+        if (v > best) { best = v; bi = l; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int64_t ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        nz += __shfl_xor(nz, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { eot[row] = bi; pad[row] = nz != 2 ? 1.f : 0.f; }
+}
+
+extern "C" int hh_text_flags(const int64_t* text, int rows, int L, int64_t* eot, float* pad, hh_stream_t stream) {
+    HH_REQUIRE(text && eot && pad && rows >= 0 && L > 0, HH_ERR_SHAPE, "hh_text_flags: bad arguments");
+    if (rows == 0) return HH_OK;
+    hipLaunchKernelGGL(text_flags_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, text, rows, L, eot, pad);
+    return hh_check_launch("hh_text_flags");
+}
+
 // ---- compute_tv_accuracy (metric.py:378-392): similarity [Bg, Bg] (row stride lds_: the first rephrase of every clip), positives
 // pos_ij = (sim_v_ij * sim_n_ij + [i == j] + [i != j and text_cos_ij > 0.99]) > 0; out[0] = mean_j pos[argmax_i sim_ij, j] (video ->
 // text), out[1] = mean_i pos[i, argmax_j sim_ij] (text -> video); first index on ties, as torch.argmax.  One workgroup.

@@ -57,10 +57,11 @@ class HungarianMatcher(nn.Module):
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
 
     @torch.no_grad()
-    def match_raw(self, pred_boxes, q0, q, raw_boxes, img=224.0):
-        """Fused prepare_targets + cost + LSAP on raw xyxy pixel boxes [F,k,4] (training path)."""
+    def match_raw(self, pred_boxes, q0, q, raw_boxes, img=224.0, count_out=None):
+        """Fused prepare_targets + cost + LSAP on raw xyxy pixel boxes [F,k,4] (training path).  count_out: int32 [F] row to receive the
+        per-frame target counts (the step keeps both box types' counts in one buffer and reduces them in one launch)."""
         return ops.match_boxes(pred_boxes.detach().float().contiguous(), q0, q, raw_boxes.float().contiguous(), img,
-                               self.cost_bbox, self.cost_giou)
+                               self.cost_bbox, self.cost_giou, count_out=count_out)
 
     @torch.no_grad()
     def match_list(self, outputs, targets, exclude_class=False):

@@ -37,14 +37,18 @@ def sim_matrix(a, b, eps=1e-8, norm=True):
     product runs on hh_qgemm_f32x3 (fp32-grade, differentiable; the contraction is zero-padded to a multiple of 4), the small batched
     form of the word loss as a broadcast multiply + sum -- no vendor BLAS on the step.  CPU tensors (tests, host-side use) take
     torch's ops."""
+    same = a is b                                     # (sim_matrix(v, v): normalise and pad once)
     if norm:
-        a, b = _unit_rows(a, eps), _unit_rows(b, eps)
+        a = _unit_rows(a, eps)
+        b = a if same else _unit_rows(b, eps)
     if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32:
         if a.dim() == 2 and b.dim() == 2:
             from .qside import linear_x3
             n = b.shape[0]
             pad_k, pad_n = (-a.shape[-1]) % 4, (-n) % 4              # the kernel wants its contiguous dimensions in multiples of 4
-            if pad_k or pad_n:
+            if same and pad_k and not pad_n:
+                a = b = F.pad(a, (0, pad_k))
+            elif pad_k or pad_n:
                 a, b = F.pad(a, (0, pad_k)), F.pad(b, (0, pad_k, 0, pad_n))
             out = linear_x3(a, b)
             return out[:, :n] if pad_n else out

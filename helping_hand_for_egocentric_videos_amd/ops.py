@@ -518,7 +518,7 @@ def xattn_bwd(q, k, v, out, lse, dout, dk, dv, heads, dropout_p=0.0, seed=0, spl
     return dq[0] if splits == 1 else dq.sum(0)
 
 
-def match_boxes(pred, q0, q, raw_boxes, img=224.0, w_l1=5.0, w_giou=2.0, given_count=None, class_cost=None, w_class=0.0):
+def match_boxes(pred, q0, q, raw_boxes, img=224.0, w_l1=5.0, w_giou=2.0, given_count=None, class_cost=None, w_class=0.0, count_out=None):
     """pred fp32 [F,Qtot,4]; raw_boxes fp32 [F,k,4] -> dict(tgt, count, pred_idx, tgt_idx, n) all on device.
     given_count int32 [F]: raw_boxes are already-prepared cxcywh targets (list API of HungarianMatcher).
     class_cost fp32 [F,q,k]: -softmax(logits)[query, label of target j] (exclude_class=False, box_utils.py:83-85)."""
@@ -529,7 +529,9 @@ def match_boxes(pred, q0, q, raw_boxes, img=224.0, w_l1=5.0, w_giou=2.0, given_c
     k = raw_boxes.shape[1]
     dev = pred.device
     tgt = torch.empty((F_, k, 4), dtype=torch.float32, device=dev)
-    cnt = torch.empty((F_,), dtype=torch.int32, device=dev)
+    cnt = torch.empty((F_,), dtype=torch.int32, device=dev) if count_out is None else count_out      # (a row of a caller's [types, F] buffer)
+    if cnt.dtype != torch.int32 or cnt.numel() != F_ or not cnt.is_contiguous():
+        raise TypeError("match_boxes: count_out must be a contiguous int32 [F]")
     mp = torch.empty((F_, k), dtype=torch.int64, device=dev)
     mt = torch.empty((F_, k), dtype=torch.int64, device=dev)
     mn = torch.empty((F_,), dtype=torch.int32, device=dev)
@@ -621,6 +623,18 @@ def _chk_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise RuntimeError("libhh ops need GPU tensors (got device %s); there is no CPU fallback" % t.device)
+
+
+def text_flags(text):
+    """text int64 [rows, L] -> (eot int64 [rows] = argmax over L, pad fp32 [rows] = (#non-zero tokens != 2)); include/hh.h: hh_text_flags."""
+    _chk(text)
+    if text.dtype != torch.int64 or text.dim() != 2:
+        raise TypeError("text_flags: int64 [rows, L]")
+    rows, L = text.shape
+    eot = torch.empty(rows, dtype=torch.int64, device=text.device)
+    pad = torch.empty(rows, dtype=torch.float32, device=text.device)
+    _lib.check(_lib.lib().hh_text_flags(_p(text), rows, L, _p(eot), _p(pad), _stream()), "hh_text_flags")
+    return eot, pad
 
 
 def rownorm_fwd(x, eps=1e-8):

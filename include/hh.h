@@ -351,6 +351,9 @@ int hh_box_loss_bwd_scaled(const float* pred, int Qtot, int q0, const float* tgt
  * = d ce[r] / d sim[r, :].  A valid row whose gt is outside [0, V) gets ce = NaN and a NaN gradient row (F.cross_entropy raises there).
  * hh_tv_accuracy: compute_tv_accuracy (model/metric.py:378-392): sim fp32 [Bg, Bg] (row stride ld), text_cos fp32 [Bg, Bg] (cosine
  * similarity of the first captions), sim_v, sim_n fp32 [Bg, Bg] -> out[0] = video->text, out[1] = text->video top-1 accuracy. */
+/* hh_text_flags: per caption row of the token matrix text int64 [rows, L] (run/train.py:124,144): eot[r] = argmax_l text[r, l] (first index on
+ * ties), pad[r] = 1.0 if the row holds anything but exactly two non-zero tokens ([SOT, EOT] = an empty rephrase slot), else 0.0. */
+int hh_text_flags(const int64_t* text, int rows, int L, int64_t* eot, float* pad, hh_stream_t stream);
 int hh_rownorm_fwd(const float* x, int64_t ldx, float* y, float* norm, int rows, int cols, float eps, hh_stream_t stream);
 int hh_rownorm_bwd(const float* y, const float* norm, const float* dy, int64_t lddy, float* dx, int rows, int cols, float eps,
                    hh_stream_t stream);

@@ -947,3 +947,20 @@ def test_gemm_ln_fold_consumer(M, N, K, variant):
     record("gemm_ln_fold_consumer[%s,%d,%d,%d]" % (variant, M, N, K), "rel-L2 vs fp32 (stand-alone LN -> GEMM route: %.2e)" % l_old, l_new, 8e-3)
     assert e_new <= 1.6e-2 and l_new <= 8e-3, (e_new, l_new)
     assert l_new <= 1.5 * l_old + 1e-4, (l_new, l_old)                           # the fold is as accurate as the route it replaces
+
+
+def test_text_flags_vs_torch():
+    """hh_text_flags: EOT position (argmax of the token ids, first index on ties) and the "caption present" flag of run/train.py:144."""
+    g = torch.Generator().manual_seed(2)
+    rows, L = 203, 77
+    text = torch.zeros(rows, L, dtype=torch.int64)
+    for r in range(rows):
+        n = int(torch.randint(0, 20, (1,), generator=g))
+        text[r, 0] = 49406
+        text[r, 1:1 + n] = torch.randint(1, 49405, (n,), generator=g)
+        text[r, 1 + n] = 49407
+    text[7] = 0                                                                   # an all-zero row: argmax 0, flag 1 (0 non-zero tokens != 2)
+    text[9, :] = 5                                                                # ties: first index
+    eot, pad = ops.text_flags(text.to(DEV))
+    assert torch.equal(eot.cpu(), text.argmax(-1)) and eot.dtype == torch.int64
+    assert torch.equal(pad.cpu(), ((text != 0).sum(-1) != 2).float())
