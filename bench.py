@@ -113,12 +113,22 @@ def rocprof_committed(kernel_substr, cfg_tag="", pipelined=True, tag_order=("r4"
     return None
 
 
-def gemm_algorithmic_bytes(cfg, B):
-    """Operand + result bytes of the vision tower's six GEMMs per block (bf16: A [M,K] and W [N,K] read once, C [M,N] written once),
-    launch-weighted mean per launch -- what the PMC traffic of the persistent GEMM is compared with."""
+def gemm_algorithmic_bytes(cfg, B, ln_fold=True):
+    """Operand + result bytes of the vision tower's six GEMMs per block, launch-weighted mean per launch -- what the PMC traffic of the
+    persistent GEMM is compared with.  bf16 A [M,K] and W [N,K] read once, bf16 C [M,N] written once; with the LayerNorm fold the three
+    branch-ending GEMMs (time proj, space proj, fc2) write no C but read the fp32 residual rows (4 B), write z (2 B) and -- space proj and
+    fc2 -- the fp32 residual rows back (4 B)."""
     M, D = B * cfg.tokens, cfg.embed_dim
-    shapes = [(3 * D, D)] * 2 + [(D, D)] * 2 + [(4 * D, D), (D, 4 * D)]          # (N, K): qkv x2, proj x2, fc1, fc2
-    return int(sum(2 * (M * K + N * K + M * N) for N, K in shapes) / len(shapes))
+    aw = lambda N, K: 2 * (M * K + N * K)
+    if not ln_fold:
+        shapes = [(3 * D, D)] * 2 + [(D, D)] * 2 + [(4 * D, D), (D, 4 * D)]      # (N, K): qkv x2, proj x2, fc1, fc2
+        return int(sum(aw(N, K) + 2 * M * N for N, K in shapes) / len(shapes))
+    tot = 2 * (aw(3 * D, D) + 2 * M * 3 * D)                                      # qkv (time), qkv (space): consumer side, C = q|k|v planes
+    tot += aw(D, D) + M * D * (4 + 2)                                             # time proj: + x read, z written
+    tot += aw(D, D) + M * D * (4 + 4 + 2)                                         # space proj: + x read, x and z written
+    tot += aw(4 * D, D) + 2 * M * 4 * D                                           # fc1: consumer side
+    tot += aw(D, 4 * D) + M * D * (4 + 4 + 2)                                     # fc2
+    return int(tot / 6)
 
 
 def _read_timeline():
@@ -332,7 +342,7 @@ def roofline_records(region, iso, dt_ms, pipelined, cfg, B):
     ach, n, seen, ms = rate(region, "gemm256", 1e12)
     if ach is not None:
         traffic, src = pmc_traffic("gemm256w4p_kernel<true", cfg_tag) if have_profile else (None, None)
-        alg_bytes = gemm_algorithmic_bytes(cfg, B)
+        alg_bytes = gemm_algorithmic_bytes(cfg, B, LaviLa.LN_FOLD)
         roof = {"kernel": "gemm256w4p_kernel (persistent 256x256x64 bf16 MFMA GEMM: 4 waves x 128x128, one wave per SIMD, continuous half-tile LDS-DMA stream across tiles) -- every template instantiation, nothing else",
                 "last_dispatched": names.get("gemm256", ""),
                 "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
@@ -340,13 +350,19 @@ def roofline_records(region, iso, dt_ms, pipelined, cfg, B):
                 "traffic_note": ("HBM-side bytes per launch, NOT measured in this run: launch-weighted mean over gemm256w4p_kernel<true, *> in the committed "
                                  "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration (profiles/%s; FETCH_SIZE doubled per the gfx950 correction)" % src) if src else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "algorithmic_bytes_note": "A [M,K] + W [N,K] read once + C [M,N] written once, bf16, mean over the vision tower's six GEMMs per block (qkv x2, proj x2, fc1, fc2) at M = %d" % (B * cfg.tokens),
+                "algorithmic_bytes_note": ("A [M,K] + W [N,K] read once + C [M,N] written once, bf16, mean over the vision tower's six GEMMs per block (qkv x2, proj x2, fc1, fc2) "
+                                           "at M = %d" % (B * cfg.tokens)) + ("; LayerNorm fold: the branch-ending GEMMs read the fp32 residual rows, write z (bf16) and -- space proj, "
+                                           "fc2 -- the fp32 rows back instead of C" if LaviLa.LN_FOLD else ""),
+                "ln_fold": bool(LaviLa.LN_FOLD),
+                "ln_fold_note": ("norm3 / norm1 / norm2 of every block run INSIDE these launches (residual add, row statistics, in-place fp32 update in the producers' "
+                                 "epilogues; rstd / mean / gamma / beta applied algebraically in the consumers'): their time counts here, `achieved` still divides 2*M*N*K "
+                                 "by it.  --no-ln-fold runs the stand-alone add+LayerNorm kernels (A/B: profiles/r4_ln_fold_ab.json)") if LaviLa.LN_FOLD else None,
                 "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
                 "algorithmic_work": "2*M*N*K of the full 256-row tiles of each launch (DESIGN.md section 5)",
                 "launches_timed": n, "launches_in_region": seen,
-                "timing": "library-side HIP events recorded on the launch stream right before and right after the kernel launch (hh_prof_enable), every %dth launch; in a pipelined "
-                          "region the bracket also holds the time the dispatch waits for CUs held by the other streams' kernels, which rocprofv3's per-dispatch duration does "
-                          "not -- `rocprofv3_committed` is that figure from the committed profile of the same command" % STRIDE,
+                "timing": "library-side HIP events recorded on the launch stream right before and right after the kernel launch (hh_prof_enable), every %dth launch.  Checked "
+                          "against rocprofv3 --kernel-trace in the SAME run (round 4: 511 vs 504 us per launch); `rocprofv3_committed` is the per-dispatch figure of the committed "
+                          "profile of this command (20 steps; the 5-step profiles of earlier rounds ended before the chip reached its steady clock and read ~8 %% low)" % STRIDE,
                 "avg_launch_us": round(ms * 1e3 / n, 1), "stream_time_over_step": round(ms * STRIDE / dt_ms, 3),
                 "region": "timed region (pipelined: decoder kernels of the previous step run beside it)" if pipelined else "timed region (un-pipelined)"}
         rp = rocprof_committed("gemm256w4p_kernel", cfg_tag, pipelined) if have_profile else None
@@ -419,6 +435,7 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-mcq", action="store_true", help="skip the EgoMCQ forward sub-record (second half of BASELINE.json's metric)")
     ap.add_argument("--no-c4", action="store_true", help="skip the config-4 sub-record (32-frame 336p)")
+    ap.add_argument("--no-selfcheck", action="store_true", help="skip the first-two-clips self check after the timed region (profiling runs: its B = 2 forward would dilute per-launch averages)")
     ap.add_argument("--no-power", action="store_true", help="do not sample package power with a rocm-smi child process")
     ap.add_argument("--enc-cus", type=int, default=None, help="CU budget of the persistent GEMMs on the pipelined encoder stream (multiple of 8; 0 = all)")
     ap.add_argument("--force-comm", action="store_true", help="1 GPU only: run the RCCL collectives of the data-parallel path in a 1-rank group (A/B of the CU reservation)")
@@ -539,7 +556,7 @@ def main():
 
     # the line's own parity bit: clips 0-1 of the benchmarked batch against the same two clips run as a batch of 2 (after the timed region)
     selfcheck = None
-    if world == 1 and args.workload == "train":
+    if world == 1 and args.workload == "train" and not args.no_selfcheck:
         selfcheck = first_clips_check(ts, batch, k=2)
         selfcheck["what"] = ("eval-mode forward (towers, decoder, hand-box matching) of the bench batch vs its first 2 clips alone; clip 0 must be bit-identical through "
                              "the encoder; the small batch's last clip holds its GEMM row tail (different K summation order: bf16 roundings); hs / boxes differ by the "
@@ -601,7 +618,7 @@ def main():
                 "config": {"workload": "%s, frozen TimeSformer-L + object-query decoder %s" % (cfg_name, "train step" if train else "EgoMCQ forward"),
                            "clips_per_gpu": clips_per_step, "pipelined_encoder": bool(train and not args.no_pipeline),
                            "global_clips": clips_per_step * world, "parallelism": "dp%d" % world,
-                           "resident_batch_reused": True, "materialize_logits": False,
+                           "resident_batch_reused": True, "materialize_logits": False, "ln_fold": bool(LaviLa.LN_FOLD),
                            "step_tflop_per_clip": round(tf, 2)},
                 "step_stats": step_stats(per, drop_first=bool(train and not args.no_pipeline)),
                 "end_to_end_mfma_frac": round(value * tf / (world * PEAK_BF16_TFLOPS), 4),
