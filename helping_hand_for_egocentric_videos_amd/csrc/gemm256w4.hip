@@ -513,8 +513,8 @@ __device__ __forceinline__ void w4p_store_rows_direct(const GemmParams& p, int64
 // skip_c -- through the wave's LDS scratch to 4-rows-x-256-B stores.  The (sum, sum of squares) of the wave's 128 columns go to
 // z_partials[row][n0 / 128 + wc]; gemm.hip's finalize pass adds the N / 128 slices in a fixed order.
 template <int IDX>
-__device__ __forceinline__ void w4p_zload(const float* xrow, f32x4 (&xa)[4], f32x4 (&xb)[4], int64_t ldx) {
-    const float* r = xrow + (int64_t)w4_rowoff(IDX) * ldx;
+__device__ __forceinline__ void w4p_zload(const float* xw0, unsigned xlo, f32x4 (&xa)[4], f32x4 (&xb)[4], int64_t ldx) {
+    const float* r = xw0 + (int64_t)w4_rowoff(IDX) * ldx + xlo;       // (wave-uniform base + the lane's 32-bit offset: see the write-back below)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         xa[j] = *(const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64);
@@ -531,10 +531,15 @@ __device__ __forceinline__ void w4p_lds_rows(char* scr, int frow, int fq, int l1
     for (int q = 0; q < 4; ++q) { const int r = 4 * q + l4; rd[q] = *(const u32x4*)(scr + r * 256 + ((l15 ^ r) << 4)); }
 }
 template <int IDX>
-__device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cptr, bf16_t* zptr, const float* xrow, float* part, int64_t rowbase, char* scr,
-                                                 int frow, int fq, int l15, int l4, const float* bias_l, float* xw0, unsigned xoff, f32x4 (&xa)[4], f32x4 (&xb)[4]) {
-    f32x4 xna[4], xnb[4];
-    if constexpr (IDX + 1 < 8) w4p_zload<IDX + 1>(xrow, xna, xnb, p.e.z_ldr);
+__device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw0, bf16_t* zw0, float* part0, char* scr,
+                                                 int frow, int fq, int l15, int l4, const float* bias_l, float* xw0, unsigned xoff, unsigned xlo, unsigned coff,
+                                                 unsigned zoff, f32x4 (&xa)[4], f32x4 (&xb)[4], f32x4 (&xna)[4], f32x4 (&xnb)[4]) {
+    // cw0 / zw0 / xw0 / part0: wave-uniform pointers to (first row of the wave's 64, its first column) of C / z / the residual / the
+    // statistics slot; coff / zoff / xoff (store phase: row l4, 16-B piece l15) and xlo (MFMA layout: row frow, columns 8 fq) are the
+    // lane's 32-bit element offsets -- four registers instead of four 64-bit per-lane pointers (the kernel sits at the 256-register limit)
+    // (xa, xb): residual rows of group IDX; (xna, xnb): group IDX + 1, already requested.  Group IDX + 2 is requested as soon as group
+    // IDX's registers are free (below): TWO groups (16 loads, 16 KB per wave) in flight on the same 64 registers that one-ahead
+    // prefetching held anyway -- the epilogue is bound by the latency of these loads
     f32x4 a[4], b[4];
     w4p_acc_group<16 * (IDX * 2)>(a, b);
 #pragma unroll
@@ -542,12 +547,12 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cp
         a[j] += *(const f32x4*)(bias_l + (j & 1) * 32 + (j >> 1) * 64);
         b[j] += *(const f32x4*)(bias_l + (j & 1) * 32 + (j >> 1) * 64 + 4);
     }
-    const int64_t r0 = rowbase + w4_rowoff(IDX) + l4;
     u32x4 rd[4];
     if (!p.e.skip_c) {
         w4p_lds_rows(scr, frow, fq, l15, l4, a, b, rd);
+        bf16_t* cw = cw0 + (int64_t)w4_rowoff(IDX) * p.ldc;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *(u32x4*)(cptr + (r0 + 4 * q) * p.ldc) = rd[q];
+        for (int q = 0; q < 4; ++q) *(u32x4*)(cw + (int64_t)(4 * q) * p.ldc + coff) = rd[q];
     }
     f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -556,6 +561,7 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cp
         s4 += a[j]; s4 += b[j];
         q4 += a[j] * a[j]; q4 += b[j] * b[j];
     }
+    if constexpr (IDX + 2 < 8) w4p_zload<IDX + 2>(xw0, xlo, xa, xb, p.e.z_ldr);      // (xa / xb are consumed: re-targeted right away)
     if (p.e.z_update) {
         // x <- x + branch in place (the rows this lane loaded xa / xb from).  Straight from the MFMA layout a store instruction would
         // cover 16 rows x 4 pieces of 16 B at a 32-B stride (measured: fc2 + 228 us per launch, most of it these 64 stores per tile);
@@ -582,11 +588,12 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cp
     float sm = (s4[0] + s4[1]) + (s4[2] + s4[3]), sq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
     sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
     sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
-    if (fq == 0) { const f32x2 o = {sm, sq}; *(f32x2*)(part + (int64_t)w4_rowoff(IDX) * 2 * (p.N >> 7)) = o; }
+    if (fq == 0) { const f32x2 o = {sm, sq}; *(f32x2*)(part0 + (int64_t)(w4_rowoff(IDX) + frow) * 2 * (p.N >> 7)) = o; }
     w4p_lds_rows(scr, frow, fq, l15, l4, a, b, rd);
+    bf16_t* zw = zw0 + (int64_t)w4_rowoff(IDX) * p.e.z_ldc;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *(u32x4*)(zptr + (r0 + 4 * q) * p.e.z_ldc) = rd[q];
-    if constexpr (IDX + 1 < 8) w4p_store_tile_z<IDX + 1>(p, cptr, zptr, xrow, part, rowbase, scr, frow, fq, l15, l4, bias_l, xw0, xoff, xna, xnb);
+    for (int q = 0; q < 4; ++q) *(u32x4*)(zw + (int64_t)(4 * q) * p.e.z_ldc + zoff) = rd[q];
+    if constexpr (IDX + 1 < 8) w4p_store_tile_z<IDX + 1>(p, cw0, zw0, part0, scr, frow, fq, l15, l4, bias_l, xw0, xoff, xlo, coff, zoff, xna, xnb, xa, xb);
 }
 
 // Dynamic tile walk: per stream slot (runtime.cpp: hh_stream_slot) 8 per-XCD tile counters + the count of finished workgroups; the last
@@ -802,7 +809,6 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
             stamp(3);
             W4Ln ln;
             f32x2 st0 = {1.f, 0.f};
-            if constexpr (EPI == 4) ln.bias_l = bias_s + nb;
             if constexpr (EPI >= 5) {
                 const float* rec = (const float*)(smem + 2 * W4_BUF + (tile_i & 1) * W4_LNREC);     // this tile's record (LDS)
                 const int cl = wc * 128 + 8 * fq;                                   // the lane's first column inside the tile
@@ -818,17 +824,24 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
             }
             if constexpr (EPI == 4) {
                 char* scr = smem + 2 * W4_BUF + p.N * 4 + wave * 4096;
-                const int l15 = lane & 15, l4 = lane >> 4;
-                const int ncol = n0 + wc * 128 + l15 * 8;              // this lane's 8 columns in the store phase
-                const float* xrow = e.z_resid + (m0 + wr * 64 + frow) * e.z_ldr + nb;
-                float* part = e.z_partials + ((m0 + wr * 64 + frow) * (int64_t)(p.N >> 7) + ((n0 >> 7) + wc)) * 2;
-                f32x4 xa[4], xb[4];
-                w4p_zload<0>(xrow, xa, xb, e.z_ldr);
-                float* xw0 = (float*)e.z_resid + (m0 + wr * 64) * e.z_ldr + n0 + wc * 128;      // wave-uniform
+                const int64_t row0 = m0 + wr * 64;                        // first of the wave's 64 rows; n0 + wc * 128: its first column (all uniform)
+                const int col0 = n0 + wc * 128;
+                float* xw0 = (float*)e.z_resid + row0 * e.z_ldr + col0;
+                bf16_t* cw0 = (bf16_t*)p.C + row0 * p.ldc + col0;
+                bf16_t* zw0 = (bf16_t*)e.z_out + row0 * e.z_ldc + col0;
+                float* part0 = e.z_partials + (row0 * (int64_t)(p.N >> 7) + ((n0 >> 7) + wc)) * 2;
                 int lo = lane;
-                asm volatile("" : "+v"(lo));                            // (recomputed per tile: not a value to keep live across the main loop)
-                const unsigned xoff = (unsigned)(lo >> 4) * (unsigned)e.z_ldr + 4u * (unsigned)(lo & 15);
-                w4p_store_tile_z<0>(p, (bf16_t*)p.C + ncol, (bf16_t*)e.z_out + ncol, xrow, part, m0 + wr * 64, scr, frow, fq, l15, l4, ln.bias_l, xw0, xoff, xa, xb);
+                asm volatile("" : "+v"(lo));                            // (recomputed per tile: not values to keep live across the main loop)
+                const unsigned l4u = (unsigned)(lo >> 4), l15u = (unsigned)(lo & 15);
+                const int l15 = (int)l15u, l4 = (int)l4u, frow_ = l15, fq_ = l4;        // (same bit fields of the lane in both layouts)
+                const float* bias_z = bias_s + col0 + 8 * fq_;
+                const unsigned xoff = l4u * (unsigned)e.z_ldr + 4u * l15u;                    // store phase, fp32 residual rows
+                const unsigned coff = l4u * (unsigned)p.ldc + 8u * l15u, zoff = l4u * (unsigned)e.z_ldc + 8u * l15u;      // store phase, bf16 rows
+                const unsigned xlo = l15u * (unsigned)e.z_ldr + 8u * l4u;                     // MFMA layout: row frow = lane & 15, columns 8 fq
+                f32x4 xa[4], xb[4], xna[4], xnb[4];
+                w4p_zload<0>(xw0, xlo, xa, xb, e.z_ldr);
+                w4p_zload<1>(xw0, xlo, xna, xnb, e.z_ldr);
+                w4p_store_tile_z<0>(p, cw0, zw0, part0, scr, frow_, fq_, l15, l4, bias_z, xw0, xoff, xlo, coff, zoff, xa, xb, xna, xnb);
             } else if constexpr (OUT_BF16 && EPI != 2 && EPI != 6) {
                 // through this wave's 4 KB of LDS: a lane finishes 4 x 16 B of one row (MFMA layout), the wave then stores 4 rows x 256 B
                 // per instruction.  A store instruction covering 16 rows x 64 B takes ~270 cycles on the CU's store path, 4 rows x 256 B
