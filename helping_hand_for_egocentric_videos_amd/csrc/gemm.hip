@@ -280,6 +280,7 @@ static int gemm_bf16_impl(const void* A, int64_t lda, const void* W, int64_t ldw
     p.m_start = 0;
     p.skew_iters = 0;
     p.skew_phases = 0;
+    p.tile_rows = 256;
     p.dynamic = 0;
     p.tile_slot = 0;
     p.group_m = 4;
@@ -291,7 +292,8 @@ static int gemm_bf16_impl(const void* A, int64_t lda, const void* W, int64_t ldw
         // full 256-row tiles on the 8-phase kernel; the (< 256)-row remainder on the 128x128 kernel so that it does not
         // cost a whole extra round of 256x256 blocks (M = B*4097 is never a multiple of 256)
         GemmParams pm = p;
-        pm.M = (M / 256) * 256;
+        pm.tile_rows = hh_gemm256_tile_rows(p, (hipStream_t)stream);
+        pm.M = (M / pm.tile_rows) * pm.tile_rows;
         // the <= 64 rows behind the last full tile (M = B * 4097: the B mod 256 CLS-ish rows) ride inside the persistent kernel: its
         // first N / 32 (x 2 beyond 32 rows) workgroups each finish one 32 x 32 piece (8 waves split K) before their tile walk -- the separate row-tail launch cost
         // ~11 us per GEMM, 144 times per step (skipping the tails altogether, a timing experiment, gave +1.3 % step throughput)

@@ -572,6 +572,10 @@ static int g_skew = -1;            // start skew of the one-tile-per-block kerne
 bool hh_gemm256w4p_ln_ext_ok(const GemmParams& p, bool w4);      // gemm256w4.hip: the 4-wave persistent kernel implements this LayerNorm-fold epilogue
 int hh_gemm256w4p_ln_epi(const hh_gemm_epilogue& e);
 void hh_gemm256w4p_set_ln_ext(int v);
+// "gemm_tile224": 224-row tiles where they remove a partial round (hh_gemm256_tile_rows).  OFF by default: alone on the chip the tower's
+// N = 1024 GEMMs gain 3-6 % (profiles/r4_tile224.md), inside the step -- which runs at the package power cap, where the idle CUs of a
+// partial round hand their power to the busy ones -- nothing (279.3 vs 279.1 clips/s, same session)
+static int g_tile224 = 0;
 static int g_ln_pskew = 0, g_ln_phases = 4;      // "gemm_ln_pskew" / "gemm_ln_phases": start skew of the LayerNorm-fold producer GEMMs (EPI 4)
 static int g_mode = 5;             // "gemm256": 0 = 128x128 kernel only, 1 = one tile per block, 2 = + wave-row stagger, 3 = persistent 8-wave kernel, 4 = 4-wave kernel of gemm256w4.hip, one tile per block, 5 = persistent 4-wave kernel where K allows, else 3 (default)
 static int g_dynamic = 1;           // "gemm256_dynamic": 4-wave persistent kernel takes its tiles from per-XCD atomic counters (1, default) or by static stride (0)
@@ -602,6 +606,7 @@ extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm256_debug_ts")) { g_debug_ts = value; g_ts_count = 0; return HH_OK; }
     if (name && !strcmp(name, "gemm256_dynamic") && (value == 0 || value == 1)) { g_dynamic = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_min_tiles") && value >= 1 && value <= 4096) { g_min_tiles = value; return HH_OK; }
+    if (name && !strcmp(name, "gemm_tile224") && value >= 0 && value <= 1) { g_tile224 = value; return HH_OK; }
     if (name && !strcmp(name, "gemm_ln_pskew") && value >= 0 && value <= 256) { g_ln_pskew = value; return HH_OK; }
     if (name && !strcmp(name, "gemm_ln_phases") && value >= 0 && value <= 32) { g_ln_phases = value; return HH_OK; }
     if (name && !strcmp(name, "gemm_ln_w4") && (value == 0 || value == 1)) { hh_gemm256w4p_set_ln_ext(value); return HH_OK; }
@@ -631,6 +636,22 @@ int hh_gemm256w4_timeline(unsigned long long* out, int blocks);
 bool hh_gemm256w4_timeline_is_last();
 void hh_gemm256w4_timeline_mark(bool w4);
 
+// Tile height for a GEMM of p.M rows (all of them) that hh_gemm256_eligible admitted: 224 where the persistent 4-wave kernel has the
+// instantiation (bf16, bias only or the LayerNorm-fold producer) and the 224-row tiling needs fewer round-equivalents -- a 224-row tile
+// takes ~0.9 of a 256-row tile's time (7/8 of the MFMAs and epilogue bytes, the same W staging) -- and >= 16 rows follow the last tile
+// (its A-hi staging over-reads that far).  The tower's N = 1024 GEMMs at B = 32: 7 x 0.9 = 6.3 against 7 rounds.
+int hh_gemm256_tile_rows(const GemmParams& p, hipStream_t s) {
+    if (!g_tile224 || g_mode != 5 || g_nostore || p.e.c_dtype != HH_BF16 || p.e.resid != nullptr || p.e.remap_group != 0) return 256;
+    if (!(p.K >= 384 && p.K % 128 == 0 && p.N <= 4096)) return 256;
+    const int epi = gemm_ln_ext(p.e) ? hh_gemm256w4p_ln_epi(p.e) : ((p.e.act == HH_ACT_NONE && p.e.colscale_cols == 0) ? 0 : -1);
+    if (epi != 0 && epi != 4) return 256;
+    const int64_t ncu = hh_stream_cu_count(s) & ~7, nt = p.N / 256;
+    const int64_t mt224 = p.M / 224, mt256 = p.M / 256;
+    if (ncu <= 0 || p.M - mt224 * 224 < 16) return 256;
+    const int64_t r224 = (mt224 * nt + ncu - 1) / ncu, r256 = (mt256 * nt + ncu - 1) / ncu;
+    return r224 * 90 < r256 * 98 ? 224 : 256;
+}
+
 int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
     if (tail_done) *tail_done = false;
     static bool attr_done = false;
@@ -652,7 +673,7 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
         const bool on = g_skew < 0 ? heavy : g_skew > 0;
         p.skew_iters = on ? (int)(((int64_t)(p.K / 64) * 3300 + (heavy ? 30000 : 12000)) / 1024) : 0;
     }
-    p.Mt = (int)((p.M + 255) / 256);
+    p.Mt = (int)((p.M + p.tile_rows - 1) / p.tile_rows);
     p.Nt = p.N / 256;
     // m-tiles per XCD-local group (scripts/gemm_group_bench.py with the four-barrier kernel): 16 for the short-K GEMMs up to 12 n-tiles
     // (proj 1084 -> 1122, qkv 1181 -> 1201 TFLOP/s), 8 otherwise (fc1, fc2); "gemm256_group" overrides
@@ -664,7 +685,7 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
     const int groups = (per_xcd_mt + GROUP - 1) / GROUP;
     const unsigned grid = 8u * (unsigned)groups * GROUP * (unsigned)p.Nt;
     const bool bf = p.e.c_dtype == HH_BF16;
-    if ((g_mode == 3 || g_mode == 5) && p.e.resid == nullptr && p.e.remap_group == 0 && p.K >= 128 && p.M % 256 == 0 && p.N <= 8192 && !g_nostore) {
+    if ((g_mode == 3 || g_mode == 5) && p.e.resid == nullptr && p.e.remap_group == 0 && p.K >= 128 && p.M % p.tile_rows == 0 && p.N <= 8192 && !g_nostore) {
         // epilogue flavour; a column scale together with an activation, or a scale boundary inside a 128-column half, take the
         // one-tile-per-block kernel below (generic epilogue)
         const bool scaled = p.e.colscale_cols > 0;
@@ -687,12 +708,12 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
                 static const char* const w4p_names[14] = {"gemm256w4p_kernel<false, 0>", "gemm256w4p_kernel<true, 0>", "gemm256w4p_kernel<false, 1>", "gemm256w4p_kernel<true, 1>",
                                                           "gemm256w4p_kernel<false, 2>", "gemm256w4p_kernel<true, 2>", "gemm256w4p_kernel<false, 3>", "gemm256w4p_kernel<true, 3>",
                                                           "", "gemm256w4p_kernel<true, 4>", "", "gemm256w4p_kernel<true, 5>", "", "gemm256w4p_kernel<true, 6>"};
-                hh_prof_note_kernel(HH_PROF_GEMM256, w4p_names[epi * 2 + (bf ? 1 : 0)]);
+                hh_prof_note_kernel(HH_PROF_GEMM256, p.tile_rows == 224 ? (epi == 4 ? "gemm256w4p_kernel<true, 4, 224>" : "gemm256w4p_kernel<true, 0, 224>") : w4p_names[epi * 2 + (bf ? 1 : 0)]);
                 int rc = hh_gemm256w4p_launch(p, epi, pg, s);
                 if (tail_done) *tail_done = p.tail_rows > 0;
                 return rc;
             }
-            if (epi >= 4) { hh_set_error("hh_gemm_bf16: internal: LayerNorm-fold epilogue on the 8-wave kernel"); return HH_ERR_UNSUPPORTED; }
+            if (epi >= 4 || p.tile_rows != 256) { hh_set_error("hh_gemm_bf16: internal: LayerNorm-fold epilogue / 224-row tiles on the 8-wave kernel"); return HH_ERR_UNSUPPORTED; }
             hh_gemm256w4_timeline_mark(false);
             hh_prof_note_kernel(HH_PROF_GEMM256, "gemm256d_kernel (8-wave persistent)");
 #define LAUNCHD(BF, E) hipLaunchKernelGGL((gemm256d_kernel<BF, E>), dim3(pg), dim3(512), P_LDS(p.N), s, p)
@@ -711,6 +732,7 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
             return hh_check_launch("hh_gemm_bf16(256x256 persistent)");
         }
     }
+    if (p.tile_rows != 256) { hh_set_error("hh_gemm_bf16: internal: 224-row tiles outside the persistent 4-wave kernel"); return HH_ERR_UNSUPPORTED; }
     if (gemm_ln_ext(p.e)) {                  // (hh_gemm256_eligible admits the fold only where the persistent 4-wave kernel takes it)
         hh_set_error("hh_gemm_bf16: internal: LayerNorm-fold epilogue reached a 256x256 kernel that does not implement it");
         return HH_ERR_UNSUPPORTED;

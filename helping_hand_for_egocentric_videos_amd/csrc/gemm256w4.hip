@@ -255,13 +255,17 @@ __device__ __forceinline__ void w4_edge(bf16x8 (&F)[4][2]) {
 }
 // 32 MFMAs AF x WF -> accumulator quadrant (MH, NH); under them the 8 reads of the half-tile at raddr + RIMM into RD and, if DMA_ON,
 // the 4 pieces of the half-tile staged from `src` to LDS offset wave base + DIMM
-template <int MH, int NH, bool ZERO, int RIMM, int DIMM, bool DMA_ON, int I>
+// TR = 224 (tile of 224 rows, see gemm256w4p_kernel): the fourth 16-row block of the A-hi half does not exist -- its MFMAs are left out,
+// the reads / DMA pieces keep their places
+template <int TR, int MH, int NH, bool ZERO, int RIMM, int DIMM, bool DMA_ON, int I>
 __device__ __forceinline__ void w4q(const bf16x8 (&AF)[4][2], const bf16x8 (&WF)[4][2], bf16x8 (&RD)[4][2], const unsigned (&raddr)[2],
                                     const unsigned (&voff)[4], const char* src, unsigned wave_lds) {
     constexpr int ks = I / 16, tn = (I / 4) % 4, tm = I % 4;
     constexpr int BASE = 4 * (((MH * 4 + tm) * 2 + NH) * 4 + tn);
-    if constexpr (ZERO && ks == 0) w4_mfma0<BASE>(WF[tn][ks], AF[tm][ks]);
-    else w4_mfma<BASE>(WF[tn][ks], AF[tm][ks]);
+    if constexpr (!(TR == 224 && MH == 1 && tm == 3)) {
+        if constexpr (ZERO && ks == 0) w4_mfma0<BASE>(WF[tn][ks], AF[tm][ks]);
+        else w4_mfma<BASE>(WF[tn][ks], AF[tm][ks]);
+    }
     if constexpr (I % 2 == 1 && I < 16) {
         constexpr int j = I / 2;                                   // read j: fragment tile j >> 1, k-step j & 1
         w4_ldsread<RIMM + (j >> 1) * 2048>(RD[j >> 1][j & 1], raddr[j & 1]);
@@ -271,7 +275,7 @@ __device__ __forceinline__ void w4q(const bf16x8 (&AF)[4][2], const bf16x8 (&WF)
         if constexpr (I % 2 == 0) asm volatile("s_add_u32 m0, %0, %1" :: "s"(wave_lds), "n"(DIMM + i * 1024) : "scc");
         else asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(voff[i]), "s"(src) : "memory");
     }
-    if constexpr (I + 1 < 32) w4q<MH, NH, ZERO, RIMM, DIMM, DMA_ON, I + 1>(AF, WF, RD, raddr, voff, src, wave_lds);
+    if constexpr (I + 1 < 32) w4q<TR, MH, NH, ZERO, RIMM, DIMM, DMA_ON, I + 1>(AF, WF, RD, raddr, voff, src, wave_lds);
 }
 
 // register-resident state of the k loop
@@ -295,7 +299,7 @@ __device__ __forceinline__ constexpr int w4_vm(int edge) {
     return V == W4V_NEXT0 ? (edge < 6 ? VM_ST : 24) : V == W4V_REBASE_LAST ? (edge < 4 ? 24 : 0) : V == W4V_TAIL_LAST ? 0 : 24;
 }
 #define W4_IMM(BUF, SLOT) ((BUF) * W4_BUF + (SLOT) * W4_HT)
-template <int V, int VM_ST>
+template <int V, int VM_ST, int TR = 256>
 __device__ __forceinline__ void w4_iter(W4State& s) {
     constexpr bool Z = V == W4V_FIRST0 || V == W4V_NEXT0;
     constexpr bool RB = V == W4V_REBASE || V == W4V_REBASE_LAST;
@@ -303,33 +307,33 @@ __device__ __forceinline__ void w4_iter(W4State& s) {
     constexpr bool ON7 = V != W4V_TAIL_LAST && V != W4V_REBASE_LAST;
     // ================= k-tile t (even: LDS buffer 0; W sets: fw0 = W-lo, fw1 = W-hi)
     // Q0 = A-lo x W-lo   reads W-hi(t)      stages W-lo(t+2)
-    w4q<0, 0, Z, W4_IMM(0, W4_BHI), W4_IMM(0, W4_BLO), ON, 0>(s.fa, s.fw0, s.fw1, s.rb0, s.woff, s.pWL, s.wave_lds);
+    w4q<TR, 0, 0, Z, W4_IMM(0, W4_BHI), W4_IMM(0, W4_BLO), ON, 0>(s.fa, s.fw0, s.fw1, s.rb0, s.woff, s.pWL, s.wave_lds);
     s.pWL += 128;
     w4_edge<w4_vm<V, VM_ST>(0)>(s.fw1);
     // Q1 = A-lo x W-hi   reads A-hi(t)      stages W-hi(t+2)
-    w4q<0, 1, Z, W4_IMM(0, W4_AHI), W4_IMM(0, W4_BHI), ON, 0>(s.fa, s.fw1, s.fa2, s.ra0, s.woff, s.pWH, s.wave_lds);
+    w4q<TR, 0, 1, Z, W4_IMM(0, W4_AHI), W4_IMM(0, W4_BHI), ON, 0>(s.fa, s.fw1, s.fa2, s.ra0, s.woff, s.pWH, s.wave_lds);
     s.pWH += 128;
     w4_edge<w4_vm<V, VM_ST>(1)>(s.fa2);
     // Q2 = A-hi x W-hi   reads A-lo(t+1)    stages A-hi(t+2)
-    w4q<1, 1, Z, W4_IMM(0, W4_ALO), W4_IMM(0, W4_AHI), ON, 0>(s.fa2, s.fw1, s.fa, s.ra1, s.aoff, s.pAH, s.wave_lds);
+    w4q<TR, 1, 1, Z, W4_IMM(0, W4_ALO), W4_IMM(0, W4_AHI), ON, 0>(s.fa2, s.fw1, s.fa, s.ra1, s.aoff, s.pAH, s.wave_lds);
     s.pAH += 128;
     w4_edge<w4_vm<V, VM_ST>(2)>(s.fa);
     // Q3 = A-hi x W-lo   reads W-lo(t+1)    stages A-lo(t+3)
-    w4q<1, 0, Z, W4_IMM(0, W4_BLO), W4_IMM(1, W4_ALO), ON, 0>(s.fa2, s.fw0, s.fw1, s.rb1, s.aoff, s.pAL, s.wave_lds);
+    w4q<TR, 1, 0, Z, W4_IMM(0, W4_BLO), W4_IMM(1, W4_ALO), ON, 0>(s.fa2, s.fw0, s.fw1, s.rb1, s.aoff, s.pAL, s.wave_lds);
     s.pAL = RB ? s.nAL : s.pAL + 128;
     w4_edge<w4_vm<V, VM_ST>(3)>(s.fw1);
     // ================= k-tile t+1 (odd: LDS buffer 1; W sets swapped: fw1 = W-lo, fw0 = W-hi)
-    w4q<0, 0, false, W4_IMM(0, W4_BHI), W4_IMM(1, W4_BLO), ON, 0>(s.fa, s.fw1, s.fw0, s.rb1, s.woff, s.pWL, s.wave_lds);
+    w4q<TR, 0, 0, false, W4_IMM(0, W4_BHI), W4_IMM(1, W4_BLO), ON, 0>(s.fa, s.fw1, s.fw0, s.rb1, s.woff, s.pWL, s.wave_lds);
     s.pWL = RB ? s.nWL : s.pWL + 128;
     w4_edge<w4_vm<V, VM_ST>(4)>(s.fw0);
-    w4q<0, 1, false, W4_IMM(0, W4_AHI), W4_IMM(1, W4_BHI), ON, 0>(s.fa, s.fw0, s.fa2, s.ra1, s.woff, s.pWH, s.wave_lds);
+    w4q<TR, 0, 1, false, W4_IMM(0, W4_AHI), W4_IMM(1, W4_BHI), ON, 0>(s.fa, s.fw0, s.fa2, s.ra1, s.woff, s.pWH, s.wave_lds);
     s.pWH = RB ? s.nWH : s.pWH + 128;
     w4_edge<w4_vm<V, VM_ST>(5)>(s.fa2);
     // (the reads of k-tile t+2 past the walk's end fetch stale LDS into registers nobody uses)
-    w4q<1, 1, false, W4_IMM(0, W4_ALO), W4_IMM(1, W4_AHI), ON, 0>(s.fa2, s.fw0, s.fa, s.ra0, s.aoff, s.pAH, s.wave_lds);
+    w4q<TR, 1, 1, false, W4_IMM(0, W4_ALO), W4_IMM(1, W4_AHI), ON, 0>(s.fa2, s.fw0, s.fa, s.ra0, s.aoff, s.pAH, s.wave_lds);
     s.pAH = RB ? s.nAH : s.pAH + 128;
     w4_edge<w4_vm<V, VM_ST>(6)>(s.fa);
-    w4q<1, 0, false, W4_IMM(0, W4_BLO), W4_IMM(0, W4_ALO), ON7, 0>(s.fa2, s.fw1, s.fw0, s.rb0, s.aoff, s.pAL, s.wave_lds);
+    w4q<TR, 1, 0, false, W4_IMM(0, W4_BLO), W4_IMM(0, W4_ALO), ON7, 0>(s.fa2, s.fw1, s.fw0, s.rb0, s.aoff, s.pAL, s.wave_lds);
     s.pAL += 128;
     w4_edge<w4_vm<V, VM_ST>(7)>(s.fw0);
 }
@@ -449,24 +453,28 @@ struct W4Ln {
 // before its epilogue) into a double-buffered record in the LDS the full-length bias vector occupies in the other instantiations.
 // With global loads at the start of the epilogue instead, every tile waited a memory latency for them (fc1: +92 us per launch).
 #define W4_LNREC 4096          // [bias 256 f32 | colsum 256 f32 | stats 256 x (rstd, -rstd * mean)]
-__device__ __forceinline__ constexpr int w4_rowoff(int IDX) { return (IDX >> 2) * 128 + (IDX & 3) * 16; }
+// first row of row group IDX = mh*4 + tm relative to the wave's first row: the wave's A-hi rows start 128 rows behind its A-lo rows (256-row
+// tile: waves interleaved in 64-row blocks) or 64 (224-row tile: 112 contiguous rows per wave row, 7 groups)
+template <int TR = 256>
+__device__ __forceinline__ constexpr int w4_rowoff(int IDX) { return (IDX >> 2) * (TR == 224 ? 64 : 128) + (IDX & 3) * 16; }
+template <int TR> __device__ __forceinline__ constexpr int w4_groups() { return TR == 224 ? 7 : 8; }
 
 // bf16 output: group IDX goes through the wave's LDS scratch (16 rows x 256 B, 16-B chunks XOR-swizzled with the row: conflict-free both
 // ways) and leaves as 4 stores of 4 rows x 256 B; the stores of group IDX - 1 are issued behind the arithmetic of group IDX.
-template <int EPI, int IDX>
+template <int EPI, int IDX, int TR = 256>
 __device__ __forceinline__ void w4p_store_tile(const GemmParams& p, bf16_t* cptr, int64_t rowbase, char* scr, int frow, int fq, int l15, int l4,
                                                float sc, const f32x4 (&bias_v)[4][2], const W4Ln& ln, f32x2 st, u32x4 (*prev)[4] = nullptr) {
     f32x4 a[4], b[4];
     f32x2 st_next = st;
     if constexpr (EPI == 5) {
-        if constexpr (IDX + 1 < 8) st_next = *(const f32x2*)(ln.stats + 2 * w4_rowoff(IDX + 1));      // one group ahead
+        if constexpr (IDX + 1 < 8) st_next = *(const f32x2*)(ln.stats + 2 * w4_rowoff(IDX + 1));      // one group ahead (TR = 256 only)
         w4p_finish_group_ln<EPI, IDX>(sc, ln.bias_l, ln.cs_v, st, a, b);
     } else w4p_finish_group<EPI, IDX>(sc, bias_v, a, b);
     u32x4 o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = (u32x4){pack_bf16(a[j][0], a[j][1]), pack_bf16(a[j][2], a[j][3]), pack_bf16(b[j][0], b[j][1]), pack_bf16(b[j][2], b[j][3])};
     if constexpr (IDX > 0) {                                           // the previous group's rows (its LDS reads were issued before this group's arithmetic)
-        const int64_t r0 = rowbase + w4_rowoff(IDX - 1) + l4;
+        const int64_t r0 = rowbase + w4_rowoff<TR>(IDX - 1) + l4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(u32x4*)(cptr + (r0 + 4 * q) * p.ldc) = (*prev)[q];
     }
@@ -475,9 +483,9 @@ __device__ __forceinline__ void w4p_store_tile(const GemmParams& p, bf16_t* cptr
     u32x4 rd[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int r = 4 * q + l4; rd[q] = *(const u32x4*)(scr + r * 256 + ((l15 ^ r) << 4)); }
-    if constexpr (IDX + 1 < 8) w4p_store_tile<EPI, IDX + 1>(p, cptr, rowbase, scr, frow, fq, l15, l4, sc, bias_v, ln, st_next, &rd);
+    if constexpr (IDX + 1 < w4_groups<TR>()) w4p_store_tile<EPI, IDX + 1, TR>(p, cptr, rowbase, scr, frow, fq, l15, l4, sc, bias_v, ln, st_next, &rd);
     else {
-        const int64_t r0 = rowbase + w4_rowoff(IDX) + l4;
+        const int64_t r0 = rowbase + w4_rowoff<TR>(IDX) + l4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(u32x4*)(cptr + (r0 + 4 * q) * p.ldc) = rd[q];
     }
@@ -512,9 +520,9 @@ __device__ __forceinline__ void w4p_store_rows_direct(const GemmParams& p, int64
 // z and z^2 over its 32 columns (the four lanes of a row are 16 apart: two cross-lane adds), and sends z -- and C = bf16(value), unless
 // skip_c -- through the wave's LDS scratch to 4-rows-x-256-B stores.  The (sum, sum of squares) of the wave's 128 columns go to
 // z_partials[row][n0 / 128 + wc]; gemm.hip's finalize pass adds the N / 128 slices in a fixed order.
-template <int IDX>
+template <int IDX, int TR = 256>
 __device__ __forceinline__ void w4p_zload(const float* xw0, unsigned xlo, f32x4 (&xa)[4], f32x4 (&xb)[4], int64_t ldx) {
-    const float* r = xw0 + (int64_t)w4_rowoff(IDX) * ldx + xlo;       // (wave-uniform base + the lane's 32-bit offset: see the write-back below)
+    const float* r = xw0 + (int64_t)w4_rowoff<TR>(IDX) * ldx + xlo;       // (wave-uniform base + the lane's 32-bit offset: see the write-back below)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         xa[j] = *(const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64);
@@ -530,7 +538,7 @@ __device__ __forceinline__ void w4p_lds_rows(char* scr, int frow, int fq, int l1
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int r = 4 * q + l4; rd[q] = *(const u32x4*)(scr + r * 256 + ((l15 ^ r) << 4)); }
 }
-template <int IDX>
+template <int IDX, int TR = 256>
 __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw0, bf16_t* zw0, float* part0, char* scr,
                                                  int frow, int fq, int l15, int l4, const float* bias_l, float* xw0, unsigned xoff, unsigned xlo, unsigned coff,
                                                  unsigned zoff, f32x4 (&xa)[4], f32x4 (&xb)[4], f32x4 (&xna)[4], f32x4 (&xnb)[4]) {
@@ -550,7 +558,7 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw
     u32x4 rd[4];
     if (!p.e.skip_c) {
         w4p_lds_rows(scr, frow, fq, l15, l4, a, b, rd);
-        bf16_t* cw = cw0 + (int64_t)w4_rowoff(IDX) * p.ldc;
+        bf16_t* cw = cw0 + (int64_t)w4_rowoff<TR>(IDX) * p.ldc;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(u32x4*)(cw + (int64_t)(4 * q) * p.ldc + coff) = rd[q];
     }
@@ -561,7 +569,7 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw
         s4 += a[j]; s4 += b[j];
         q4 += a[j] * a[j]; q4 += b[j] * b[j];
     }
-    if constexpr (IDX + 2 < 8) w4p_zload<IDX + 2>(xw0, xlo, xa, xb, p.e.z_ldr);      // (xa / xb are consumed: re-targeted right away)
+    if constexpr (IDX + 2 < w4_groups<TR>()) w4p_zload<IDX + 2, TR>(xw0, xlo, xa, xb, p.e.z_ldr);      // (xa / xb are consumed: re-targeted right away)
     if (p.e.z_update) {
         // x <- x + branch in place (the rows this lane loaded xa / xb from).  Straight from the MFMA layout a store instruction would
         // cover 16 rows x 4 pieces of 16 B at a 32-B stride (measured: fc2 + 228 us per launch, most of it these 64 stores per tile);
@@ -569,7 +577,7 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw
         // rows leave as 4-rows-x-256-B stores of whole lines.
         // (wave-uniform base + ONE lane-invariant 32-bit offset: per-lane 64-bit row pointers would be hoisted out of the tile loop and,
         // live across the main loop, push the register allocator into the asm-owned AGPRs -- scripts/check_isa_hazards.py)
-        float* xw = xw0 + (int64_t)w4_rowoff(IDX) * p.e.z_ldr;          // row 0 of the group, the wave's column 0 (uniform)
+        float* xw = xw0 + (int64_t)w4_rowoff<TR>(IDX) * p.e.z_ldr;          // row 0 of the group, the wave's column 0 (uniform)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -588,23 +596,33 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw
     float sm = (s4[0] + s4[1]) + (s4[2] + s4[3]), sq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
     sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
     sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
-    if (fq == 0) { const f32x2 o = {sm, sq}; *(f32x2*)(part0 + (int64_t)(w4_rowoff(IDX) + frow) * 2 * (p.N >> 7)) = o; }
+    if (fq == 0) { const f32x2 o = {sm, sq}; *(f32x2*)(part0 + (int64_t)(w4_rowoff<TR>(IDX) + frow) * 2 * (p.N >> 7)) = o; }
     w4p_lds_rows(scr, frow, fq, l15, l4, a, b, rd);
-    bf16_t* zw = zw0 + (int64_t)w4_rowoff(IDX) * p.e.z_ldc;
+    bf16_t* zw = zw0 + (int64_t)w4_rowoff<TR>(IDX) * p.e.z_ldc;
 #pragma unroll
     for (int q = 0; q < 4; ++q) *(u32x4*)(zw + (int64_t)(4 * q) * p.e.z_ldc + zoff) = rd[q];
-    if constexpr (IDX + 1 < 8) w4p_store_tile_z<IDX + 1>(p, cw0, zw0, part0, scr, frow, fq, l15, l4, bias_l, xw0, xoff, xlo, coff, zoff, xna, xnb, xa, xb);
+    if constexpr (IDX + 1 < w4_groups<TR>()) w4p_store_tile_z<IDX + 1, TR>(p, cw0, zw0, part0, scr, frow, fq, l15, l4, bias_l, xw0, xoff, xlo, coff, zoff, xna, xnb, xa, xb);
 }
 
 // Dynamic tile walk: per stream slot (runtime.cpp: hh_stream_slot) 8 per-XCD tile counters + the count of finished workgroups; the last
 // workgroup of a launch zeroes them again (kernels of one stream never overlap).  Zero-initialised device memory, no allocation.
 __device__ unsigned g_w4_tile_cnt[32][16];
 
-template <bool OUT_BF16, int EPI>
+//
+// TR = 224: tiles of 224 rows x 256 columns.  A launch whose 256-row tiles do not fill whole rounds ends with most CUs idle -- the tower's
+// N = 1024 GEMMs have 392 x 4 = 1568 tiles = 6.125 rounds on 256 CUs: 224 workgroups run 6 tiles, 32 run 7, and the seventh round
+// (12 % of the launch) keeps one CU in eight busy.  The same rows in 224-row tiles are 448 x 4 = 1792 tiles = exactly 7 rounds of 7/8 the
+// work.  A wave row owns 112 CONTIGUOUS rows (A-lo: its first 64, A-hi: the next 48): the lane offsets of the two A half-tiles stay
+// equal, A-hi starts 64 rows in, the 16 A-hi rows per wave row that do not exist are staged from whatever follows (the next wave row's /
+// the next tile's rows -- the caller guarantees >= 16 rows behind the last tile) and never multiplied: the MFMAs of row group 7 are
+// left out of the instruction stream (w4q), the epilogue stops after group 6.  Per-element arithmetic is unchanged: bit-identical results.
+template <bool OUT_BF16, int EPI, int TR = 256>
 __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
+    static_assert(TR == 256 || (TR == 224 && OUT_BF16 && (EPI == 0 || EPI == 4)), "224-row tiles: bf16 bias-only and LayerNorm-fold producer epilogues");
+    constexpr int WROWS = TR == 224 ? 112 : 64;              // tile row of wave row 1's first A-lo row
     // global_store_dwordx4 per wave and tile in the epilogue that are younger than every load of it (checked in the ISA); the producer
     // side of the LayerNorm fold (EPI 4) waits for its residual loads group by group: only the last group's z stores are certain to trail
-    constexpr int STORES = EPI == 4 ? 4 : OUT_BF16 ? 32 : 64;
+    constexpr int STORES = EPI == 4 ? 4 : OUT_BF16 ? 4 * w4_groups<TR>() : 64;
     constexpr int VM_ST = 24 + STORES > 63 ? 63 : 24 + STORES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -628,7 +646,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
         int kg, nt_i, mi;
         if (d < gfull * per) { kg = d / per; const int r = d % per; nt_i = r / GROUP; mi = r % GROUP; }
         else { const int r = d - gfull * per; kg = gfull; nt_i = r / grem; mi = r % grem; }
-        m0 = (int64_t)(xcd + 8 * (kg * GROUP + mi)) * 256;
+        m0 = (int64_t)(xcd + 8 * (kg * GROUP + mi)) * TR;
         n0 = nt_i * 256;
     };
     unsigned* tcnt = g_w4_tile_cnt[p.tile_slot];
@@ -657,13 +675,14 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (row & 7);
-        s.aoff[i] = (unsigned)((row * p.lda + c * 8) * 2);
+        const int arow = TR == 224 ? (row >> 6) * 112 + (row & 63) : row;      // half-tile row -> row of the tile (A-lo; A-hi: + hiA)
+        s.aoff[i] = (unsigned)((arow * p.lda + c * 8) * 2);
         // W half-tile row R (its 64-row halves belong to wave columns wc = 0 / 1) holds column 128 wc + 64 NH + perm(R & 63) of the
         // tile: a wave owns 128 CONTIGUOUS columns, so that the epilogue can write 256-byte row segments
         const int rl = row & 31, nperm = (row >> 6) * 128 + (row & 32) + 8 * ((rl & 15) >> 2) + 4 * (rl >> 4) + (rl & 3);
         s.woff[i] = (unsigned)((nperm * p.ldw + c * 8) * 2);
     }
-    const int64_t hiA = 128 * p.lda * 2, hiW = 64 * p.ldw * 2;
+    const int64_t hiA = (TR == 224 ? 64 : 128) * p.lda * 2, hiW = 64 * p.ldw * 2;
 
     float* bias_s = (float*)(smem + 2 * W4_BUF);
     if constexpr (EPI < 5) {
@@ -762,8 +781,8 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
             asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk) : "v"(zero), "v"(one), "s"(tcnt + xcd) : "memory");
         }
         stamp(1);
-        if (first) w4_iter<W4V_FIRST0, VM_ST>(s); else w4_iter<W4V_NEXT0, VM_ST>(s);
-        for (int t = 2; t < nk - 4; t += 2) w4_iter<W4V_MID, VM_ST>(s);
+        if (first) w4_iter<W4V_FIRST0, VM_ST, TR>(s); else w4_iter<W4V_NEXT0, VM_ST, TR>(s);
+        for (int t = 2; t < nk - 4; t += 2) w4_iter<W4V_MID, VM_ST, TR>(s);
         int nd = d + nwx;
         if (p.dynamic) {                                       // publish the fetched index to the four waves (one barrier per tile)
             volatile __attribute__((address_space(3))) unsigned* slot = (volatile __attribute__((address_space(3))) unsigned*)(smem + 2 * W4_BUF + p.N * 4 + 4 * 4096 - 16);      // (the end of the epilogue scratch, idle between epilogues)
@@ -784,8 +803,8 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
             if constexpr (EPI >= 5) ln_prefetch((tile_i + 1) & 1, nm0, nn0);
         }
         asm volatile("" : "+s"(s.nAL), "+s"(s.nAH), "+s"(s.nWL), "+s"(s.nWH));
-        if (has_next) { w4_iter<W4V_REBASE, VM_ST>(s); w4_iter<W4V_MID, VM_ST>(s); }
-        else { w4_iter<W4V_REBASE_LAST, VM_ST>(s); w4_iter<W4V_TAIL_LAST, VM_ST>(s); }
+        if (has_next) { w4_iter<W4V_REBASE, VM_ST, TR>(s); w4_iter<W4V_MID, VM_ST, TR>(s); }
+        else { w4_iter<W4V_REBASE_LAST, VM_ST, TR>(s); w4_iter<W4V_TAIL_LAST, VM_ST, TR>(s); }
         stamp(2);
         asm volatile("s_nop 15\n s_nop 15" ::: "memory");      // the last MFMAs have written their AGPRs; the next tile's first fragments are in registers
 
@@ -813,7 +832,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
                 const float* rec = (const float*)(smem + 2 * W4_BUF + (tile_i & 1) * W4_LNREC);     // this tile's record (LDS)
                 const int cl = wc * 128 + 8 * fq;                                   // the lane's first column inside the tile
                 ln.bias_l = rec + cl;
-                ln.stats = rec + 512 + 2 * (wr * 64 + frow);
+                ln.stats = rec + 512 + 2 * (wr * 64 + frow);                         // (consumer epilogues: 256-row tiles only)
                 st0 = *(const f32x2*)(ln.stats);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -824,7 +843,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
             }
             if constexpr (EPI == 4) {
                 char* scr = smem + 2 * W4_BUF + p.N * 4 + wave * 4096;
-                const int64_t row0 = m0 + wr * 64;                        // first of the wave's 64 rows; n0 + wc * 128: its first column (all uniform)
+                const int64_t row0 = m0 + wr * WROWS;                     // first of the wave's rows; n0 + wc * 128: its first column (all uniform)
                 const int col0 = n0 + wc * 128;
                 float* xw0 = (float*)e.z_resid + row0 * e.z_ldr + col0;
                 bf16_t* cw0 = (bf16_t*)p.C + row0 * p.ldc + col0;
@@ -839,9 +858,9 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
                 const unsigned coff = l4u * (unsigned)p.ldc + 8u * l15u, zoff = l4u * (unsigned)e.z_ldc + 8u * l15u;      // store phase, bf16 rows
                 const unsigned xlo = l15u * (unsigned)e.z_ldr + 8u * l4u;                     // MFMA layout: row frow = lane & 15, columns 8 fq
                 f32x4 xa[4], xb[4], xna[4], xnb[4];
-                w4p_zload<0>(xw0, xlo, xa, xb, e.z_ldr);
-                w4p_zload<1>(xw0, xlo, xna, xnb, e.z_ldr);
-                w4p_store_tile_z<0>(p, cw0, zw0, part0, scr, frow_, fq_, l15, l4, bias_z, xw0, xoff, xlo, coff, zoff, xa, xb, xna, xnb);
+                w4p_zload<0, TR>(xw0, xlo, xa, xb, e.z_ldr);
+                w4p_zload<1, TR>(xw0, xlo, xna, xnb, e.z_ldr);
+                w4p_store_tile_z<0, TR>(p, cw0, zw0, part0, scr, frow_, fq_, l15, l4, bias_z, xw0, xoff, xlo, coff, zoff, xa, xb, xna, xnb);
             } else if constexpr (OUT_BF16 && EPI != 2 && EPI != 6) {
                 // through this wave's 4 KB of LDS: a lane finishes 4 x 16 B of one row (MFMA layout), the wave then stores 4 rows x 256 B
                 // per instruction.  A store instruction covering 16 rows x 64 B takes ~270 cycles on the CU's store path, 4 rows x 256 B
@@ -850,7 +869,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
                 const int l15 = lane & 15, l4 = lane >> 4;
                 const int ncol = n0 + wc * 128 + l15 * 8;              // this lane's 8 columns in the store phase
                 bf16_t* cptr = (bf16_t*)p.C + gemm_ccol(e, ncol);
-                w4p_store_tile<EPI, 0>(p, cptr, m0 + wr * 64, scr, frow, fq, l15, l4, sc, bias_v, ln, st0);
+                w4p_store_tile<EPI, 0, TR>(p, cptr, m0 + wr * WROWS, scr, frow, fq, l15, l4, sc, bias_v, ln, st0);
             } else {
                 int64_t ccol[4];
 #pragma unroll
@@ -902,10 +921,19 @@ int hh_gemm256w4p_launch(const GemmParams& p, int epi, unsigned pg, hipStream_t 
         ATTRP(true, 0); ATTRP(false, 0); ATTRP(true, 1); ATTRP(false, 1); ATTRP(true, 2); ATTRP(false, 2); ATTRP(true, 3); ATTRP(false, 3);
         ATTRP(true, 4); ATTRP(true, 5); ATTRP(true, 6);
 #undef ATTRP
+        hipFuncSetAttribute((const void*)gemm256w4p_kernel<true, 0, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096));
+        hipFuncSetAttribute((const void*)gemm256w4p_kernel<true, 4, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096));
         attr_done = true;
     }
     const bool bf = p.e.c_dtype == HH_BF16;
 #define LAUNCHP(BF, E) hipLaunchKernelGGL((gemm256w4p_kernel<BF, E>), dim3(pg), dim3(256), W4P_LDS(p.N), s, p)
+    if (p.tile_rows == 224) {
+        if (!bf || (epi != 0 && epi != 4)) { hh_set_error("hh_gemm_bf16: internal: 224-row tiles with an epilogue that has no such instantiation"); return HH_ERR_UNSUPPORTED; }
+        if (epi == 0) hipLaunchKernelGGL((gemm256w4p_kernel<true, 0, 224>), dim3(pg), dim3(256), W4P_LDS(p.N), s, p);
+        else hipLaunchKernelGGL((gemm256w4p_kernel<true, 4, 224>), dim3(pg), dim3(256), W4P_LDS(p.N), s, p);
+        g_w4_ts_last = true;
+        return hh_check_launch("hh_gemm_bf16(224x256 persistent, 4 waves)");
+    }
     if (epi >= 4) {
         if (!bf) { hh_set_error("hh_gemm_bf16: the LayerNorm-fold epilogues of the persistent kernel write bf16"); return HH_ERR_UNSUPPORTED; }
         if (epi == 4) LAUNCHP(true, 4); else if (epi == 5) LAUNCHP(true, 5); else LAUNCHP(true, 6);

@@ -12,6 +12,7 @@ struct GemmParams {
     int debug_ts;             // persistent 256x256 kernel: record the per-tile timeline (debug)
     int group_m;              // 256x256 kernel: m-tiles per XCD-local group
     int skew_iters;           // 256x256 kernel: start-time skew quantum (0 = off)
+    int tile_rows;            // persistent 4-wave kernel: 256, or 224 (gemm256w4.hip: whole rounds for the tower's N = 1024 GEMMs)
     int skew_phases;          // persistent 4-wave kernel: 0 = the quantum times (workgroup index in its XCD) & 31, P > 0 = times (index % P)
     int dynamic, tile_slot;   // 4-wave persistent kernel: tiles beyond a workgroup's first come from per-XCD atomic counters (slot of the launch stream)
     int64_t m_start;          // first row handled by this launch (rows [m_start, M) are tiled)
@@ -94,5 +95,6 @@ __device__ __forceinline__ void gemm_store8(const hh_gemm_epilogue& e, char* Cba
 // include/hh.h: LayerNorm-fold fields of the epilogue in use (only gemm_store4 and the persistent 4-wave kernel implement them)
 __host__ __device__ __forceinline__ bool gemm_ln_ext(const hh_gemm_epilogue& e) { return e.ln_stats != nullptr || e.z_out != nullptr; }
 
+int hh_gemm256_tile_rows(const GemmParams& p, hipStream_t s);                  // gemm256.hip: 256, or 224 where that removes a partial round
 int hh_gemm256_launch(const GemmParams& p, hipStream_t s, bool* tail_done);   // gemm256.hip; returns HH_OK or an error; *tail_done: p.tail_rows were computed
 bool hh_gemm256_eligible(const GemmParams& p);

@@ -95,6 +95,15 @@ QKV_HEAD_MAJOR_PLANES = True       # False: the QKV projection writes nn.Linear'
 # sum back; the time qkv / space qkv / fc1 GEMMs apply rstd / mean / gamma / beta algebraically (include/hh.h, hh_gemm_epilogue.ln_stats /
 # z_out / z_update): no stand-alone add+LayerNorm pass is left inside the tower.  False: the fused add+LayerNorm kernels (A/B measurements).
 LN_FOLD = True
+TOWER_STREAMS = 1          # 2: the vision tower runs its batch as two half-batches on two streams (experiment, scripts/tower_trace.py)
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
 
 
 class VarAttention(nn.Module):
@@ -331,8 +340,24 @@ class SpaceTimeTransformer(nn.Module):
         del patches, tok
         xs = xs.view(B * (1 + T * n), D)
         pending = None
-        for blk in self.blocks:
-            pending = blk.fused(xs, B, T, n, pending)
+        if TOWER_STREAMS == 2 and B % 2 == 0 and "qkv_n1" in self.blocks[0].packed():
+            # two half-batches, one block apart in launch order, on two streams: the clips of a batch never meet inside the tower, and a
+            # persistent GEMM whose tile count is not a multiple of the CU count ends with most CUs idle (1568 tiles on 256 CUs = 6.125
+            # rounds) -- the other half's next kernel starts on the CUs the tail leaves free
+            cur = torch.cuda.current_stream()
+            side = _side_stream(x.device)
+            side.wait_stream(cur)
+            rows = (B // 2) * (1 + T * n)
+            halves, pend = (xs[:rows], xs[rows:]), [None, None]
+            for blk in self.blocks:
+                for h, st in enumerate((cur, side)):
+                    with torch.cuda.stream(st):
+                        pend[h] = blk.fused(halves[h], B // 2, T, n, pend[h])
+            del pend
+            cur.wait_stream(side)
+        else:
+            for blk in self.blocks:
+                pending = blk.fused(xs, B, T, n, pending)
         if pending is None or "qkv_n1" in self.blocks[0].packed():       # (with the fold xs already holds the full residual stream)
             out = ops.layernorm(xs, *pk["norm"], out_dtype=out_dtype)
         else:

@@ -15,7 +15,7 @@ for n, d in seq:
 for k, (c, t) in sorted(agg.items(), key=lambda x: -x[1][1]):
     print("  %-70s %4d  %8.1f us avg  %7.2f ms" % (k, c, t / c, t / 1e3))
 print("block 12, in launch order:")
-blk = [i for i, (n, _) in enumerate(seq) if "add_ln_kernel" in n and ("true" in n or "Lb1" in n)]
-if len(blk) > 13:
-    for n, d in seq[blk[12]:blk[13]]:
+blk = [i for i, (n, _) in enumerate(seq) if "time_attn" in n]
+if len(blk) > 12:
+    for n, d in seq[blk[11] - 1:blk[12] - 1]:
         print("     %-80s %8.1f us" % (n[:80], d))

@@ -883,6 +883,48 @@ def test_gemm_ln_fold_producer_updates_the_residual_stream_in_place(M, N, K):
     assert ((st[:, 0] - rstd) / rstd).abs().max().item() <= 2e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(224 * 64 + 40, 1024, 1024), (224 * 75 + 20, 1024, 640), (224 * 70 + 16, 1024, 4096), (32 * 3137, 1024, 1024)])
+def test_gemm_224_row_tiles_match_256_row_tiles(M, N, K):
+    """hh_set_tuning("gemm_tile224", 1) (opt-in): where 224-row tiles remove a partial round of the persistent kernel (csrc/gemm256.hip:
+    hh_gemm256_tile_rows -- the tower's N = 1024 GEMMs: 1792 tiles = 7 whole rounds instead of 1568 = 6.125) the bias-only bf16 GEMM and the
+    producer side of the LayerNorm fold run on them.  Same arithmetic per element: everything equal bit for bit to the 256-row tiling."""
+    import ctypes
+    from helping_hand_for_egocentric_videos_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    x = torch.randn(M, N, device=DEV, generator=g) * 2.0 + 0.3
+    def run():
+        out = [ops.gemm(a, w, bias)]
+        name = _lib.lib().hh_prof_kernel_name(0).decode()
+        out += list(ops.gemm(a, w, bias, z=(x, 1e-6, True)))
+        out += list(ops.gemm(a, w, bias, z=(x, 1e-6, False)))[1:]
+        xu = x.clone()
+        out += list(ops.gemm(a, w, bias, z=(xu, 1e-6, False, True)))[1:] + [xu]
+        return out, name, _lib.lib().hh_prof_kernel_name(0).decode()
+    try:
+        _lib.check(_lib.lib().hh_prof_enable(1), "prof")                         # (kernel names are noted while the timers are on)
+        ops.set_tuning("gemm_tile224", 1)
+        got, n0, n4 = run()
+        assert n0.endswith("<true, 0, 224>") and n4.endswith("<true, 4, 224>"), (n0, n4)
+        ops.set_tuning("gemm_tile224", 0)
+        want, m0, m4 = run()
+        assert m0.endswith("<true, 0>") and m4.endswith("<true, 4>"), (m0, m4)
+    finally:
+        ops.set_tuning("gemm_tile224", 0)
+        _lib.lib().hh_prof_enable(0)
+    for i, (u, v) in enumerate(zip(got, want)):
+        if u.dtype == torch.float32 and u.shape[1] == 2:
+            # row statistics: the rows behind the last full tile (a different set in the two tilings) take theirs from z, the others from
+            # the fp32 partial sums of the epilogue
+            assert ((u - v).abs() <= 2e-3 * (1.0 + v.abs())).all(), i
+        else:
+            assert torch.equal(u, v), i
+    ref = a.float() @ w.float().t() + bias
+    assert (got[0].float() - ref).abs().max().item() <= 8e-3 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("M,N,K", LN_FOLD_SHAPES)
 @pytest.mark.parametrize("keep_c", [True, False])
 def test_gemm_ln_fold_producer(M, N, K, keep_c):
