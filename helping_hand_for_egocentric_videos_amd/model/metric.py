@@ -32,6 +32,23 @@ def _unit_rows(x, eps):
     return x / x.norm(dim=-1, keepdim=True).clamp_min(eps)
 
 
+_ZEROS = {}
+
+
+def _pad_zero(x, pad_cols, pad_rows):
+    """x [r, c] with pad_cols zero columns / pad_rows zero rows appended.  One padded side: a concatenation with a cached block of zeros (one
+    launch; F.pad is a fill + a copy); both: F.pad."""
+    if not pad_cols and not pad_rows:
+        return x
+    if pad_cols and pad_rows:
+        return F.pad(x, (0, pad_cols, 0, pad_rows))
+    shape = (x.shape[0], pad_cols) if pad_cols else (pad_rows, x.shape[1])
+    key = (shape, x.dtype, x.device)
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(shape, dtype=x.dtype, device=x.device)
+    return torch.cat((x, _ZEROS[key]), dim=1 if pad_cols else 0)
+
+
 def sim_matrix(a, b, eps=1e-8, norm=True):
     """Cosine similarity with eps-clamped norms (metric.py:363-375).  On the GPU the operands are normalised by hh_rownorm_fwd, the 2-D
     product runs on hh_qgemm_f32x3 (fp32-grade, differentiable; the contraction is zero-padded to a multiple of 4), the small batched
@@ -47,9 +64,9 @@ def sim_matrix(a, b, eps=1e-8, norm=True):
             n = b.shape[0]
             pad_k, pad_n = (-a.shape[-1]) % 4, (-n) % 4              # the kernel wants its contiguous dimensions in multiples of 4
             if same and pad_k and not pad_n:
-                a = b = F.pad(a, (0, pad_k))
+                a = b = _pad_zero(a, pad_k, 0)
             elif pad_k or pad_n:
-                a, b = F.pad(a, (0, pad_k)), F.pad(b, (0, pad_k, 0, pad_n))
+                a, b = _pad_zero(a, pad_k, 0), _pad_zero(b, pad_k, pad_n)
             out = linear_x3(a, b)
             return out[:, :n] if pad_n else out
         if a.dim() == 3 and b.dim() == 3 and a.shape[0] * a.shape[1] * b.shape[1] * a.shape[2] <= (1 << 22):
