@@ -572,9 +572,9 @@ static int g_skew = -1;            // start skew of the one-tile-per-block kerne
 bool hh_gemm256w4p_ln_ext_ok(const GemmParams& p, bool w4);      // gemm256w4.hip: the 4-wave persistent kernel implements this LayerNorm-fold epilogue
 int hh_gemm256w4p_ln_epi(const hh_gemm_epilogue& e);
 void hh_gemm256w4p_set_ln_ext(int v);
-// "gemm_tile224": 224-row tiles where they remove a partial round (hh_gemm256_tile_rows).  OFF by default: alone on the chip the tower's
-// N = 1024 GEMMs gain 3-6 % (profiles/r4_tile224.md), inside the step -- which runs at the package power cap, where the idle CUs of a
-// partial round hand their power to the busy ones -- nothing (279.3 vs 279.1 clips/s, same session)
+// "gemm_tile224": 224-row tiles where they remove a partial round (hh_gemm256_tile_rows).  OFF by default: at M = 100384 (196-token
+// frames), N = 1024 it gains 3-6 % per launch alone (profiles/r4_tile224.md), but the benchmarked row counts (n = 256 tokens per frame:
+// M = B * 4097) are whole rounds of 256-row tiles already -- the rule below never selects it there
 static int g_tile224 = 0;
 static int g_ln_pskew = 0, g_ln_phases = 4;      // "gemm_ln_pskew" / "gemm_ln_phases": start skew of the LayerNorm-fold producer GEMMs (EPI 4)
 static int g_mode = 5;             // "gemm256": 0 = 128x128 kernel only, 1 = one tile per block, 2 = + wave-row stagger, 3 = persistent 8-wave kernel, 4 = 4-wave kernel of gemm256w4.hip, one tile per block, 5 = persistent 4-wave kernel where K allows, else 3 (default)
@@ -639,7 +639,7 @@ void hh_gemm256w4_timeline_mark(bool w4);
 // Tile height for a GEMM of p.M rows (all of them) that hh_gemm256_eligible admitted: 224 where the persistent 4-wave kernel has the
 // instantiation (bf16, bias only or the LayerNorm-fold producer) and the 224-row tiling needs fewer round-equivalents -- a 224-row tile
 // takes ~0.9 of a 256-row tile's time (7/8 of the MFMAs and epilogue bytes, the same W staging) -- and >= 16 rows follow the last tile
-// (its A-hi staging over-reads that far).  The tower's N = 1024 GEMMs at B = 32: 7 x 0.9 = 6.3 against 7 rounds.
+// (its A-hi staging over-reads that far).  M = 100384, N = 1024: 7 x 0.9 = 6.3 against 7 rounds; M = 131104 (config 2): 10 x 0.9 against 8 -> 256.
 int hh_gemm256_tile_rows(const GemmParams& p, hipStream_t s) {
     if (!g_tile224 || g_mode != 5 || g_nostore || p.e.c_dtype != HH_BF16 || p.e.resid != nullptr || p.e.remap_group != 0) return 256;
     if (!(p.K >= 384 && p.K % 128 == 0 && p.N <= 4096)) return 256;

@@ -609,8 +609,8 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw
 __device__ unsigned g_w4_tile_cnt[32][16];
 
 //
-// TR = 224: tiles of 224 rows x 256 columns.  A launch whose 256-row tiles do not fill whole rounds ends with most CUs idle -- the tower's
-// N = 1024 GEMMs have 392 x 4 = 1568 tiles = 6.125 rounds on 256 CUs: 224 workgroups run 6 tiles, 32 run 7, and the seventh round
+// TR = 224: tiles of 224 rows x 256 columns.  A launch whose 256-row tiles do not fill whole rounds ends with most CUs idle -- M = 100384
+// (196-token frames), N = 1024: 392 x 4 = 1568 tiles = 6.125 rounds on 256 CUs: 224 workgroups run 6 tiles, 32 run 7, and the seventh round
 // (12 % of the launch) keeps one CU in eight busy.  The same rows in 224-row tiles are 448 x 4 = 1792 tiles = exactly 7 rounds of 7/8 the
 // work.  A wave row owns 112 CONTIGUOUS rows (A-lo: its first 64, A-hi: the next 48): the lane offsets of the two A half-tiles stay
 // equal, A-hi starts 64 rows in, the 16 A-hi rows per wave row that do not exist are staged from whatever follows (the next wave row's /

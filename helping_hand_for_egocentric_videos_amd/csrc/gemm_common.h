@@ -12,7 +12,7 @@ struct GemmParams {
     int debug_ts;             // persistent 256x256 kernel: record the per-tile timeline (debug)
     int group_m;              // 256x256 kernel: m-tiles per XCD-local group
     int skew_iters;           // 256x256 kernel: start-time skew quantum (0 = off)
-    int tile_rows;            // persistent 4-wave kernel: 256, or 224 (gemm256w4.hip: whole rounds for the tower's N = 1024 GEMMs)
+    int tile_rows;            // persistent 4-wave kernel: 256, or 224 (gemm256w4.hip: whole rounds where 256-row tiles leave a partial one; opt-in)
     int skew_phases;          // persistent 4-wave kernel: 0 = the quantum times (workgroup index in its XCD) & 31, P > 0 = times (index % P)
     int dynamic, tile_slot;   // 4-wave persistent kernel: tiles beyond a workgroup's first come from per-XCD atomic counters (slot of the launch stream)
     int64_t m_start;          // first row handled by this launch (rows [m_start, M) are tiled)
