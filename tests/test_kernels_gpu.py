@@ -910,7 +910,7 @@ def test_gemm_224_row_tiles_match_256_row_tiles(M, N, K):
         assert n0.endswith("<true, 0, 224>") and n4.endswith("<true, 4, 224>"), (n0, n4)
         ops.set_tuning("gemm_tile224", 0)
         want, m0, m4 = run()
-        assert m0.endswith("<true, 0>") and m4.endswith("<true, 4>"), (m0, m4)
+        assert m0.endswith("<true, 0, 256>") and m4.endswith("<true, 4, 256>"), (m0, m4)
     finally:
         ops.set_tuning("gemm_tile224", 0)
         _lib.lib().hh_prof_enable(0)
