@@ -435,6 +435,7 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-mcq", action="store_true", help="skip the EgoMCQ forward sub-record (second half of BASELINE.json's metric)")
     ap.add_argument("--no-c4", action="store_true", help="skip the config-4 sub-record (32-frame 336p)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the opt-in variant sub-record (caption-length hint: text tower on the captions' own length)")
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the first-two-clips self check after the timed region (profiling runs: its B = 2 forward would dilute per-launch averages)")
     ap.add_argument("--no-power", action="store_true", help="do not sample package power with a rocm-smi child process")
     ap.add_argument("--enc-cus", type=int, default=None, help="CU budget of the persistent GEMMs on the pipelined encoder stream (multiple of 8; 0 = all)")
@@ -562,6 +563,20 @@ def main():
                              "the encoder; the small batch's last clip holds its GEMM row tail (different K summation order: bf16 roundings); hs / boxes differ by the "
                              "cross-attention's key-slice count (fp32 re-association)")
 
+    # opt-in variant, NOT part of `value`: the same step with the data pipeline's caption-length hint (batch["text_max_len"], a host int):
+    # the text tower then runs on ceil16(longest caption) positions instead of the 77 the reference computes (step.py: TrainStep.encode)
+    variants = None
+    if world == 1 and args.workload == "train" and args.config == "c2" and not args.no_variants:
+        longest = int((batch["text"] != 0).sum(1).max())          # (outside any timed region; a loader knows it from the tokenizer)
+        hinted = dict(batch, text_max_len=longest)
+        kv = max(5, min(args.steps, 20))
+        dtv, _, _, outv = timed_region(lambda: ts.step(hinted, next_batch=None if args.no_pipeline else hinted), kv, 3, world, False)
+        variants = {"caption_length_hint": {"value": round(clips_per_step * kv / dtv, 2), "unit": "clips/s", "ms_per_step": round(dtv / kv * 1e3, 2), "steps": kv,
+                                            "text_positions": min(cfg.context_length, (longest + 15) // 16 * 16), "of": cfg.context_length,
+                                            "loss": round(float(outv["total_loss"]), 4),
+                                            "note": "opt-in: batch['text_max_len'] from the data pipeline; the causal text tower skips the positions behind the longest "
+                                                    "caption's EOT (dead work: only EOT rows are read).  The headline `value` computes all 77 positions like the reference"}}
+
     # second half of BASELINE.json's metric in the same line: EgoMCQ forward clips/s (config 5: q = 8 items = 40 clips + 8 queries)
     mcq_rec = None
     if args.workload == "train" and not args.no_mcq and args.config == "c2":
@@ -636,6 +651,8 @@ def main():
             line["mcq"] = mcq_rec
         if c4_rec is not None:
             line["c4"] = c4_rec
+        if variants is not None:
+            line["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, enc_sd, dec_sd, seed=1000)
         if train:

@@ -63,11 +63,21 @@ class TrainStep:
         backbone.eval()                               # run/train.py:89
 
     # ------------------------------------------------------------------ forward
-    def encode(self, video, text):
+    def encode(self, video, text, text_max_len=None):
         """Frozen towers (run/train.py:108-116): returns video_grid bf16 [B,T,n,D] and text feature map fp32.
 
         The text tower (12 k token rows) cannot fill the chip: it runs on a side HIP stream concurrently with the vision
-        tower and is joined before returning."""
+        tower and is joined before returning.
+
+        text_max_len (opt-in, a HOST int from the data pipeline -- batch["text_max_len"]: tokens of the longest caption incl. SOT and EOT):
+        the tower runs on the first ceil16(text_max_len) positions only.  The attention mask is causal (LaviLa.py:636-642) and only the EOT
+        row of each caption is read (run/train.py:124), so the positions behind the longest caption's EOT are dead work: EgoClip narrations
+        are ~10 tokens of the 77.  The feature map then has that many positions; the EOT rows are the same up to the GEMM kernels' summation
+        order (tests/test_step_gpu.py).  Without the hint all 77 positions are computed, as the reference does (no host sync to find out)."""
+        if text_max_len is not None:
+            keep = min(text.shape[1], (int(text_max_len) + 15) // 16 * 16)
+            if keep < text.shape[1]:
+                text = text[:, :keep].contiguous()
         B, T = video.shape[:2]
         n = self.cfg.patches_per_frame
         cur = torch.cuda.current_stream()
@@ -95,7 +105,7 @@ class TrainStep:
         main = torch.cuda.current_stream()
         self.enc_stream.wait_stream(main)
         with torch.cuda.stream(self.enc_stream):
-            grid, tmap = self.encode(batch["video"], batch["text"])
+            grid, tmap = self.encode(batch["video"], batch["text"], batch.get("text_max_len"))
             ev = torch.cuda.Event()
             ev.record(self.enc_stream)
         self._pending = (batch, grid, tmap, ev)
@@ -110,7 +120,7 @@ class TrainStep:
             tmap.record_stream(main)
             return grid, tmap
         self._pending = None
-        return self.encode(batch["video"], batch["text"])
+        return self.encode(batch["video"], batch["text"], batch.get("text_max_len"))
 
     def losses(self, batch, next_batch=None):
         cfg = self.cfg
@@ -123,9 +133,9 @@ class TrainStep:
         det, hs, _, _ = self.decoder(grid)
         # EOT position and "caption present" flag of every caption row in one launch (run/train.py:124,144; hh_text_flags)
         eot, pad_flag = ops.text_flags(text.contiguous())
-        key = (text.shape[0], text.shape[1], text.device)
+        key = (text.shape[0], tmap.shape[1], text.device)                          # (tmap holds fewer positions under text_max_len)
         if self._row_base is None or self._row_base[0] != key:
-            self._row_base = (key, torch.arange(text.shape[0], device=text.device) * text.shape[1])
+            self._row_base = (key, torch.arange(text.shape[0], device=text.device) * tmap.shape[1])
         text_embeds = self.decoder.txt_proj(tmap.reshape(-1, tmap.shape[-1]).index_select(0, self._row_base[1] + eot))
         obj = self.decoder.obj_proj(hs[-1])                                        # [B,Q,256]
         video_embeds = obj[:, -1]
@@ -272,7 +282,10 @@ def batch_slice(batch, k, captions_per_clip):
     """The first k clips of a batch dict (synth.make_batch contract: `text` holds captions_per_clip rows per clip, `all_nouns` is shared)."""
     out = {}
     for name, v in batch.items():
-        out[name] = v if name == "all_nouns" else (v[:k * captions_per_clip] if name == "text" else v[:k])
+        if not torch.is_tensor(v):
+            out[name] = v                              # host-side hints (text_max_len)
+        else:
+            out[name] = v if name == "all_nouns" else (v[:k * captions_per_clip] if name == "text" else v[:k])
     return out
 
 

@@ -15,7 +15,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
 rm -rf $R/gpurun_out/prof_p $R/gpurun_out/prof_u $R/gpurun_out/pmc_FETCH_SIZE $R/gpurun_out/pmc_WRITE_SIZE $R/gpurun_out/pmc_SQ
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-kernel-timers --no-mcq --no-c4 --no-power --no-selfcheck $EXTRA"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-kernel-timers --no-mcq --no-c4 --no-variants --no-power --no-selfcheck $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_p -- $BENCH --steps 12 --warmup 8 > $OUT/${TAG}_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_u -- $BENCH --steps 12 --warmup 8 --no-pipeline > $OUT/${TAG}_bench_unpipelined.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -27,7 +27,7 @@ TAG=$TAG python3 - <<'PY'
 import csv, glob, json, os, collections
 R, TAG = os.environ["GRAFT_REPO_ROOT"], os.environ["TAG"]
 EXTRA = os.environ.get("HH_PROFILE_EXTRA", "").strip()
-FLAGS = "--no-cpu-baseline --no-kernel-timers --no-mcq --no-c4 --no-power --no-selfcheck" + (" " + EXTRA if EXTRA else "")
+FLAGS = "--no-cpu-baseline --no-kernel-timers --no-mcq --no-c4 --no-variants --no-power --no-selfcheck" + (" " + EXTRA if EXTRA else "")
 WHAT = ("config 4 (32-frame 336p, nq=12), B = 4 clips" if "c4" in EXTRA else "config 2 (16-frame 224p, nq=12), B = 32 clips") if "--batch" not in EXTRA or "c4" in EXTRA else "bench.py " + EXTRA
 OUT = R + "/gpurun_out/profiles_new/"
 STEPS = 20

@@ -390,6 +390,41 @@ def test_headline_config_c2_losses_vs_oracle():
     record("c2_headline_step", "statistic: end-to-end object-index agreement with the fp32 oracle (fraction of frames)", sum(agree) / len(agree), 1.0)
 
 
+def test_caption_length_hint_trims_the_text_tower_without_changing_the_step():
+    """batch["text_max_len"] (opt-in, a host int from the data pipeline): the text tower runs on the first ceil16(max caption length)
+    positions instead of all 77 -- causal mask + only the EOT row is read (LaviLa.py:636-642,660-670; run/train.py:124), so the rest is
+    dead work.  Full-width config 2, B = 2, eval mode: EOT features equal up to the GEMM kernels' summation order, every loss term within
+    1e-4 of the untrimmed step, same matching."""
+    from helping_hand_for_egocentric_videos_amd import C2
+    cfg = C2
+    esd, dsd = synth.encoder_state(cfg, seed=0), synth.decoder_state(cfg, seed=0)
+    batch = to_dev(synth.make_batch(cfg, 2, seed=1000))
+    backbone = LaviLa.build_backbone(cfg, esd)
+    dec = tfm_decoder.build_decoder(cfg, dsd)
+    ts = TrainStep(cfg, backbone, dec)
+    dec.eval()
+    text = batch["text"]
+    longest = int((text != 0).sum(1).max())                      # (test only: the step itself never asks the device)
+    assert longest <= 14
+    with torch.no_grad():
+        _, full = ts.encode(batch["video"], text)
+        _, trim = ts.encode(batch["video"], text, text_max_len=longest)
+    assert full.shape[1] == cfg.context_length and trim.shape[1] == 16
+    eot = text.float().argmax(1)
+    rows = torch.arange(text.shape[0], device=text.device)
+    a, b = full[rows, eot], trim[rows, eot]
+    assert float((a - b).norm() / a.norm()) <= 5e-3
+    ts.arena.zero_grad()
+    ref = ts.losses(batch)
+    ts.arena.zero_grad()
+    got = ts.losses(dict(batch, text_max_len=longest))
+    for k in ("total_loss", "nce_loss", "box_loss_hand", "box_loss_obj", "word_loss"):
+        assert abs(float(got[k]) - float(ref[k])) <= 1e-4 * abs(float(ref[k])), (k, float(got[k]), float(ref[k]))
+    for key in ("match_hand", "match_obj"):
+        for (p, q), (r, s) in zip(got[key], ref[key]):
+            assert torch.equal(p, r) and torch.equal(q, s)
+
+
 def test_c4_full_width_step_losses_vs_oracle():
     """BASELINE config 4 ITSELF (full-width TimeSformer-L, T = 32 frames, 336 px: N = 18 433 tokens and M = 18 432 memory tokens
     per clip, nq = 12), B = 2: every loss term of the GPU step vs the CPU oracle on identical synthetic weights / inputs (north-star
