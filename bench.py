@@ -209,7 +209,7 @@ while True:
         w = [float(r[1]) for r in rows if t0 <= float(r[0]) <= t1 and r[1] != "nan"]
         mhz = [float(r[2]) for r in rows if t0 <= float(r[0]) <= t1 and r[2] != "nan"]
         if not w:
-            return None
+            return {"samples": 0, "rows_seen": len(rows), "note": "rocm-smi gave no power sample inside the timed region on this box (cap: 1400 W; other runs: profiles/r4_bench_line.json)"}
         return {"package_power_w_mean": round(sum(w) / len(w), 1), "package_power_w_max": max(w), "samples": len(w),
                 "sclk_mhz_mean_reported": round(sum(mhz) / len(mhz), 1) if mhz else None,
                 "source": "rocm-smi --showpower --showclocks sampled by a child process during the timed region (cap: 1400 W)"}
