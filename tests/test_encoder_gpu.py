@@ -100,6 +100,27 @@ def test_layernorm_fold_equals_the_standalone_layernorm_route():
     check("ln_fold_vs_standalone", "fold vs stand-alone route rel-L2", rel_l2(outs[True], outs[False]), 4.4e-3)
 
 
+def test_two_half_batch_streams_give_the_same_feature_map():
+    """LaviLa.TOWER_STREAMS = 2 (experiment, DESIGN.md 4.6: the batch as two half-batches one block apart on two streams): the clips of a
+    batch never meet inside the tower: same feature map up to the kernels' summation order."""
+    cfg = TINY16
+    sd = synth.encoder_state(cfg, seed=6, with_text=False)
+    video = synth.make_batch(cfg, 4, seed=6)["video"].cuda()
+    vis = LaviLa.build_backbone(cfg, None).visual
+    vis.load_state_dict({k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}, strict=True)
+    vis = vis.cuda()
+    was = LaviLa.TOWER_STREAMS
+    try:
+        with torch.no_grad():
+            _, one = vis.forward_features(video)
+            LaviLa.TOWER_STREAMS = 2
+            _, two = vis.forward_features(video)
+        torch.cuda.synchronize()
+    finally:
+        LaviLa.TOWER_STREAMS = was
+    assert rel_l2(two, one) <= 2e-3                          # (same function per clip; kernel choice / row tails move with the row count)
+
+
 def test_module_api_shapes_and_standalone_forms():
     cfg = TINY4
     sd = synth.encoder_state(cfg, seed=2)
