@@ -547,7 +547,8 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw
     // lane's 32-bit element offsets -- four registers instead of four 64-bit per-lane pointers (the kernel sits at the 256-register limit)
     // (xa, xb): residual rows of group IDX; (xna, xnb): group IDX + 1, already requested.  Group IDX + 2 is requested as soon as group
     // IDX's registers are free (below): TWO groups (16 loads, 16 KB per wave) in flight on the same 64 registers that one-ahead
-    // prefetching held anyway -- the epilogue is bound by the latency of these loads
+    // prefetching held anyway (measured: no faster than one group ahead -- all workgroups run this epilogue at once and together
+    // sit at the HBM ceiling)
     f32x4 a[4], b[4];
     w4p_acc_group<16 * (IDX * 2)>(a, b);
 #pragma unroll
