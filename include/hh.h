@@ -49,11 +49,17 @@ int hh_version(void);
  *   "gemm256_group" m-tiles per XCD-local group of the tile walk (0 = per-shape default)
  *   "gemm256_skew"  -1 auto / 0 off / 1 on: start-time skew of the one-tile-per-block kernel (spreads the epilogue HBM bursts)
  *   "gemm256_pskew" 0..64: start skew quantum of the persistent kernel (default 0)
+ *   "gemm_ln_w4"    1 (default) = LayerNorm-fold epilogues (ln_stats / z_out below) on the persistent 4-wave kernel where it takes the shape,
+ *                   0 = on the 128x128 kernel (A/B, debugging);  "gemm_ln_pskew" 0..256 / "gemm_ln_phases" 0..32: start skew of the fold's
+ *                   producer launches in s_sleep(8) steps x phases (default 0: measured +-0 in the step)
+ *   "gemm_tile224"  0 (default) / 1: 224-row tiles on the persistent 4-wave kernel (bf16 bias-only and fold-producer epilogues) where they
+ *                   turn a partial last round into whole rounds (hh_gemm256_tile_rows); bit-identical results
  *   "space_joint"   1 (default) = space attention on the joint-block kernel where n / 16 divides by 4 waves x {4, 3, 2} blocks,
  *                   0 = always the 16-query-block kernel;  "space_waves" waves per workgroup of the joint kernel: 0 (default) = automatic (12 waves x
  *                   3 blocks when K / V fill the LDS, i.e. one workgroup per CU, and n / 16 divides by 36 -- config 4's n = 576 --, else 4), 4 / 12 =
  *                   force where the shape divides;  "space_prog" 1 (default) = K / V staged progressively (compute starts on the first key
- *                   segment while the rest is in flight) where a specialised kernel exists: n = 576; 0 = off; 2 = also n = 256 (experiment);
+ *                   segment while the rest is in flight) where a specialised kernel exists: n = 576; 0 = off; 2 = also n = 256 (experiment); 3 = n = 256 on
+ *                   the persistent cross-problem-prefetch kernel (space_attnpp_kernel; slower, kept as a recorded experiment);
  *                   "space_debug" 0 / 1 / 2: full kernel / memory traffic only / no staging
  *   "gemm256_debug_ts", "gemm256_debug_nostore": diagnostics (timeline recording; skip the epilogue stores) */
 int hh_set_tuning(const char* name, int value);
