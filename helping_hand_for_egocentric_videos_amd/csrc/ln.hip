@@ -176,6 +176,7 @@ int hh_ln_fold_stats_launch(const float* partials, int slices, float* stats, int
 
 extern "C" int hh_ln_rowstats(const void* z, int64_t ldz, float* stats, int64_t rows, int cols, float eps, hh_stream_t stream) {
     HH_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 2048 && ldz >= cols && ldz % 4 == 0, HH_ERR_SHAPE, "hh_ln_rowstats: cols=%d must be a multiple of 8 and <= 2048", cols);
+    if (rows == 0) return HH_OK;                      // (an empty tensor's data pointer is null)
     HH_REQUIRE(z != nullptr && stats != nullptr && HH_ALIGNED16(z) && (((uintptr_t)stats) & 7) == 0, HH_ERR_ALIGN, "hh_ln_rowstats: bad pointers");
     return hh_ln_rowstats_launch(z, ldz, stats, 0, rows, cols, eps, (hipStream_t)stream);
 }

@@ -273,8 +273,9 @@ __global__ __launch_bounds__(256) void text_flags_kernel(const int64_t* __restri
 }
 
 extern "C" int hh_text_flags(const int64_t* text, int rows, int L, int64_t* eot, float* pad, hh_stream_t stream) {
-    HH_REQUIRE(text && eot && pad && rows >= 0 && L > 0, HH_ERR_SHAPE, "hh_text_flags: bad arguments");
-    if (rows == 0) return HH_OK;
+    HH_REQUIRE(rows >= 0 && L > 0, HH_ERR_SHAPE, "hh_text_flags: bad arguments");
+    if (rows == 0) return HH_OK;                      // (an empty tensor's data pointer is null)
+    HH_REQUIRE(text && eot && pad, HH_ERR_SHAPE, "hh_text_flags: null pointer");
     hipLaunchKernelGGL(text_flags_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, text, rows, L, eot, pad);
     return hh_check_launch("hh_text_flags");
 }

@@ -1060,3 +1060,22 @@ def test_space_attention_persistent_kernel_slow_path():
     assert_close_bf16(out, ref, 1.2e-2, "attn-space-persistent-redo")
     err = (out.float().cpu() - ref).abs().amax(1)
     assert (err / (ref.abs().amax(1) + 1e-3)).max() < 5e-2
+
+
+def test_round4_entry_points_accept_empty_inputs():
+    """M = 0 / no captions: the LayerNorm-fold GEMMs, hh_ln_rowstats and hh_text_flags return empty results instead of failing on the
+    null data pointer of an empty tensor."""
+    z = torch.empty(0, 1024, dtype=torch.bfloat16, device=DEV)
+    assert ops.ln_rowstats(z, 1e-6).shape == (0, 2)
+    a = torch.empty(0, 1024, dtype=torch.bfloat16, device=DEV)
+    w = torch.randn(1024, 1024, device=DEV).to(torch.bfloat16)
+    b = torch.randn(1024, device=DEV)
+    x = torch.empty(0, 1024, device=DEV)
+    c, zz, st = ops.gemm(a, w, b, z=(x, 1e-6, True))
+    assert c.shape == (0, 1024) and zz.shape == (0, 1024) and st.shape == (0, 2)
+    c, zz, st = ops.gemm(a, w, b, z=(x, 1e-6, False, True))
+    assert c is None and zz.shape == (0, 1024)
+    assert ops.gemm(a, w, b, ln=(torch.empty(0, 2, device=DEV), torch.randn(1024, device=DEV))).shape == (0, 1024)
+    eot, pad = ops.text_flags(torch.empty(0, 77, dtype=torch.int64, device=DEV))
+    assert eot.shape == (0,) and pad.shape == (0,)
+    torch.cuda.synchronize()
