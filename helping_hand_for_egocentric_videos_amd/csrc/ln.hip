@@ -344,6 +344,7 @@ extern "C" int hh_layernorm_pos_fwd(const void* x, int x_dtype, const float* gam
                                     hh_stream_t stream) {
     HH_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 2048 && pos_rows > 0, HH_ERR_SHAPE, "hh_layernorm_pos_fwd: cols=%d must be a multiple of 8 and <= 2048, pos_rows > 0", cols);
     HH_REQUIRE((x_dtype == HH_F32 || x_dtype == HH_BF16) && (y_dtype == HH_F32 || y_dtype == HH_BF16), HH_ERR_DTYPE, "hh_layernorm_pos_fwd: bad dtype");
+    if (rows == 0) return HH_OK;                      // (empty tensors have null data pointers)
     HH_REQUIRE(y_plus_pos != nullptr && pos != nullptr, HH_ERR_SHAPE, "hh_layernorm_pos_fwd: y_plus_pos / pos are NULL (use hh_layernorm_fwd)");
     HH_REQUIRE(HH_ALIGNED16(x) && HH_ALIGNED16(y) && HH_ALIGNED16(y_plus_pos) && HH_ALIGNED16(pos) && HH_ALIGNED16(gamma) && HH_ALIGNED16(beta), HH_ERR_ALIGN,
                "hh_layernorm_pos_fwd: pointers must be 16-byte aligned");
@@ -392,6 +393,7 @@ extern "C" int hh_add_layernorm_fwd(float* x, const void* delta, const void* del
                                     int y_dtype, int64_t rows, int cols, float eps, hh_stream_t stream) {
     HH_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 2048, HH_ERR_SHAPE, "hh_add_layernorm_fwd: cols=%d must be a multiple of 8 and <= 2048", cols);
     HH_REQUIRE(y_dtype == HH_F32 || y_dtype == HH_BF16, HH_ERR_DTYPE, "hh_add_layernorm_fwd: bad dtype");
+    if (rows == 0) return HH_OK;                      // (empty tensors have null data pointers)
     HH_REQUIRE(delta != nullptr, HH_ERR_SHAPE, "hh_add_layernorm_fwd: delta is NULL (use hh_layernorm_fwd)");
     HH_REQUIRE(HH_ALIGNED16(x) && HH_ALIGNED16(delta) && HH_ALIGNED16(y) && HH_ALIGNED16(gamma) && HH_ALIGNED16(beta), HH_ERR_ALIGN,
                "hh_add_layernorm_fwd: pointers must be 16-byte aligned");

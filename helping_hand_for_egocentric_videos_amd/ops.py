@@ -407,6 +407,9 @@ def gemm_tn(at, bt, splits=None, colsum=False):
     N = bt.shape[1]
     if at.dtype != torch.bfloat16 or bt.dtype != torch.bfloat16 or bt.shape[0] != K or at.stride(1) != 1 or bt.stride(1) != 1:
         raise ValueError("gemm_tn: operands must be bf16 [K, M] / [K, N] with unit column stride")
+    if K == 0:                                  # no tokens: the sum over nothing
+        z = torch.zeros((M, N), dtype=torch.float32, device=at.device)
+        return (z, torch.zeros((M,), dtype=torch.float32, device=at.device)) if colsum else z
     if splits is None:
         tiles = (M // 128) * (N // 128)
         splits = max(1, min(256, 1024 // max(tiles, 1), (K + 511) // 512))
@@ -450,6 +453,8 @@ def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
         raise ValueError(mode)
     if out is None:
         out = torch.empty((B * N, D), dtype=torch.bfloat16, device=qkv.device)
+    if B == 0:
+        return out
     L = _lib.lib()
     part, G = None, 0
     if fold_cls:

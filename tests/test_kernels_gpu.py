@@ -1078,4 +1078,11 @@ def test_round4_entry_points_accept_empty_inputs():
     assert ops.gemm(a, w, b, ln=(torch.empty(0, 2, device=DEV), torch.randn(1024, device=DEV))).shape == (0, 1024)
     eot, pad = ops.text_flags(torch.empty(0, 77, dtype=torch.int64, device=DEV))
     assert eot.shape == (0,) and pad.shape == (0,)
+    g1, b1 = torch.ones(1024, device=DEV), torch.zeros(1024, device=DEV)
+    assert ops.add_layernorm(torch.empty(0, 1024, device=DEV), z, g1, b1, 1e-5).shape == (0, 1024)
+    y, yp, mean, rstd = ops.layernorm_pos(torch.empty(0, 512, device=DEV), g1[:512], b1[:512], 1e-5, torch.randn(16, 512, device=DEV), save_stats=True)
+    assert y.shape == (0, 512) and yp.shape == (0, 512)
+    dw, db = ops.gemm_tn(torch.empty(0, 512, dtype=torch.bfloat16, device=DEV), torch.empty(0, 256, dtype=torch.bfloat16, device=DEV), colsum=True)
+    assert dw.shape == (512, 256) and float(dw.abs().max()) == 0.0 and db.shape == (512,)
+    assert ops.divided_attention(torch.empty(0, 3072, dtype=torch.bfloat16, device=DEV), 0, 4, 32, 16, "space").shape == (0, 1024)
     torch.cuda.synchronize()
