@@ -1,7 +1,7 @@
 #!/bin/bash
-# round-4 final verification on the GPU box: full -m gpu suite, smoke, the default bench line, LayerNorm-fold A/B, tower traces
+# GPU-box verification of a build (run through gpurun): full -m gpu suite, smoke, the default bench line, LayerNorm-fold A/B, tower traces -> gpurun_out/verify/
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r4final; mkdir -p $O
+O=gpurun_out/verify; mkdir -p $O
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $O/tests_gpu.log; cat $O/tests_gpu.log
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 > $O/smoke.log; cat $O/smoke.log
 timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench_default.err | tail -1 > $O/bench_default.json
@@ -12,7 +12,7 @@ for rep in 1 2; do
 done
 python - <<'PY'
 import json,glob
-for f in ['gpurun_out/r4final/bench_default.json']+sorted(glob.glob('gpurun_out/r4final/bench_*.log')):
+for f in ['gpurun_out/verify/bench_default.json']+sorted(glob.glob('gpurun_out/verify/bench_*.log')):
     try:
         d=json.loads(open(f).read()); r=d['roofline']
         print(f, d['value'], d['ms_per_step'], 'gemm', r['achieved'], r['avg_launch_us'], r['stream_time_over_step'], 'iso', r['isolated']['achieved'], 'loss', d['loss'], d['selfcheck'])

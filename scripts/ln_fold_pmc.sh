@@ -1,8 +1,8 @@
 #!/bin/bash
-# HBM-side traffic of ONE vision-tower pass with and without the LayerNorm fold (rocprofv3 --pmc, one counter per pass) -> gpurun_out/r4t/ln_fold_pmc.md
+# HBM-side traffic of ONE vision-tower pass with and without the LayerNorm fold (rocprofv3 --pmc, one counter per pass) -> gpurun_out/ln_fold_pmc/ln_fold_pmc.md
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r4t; mkdir -p $O
+O=$R/gpurun_out/ln_fold_pmc; mkdir -p $O
 for v in 1 0; do for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm_${v}_$c
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pm_${v}_$c -- python3 $R/scripts/tower_trace.py $v > $O/pmc_${v}_$c.log 2>&1
@@ -39,6 +39,6 @@ for v,name in ((1,"fold"),(0,"no fold")):
     out+=["","total: %.1f GiB per pass = %.1f B per element and block"%(T/2**30,T/EL/24),""]
     tot[name]=T
 out+=["Difference: %.1f GiB per pass = %.1f B per element and block removed by the fold."%((tot["no fold"]-tot["fold"])/2**30,(tot["no fold"]-tot["fold"])/EL/24),""]
-open(R+"/gpurun_out/r4t/ln_fold_pmc.md","w").write("\n".join(out))
+open(R+"/gpurun_out/ln_fold_pmc/ln_fold_pmc.md","w").write("\n".join(out))
 print("\n".join(out))
 PY

@@ -1,9 +1,10 @@
 #!/bin/bash
+# space attention variants at the headline shape: tests, kernel-trace, SQ / FETCH / WRITE counters -> gpurun_out/space_variants/ (profiles/r4_space_variants.md)
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4i
-timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "space_attention_persistent" 2>&1 | tail -25 > gpurun_out/r4i/tests_space.log
-tail -25 gpurun_out/r4i/tests_space.log
-timeout 300 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4i/space_bench.txt
+mkdir -p gpurun_out/space_variants
+timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "space_attention_persistent" 2>&1 | tail -25 > gpurun_out/space_variants/tests_space.log
+tail -25 gpurun_out/space_variants/tests_space.log
+timeout 300 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee gpurun_out/space_variants/space_bench.txt
 import torch, ctypes, sys
 sys.path.insert(0, ".")
 from helping_hand_for_egocentric_videos_amd import ops, _lib
