@@ -557,7 +557,7 @@ def main():
 
     # the line's own parity bit: clips 0-1 of the benchmarked batch against the same two clips run as a batch of 2 (after the timed region)
     selfcheck = None
-    if world == 1 and args.workload == "train" and not args.no_selfcheck:
+    if world == 1 and args.workload == "train" and not args.no_selfcheck and clips_per_step >= 2:
         selfcheck = first_clips_check(ts, batch, k=2)
         selfcheck["what"] = ("eval-mode forward (towers, decoder, hand-box matching) of the bench batch vs its first 2 clips alone; clip 0 must be bit-identical through "
                              "the encoder; the small batch's last clip holds its GEMM row tail (different K summation order: bf16 roundings); hs / boxes differ by the "

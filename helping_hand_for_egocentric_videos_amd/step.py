@@ -299,6 +299,8 @@ def first_clips_check(ts, batch, k=2):
     BIT-IDENTICAL through the encoder; (2) the cross-attention's key slices (`ops.xattn_fwd` cuts the keys into more slices when
     B * heads cannot fill the chip), fp32 re-association ~1e-6 of `hs`.  bench.py prints this as `selfcheck`; tests/test_step_gpu.py
     asserts it at the benchmarked batch."""
+    if not 1 <= k <= batch["video"].shape[0]:
+        raise ValueError("first_clips_check: k=%d clips of a batch of %d" % (k, batch["video"].shape[0]))
     dec, cfg = ts.decoder, ts.cfg
     was_training = dec.training
     dec.eval()
