@@ -5,7 +5,7 @@ fc1 GEMM epilogue (csrc/gemm.hip); the nn.Module here only carries the name for 
 The CLIP text Transformer (openai_model.py:182-232) is on the call path of `CLIP.forward` (SURVEY.md section 8f
 rank 1).  With frozen weights on the GPU (`Transformer.forward_frozen`) its Linears / LayerNorms run on the libhh
 GEMM (bias / QuickGELU / residual epilogues) and LayerNorm kernels and the 77x77 causal attention core on
-hh_text_attn_fwd (csrc/attn_text.hip; head dim 64, L <= 80 -- other shapes fall back to torch SDPA).  The stock-module
+hh_text_attn_fwd (csrc/attn_text.hip; head dim 64, L <= 80 -- other shapes raise: there is no stock-op fallback).  The stock-module
 `forward` is kept for trainable / CPU use.
 """
 from collections import OrderedDict
@@ -75,22 +75,19 @@ class Transformer(nn.Module):
         """Inference path for frozen weights on the GPU: x fp32 [S, L, W] (batch-first) -> fp32 [S, L, W].
         Same maths as forward() (pre-LN causal MHA + QuickGELU MLP), bf16 GEMM operands, fp32 residual stream."""
         from .. import ops
-        import torch.nn.functional as F
         S, L, W = x.shape
         h, d = self.heads, W // self.heads
         if W % 64 or (3 * W) % 128 or (4 * W) % 128:
             raise NotImplementedError("Transformer.forward_frozen: width must be a multiple of 64 (GEMM tiling)")
+        if d != 64 or L > 80:
+            raise NotImplementedError("Transformer.forward_frozen: the causal attention core (hh_text_attn_fwd) takes head dim 64 and context <= 80 "
+                                      "(CLIP's 12 x 64, 77); there is no stock-op fallback")
         xs = x.reshape(S * L, W).float().contiguous().clone()
         pending = None                        # bf16 branch output not yet added to the fp32 residual stream (as in SpaceTimeBlock.fused)
         for pk in self.packed():
             xn = ops.layernorm(xs, *pk["ln1"]) if pending is None else ops.add_layernorm(xs, pending, *pk["ln1"], write_x=True)
             qkv = ops.gemm(xn, pk["win"], pk["bin"], colscale=d ** -0.5, colscale_cols=W)                  # bf16 [S*L, 3W], q scaled
-            if d == 64 and L <= 80:
-                o = ops.text_attention(qkv, S, L, h)                                                       # libhh causal attention
-            else:                                                                                          # other head sizes: stock SDPA
-                q, k, v = qkv.view(S, L, 3, h, d).permute(2, 0, 3, 1, 4)
-                o = F.scaled_dot_product_attention(q, k, v, is_causal=True, scale=1.0)                     # [S,h,L,d]
-                o = o.permute(0, 2, 1, 3).reshape(S * L, W).contiguous()
+            o = ops.text_attention(qkv, S, L, h)                                                           # libhh causal attention
             a = ops.gemm(o, pk["wout"], pk["bout"])                                                        # bf16 branch
             hid = ops.gemm(ops.add_layernorm(xs, a, *pk["ln2"], write_x=True), pk["wfc"], pk["bfc"], act=ops.ACT_QUICKGELU)
             pending = ops.gemm(hid, pk["wpr"], pk["bpr"])
