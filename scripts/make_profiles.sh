@@ -46,6 +46,29 @@ L = stats("prof_p", TAG + "_bench", TAG + " build", "python3 bench.py --steps 12
           "MI355X, " + WHAT + ", software-pipelined step, 20 steps profiled (8 warm-up + 12 timed).\nSum of kernel durations %.1f ms over 20 steps = %.1f ms/step (kernels of the encoder stream and of the decoder stream overlap, so this sum exceeds the wall time per step).")
 L += [""] + stats("prof_u", TAG + "_unpipelined", "Same build, un-pipelined step", "python3 bench.py --steps 12 --warmup 8 " + FLAGS + " --no-pipeline",
                   "Every kernel runs alone on the chip here, so the averages are the isolated kernel durations.\nSum of kernel durations %.1f ms over 20 steps = %.1f ms/step.")
+# ---- steady state of the un-pipelined run: the dispatches between the first and the last optimizer launch (adamw_arena_kernel = one per step), so
+# that the process's start-up (weight packing, copies, fills) does not count as "per step"
+LIBHH = ("gemm", "attn", "ln_", "add_ln", "embed", "im2col", "cast_", "transpose", "qgemm", "qself", "xattn", "lsap", "match_boxes", "box_", "rownorm", "egonce",
+         "masked_ce", "tv_accuracy", "adamw", "cls_combine", "text_flags", "_Z13ln_fwd", "accuracy", "gather_rows", "word_", "dropout_")
+tf = glob.glob(R + "/gpurun_out/prof_u/**/*kernel_trace.csv", recursive=True)
+if tf:
+    tr = sorted(csv.DictReader(open(tf[0])), key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(tr) if "adamw_arena_kernel" in r["Kernel_Name"]]
+    if len(marks) >= 3:
+        seg = tr[marks[0] + 1:marks[-1] + 1]
+        nsteps = len(marks) - 1
+        cnt, dur = collections.Counter(), collections.Counter()
+        for r in seg:
+            cnt[r["Kernel_Name"]] += 1; dur[r["Kernel_Name"]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        is_lib = lambda n: any(t in n for t in LIBHH) and "at::native" not in n and "rocclr" not in n and "rocblas" not in n
+        lib = sum(c for n, c in cnt.items() if is_lib(n)); oth = sum(c for n, c in cnt.items() if not is_lib(n))
+        with open(OUT + TAG + "_unpipelined_steady_kernel_stats.csv", "w") as f:
+            w = csv.writer(f); w.writerow(["Name", "Calls", "CallsPerStep", "TotalDurationNs", "AverageNs", "libhh"])
+            for n, c in sorted(cnt.items(), key=lambda x: -dur[x[0]]):
+                w.writerow([n, c, "%.2f" % (c / nsteps), dur[n], "%.0f" % (dur[n] / c), int(is_lib(n))])
+        L += ["", "## Steady state of the un-pipelined run (" + TAG + "_unpipelined_steady_kernel_stats.csv)", "",
+              "Dispatches between the first and the last `adamw_arena_kernel` launch (one per step): %d steps, **%.1f launches per step: %.1f libhh + %.1f other** "
+              "(stock torch ops, blits); the whole-process table above also counts the start-up (weight packing, copies, fills)." % (nsteps, (lib + oth) / nsteps, lib / nsteps, oth / nsteps)]
 open(OUT + TAG + "_summary.md", "w").write("\n".join(L) + "\n")
 # ---- PMC
 val = {}
