@@ -94,16 +94,9 @@ QKV_HEAD_MAJOR_PLANES = True       # False: the QKV projection writes nn.Linear'
 # add the fp32 residual stream in their epilogue, emit z = bf16(x + branch) with its row statistics and (space proj, fc2) write the fp32
 # sum back; the time qkv / space qkv / fc1 GEMMs apply rstd / mean / gamma / beta algebraically (include/hh.h, hh_gemm_epilogue.ln_stats /
 # z_out / z_update): no stand-alone add+LayerNorm pass is left inside the tower.  False: the fused add+LayerNorm kernels (A/B measurements).
+# The flag is read when a block packs its weights; a block whose pack was made under the other setting re-packs on its next use
+# (SpaceTimeBlock.packed), and `SpaceTimeTransformer.ln_fold_packed()` reports what the tower actually runs (bench.py records that).
 LN_FOLD = True
-TOWER_STREAMS = 1          # 2: the vision tower runs its batch as two half-batches on two streams (experiment, scripts/tower_trace.py)
-_SIDE = {}
-
-
-def _side_stream(device):
-    key = (device.type, device.index)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
-    return _SIDE[key]
 
 
 class VarAttention(nn.Module):
@@ -192,9 +185,9 @@ class SpaceTimeBlock(nn.Module):
         self._pack = None
 
     def packed(self, refresh=False):
-        if self._pack is None or refresh:
+        if self._pack is None or refresh or self._pack["ln_fold"] != bool(LN_FOLD):
             ln = lambda m: (m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous(), m.eps)
-            self._pack = {"n1": ln(self.norm1), "n2": ln(self.norm2), "n3": ln(self.norm3), "time": self.timeattn.packed(),
+            self._pack = {"ln_fold": bool(LN_FOLD), "n1": ln(self.norm1), "n2": ln(self.norm2), "n3": ln(self.norm3), "time": self.timeattn.packed(),
                           "space": self.attn.packed(), "w1": ops.to_bf16(self.mlp.fc1.weight.detach()),
                           "b1": self.mlp.fc1.bias.detach().float(), "w2": ops.to_bf16(self.mlp.fc2.weight.detach()),
                           "b2": self.mlp.fc2.bias.detach().float()}
@@ -312,6 +305,11 @@ class SpaceTimeTransformer(nn.Module):
         self.refresh_weights()
         return r
 
+    def ln_fold_packed(self):
+        """True / False: every block's packed operands are the LayerNorm-fold / stand-alone set (None: mixed or nothing packed yet)."""
+        modes = {b._pack["ln_fold"] if b._pack is not None else None for b in self.blocks}
+        return modes.pop() if len(modes) == 1 else None
+
     def packed(self):
         if self._pack is None:
             f = lambda t: t.detach().float().contiguous()
@@ -340,24 +338,8 @@ class SpaceTimeTransformer(nn.Module):
         del patches, tok
         xs = xs.view(B * (1 + T * n), D)
         pending = None
-        if TOWER_STREAMS == 2 and B % 2 == 0 and "qkv_n1" in self.blocks[0].packed():
-            # two half-batches, one block apart in launch order, on two streams: the clips of a batch never meet inside the tower, and a
-            # persistent GEMM's epilogues run in lockstep on all CUs (a 164 MB burst per round while no matrix core works) -- one half's
-            # bursts could run under the other half's main loops.  Measured: 108.9 vs 108.7 ms per pass; experiment only
-            cur = torch.cuda.current_stream()
-            side = _side_stream(x.device)
-            side.wait_stream(cur)
-            rows = (B // 2) * (1 + T * n)
-            halves, pend = (xs[:rows], xs[rows:]), [None, None]
-            for blk in self.blocks:
-                for h, st in enumerate((cur, side)):
-                    with torch.cuda.stream(st):
-                        pend[h] = blk.fused(halves[h], B // 2, T, n, pend[h])
-            del pend
-            cur.wait_stream(side)
-        else:
-            for blk in self.blocks:
-                pending = blk.fused(xs, B, T, n, pending)
+        for blk in self.blocks:
+            pending = blk.fused(xs, B, T, n, pending)
         if pending is None or "qkv_n1" in self.blocks[0].packed():       # (with the fold xs already holds the full residual stream)
             out = ops.layernorm(xs, *pk["norm"], out_dtype=out_dtype)
         else:

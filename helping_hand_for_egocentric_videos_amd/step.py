@@ -72,7 +72,8 @@ class TrainStep:
         text_max_len (opt-in, a HOST int from the data pipeline -- batch["text_max_len"]: tokens of the longest caption incl. SOT and EOT):
         the tower runs on the first ceil16(text_max_len) positions only.  The attention mask is causal (LaviLa.py:636-642) and only the EOT
         row of each caption is read (run/train.py:124), so the positions behind the longest caption's EOT are dead work: EgoClip narrations
-        are ~10 tokens of the 77.  The feature map then has that many positions; the EOT rows are the same up to the GEMM kernels' summation
+        are ~10 tokens of the 77.  The hint must be an UPPER BOUND: a caption longer than it loses its EOT row and `losses` turns its
+        feature row (hence the loss) into NaN rather than reading another caption's row.  The feature map then has that many positions; the EOT rows are the same up to the GEMM kernels' summation
         order (tests/test_step_gpu.py).  Without the hint all 77 positions are computed, as the reference does (no host sync to find out)."""
         if text_max_len is not None:
             keep = min(text.shape[1], (int(text_max_len) + 15) // 16 * 16)
@@ -136,7 +137,16 @@ class TrainStep:
         key = (text.shape[0], tmap.shape[1], text.device)                          # (tmap holds fewer positions under text_max_len)
         if self._row_base is None or self._row_base[0] != key:
             self._row_base = (key, torch.arange(text.shape[0], device=text.device) * tmap.shape[1])
-        text_embeds = self.decoder.txt_proj(tmap.reshape(-1, tmap.shape[-1]).index_select(0, self._row_base[1] + eot))
+        if tmap.shape[1] < text.shape[1]:
+            # text_max_len hint in use: it MUST be an upper bound of every caption's length.  A caption whose EOT lies behind the
+            # trimmed positions has no EOT row in tmap (row_base + eot would read another caption's row, or run past the end): its
+            # feature row is poisoned with NaN instead -- the loss then exposes the bad hint, without a host sync
+            bad = eot >= tmap.shape[1]
+            rows = tmap.reshape(-1, tmap.shape[-1]).index_select(0, self._row_base[1] + eot.clamp(max=tmap.shape[1] - 1))
+            rows = torch.where(bad[:, None], torch.full((), float("nan"), dtype=rows.dtype, device=rows.device), rows)
+        else:
+            rows = tmap.reshape(-1, tmap.shape[-1]).index_select(0, self._row_base[1] + eot)
+        text_embeds = self.decoder.txt_proj(rows)
         obj = self.decoder.obj_proj(hs[-1])                                        # [B,Q,256]
         video_embeds = obj[:, -1]
         if self._zeroed_idx is None or self._zeroed_idx.device != text.device:

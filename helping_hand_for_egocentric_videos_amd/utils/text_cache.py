@@ -27,7 +27,7 @@ class TokenizedTextCache:
     def __call__(self, texts):
         """list[str] -> int64 [len(texts), context_length] on the cache's device."""
         new = [t for t in dict.fromkeys(texts) if t not in self.index]
-        extra = {}                                                    # captions beyond the cap: rows of this call only
+        extra = {}                                                    # captions beyond the cap: caption -> row of `rows_extra` (this call only)
         rows_extra = None
         if new:
             rows = self.tokenizer(new)
@@ -45,12 +45,25 @@ class TokenizedTextCache:
                     self.index[t] = start + i
             if keep < len(new):
                 rows_extra = rows[keep:].to(device=self.device, dtype=torch.int32, non_blocking=True)
-                extra = {t: self.table.shape[0] + i for i, t in enumerate(new[keep:])}      # indices past the table: rows of `rows_extra`
+                extra = {t: i for i, t in enumerate(new[keep:])}
                 self.bypassed += len(new) - keep
         self.misses += len(new)
         self.hits += len(texts) - len(new)
-        idx = torch.tensor([self.index[t] if t in self.index else extra[t] for t in texts], dtype=torch.int64)
+        if rows_extra is None:
+            return self.table.index_select(0, self._dev_index([self.index[t] for t in texts])).to(torch.int64)
+        # Some captions are not in the (full) table: gather the cached rows from the table and the bypassed rows from this call's
+        # upload, each into its own positions of the output.  The table itself is never copied (concatenating it with
+        # `rows_extra` moved 0.65 GB per step once the cap was reached).
+        pos_c = [i for i, t in enumerate(texts) if t in self.index]
+        pos_x = [i for i, t in enumerate(texts) if t not in self.index]
+        out = torch.empty((len(texts), self.context_length), dtype=torch.int64, device=self.device)
+        if pos_c:
+            out[self._dev_index(pos_c)] = self.table.index_select(0, self._dev_index([self.index[texts[i]] for i in pos_c])).to(torch.int64)
+        out[self._dev_index(pos_x)] = rows_extra.index_select(0, self._dev_index([extra[texts[i]] for i in pos_x])).to(torch.int64)
+        return out
+
+    def _dev_index(self, rows):
+        idx = torch.tensor(rows, dtype=torch.int64)
         if self.device.type == "cuda":
             idx = idx.pin_memory().to(self.device, non_blocking=True)
-        src = self.table if rows_extra is None else torch.cat([self.table, rows_extra], dim=0)
-        return src.index_select(0, idx).to(torch.int64)
+        return idx

@@ -14,10 +14,23 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 WAIT_STATES = 5
 
 
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S"]
+
+
+def _cache_key():
+    """The cached assembly depends on the compiler and its flags as well as on the sources: hash both into the file name."""
+    import hashlib
+    try:
+        ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True, check=True).stdout
+    except (OSError, subprocess.CalledProcessError):
+        ver = "unknown"
+    return hashlib.sha1((ver + " ".join(FLAGS)).encode()).hexdigest()[:10]
+
+
 def device_asm(src):
-    out = os.path.join(tempfile.gettempdir(), "hh_isa_" + os.path.basename(src) + ".s")
+    out = os.path.join(tempfile.gettempdir(), "hh_isa_%s_%s.s" % (_cache_key(), os.path.basename(src)))
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), max(os.path.getmtime(os.path.join(CSRC, h)) for h in os.listdir(CSRC) if h.endswith(".h"))):
-        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", out], check=True, capture_output=True)
+        subprocess.run([HIPCC] + FLAGS + [src, "-o", out], check=True, capture_output=True)
     return out
 
 

@@ -4,7 +4,8 @@
 
 Writes tests/golden/step_<cfg>.npz (reduced-width configs that run the identical reference code
 path: D=128, 2 heads of d=64, depth 2, n=256, T in {4,16}; real 512-wide decoder) and
-tests/golden/lsap_scipy.npz (scipy.optimize.linear_sum_assignment known answers incl. ties).
+tests/golden/lsap_scipy.npz (scipy.optimize.linear_sum_assignment known answers incl. ties), and
+tests/golden/tower_full_T{4,16}.npz (checksums of the reference's FULL-WIDTH vision tower on one seeded clip).
 Inputs/weights are regenerated from seeds by helping_hand_for_egocentric_videos_amd.synth; the
 fixture stores checksums of them so generator drift is detected.  A fixture is data only.
 """
@@ -19,7 +20,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import refglue  # noqa: E402
 from refglue import _refload  # noqa: E402
-from helping_hand_for_egocentric_videos_amd import synth, TINY4, TINY16  # noqa: E402
+from helping_hand_for_egocentric_videos_amd import synth, TINY4, TINY16, HHConfig  # noqa: E402
 
 SEED_W, SEED_B = 4, 9
 
@@ -97,6 +98,45 @@ def emit_step(R, cfg, name, B=2):
     print(name, {k: float(out["loss_" + k]) for k in ("total_loss", "nce_loss", "box_loss_hand", "box_loss_obj", "word_loss")})
 
 
+FULL_SEED_W, FULL_SEED_B = 11, 12
+
+
+def strided(t, k=64):
+    """k samples of t at a fixed stride over its flattened elements (the first and the last element included)."""
+    f = t.detach().flatten()
+    idx = torch.linspace(0, f.numel() - 1, k).long()
+    return idx.numpy(), f[idx].numpy()
+
+
+def emit_full_width(R, T):
+    """checksums of the REFERENCE's own full-width vision tower (TimeSformer-L: 24 x 1024, 16 heads, patch
+    14, 224 px; /root/reference/model/LaviLa.py:537-581) on one seeded clip of T frames -- sum, abs-sum and 64 strided samples of the
+    feature map `x` [1, 1 + T*256, 1024] and of `x_cls` [1, 1024], plus per-frame abs-sums.  The GPU tower is compared with these
+    directly (tests/test_encoder_gpu.py), the oracle too (tests/test_oracle_vs_reference.py keeps the oracle within 1e-5 of the same
+    module at full width)."""
+    cfg = HHConfig(num_frames=T, text_layers=1, vocab_size=512)
+    sd = synth.encoder_state(cfg, seed=FULL_SEED_W)
+    video = synth.make_batch(cfg, 1, seed=FULL_SEED_B)["video"]
+    vis = refglue.build_backbone(R, cfg, sd).visual
+    with torch.no_grad():
+        x_cls, x = vis(video)
+    n = cfg.patches_per_frame
+    ix, sx = strided(x)
+    ic, sc = strided(x_cls)
+    out = {"meta_T": np.array(T), "meta_seed_w": np.array(FULL_SEED_W), "meta_seed_b": np.array(FULL_SEED_B),
+           "in_video_checksum": checksum(video),
+           "w_visual_checksum": checksum(torch.cat([v.flatten() for k, v in sd.items() if k.startswith("visual.")])),
+           "x_sum": np.array(float(x.double().sum())), "x_abs_sum": np.array(float(x.double().abs().sum())),
+           "x_sq_sum": np.array(float((x.double() ** 2).sum())),
+           "x_sample_idx": ix, "x_sample": sx,
+           "x_frame_abs_sum": x[0, 1:].double().abs().view(T, n, -1).sum((1, 2)).numpy(),
+           "x_row_sample": x[0, ::(x.shape[1] - 1) // 16][:, ::8].numpy(),          # 17 whole rows (CLS, 15 inside, last), every 8th column
+           "cls_sum": np.array(float(x_cls.double().sum())), "cls_abs_sum": np.array(float(x_cls.double().abs().sum())),
+           "cls_sample_idx": ic, "cls_sample": sc, "cls_row": x_cls[0].numpy()}
+    np.savez_compressed(os.path.join(HERE, f"tower_full_T{T}.npz"), **out)
+    print("full-width tower T=%d: sum %.6f abs-sum %.3f" % (T, float(out["x_sum"]), float(out["x_abs_sum"])))
+
+
 def emit_lsap():
     from scipy.optimize import linear_sum_assignment
     rng = np.random.default_rng(123)
@@ -122,3 +162,5 @@ if __name__ == "__main__":
     emit_step(R, TINY4, "tiny4")
     emit_step(R, TINY16, "tiny16")
     emit_lsap()
+    emit_full_width(R, 4)
+    emit_full_width(R, 16)

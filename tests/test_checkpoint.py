@@ -95,3 +95,21 @@ def test_tokenized_text_cache_equals_the_tokenizer():
     c = ["a b", "c d", "e f", "g h", "a b", "i j"]
     assert torch.equal(small(c), fake_tokenizer(c)) and len(small) == 3 and small.table.shape[0] == 3 and small.bypassed == 2
     assert torch.equal(small(c), fake_tokenizer(c)) and len(small) == 3 and small.bypassed == 4
+    # the cap reached on a table of a realistic width: a call with bypassed captions must not copy the table (torch.cat of
+    # the 0.65 GB table per step) -- no tensor as large as the table is allocated, cached and bypassed rows land in their own positions
+    big = TokenizedTextCache(fake_tokenizer, device="cpu", capacity=512, max_rows=512)
+    fill = ["cap %d" % i for i in range(512)]
+    big(fill)
+    assert len(big) == 512 and big.table.shape[0] == 512
+    seen = []
+    real_cat, real_empty = torch.cat, torch.empty
+    try:
+        torch.cat = lambda ts, *a, **k: (seen.append(sum(t.numel() for t in ts)), real_cat(ts, *a, **k))[1]
+        torch.empty = lambda *a, **k: (lambda r: (seen.append(r.numel()), r)[1])(real_empty(*a, **k))
+        mixed = ["new x", "cap 7", "new y", "cap 500", "new x", "cap 7"]
+        got = big(mixed)
+        only_new = big(["new z", "new w"])
+    finally:
+        torch.cat, torch.empty = real_cat, real_empty
+    assert torch.equal(got, fake_tokenizer(mixed)) and torch.equal(only_new, fake_tokenizer(["new z", "new w"]))
+    assert max(seen) < big.table.numel() // 8, seen

@@ -3,13 +3,19 @@ an SGPR reloaded by a VALU instruction (v_readlane_b32: a spilled pointer) and u
 an inline-asm statement fewer than 5 wait states later.  Found in round 4 as a memory access fault of the persistent GEMM's tile-counter
 atomic; scripts/check_isa_hazards.py scans every file whose inline asm issues VMEM with a scalar address."""
 import os
+import shutil
 import subprocess
 import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_no_sgpr_reload_to_inline_asm_vmem_hazard():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("hipcc not found: the check compiles the kernels to gfx950 assembly")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_isa_hazards.py")], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "gemm256w4.hip: 0 hazard(s)" in r.stdout, r.stdout

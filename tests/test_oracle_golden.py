@@ -101,3 +101,28 @@ def test_query_side_on_given_kv_equals_the_plain_decoder():
         b, hs_b = OD.objdecoder_forward(feats, dsd, cfg, compute_logits=False, kv=OD.memory_kv(feats, dsd, cfg))
     torch.testing.assert_close(hs_a, hs_b, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(a["pred_boxes"], b["pred_boxes"], rtol=1e-5, atol=1e-6)
+
+
+def test_oracle_full_width_tower_against_reference_checksums():
+    """the oracle's FULL-WIDTH vision tower (24 x 1024, 16 heads) on the seeded T = 4 clip against the checksums the
+    imported reference produced for it (tests/golden/tower_full_T4.npz, emitted by make_golden.py: sum, abs-sum, 64 strided samples,
+    17 row samples, per-frame abs-sums).  ~1 TFLOP of fp32 on the host; the T = 16 fixture is checked on the GPU box
+    (tests/test_encoder_gpu.py) against both the oracle and the HIP tower."""
+    from helping_hand_for_egocentric_videos_amd import HHConfig
+    from oracle import encoder as OE
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    g = np.load(os.path.join(GOLD, "tower_full_T4.npz"))
+    cfg = HHConfig(num_frames=int(g["meta_T"]), text_layers=1, vocab_size=512)
+    sd = synth.encoder_state(cfg, seed=int(g["meta_seed_w"]))
+    video = synth.make_batch(cfg, 1, seed=int(g["meta_seed_b"]))["video"]
+    np.testing.assert_allclose(_checksum(video), g["in_video_checksum"], rtol=1e-9)
+    np.testing.assert_allclose(_checksum(torch.cat([v.flatten() for k, v in sd.items() if k.startswith("visual.")])), g["w_visual_checksum"], rtol=1e-9)
+    with torch.no_grad():
+        x_cls, x = OE.vision_forward(video, sd, cfg)
+    np.testing.assert_allclose(x.flatten()[torch.from_numpy(g["x_sample_idx"])].numpy(), g["x_sample"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(x[0, ::(x.shape[1] - 1) // 16][:, ::8].numpy(), g["x_row_sample"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(x_cls[0].numpy(), g["cls_row"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(float(x.double().abs().sum()), float(g["x_abs_sum"]), rtol=1e-6)
+    np.testing.assert_allclose(float(x.double().sum()), float(g["x_sum"]), atol=1e-6 * float(g["x_abs_sum"]))
+    n = cfg.patches_per_frame
+    np.testing.assert_allclose(x[0, 1:].double().abs().view(cfg.num_frames, n, -1).sum((1, 2)).numpy(), g["x_frame_abs_sum"], rtol=1e-6)

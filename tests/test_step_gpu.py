@@ -358,13 +358,15 @@ def test_cross_attention_dropout_statistics():
     assert abs(fd - an) <= 0.05 * abs(fd) + 1e-3, (fd, an)
 
 
-def test_headline_config_c2_losses_vs_oracle():
+@pytest.mark.parametrize("wseed,bseed", [(0, 1000), (1, 1001), (2, 1002)])
+def test_headline_config_c2_losses_vs_oracle(wseed, bseed):
     """BASELINE config 2 itself (full-width TimeSformer-L, T=16, 224p, nq=12), B=2: every loss term of the GPU step vs the
-    CPU oracle on identical synthetic weights/inputs; bit-exact matching on the GPU's own fp32 boxes."""
+    CPU oracle on identical synthetic weights/inputs; bit-exact matching on the GPU's own fp32 boxes.  Three (weight, batch) seed
+    pairs (the thinnest margin -- word_loss at 0.62 of the 1e-3 bound -- had been measured on one seed only)."""
     from helping_hand_for_egocentric_videos_amd import C2
     cfg = C2
-    esd, dsd = synth.encoder_state(cfg, seed=0), synth.decoder_state(cfg, seed=0)
-    batch = synth.make_batch(cfg, 2, seed=1000)
+    esd, dsd = synth.encoder_state(cfg, seed=wseed), synth.decoder_state(cfg, seed=wseed)
+    batch = synth.make_batch(cfg, 2, seed=bseed)
     backbone = LaviLa.build_backbone(cfg, esd)
     dec = tfm_decoder.build_decoder(cfg, dsd)
     ts = TrainStep(cfg, backbone, dec)
@@ -377,7 +379,7 @@ def test_headline_config_c2_losses_vs_oracle():
     for k, tol in (("total_loss", 1e-3), ("box_loss_hand", 1e-3), ("box_loss_obj", 1e-3), ("nce_loss", 1e-3), ("word_loss", 1e-3)):
         got, want = float(res[k]), float(ref[k])
         rep[k] = abs(got - want) / abs(want)
-        record("c2_headline_step", k + " rel error vs oracle", rep[k], tol)
+        record("c2_headline_step_seed%d" % wseed, k + " rel error vs oracle", rep[k], tol)
         assert rep[k] <= tol, (k, got, want)
     print("C2 rel loss errors vs oracle:", {k: f"{v:.2e}" for k, v in rep.items()})
     pb = res["pred_boxes"].detach().cpu()
@@ -387,7 +389,7 @@ def test_headline_config_c2_losses_vs_oracle():
             assert torch.equal(a, c) and torch.equal(b, d)
     agree = [torch.equal(a, c) for (a, _), (c, _) in zip(res["match_obj"], ref["idx_obj"])]
     print("C2 end-to-end object-index agreement with the fp32 oracle: %.3f" % (sum(agree) / len(agree)))
-    record("c2_headline_step", "statistic: end-to-end object-index agreement with the fp32 oracle (fraction of frames)", sum(agree) / len(agree), 1.0)
+    record("c2_headline_step_seed%d" % wseed, "statistic: end-to-end object-index agreement with the fp32 oracle (fraction of frames)", sum(agree) / len(agree), 1.0)
 
 
 def test_caption_length_hint_trims_the_text_tower_without_changing_the_step():
@@ -425,15 +427,17 @@ def test_caption_length_hint_trims_the_text_tower_without_changing_the_step():
             assert torch.equal(p, r) and torch.equal(q, s)
 
 
-def test_c4_full_width_step_losses_vs_oracle():
+@pytest.mark.parametrize("wseed,bseed", [(0, 1004), (1, 1005), (2, 1006)])
+def test_c4_full_width_step_losses_vs_oracle(wseed, bseed):
     """BASELINE config 4 ITSELF (full-width TimeSformer-L, T = 32 frames, 336 px: N = 18 433 tokens and M = 18 432 memory tokens
     per clip, nq = 12), B = 2: every loss term of the GPU step vs the CPU oracle on identical synthetic weights / inputs (north-star
     bound 1e-3), bit-exact matching of all 64 frames on the GPU's own fp32 boxes."""
     from helping_hand_for_egocentric_videos_amd import C4
     from _record import check
     cfg = C4
-    esd, dsd = synth.encoder_state(cfg, seed=0), synth.decoder_state(cfg, seed=0)
-    batch = synth.make_batch(cfg, 2, seed=1004)
+    esd, dsd = synth.encoder_state(cfg, seed=wseed), synth.decoder_state(cfg, seed=wseed)
+    batch = synth.make_batch(cfg, 2, seed=bseed)
+    tag = "c4_full_width_step_seed%d" % wseed
     backbone = LaviLa.build_backbone(cfg, esd)
     dec = tfm_decoder.build_decoder(cfg, dsd)
     ts = TrainStep(cfg, backbone, dec)
@@ -444,10 +448,10 @@ def test_c4_full_width_step_losses_vs_oracle():
         ref = OS.step_losses(esd, dsd, batch, cfg)
     for k in ("total_loss", "box_loss_hand", "box_loss_obj", "nce_loss", "word_loss"):
         got, want = float(res[k]), float(ref[k])
-        check("c4_full_width_step", k + " rel error vs oracle", abs(got - want) / abs(want), 1e-3)
+        check(tag, k + " rel error vs oracle", abs(got - want) / abs(want), 1e-3)
     assert res["pred_boxes"].shape == (64, 13, 4)
-    check("c4_full_width_step", "hs scaled max error vs oracle", scaled_err(res["hs"], ref["hs"]), 2e-2)
-    check("c4_full_width_step", "pred_boxes max abs error vs oracle", float((res["pred_boxes"].detach().cpu() - ref["pred_boxes"]).abs().max()), 5e-3)
+    check(tag, "hs scaled max error vs oracle", scaled_err(res["hs"], ref["hs"]), 2e-2)
+    check(tag, "pred_boxes max abs error vs oracle", float((res["pred_boxes"].detach().cpu() - ref["pred_boxes"]).abs().max()), 5e-3)
     pb = res["pred_boxes"].detach().cpu()
     for key, sl, qs in (("match_hand", slice(0, 2), slice(0, 2)), ("match_obj", slice(2, 4), slice(2, cfg.num_queries))):
         raw = batch["boxes"][:, :, sl].flatten(0, 1)
@@ -457,7 +461,7 @@ def test_c4_full_width_step_losses_vs_oracle():
             assert torch.equal(a, c) and torch.equal(b, d)
     agree = [torch.equal(a, c) for (a, _), (c, _) in zip(res["match_obj"], ref["idx_obj"])]
     print("C4 end-to-end object-index agreement with the fp32 oracle: %.3f" % (sum(agree) / len(agree)))
-    record("c4_full_width_step", "statistic: end-to-end object-index agreement with the fp32 oracle (fraction of frames)", sum(agree) / len(agree), 1.0)
+    record(tag, "statistic: end-to-end object-index agreement with the fp32 oracle (fraction of frames)", sum(agree) / len(agree), 1.0)
     res["total_loss"].backward()
     for name, p in dec.named_parameters():
         if name in ts.arena.offsets:
