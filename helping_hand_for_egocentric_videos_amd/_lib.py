@@ -23,7 +23,9 @@ class QGemmOpts(ctypes.Structure):
     _fields_ = [("a_scale", c_float), ("a_drop_p", c_float), ("a_drop_seed", ctypes.c_uint32), ("a_drop_ld", ctypes.c_int32),
                 ("bias", c_vp), ("scale", c_float), ("scale_ncols", ctypes.c_int32), ("relu", ctypes.c_int32),
                 ("drop_p", c_float), ("drop_seed", ctypes.c_uint32), ("relu_mask", c_vp), ("ldmask", c_i64), ("mask_scale", c_float),
-                ("resid", c_vp), ("ldr", c_i64), ("colsum", c_vp), ("splitk", ctypes.c_int32)]
+                ("resid", c_vp), ("ldr", c_i64), ("colsum", c_vp), ("splitk", ctypes.c_int32),
+                ("batch", ctypes.c_int32), ("stride_a", c_i64), ("stride_b", c_i64), ("stride_c", c_i64), ("stride_bias", c_i64),
+                ("stride_colsum", c_i64), ("rowscale", c_vp), ("ld_rowscale", c_i64), ("stride_rowscale", c_i64)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); must list every symbol of include/hh.h
@@ -44,6 +46,13 @@ SIGNATURES = {
     "hh_workspace_bytes_xattn_bwd": [c_int, c_int, c_int, c_int],
     "hh_workspace_bytes_xattn_fwd": [c_int, c_int, c_int, c_int],
     "hh_workspace_bytes_attn_cls_partial": [c_int, c_int, c_int, c_int, c_int],
+    "hh_workspace_bytes_mattn_fwd": [c_int, c_int, c_int],
+    "hh_workspace_bytes_mattn_bwd": [c_int, c_int, c_int],
+    "hh_mattn_slices": [c_int, c_int],
+    "hh_mattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
+    "hh_mattn_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
+                     c_int, c_int, c_float, ctypes.c_uint32, c_vp],
+    "hh_gemm_tn_bf16_batched2": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_int, c_int, c_i64, c_int, c_vp],
     "hh_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_float, c_vp],
     "hh_add_layernorm_fwd": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_float, c_vp],
     "hh_layernorm_bwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
@@ -87,7 +96,8 @@ SIGNATURES = {
                             c_float, c_int, c_vp],
 }
 _RESTYPES = {"hh_last_error_string": ctypes.c_char_p, "hh_prof_kernel_name": ctypes.c_char_p, "hh_workspace_bytes_gemm_splitk": c_i64, "hh_workspace_bytes_gemm_tn": c_i64, "hh_workspace_bytes_gemm_zstats": c_i64,
-             "hh_workspace_bytes_xattn_bwd": c_i64, "hh_workspace_bytes_xattn_fwd": c_i64, "hh_workspace_bytes_attn_cls_partial": c_i64, "hh_workspace_bytes_egonce": c_i64}
+             "hh_workspace_bytes_xattn_bwd": c_i64, "hh_workspace_bytes_xattn_fwd": c_i64, "hh_workspace_bytes_attn_cls_partial": c_i64, "hh_workspace_bytes_egonce": c_i64,
+             "hh_workspace_bytes_mattn_fwd": c_i64, "hh_workspace_bytes_mattn_bwd": c_i64}
 
 _lib = None
 

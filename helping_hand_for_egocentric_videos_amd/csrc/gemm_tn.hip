@@ -30,6 +30,9 @@ struct TnParams {
     float* colsum;                         // optional [splits][M]: sum_k At[k, m] of the slice (the bias gradient of dY = At), or NULL
     int M, N; int64_t K;
     int k_per_split;                       // multiple of 64
+    // batched two-pair form (hh_gemm_tn_bf16_batched2): C_z = At_z^T Bt_z + At2_z^T Bt2_z, z = blockIdx.z, no split-K
+    const bf16_t* At2; const bf16_t* Bt2;  // second operand pair (same leading dimensions and K), or NULL
+    int64_t sA, sB, sC;                    // batch strides in elements
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
@@ -42,22 +45,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
     const int64_t k_begin = (int64_t)blockIdx.y * p.k_per_split;
     int64_t k_end = k_begin + p.k_per_split;
     if (k_end > p.K) k_end = p.K;
-    float* Cp = p.C + (int64_t)blockIdx.y * p.split_stride;
-    const int nk = (int)((k_end - k_begin + 63) / 64);
+    float* Cp = p.C + (int64_t)blockIdx.y * p.split_stride + (int64_t)blockIdx.z * p.sC;
+    const int nk1 = (int)((k_end - k_begin + 63) / 64);
+    const int nk = p.At2 ? 2 * nk1 : nk1;                                  // the second pair's k-tiles follow the first's (batched form: one slice)
+    const bf16_t* A1 = p.At + (int64_t)blockIdx.z * p.sA;
+    const bf16_t* B1 = p.Bt + (int64_t)blockIdx.z * p.sB;
+    const bf16_t* A2 = p.At2 ? p.At2 + (int64_t)blockIdx.z * p.sA : nullptr;
+    const bf16_t* B2 = p.Bt2 ? p.Bt2 + (int64_t)blockIdx.z * p.sB : nullptr;
 
     // staging: wave w stages rows 16 w .. 16 w + 15 of both operands: 4 instructions x 4 rows each
     const int srow = lane >> 4, schunk = lane & 15;
     auto stage = [&](int kt, int buf) {
         char* dA = smem + buf * 32768 + wave * 4096;
         char* dB = dA + 16384;
+        const bool second = kt >= nk1;
+        const bf16_t* Ap = second ? A2 : A1;
+        const bf16_t* Bp = second ? B2 : B1;
+        if (second) kt -= nk1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = wave * 16 + 4 * i + srow;                      // row inside the k-tile
             const int c = schunk ^ (2 * (r & 3));                         // logical chunk that lives at this lane's position
             const int64_t k = k_begin + (int64_t)kt * 64 + r;
             const bool ok = k < k_end;
-            tn_glds16(ok ? (const void*)(p.At + k * p.lda + m0 + c * 8) : (const void*)g_tn_zero, dA + i * 1024);
-            tn_glds16(ok ? (const void*)(p.Bt + k * p.ldb + n0 + c * 8) : (const void*)g_tn_zero, dB + i * 1024);
+            tn_glds16(ok ? (const void*)(Ap + k * p.lda + m0 + c * 8) : (const void*)g_tn_zero, dA + i * 1024);
+            tn_glds16(ok ? (const void*)(Bp + k * p.ldb + n0 + c * 8) : (const void*)g_tn_zero, dB + i * 1024);
         }
     };
     // fragment reads: 16-lane group g of the wave reads k rows 8g .. 8g+7 (+ 32 per k-step); lane i = 4 q + pc inside the group
@@ -136,9 +148,33 @@ extern "C" int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int6
     TnParams p;
     p.At = (const bf16_t*)At; p.lda = lda; p.Bt = (const bf16_t*)Bt; p.ldb = ldb; p.C = partials; p.split_stride = (int64_t)M * N; p.colsum = colsum_partials;
     p.M = M; p.N = N; p.K = K;
+    p.At2 = p.Bt2 = nullptr; p.sA = p.sB = p.sC = 0;
     const int64_t ktiles = (K + 63) / 64;
     p.k_per_split = (int)(((ktiles + splits - 1) / splits) * 64);
     HHProfScope prof(HH_PROF_GEMM_TN, 2.0 * (double)M * N * (double)K, (hipStream_t)stream);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((M / 128) * (N / 128)), (unsigned)splits), dim3(256), 0, (hipStream_t)stream, p);
     return hh_check_launch("hh_gemm_tn_bf16");
+}
+
+// C_z [M, N] fp32 = At_z^T Bt_z (+ At2_z^T Bt2_z), z = 0 .. batch - 1: the d-memory GEMM of the K/V-projection-free decoder cross-attention
+// (mattn.hip): per clip, At = the transposed probabilities Pd^T [rows, M keys], Bt = the pooled-row gradients [rows, 512]; second pair =
+// the score gradients dS^T and the mapped queries; rows = 6 layers x 128.  K (rows) is short, M (keys) long: one workgroup per 128 x 128
+// output tile walks all of K, no split-K, no partial planes.
+extern "C" int hh_gemm_tn_bf16_batched2(const void* At, const void* Bt, const void* At2, const void* Bt2, int64_t lda, int64_t ldb, int64_t stride_a,
+                                        int64_t stride_b, float* C, int64_t stride_c, int M, int N, int64_t K, int batch, hh_stream_t stream) {
+    HH_REQUIRE(M > 0 && N > 0 && K > 0 && M % 128 == 0 && N % 128 == 0 && batch >= 0 && batch <= 65535, HH_ERR_SHAPE,
+               "hh_gemm_tn_bf16_batched2: need M %% 128 == 0, N %% 128 == 0, batch <= 65535 (M=%d N=%d K=%lld batch=%d)", M, N, (long long)K, batch);
+    HH_REQUIRE((At2 == nullptr) == (Bt2 == nullptr) && (At2 == nullptr || K % 64 == 0), HH_ERR_SHAPE, "hh_gemm_tn_bf16_batched2: the second pair comes whole and needs K %% 64 == 0");
+    HH_REQUIRE(lda >= M && ldb >= N && lda % 8 == 0 && ldb % 8 == 0 && stride_a % 8 == 0 && stride_b % 8 == 0 && stride_c % 4 == 0, HH_ERR_SHAPE,
+               "hh_gemm_tn_bf16_batched2: bad leading dimensions / strides");
+    HH_REQUIRE(HH_ALIGNED16(At) && HH_ALIGNED16(Bt) && HH_ALIGNED16(At2) && HH_ALIGNED16(Bt2) && HH_ALIGNED16(C), HH_ERR_ALIGN, "hh_gemm_tn_bf16_batched2: pointers must be 16-byte aligned");
+    if (batch == 0) return HH_OK;
+    TnParams p;
+    p.At = (const bf16_t*)At; p.lda = lda; p.Bt = (const bf16_t*)Bt; p.ldb = ldb; p.C = C; p.split_stride = 0; p.colsum = nullptr;
+    p.M = M; p.N = N; p.K = K;
+    p.k_per_split = (int)(((K + 63) / 64) * 64);
+    p.At2 = (const bf16_t*)At2; p.Bt2 = (const bf16_t*)Bt2; p.sA = stride_a; p.sB = stride_b; p.sC = stride_c;
+    HHProfScope prof(HH_PROF_GEMM_TN, 2.0 * (double)M * N * (double)K * (At2 ? 2 : 1) * batch, (hipStream_t)stream);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)((M / 128) * (N / 128)), 1u, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, p);
+    return hh_check_launch("hh_gemm_tn_bf16_batched2");
 }

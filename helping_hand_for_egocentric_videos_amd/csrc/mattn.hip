@@ -1,0 +1,608 @@
+// Decoder cross-attention WITHOUT the memory-side K/V projections ("memory-space attention"; nn.MultiheadAttention inside
+// TransformerDecoderLayer.forward_pre, /root/reference/model/tfm_decoder.py:433-441, round 5).
+//
+// The reference projects all M = T*n memory tokens to K_l = (memory + pos) Wk_l^T + bk_l and V_l = memory Wv_l^T + bv_l for each of
+// the six layers (825 GFLOP forward at B = 32, twice that backward, a 1.6 GB bf16 buffer written once and read three times).  But
+//     q_h . K_l[i]          = (q_h Wk_l[h]) . (memory + pos)[i]  +  q_h . bk_l[h]        (the bias is constant over the keys of a query:
+//                                                                                        it drops out of the softmax)
+//     sum_i p_i V_l[i]      = (sum_i p_i memory[i]) Wv_l[h]^T  +  (sum_i p_i) bv_l[h]
+// so the 13 query rows of a head are mapped INTO memory space (qt = q_h Wk_l[h], 512 wide), attend over the un-projected rows
+// mp = memory + pos / mem = memory that all layers and heads share, and the value projection is applied to the 13 pooled rows
+// afterwards (both by head-batched hh_qgemm_f32x3 launches on the query side).  This file is the attention core at d = 512:
+//
+//   hh_mattn_fwd   pooled[r, h, :] = sum_i Pd[r, h, i] mem[i, :],  lse2,  rsum = sum_i Pd   (Pd = dropout(softmax(qt . mp^T)))
+//   hh_mattn_bwd   dqt[r, h, :]    = sum_i dS[r, h, i] mp[i, :]    and the transposed probabilities / score gradients Pd^T, dS^T
+//                  (bf16 [B, rows, M], rows = layer*128 + head*16 + query) from which ONE batched TN GEMM after the last layer makes
+//                  d memory = sum_layers Pd^T dpooled + dS^T qt  (gemm_tn.hip: hh_gemm_tn_bf16_batched2) -- the layers' contributions
+//                  to d memory are never accumulated through HBM.
+//
+// Work decomposition (both kernels): one workgroup of 8 waves per (clip, group of 4 heads, key slice); wave w owns head 4 hg + (w >> 1)
+// -- 16 query slots, Q <= 16 real -- and HALF of the 512 contraction / output dims (w & 1).  Keys are streamed in chunks of 32 rows:
+// the chunk's mp and mem rows (64 KB) are staged once per workgroup by LDS-DMA (one 1-KB row per wave instruction, XOR-swizzled
+// through the per-lane source address) into a double buffer and feed all 4 heads;
+//   S^T partial = mp[32 keys, my 256 dims] . qt^T      16 row reads (ds_read_b128) x 2 MFMAs (qt enters as a bf16 hi + lo pair)
+//   the two dim-halves of a head swap their partials through LDS (2 KB per wave) and both hold S^T = the B operand layout of
+//   O^T += mem^T[my 256 dims, 32 keys] . Pd^T          32 transposing reads (ds_read_b64_tr_b16) x 2 MFMAs (Pd as hi + lo)
+// Every product is exact with respect to the stored bf16 memory rows (query-side values as hi + lo pairs: x = hi + lo + O(2^-17 x)),
+// as in xattn.hip.  Per chunk and wave 64 MFMAs (forward) / 96 (backward) against 16 KB / 24 KB of LDS fragment reads; the same
+// 64 KB of staging serve 4 heads, so the kernels sit near the balance point of HBM (2 KB per key and layer) and the matrix cores.
+// Bank model of MI355X_MICROARCH.md: 16-B chunk c of row r lives at position c ^ (2 (r & 7)); both the row reads (16 keys x 4
+// chunks per instruction) and the transposed reads (8 rows x 32 B per half wave) are conflict-free with it.
+//
+// hipcc and LDS-DMA (see attn_space.hip): the DMA, every LDS access of the main loop and every wait are opaque inline asm; the
+// compiler sees no vector-memory dependency it could turn into vmcnt(0).
+#include "common.h"
+
+typedef short ma_s16x4 __attribute__((ext_vector_type(4)));
+
+#define MA_C 512                       // decoder width = contraction length of the scores = width of the pooled rows
+#define MA_H 8                         // heads
+#define MA_KC 32                       // keys per chunk
+#define MA_ROWB (MA_C * 2)             // bytes per staged row
+#define MA_HALF (MA_KC * MA_ROWB)      // 32 KB: the chunk's mp rows; the mem rows follow
+#define MA_STAGE (2 * MA_HALF)         // 64 KB per stage, two stages
+#define MA_XOFF (2 * MA_STAGE)         // exchange area behind the stages
+#define MA_LOG2E 1.4426950408889634f
+
+#define ma_split_hl(X, HI, LO) do { const float x_ = (X); const bf16_t h_ = (bf16_t)x_; (HI) = h_; (LO) = (bf16_t)(x_ - (float)h_); } while (0)
+
+// same counter-based mask as xattn.hip: element (clip * heads + head, query, key) kept iff hash >= thresh (= p * 2^32)
+__device__ __forceinline__ bool ma_keep(unsigned seed, unsigned bh, unsigned qq, unsigned key, unsigned thresh) {
+    unsigned h = seed ^ (bh * 0x9E3779B9u) ^ (key * 0x85EBCA6Bu) ^ (qq * 0xC2B2AE35u);
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h >= thresh;
+}
+
+__device__ __forceinline__ unsigned ma_lds_u32(const char* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 ma_rd128(unsigned a) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
+    return __builtin_bit_cast(bf16x8, r);
+}
+template <int OFF>
+__device__ __forceinline__ f32x4 ma_rd128f(unsigned a) {
+    f32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
+    return r;
+}
+// (the value is an MFMA result: an LDS instruction that reads the destination of an 8-pass MFMA needs 11 wait states after it, and the
+// compiler's hazard recogniser does not look inside inline asm -- without the s_nops the write stored the accumulator of an MFMA still in flight)
+template <int OFF>
+__device__ __forceinline__ void ma_wr128f(unsigned a, f32x4 v) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\tds_write_b128 %0, %1 offset:%2" :: "v"(a), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ bf16x4 ma_tr4(unsigned a) {
+    ma_s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
+    return __builtin_bit_cast(bf16x4, r);
+}
+// counted LDS waits that "touch" the registers they make valid, so that no consumer is scheduled above them
+#define MA_LGKM4(N, A, B, C, D) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A), "+v"(B), "+v"(C), "+v"(D) : "n"(N))
+#define MA_LGKM8(N, A, B, C, D, E, F, G, H) asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(A), "+v"(B), "+v"(C), "+v"(D), "+v"(E), "+v"(F), "+v"(G), "+v"(H) : "n"(N))
+#define MA_LGKM2(N, A, B) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(A), "+v"(B) : "n"(N))
+#define MA_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define MA_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define MA_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// one 1-KB row of the stage: lane l fetches the 16 bytes at src + voff (voff = 16 (l ^ key(row)): the swizzle) to LDS dst + 16 l
+__device__ __forceinline__ void ma_dma_row(const bf16_t* src, unsigned voff, unsigned dst) {
+    // (s_nop 4: the scalar operands may come straight out of a v_readfirstlane -- VALU writes SGPR -> VMEM reads it needs 5 wait states, and
+    // the compiler's hazard recogniser does not look inside inline asm; scripts/check_isa_hazards.py)
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src), "s"(dst) : "memory");
+}
+
+struct MaCommon {
+    const bf16_t* mp; const bf16_t* mem; int64_t ld;     // [B, M, ld] bf16 (ld >= 512)
+    int B, Q, M, slices, keys_per_slice;
+    unsigned drop_thresh; float drop_scale; unsigned seed;
+};
+
+// lane-constant LDS byte offsets (inside a stage half): row reads rb[b] for k-step ks = 4 a + b (a adds 256 B), transposed reads
+// tb[dl] for d-tile dt = 8 a + dl (a adds 256 B); key tile 1 adds 16 rows = 16 KB in both
+struct MaAddr { unsigned rb[4], tb[8]; };       // (they carry the stage: ma_addr_flip after every chunk)
+
+__device__ __forceinline__ MaAddr ma_addr(int lane, int dh, unsigned lds0) {
+    MaAddr A;
+    const int kq = lane & 15, g = lane >> 4;
+    const int f = 2 * (kq & 7);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) A.rb[b] = lds0 + (unsigned)(kq * MA_ROWB + 16 * (32 * dh + ((4 * b + g) ^ f)));
+    const int i = lane & 15;
+    const int kr = 4 * g + (i >> 2), f2 = kr & 7, b1 = (i >> 1) & 1;
+#pragma unroll
+    for (int dl = 0; dl < 8; ++dl) A.tb[dl] = lds0 + (unsigned)(kr * MA_ROWB + 16 * (32 * dh + 2 * (dl ^ f2) + b1) + 8 * (i & 1));
+    return A;
+}
+
+__device__ __forceinline__ void ma_addr_flip(MaAddr& A) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) A.rb[b] ^= MA_STAGE;
+#pragma unroll
+    for (int dl = 0; dl < 8; ++dl) A.tb[dl] ^= MA_STAGE;
+}
+
+// wave w stages rows 4 w .. 4 w + 3 of the chunk's mp rows and of its mem rows (8 DMAs of 1 KB)
+__device__ __forceinline__ void ma_stage(const MaCommon& p, int b, int k0, int wave, unsigned lane16, unsigned stage_lds) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kr = 4 * wave + i;
+        const int64_t row = ((int64_t)b * p.M + k0 + kr) * p.ld;
+        const unsigned voff = lane16 ^ (unsigned)(32 * (kr & 7));              // 16 (lane ^ 2 (kr & 7)): the swizzle key is wave-uniform
+        ma_dma_row(p.mp + row, voff, stage_lds + kr * MA_ROWB);
+        ma_dma_row(p.mem + row, voff, stage_lds + MA_HALF + kr * MA_ROWB);
+    }
+}
+
+// fp32 rows -> MFMA B operand fragments (lane (q = lane & 15, g): dims 256 dh + 32 ks + 8 g .. + 7) as bf16 hi + lo
+__device__ __forceinline__ void ma_load_q(const float* row, bool valid, int dh, int g, bf16x8 (&hi)[8], bf16x8 (&lo)[8]) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        if (valid) {
+            const float* s = row + 256 * dh + 32 * ks + 8 * g;
+            const f32x4 a = *(const f32x4*)s, b = *(const f32x4*)(s + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ma_split_hl(a[j], hi[ks][j], lo[ks][j]); ma_split_hl(b[j], hi[ks][4 + j], lo[ks][4 + j]); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hi[ks][j] = (bf16_t)0.f; lo[ks][j] = (bf16_t)0.f; }
+        }
+    }
+}
+
+// S^T partial of one 32-key chunk over this wave's 256 dims: acc[kt] (lane (q, keys 16 kt + 4 g + r)) += rows[HALF_OFF] . (hi + lo)^T
+template <int HALF_OFF>
+__device__ __forceinline__ void ma_scores(const MaAddr& A, const bf16x8 (&hi)[8], const bf16x8 (&lo)[8], f32x4 (&acc)[2]) {
+    const unsigned a0 = A.rb[0], a1 = A.rb[1], a2 = A.rb[2], a3 = A.rb[3];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        // k-steps 0..3 then 4..7 of this key tile: eight reads in flight, consumed four at a time
+        bf16x8 f0 = kt == 0 ? ma_rd128<HALF_OFF>(a0) : ma_rd128<HALF_OFF + 16384>(a0);
+        bf16x8 f1 = kt == 0 ? ma_rd128<HALF_OFF>(a1) : ma_rd128<HALF_OFF + 16384>(a1);
+        bf16x8 f2 = kt == 0 ? ma_rd128<HALF_OFF>(a2) : ma_rd128<HALF_OFF + 16384>(a2);
+        bf16x8 f3 = kt == 0 ? ma_rd128<HALF_OFF>(a3) : ma_rd128<HALF_OFF + 16384>(a3);
+        bf16x8 f4 = kt == 0 ? ma_rd128<HALF_OFF + 256>(a0) : ma_rd128<HALF_OFF + 16384 + 256>(a0);
+        bf16x8 f5 = kt == 0 ? ma_rd128<HALF_OFF + 256>(a1) : ma_rd128<HALF_OFF + 16384 + 256>(a1);
+        bf16x8 f6 = kt == 0 ? ma_rd128<HALF_OFF + 256>(a2) : ma_rd128<HALF_OFF + 16384 + 256>(a2);
+        bf16x8 f7 = kt == 0 ? ma_rd128<HALF_OFF + 256>(a3) : ma_rd128<HALF_OFF + 16384 + 256>(a3);
+        MA_LGKM4(4, f0, f1, f2, f3);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, hi[0], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, lo[0], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, hi[1], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, lo[1], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f2, hi[2], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f2, lo[2], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f3, hi[3], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f3, lo[3], acc[kt], 0, 0, 0);
+        MA_LGKM4(0, f4, f5, f6, f7);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f4, hi[4], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f4, lo[4], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f5, hi[5], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f5, lo[5], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f6, hi[6], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f6, lo[6], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f7, hi[7], acc[kt], 0, 0, 0);
+        acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f7, lo[7], acc[kt], 0, 0, 0);
+    }
+}
+
+// X^T[my 256 dims, q] += rows[HALF_OFF]^T[dims, 32 keys] . (ph + pl)[keys, q]: 16 d-tiles, the rows fetched by transposing reads in the
+// key order of the S^T accumulator layout (lane (q, g): keys 4 g .. 4 g + 3 of key tile 0, then of key tile 1)
+template <int HALF_OFF>
+__device__ __forceinline__ void ma_pool(const MaAddr& A, const bf16x8& ph, const bf16x8& pl, f32x4 (&o)[16]) {
+    const unsigned (&t)[8] = A.tb;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int quad = 0; quad < 2; ++quad) {
+            // four d-tiles: eight transposing reads, consumed as they land
+            bf16x4 a0, b0, a1, b1, a2, b2, a3, b3;
+            if (half == 0) {
+                a0 = ma_tr4<HALF_OFF>(t[4 * quad + 0]); b0 = ma_tr4<HALF_OFF + 16384>(t[4 * quad + 0]);
+                a1 = ma_tr4<HALF_OFF>(t[4 * quad + 1]); b1 = ma_tr4<HALF_OFF + 16384>(t[4 * quad + 1]);
+                a2 = ma_tr4<HALF_OFF>(t[4 * quad + 2]); b2 = ma_tr4<HALF_OFF + 16384>(t[4 * quad + 2]);
+                a3 = ma_tr4<HALF_OFF>(t[4 * quad + 3]); b3 = ma_tr4<HALF_OFF + 16384>(t[4 * quad + 3]);
+            } else {
+                a0 = ma_tr4<HALF_OFF + 256>(t[4 * quad + 0]); b0 = ma_tr4<HALF_OFF + 16384 + 256>(t[4 * quad + 0]);
+                a1 = ma_tr4<HALF_OFF + 256>(t[4 * quad + 1]); b1 = ma_tr4<HALF_OFF + 16384 + 256>(t[4 * quad + 1]);
+                a2 = ma_tr4<HALF_OFF + 256>(t[4 * quad + 2]); b2 = ma_tr4<HALF_OFF + 16384 + 256>(t[4 * quad + 2]);
+                a3 = ma_tr4<HALF_OFF + 256>(t[4 * quad + 3]); b3 = ma_tr4<HALF_OFF + 16384 + 256>(t[4 * quad + 3]);
+            }
+            const int dt = 8 * half + 4 * quad;
+            MA_LGKM4(4, a0, b0, a1, b1);
+            const bf16x8 v0 = {a0[0], a0[1], a0[2], a0[3], b0[0], b0[1], b0[2], b0[3]};
+            const bf16x8 v1 = {a1[0], a1[1], a1[2], a1[3], b1[0], b1[1], b1[2], b1[3]};
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, ph, o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pl, o[dt], 0, 0, 0);
+            o[dt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, ph, o[dt + 1], 0, 0, 0);
+            o[dt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pl, o[dt + 1], 0, 0, 0);
+            MA_LGKM4(0, a2, b2, a3, b3);
+            const bf16x8 v2 = {a2[0], a2[1], a2[2], a2[3], b2[0], b2[1], b2[2], b2[3]};
+            const bf16x8 v3 = {a3[0], a3[1], a3[2], a3[3], b3[0], b3[1], b3[2], b3[3]};
+            o[dt + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v2, ph, o[dt + 2], 0, 0, 0);
+            o[dt + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v2, pl, o[dt + 2], 0, 0, 0);
+            o[dt + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v3, ph, o[dt + 3], 0, 0, 0);
+            o[dt + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v3, pl, o[dt + 3], 0, 0, 0);
+        }
+    }
+}
+
+// workgroup index -> (clip, head group, key slice); the two head groups of a (clip, slice) unit are blockIdx b and b + 8: the same
+// XCD under round-robin placement (speed only), so the second one finds the unit's rows in that XCD's L2
+__device__ __forceinline__ bool ma_unit(const MaCommon& p, int& b, int& hg, int& slice) {
+    const int idx = blockIdx.x, xcd = idx & 7, j = idx >> 3;
+    hg = j & 1;
+    const int u = (j >> 1) * 8 + xcd;
+    if (u >= p.B * p.slices) return false;
+    b = u / p.slices;
+    slice = u % p.slices;
+    return true;
+}
+
+struct MaFwd {
+    MaCommon c;
+    const float* qt;          // [B*Q, H*C] fp32: row (clip, query), column head * 512 + k
+    float* o_part;            // [slices][B*Q, H*C]: un-normalised partial pooled rows (slices == 1: the final, normalised rows)
+    float* st_part;           // [slices][B*Q, H][4]: running maximum (base-2 logits), sum of p, sum of dropped p, -
+    float* lse2; float* rsum; // slices == 1 only: [B*Q, H] final statistics
+};
+
+__global__ __launch_bounds__(512) void mattn_fwd_kernel(MaFwd p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int b, hg, slice;
+    if (!ma_unit(p.c, b, hg, slice)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = wave >> 1, dh = wave & 1, head = 4 * hg + rt;
+    const int ql = lane & 15, g = lane >> 4;
+    const int Q = p.c.Q;
+    const unsigned lds0 = ma_lds_u32(smem);
+    MaAddr A = ma_addr(lane, dh, lds0);
+    const unsigned voff = 16u * (unsigned)lane;
+    const int k_begin = slice * p.c.keys_per_slice;
+    const int k_end = min(p.c.M, k_begin + p.c.keys_per_slice);
+    const int nchunks = (k_end - k_begin) / MA_KC;
+    if (nchunks > 0) ma_stage(p.c, b, k_begin, wave, voff, lds0);
+
+    bf16x8 qh[8], qlo[8];
+    const int64_t qrow = (int64_t)b * Q + (ql < Q ? ql : 0);
+    ma_load_q(p.qt + qrow * (MA_H * MA_C) + head * MA_C, ql < Q, dh, g, qh, qlo);
+    f32x4 o[16];
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f, rs_run = 0.f;
+    const unsigned xme = lds0 + MA_XOFF + wave * 2048 + lane * 16, xpartner = lds0 + MA_XOFF + (wave ^ 1) * 2048 + lane * 16;
+    const unsigned bh = (unsigned)(b * MA_H + head);
+
+    for (int c = 0; c < nchunks; ++c) {
+        MA_WAIT_VM0();                                   // this wave's rows of chunk c have landed
+        MA_BARRIER();                                    // everyone's have; everyone has left chunk c - 1 (its stage is free)
+        if (c + 1 < nchunks) ma_stage(p.c, b, k_begin + (c + 1) * MA_KC, wave, voff, lds0 + ((c + 1) & 1) * MA_STAGE);
+        f32x4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        ma_scores<0>(A, qh, qlo, s);
+        ma_wr128f<0>(xme, s[0]);
+        ma_wr128f<1024>(xme, s[1]);
+        MA_WAIT_LGKM0();
+        MA_BARRIER();
+        f32x4 x0 = ma_rd128f<0>(xpartner), x1 = ma_rd128f<1024>(xpartner);
+        MA_LGKM2(0, x0, x1);
+        s[0] += x0;
+        s[1] += x1;
+        // online softmax in base 2 (this lane: query ql, keys 4 g + r of both key tiles)
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { t[r] = s[0][r] * MA_LOG2E; t[4 + r] = s[1][r] * MA_LOG2E; }
+        float mx = fmaxf(fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])), fmaxf(fmaxf(t[4], t[5]), fmaxf(t[6], t[7])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {              // rescale only when some row's maximum moved
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+            for (int dt = 0; dt < 16; ++dt) o[dt] *= alpha;
+            l_run *= alpha;
+            rs_run *= alpha;
+            m_run = m_new;
+        }
+        bf16x8 ph, pl;
+        const int kbase = k_begin + c * MA_KC + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float pv = __builtin_amdgcn_exp2f(t[j] - m_run);
+            l_run += pv;
+            if (p.c.drop_thresh) pv = ma_keep(p.c.seed, bh, (unsigned)ql, (unsigned)(kbase + 16 * (j >> 2) + (j & 3)), p.c.drop_thresh) ? pv * p.c.drop_scale : 0.f;
+            rs_run += pv;
+            ma_split_hl(pv, ph[j], pl[j]);
+        }
+        ma_pool<MA_HALF>(A, ph, pl, o);
+        ma_addr_flip(A);
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    rs_run += __shfl_xor(rs_run, 16, 64);
+    rs_run += __shfl_xor(rs_run, 32, 64);
+    if (ql >= Q) return;
+    const int64_t r = (int64_t)b * Q + ql;
+    const bool final_ = p.c.slices == 1;
+    const float sc = final_ ? 1.f / l_run : 1.f;
+    float* orow = p.o_part + ((int64_t)slice * p.c.B * Q + r) * (MA_H * MA_C) + head * MA_C + 256 * dh + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt) *(f32x4*)(orow + 16 * dt) = o[dt] * sc;
+    if (dh == 0 && g == 0) {
+        if (final_) {
+            p.lse2[r * MA_H + head] = m_run + __builtin_amdgcn_logf(l_run);      // v_log_f32 is base 2
+            p.rsum[r * MA_H + head] = rs_run * sc;
+        } else {
+            *(f32x4*)(p.st_part + (((int64_t)slice * p.c.B * Q + r) * MA_H + head) * 4) = (f32x4){m_run, l_run, rs_run, 0.f};
+        }
+    }
+}
+
+// pooled[r, h, :] = sum_s 2^(m_s - m) O_s[r, h, :] / L,  L = sum_s 2^(m_s - m) l_s,  lse2 = m + log2 L,  rsum likewise
+__global__ __launch_bounds__(128) void mattn_fwd_merge_kernel(const float* __restrict__ o_part, const float* __restrict__ st_part, float* __restrict__ pooled,
+                                                              float* __restrict__ lse2, float* __restrict__ rsum, int64_t rows_h, int slices) {
+    const int64_t rh = blockIdx.x;                       // (row, head)
+    const int tid = threadIdx.x;
+    float m = -INFINITY;
+    for (int s = 0; s < slices; ++s) m = fmaxf(m, st_part[((int64_t)s * rows_h + rh) * 4]);
+    float L = 0.f, RS = 0.f;
+    for (int s = 0; s < slices; ++s) {
+        const f32x4 st = *(const f32x4*)(st_part + ((int64_t)s * rows_h + rh) * 4);
+        const float w = __builtin_amdgcn_exp2f(st[0] - m);
+        L += w * st[1];
+        RS += w * st[2];
+    }
+    const float inv = 1.f / L;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < slices; ++s) {
+        const float w = __builtin_amdgcn_exp2f(st_part[((int64_t)s * rows_h + rh) * 4] - m);
+        acc += *(const f32x4*)(o_part + ((int64_t)s * rows_h + rh) * MA_C + 4 * tid) * w;
+    }
+    *(f32x4*)(pooled + rh * MA_C + 4 * tid) = acc * inv;
+    if (tid == 0) {
+        lse2[rh] = m + __builtin_amdgcn_logf(L);
+        rsum[rh] = RS * inv;
+    }
+}
+
+static void ma_drop_params(float p, unsigned* thresh, float* scale) {
+    if (p <= 0.f) { *thresh = 0u; *scale = 1.f; return; }
+    double t = (double)p * 4294967296.0;
+    *thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    if (*thresh == 0u) *thresh = 1u;
+    *scale = 1.f / (1.f - p);
+}
+
+static int ma_check(const char* what, int B, int Q, int M, int heads, int C, int64_t ld, int slices) {
+    HH_REQUIRE(heads == MA_H && C == MA_C, HH_ERR_UNSUPPORTED, "%s: built for the reference decoder's d_model 512 / 8 heads (tfm_decoder.py:51) (heads=%d C=%d)", what, heads, C);
+    HH_REQUIRE(B >= 0 && Q > 0 && Q <= 16 && M > 0 && M % MA_KC == 0, HH_ERR_SHAPE, "%s: need 0 < Q <= 16 and M %% 32 == 0 (Q=%d M=%d)", what, Q, M);
+    HH_REQUIRE(ld >= MA_C && ld % 8 == 0, HH_ERR_SHAPE, "%s: memory leading dimension %lld too small / unaligned", what, (long long)ld);
+    HH_REQUIRE(slices >= 1 && slices <= 256, HH_ERR_SHAPE, "%s: slices must be in [1, 256]", what);
+    return HH_OK;
+}
+
+// keys per slice: whole chunks, no empty slice
+static void ma_slicing(int M, int* slices, int* per) {
+    int chunks = M / MA_KC;
+    int s = *slices < chunks ? *slices : chunks;
+    int cps = (chunks + s - 1) / s;
+    *per = cps * MA_KC;
+    *slices = (chunks + cps - 1) / cps;
+}
+
+extern "C" int hh_mattn_slices(int M, int slices) {
+    if (M <= 0 || M % MA_KC != 0 || slices < 1) return -1;
+    int per;
+    ma_slicing(M, &slices, &per);
+    return slices;
+}
+
+extern "C" int64_t hh_workspace_bytes_mattn_fwd(int B, int Q, int slices) {
+    if (B < 0 || Q <= 0 || Q > 16 || slices < 1) return -1;
+    if (slices == 1) return 16;
+    return (int64_t)slices * B * Q * MA_H * (MA_C + 4) * 4;
+}
+
+extern "C" int hh_mattn_fwd(const float* qt, const void* mp, const void* mem, int64_t ld, float* pooled, float* lse2, float* rsum, float* workspace,
+                            int slices, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, hh_stream_t stream) {
+    int rc = ma_check("hh_mattn_fwd", B, Q, M, heads, C, ld, slices);
+    if (rc) return rc;
+    HH_REQUIRE(HH_ALIGNED16(qt) && HH_ALIGNED16(mp) && HH_ALIGNED16(mem) && HH_ALIGNED16(pooled) && HH_ALIGNED16(workspace), HH_ERR_ALIGN,
+               "hh_mattn_fwd: pointers must be 16-byte aligned");
+    HH_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, HH_ERR_SHAPE, "hh_mattn_fwd: dropout_p must be in [0,1)");
+    if (B == 0) return HH_OK;
+    MaFwd p;
+    p.c.mp = (const bf16_t*)mp; p.c.mem = (const bf16_t*)mem; p.c.ld = ld; p.c.B = B; p.c.Q = Q; p.c.M = M;
+    p.c.slices = slices;
+    ma_slicing(M, &p.c.slices, &p.c.keys_per_slice);
+    ma_drop_params(dropout_p, &p.c.drop_thresh, &p.c.drop_scale);
+    p.c.seed = seed;
+    HH_REQUIRE(p.c.slices == 1 || workspace != nullptr, HH_ERR_SHAPE, "hh_mattn_fwd: slices > 1 needs hh_workspace_bytes_mattn_fwd() bytes of workspace");
+    p.qt = qt; p.lse2 = lse2; p.rsum = rsum;
+    const int64_t rows_h = (int64_t)B * Q * MA_H;
+    if (p.c.slices == 1) { p.o_part = pooled; p.st_part = nullptr; }
+    else { p.o_part = workspace; p.st_part = workspace + (int64_t)p.c.slices * rows_h * MA_C; }
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)mattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MA_XOFF + 8 * 2048);
+        attr_done = true;
+    }
+    const int units = B * p.c.slices;
+    const unsigned grid = 16u * (unsigned)((units + 7) / 8);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        HHProfScope prof(HH_PROF_XATTN_FWD, 4.0 * (double)B * M * MA_C, s);                  // mp and mem rows, bf16, once
+        hipLaunchKernelGGL(mattn_fwd_kernel, dim3(grid), dim3(512), MA_XOFF + 8 * 2048, s, p);
+    }
+    if (p.c.slices > 1)
+        hipLaunchKernelGGL(mattn_fwd_merge_kernel, dim3((unsigned)rows_h), dim3(128), 0, s, p.o_part, p.st_part, pooled, lse2, rsum, rows_h, p.c.slices);
+    return hh_check_launch("hh_mattn_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of one layer's cross-attention in memory space.  With Pd = mask o P / (1 - p) (P = softmax of the scores), pooled = Pd mem,
+// rsum = Pd 1 and the head output O = pooled Wv^T + rsum bv:
+//     d Pd[q, i] = dpooled[q] . mem[i] + cb[q]          (cb = dO . bv, the rsum term)
+//     d P        = mask / (1 - p) o d Pd,      dS = P o (dP - delta),      delta[q] = sum_i P dP = dO[q] . O[q]
+//     d qt[q]    = sum_i dS[q, i] mp[i]                 (this kernel, per key slice)
+//     d mem     += Pd^T dpooled,   d mp += dS^T qt      (all layers at once: hh_gemm_tn_bf16_batched2 on the Pd^T / dS^T this kernel
+//                                                        leaves in bf16, rows layer * 128 + head * 16 + query, keys contiguous)
+// Same decomposition as the forward; per chunk and wave: S^T and dP^T partials (32 MFMAs each, exchanged together: 4 KB per wave),
+// P / dS on the vector unit, d qt^T += mp^T . dS^T (32 MFMAs, dS as hi + lo).  The wave with dim-half 0 stores Pd^T, the other dS^T.
+struct MaBwd {
+    MaCommon c;
+    const float* qt;          // [B*Q, H*C]
+    const float* dpooled;     // [B*Q, H*C]
+    const float* lse2;        // [B*Q, H]
+    const float* dca;         // [B*Q, C'] gradient of the attention output (C' = H * 64 columns, head-major)
+    const float* ca;          // [B*Q, C'] the attention output itself (delta = sum_n dca * ca over a head's 64 columns)
+    const float* bv;          // [C'] value bias of the layer (cb = sum_n dca * bv)
+    float* dqt_part;          // [slices][B*Q, H*C]
+    bf16_t* pdT; bf16_t* dsT; // [B, rows_total, M] bf16; this layer's rows start at row_off
+    bf16_t* qt16; bf16_t* dp16; // [B, rows_total, C] bf16 copies of qt / dpooled (rows as above; slice 0 writes them), or NULL
+    int rows_total, row_off;
+};
+
+__global__ __launch_bounds__(512) void mattn_bwd_kernel(MaBwd p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int b, hg, slice;
+    if (!ma_unit(p.c, b, hg, slice)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rt = wave >> 1, dh = wave & 1, head = 4 * hg + rt;
+    const int ql = lane & 15, g = lane >> 4;
+    const int Q = p.c.Q;
+    const unsigned lds0 = ma_lds_u32(smem);
+    MaAddr A = ma_addr(lane, dh, lds0);
+    const unsigned voff = 16u * (unsigned)lane;
+    const int k_begin = slice * p.c.keys_per_slice;
+    const int k_end = min(p.c.M, k_begin + p.c.keys_per_slice);
+    const int nchunks = (k_end - k_begin) / MA_KC;
+    if (nchunks > 0) ma_stage(p.c, b, k_begin, wave, voff, lds0);
+
+    const bool live = ql < Q;
+    const int64_t r = (int64_t)b * Q + (live ? ql : 0);
+    bf16x8 qh[8], qlo[8], dh_[8], dlo[8];
+    ma_load_q(p.qt + r * (MA_H * MA_C) + head * MA_C, live, dh, g, qh, qlo);
+    ma_load_q(p.dpooled + r * (MA_H * MA_C) + head * MA_C, live, dh, g, dh_, dlo);
+    // row constants: lse2, delta = dO . O and cb = dO . bv over the head's 64 columns (16 per lane, summed over the 4 lane groups)
+    float delta = 0.f, cb = 0.f;
+    {
+        const float* d = p.dca + r * (MA_H * 64) + head * 64 + 16 * g;
+        const float* o_ = p.ca + r * (MA_H * 64) + head * 64 + 16 * g;
+        const float* bvp = p.bv + head * 64 + 16 * g;
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+            const f32x4 dv = *(const f32x4*)(d + e), ov = *(const f32x4*)(o_ + e);
+            delta += dv[0] * ov[0] + dv[1] * ov[1] + dv[2] * ov[2] + dv[3] * ov[3];
+            const f32x4 bb = *(const f32x4*)(bvp + e);
+            cb += dv[0] * bb[0] + dv[1] * bb[1] + dv[2] * bb[2] + dv[3] * bb[3];
+        }
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+        cb += __shfl_xor(cb, 16, 64);
+        cb += __shfl_xor(cb, 32, 64);
+    }
+    const float lse = live ? p.lse2[r * MA_H + head] : 0.f;
+    // bf16 copies of this head's qt / dpooled rows for the batched d-memory GEMM (hi halves = the rounded values; zero rows beyond Q)
+    if (slice == 0 && p.qt16 != nullptr) {
+        const int64_t row16 = ((int64_t)b * p.rows_total + p.row_off + head * 16 + ql) * MA_C + 256 * dh + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            *(bf16x8*)(p.qt16 + row16 + 32 * ks) = qh[ks];
+            *(bf16x8*)(p.dp16 + row16 + 32 * ks) = dh_[ks];
+        }
+    }
+    f32x4 acc[16];
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned xme = lds0 + MA_XOFF + wave * 4096 + lane * 16, xpartner = lds0 + MA_XOFF + (wave ^ 1) * 4096 + lane * 16;
+    const unsigned bh = (unsigned)(b * MA_H + head);
+    bf16_t* outT = (dh == 0 ? p.pdT : p.dsT) + ((int64_t)b * p.rows_total + p.row_off + head * 16 + ql) * p.c.M;
+
+    for (int c = 0; c < nchunks; ++c) {
+        MA_WAIT_VM0();
+        MA_BARRIER();
+        if (c + 1 < nchunks) ma_stage(p.c, b, k_begin + (c + 1) * MA_KC, wave, voff, lds0 + ((c + 1) & 1) * MA_STAGE);
+        f32x4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dp[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        ma_scores<0>(A, qh, qlo, s);
+        ma_wr128f<0>(xme, s[0]);
+        ma_wr128f<1024>(xme, s[1]);
+        ma_scores<MA_HALF>(A, dh_, dlo, dp);
+        ma_wr128f<2048>(xme, dp[0]);
+        ma_wr128f<3072>(xme, dp[1]);
+        MA_WAIT_LGKM0();
+        MA_BARRIER();
+        f32x4 x0 = ma_rd128f<0>(xpartner), x1 = ma_rd128f<1024>(xpartner), x2 = ma_rd128f<2048>(xpartner), x3 = ma_rd128f<3072>(xpartner);
+        MA_LGKM4(0, x0, x1, x2, x3);
+        s[0] += x0; s[1] += x1; dp[0] += x2; dp[1] += x3;
+        bf16x8 sh, sl;
+        bf16x4 st0, st1;                                  // what this wave stores: Pd (dim-half 0) or dS (dim-half 1), keys 4 g .. of each key tile
+        const int kbase = k_begin + c * MA_KC + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sv = j < 4 ? s[0][j] : s[1][j - 4], dv = j < 4 ? dp[0][j] : dp[1][j - 4];
+            const float pv = live ? __builtin_amdgcn_exp2f(sv * MA_LOG2E - lse) : 0.f;
+            // (delta = dO . O contains the value-bias term rsum * cb, so cb belongs to dP with or without dropout)
+            float pd = pv, dpm = dv + cb;
+            if (p.c.drop_thresh) {
+                const bool keep = ma_keep(p.c.seed, bh, (unsigned)ql, (unsigned)(kbase + 16 * (j >> 2) + (j & 3)), p.c.drop_thresh);
+                pd = keep ? pv * p.c.drop_scale : 0.f;
+                dpm = keep ? (dv + cb) * p.c.drop_scale : 0.f;
+            }
+            const float ds = pv * (dpm - delta);
+            ma_split_hl(ds, sh[j], sl[j]);
+            const bf16_t ov = (bf16_t)(dh == 0 ? pd : ds);
+            if (j < 4) st0[j] = ov; else st1[j - 4] = ov;
+        }
+        *(bf16x4*)(outT + kbase) = st0;
+        *(bf16x4*)(outT + kbase + 16) = st1;
+        ma_pool<0>(A, sh, sl, acc);
+        ma_addr_flip(A);
+    }
+    if (!live) return;
+    float* orow = p.dqt_part + ((int64_t)slice * p.c.B * Q + r) * (MA_H * MA_C) + head * MA_C + 256 * dh + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 16; ++dt) *(f32x4*)(orow + 16 * dt) = acc[dt];
+}
+
+extern "C" int64_t hh_workspace_bytes_mattn_bwd(int B, int Q, int slices) {
+    if (B < 0 || Q <= 0 || Q > 16 || slices < 1) return -1;
+    return (int64_t)slices * B * Q * MA_H * MA_C * 4;
+}
+
+extern "C" int hh_mattn_bwd(const float* qt, const float* dpooled, const float* lse2, const float* dca, const float* ca, const float* bv,
+                            const void* mp, const void* mem, int64_t ld, float* dqt_partials, int slices, void* pdT, void* dsT, void* qt16, void* dp16,
+                            int rows_total, int row_off, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, hh_stream_t stream) {
+    int rc = ma_check("hh_mattn_bwd", B, Q, M, heads, C, ld, slices);
+    if (rc) return rc;
+    HH_REQUIRE(HH_ALIGNED16(qt) && HH_ALIGNED16(dpooled) && HH_ALIGNED16(dca) && HH_ALIGNED16(ca) && HH_ALIGNED16(bv) && HH_ALIGNED16(mp) && HH_ALIGNED16(mem) &&
+               HH_ALIGNED16(dqt_partials) && HH_ALIGNED16(pdT) && HH_ALIGNED16(dsT) && HH_ALIGNED16(qt16) && HH_ALIGNED16(dp16), HH_ERR_ALIGN,
+               "hh_mattn_bwd: pointers must be 16-byte aligned");
+    HH_REQUIRE(pdT != nullptr && dsT != nullptr && (qt16 == nullptr) == (dp16 == nullptr), HH_ERR_SHAPE, "hh_mattn_bwd: pdT / dsT are required; qt16 and dp16 come together");
+    HH_REQUIRE(rows_total >= row_off + MA_H * 16 && row_off >= 0 && row_off % 16 == 0, HH_ERR_SHAPE, "hh_mattn_bwd: the layer's 128 rows [row_off, row_off + 128) must lie inside rows_total");
+    HH_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, HH_ERR_SHAPE, "hh_mattn_bwd: dropout_p must be in [0,1)");
+    if (B == 0) return HH_OK;
+    MaBwd p;
+    p.c.mp = (const bf16_t*)mp; p.c.mem = (const bf16_t*)mem; p.c.ld = ld; p.c.B = B; p.c.Q = Q; p.c.M = M;
+    p.c.slices = slices;
+    ma_slicing(M, &p.c.slices, &p.c.keys_per_slice);
+    HH_REQUIRE(p.c.slices == slices, HH_ERR_SHAPE, "hh_mattn_bwd: pass slices = hh_mattn_slices(M, wanted) (got %d, usable %d): the caller sums that many partial planes", slices, p.c.slices);
+    ma_drop_params(dropout_p, &p.c.drop_thresh, &p.c.drop_scale);
+    p.c.seed = seed;
+    p.qt = qt; p.dpooled = dpooled; p.lse2 = lse2; p.dca = dca; p.ca = ca; p.bv = bv; p.dqt_part = dqt_partials;
+    p.pdT = (bf16_t*)pdT; p.dsT = (bf16_t*)dsT; p.qt16 = (bf16_t*)qt16; p.dp16 = (bf16_t*)dp16; p.rows_total = rows_total; p.row_off = row_off;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)mattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MA_XOFF + 8 * 4096);
+        attr_done = true;
+    }
+    const int units = B * p.c.slices;
+    const unsigned grid = 16u * (unsigned)((units + 7) / 8);
+    hipStream_t s = (hipStream_t)stream;
+    HHProfScope prof(HH_PROF_XATTN_BWD, 4.0 * (double)B * M * MA_C + 4.0 * (double)B * M * MA_H * 16 * 2, s);      // rows read once + Pd^T / dS^T written
+    hipLaunchKernelGGL(mattn_bwd_kernel, dim3(grid), dim3(512), MA_XOFF + 8 * 4096, s, p);
+    return hh_check_launch("hh_mattn_bwd");
+}

@@ -31,6 +31,10 @@ struct QGemm {
     const float* resid; int64_t ldr;
     float* colsum;
     int k_per_split;           // k-steps (of 64) per blockIdx.z slice; gridDim.z > 1: partial products are ADDED atomically into a zeroed C / colsum
+    // head-batched form (round 5: the per-head maps into / out of memory space of the K/V-projection-free cross-attention): blockIdx.z
+    // is the batch index (no split-K then) and offsets every operand by its stride
+    int batch; int64_t sA, sB, sC, sBias, sColsum;
+    const float* rowscale; int64_t ld_rs, sRs;     // NT / NN: bias[n] * rowscale[m * ld_rs];  TN: colsum[m] = sum_k A[k, m] * rowscale[k * ld_rs]
 };
 
 __device__ __forceinline__ bool q_keep(unsigned seed, unsigned idx, unsigned thresh) {
@@ -65,9 +69,16 @@ __global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int nk_all = (p.K + QBK - 1) / QBK;
-    const int kt0 = blockIdx.z * p.k_per_split;
+    if (p.batch > 1) {
+        const int64_t z = blockIdx.z;
+        p.A += z * p.sA; p.B += z * p.sB; p.C += z * p.sC;
+        if (p.bias) p.bias += z * p.sBias;
+        if (p.colsum) p.colsum += z * p.sColsum;
+        if (p.rowscale) p.rowscale += z * p.sRs;
+    }
+    const int kt0 = p.batch > 1 ? 0 : blockIdx.z * p.k_per_split;
     const int nk = min(nk_all - kt0, p.k_per_split);                          // this slice's k-steps (split-K over blockIdx.z)
-    const bool split = gridDim.z > 1;
+    const bool split = p.batch <= 1 && gridDim.z > 1;
     const bool want_cs = A_T && p.colsum != nullptr && blockIdx.x == 0;
     if (tid < 64) scs[tid] = 0.f;
 
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
                 const bool ok = r < p.K && c < p.M;
                 ra[u] = ok ? *(const f32x4*)(p.A + (int64_t)r * p.lda + c) : z4;
                 if (ok) prologue(ra[u], r, c);
-                if (want_cs) cs += ra[u];
+                if (want_cs) cs += (p.rowscale && ok) ? ra[u] * p.rowscale[(int64_t)r * p.ld_rs] : ra[u];
             }
             if constexpr (!B_T) {
                 const int r = n0 + (tid >> 2), kk = k0 + 16 * (tid & 3) + 4 * u;
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
             const int n = n0 + 16 * t + 4 * (lane >> 4);
             if (n >= p.N) continue;
             f32x4 v = acc[t];
-            if (p.bias) v += *(const f32x4*)(p.bias + n);
+            if (p.bias) v += p.rowscale ? *(const f32x4*)(p.bias + n) * p.rowscale[(int64_t)m * p.ld_rs] : *(const f32x4*)(p.bias + n);
             if (n < p.scale_ncols) v *= p.scale;
             if (p.relu) {
 #pragma unroll
@@ -241,6 +252,13 @@ extern "C" int hh_qgemm_f32x3(const float* A, int64_t lda, const float* B, int64
     p.drop_seed = o->drop_seed;
     p.mask = o->relu_mask; p.ldmask = o->ldmask; p.mask_scale = o->mask_scale == 0.f ? 1.f : o->mask_scale;
     p.resid = o->resid; p.ldr = o->ldr; p.colsum = o->colsum;
+    p.batch = o->batch > 1 ? o->batch : 1;
+    p.sA = o->stride_a; p.sB = o->stride_b; p.sC = o->stride_c; p.sBias = o->stride_bias; p.sColsum = o->stride_colsum;
+    p.rowscale = o->rowscale; p.ld_rs = o->ld_rowscale; p.sRs = o->stride_rowscale;
+    HH_REQUIRE(p.batch == 1 || (o->splitk <= 1 && p.batch <= 65535 && p.sA % 4 == 0 && p.sB % 4 == 0 && p.sC % 4 == 0 && p.sBias % 4 == 0 && !o->relu_mask && !o->resid),
+               HH_ERR_UNSUPPORTED, "hh_qgemm_f32x3: the batched form takes no split-K / relu_mask / residual; strides must be multiples of 4");
+    HH_REQUIRE(o->rowscale == nullptr || (mode == 2 ? o->colsum != nullptr : o->bias != nullptr), HH_ERR_UNSUPPORTED,
+               "hh_qgemm_f32x3: rowscale weights the bias (NT / NN) or the column sums (TN): pass the one it applies to");
     const int nk_all = (K + QBK - 1) / QBK;
     int splits = o->splitk > 1 ? o->splitk : 1;
     if (splits > nk_all) splits = nk_all;
@@ -248,7 +266,7 @@ extern "C" int hh_qgemm_f32x3(const float* A, int64_t lda, const float* B, int64
                "hh_qgemm_f32x3: split-K adds partial products atomically into a zeroed C: no epilogue options");
     p.k_per_split = (nk_all + splits - 1) / splits;
     splits = (nk_all + p.k_per_split - 1) / p.k_per_split;
-    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)splits);
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)(p.batch > 1 ? p.batch : splits));
     hipStream_t s = (hipStream_t)stream;
     if (mode == 0) hipLaunchKernelGGL(qgemm_kernel<0>, grid, dim3(256), 0, s, p);
     else if (mode == 1) hipLaunchKernelGGL(qgemm_kernel<1>, grid, dim3(256), 0, s, p);

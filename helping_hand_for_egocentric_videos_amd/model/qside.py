@@ -10,8 +10,11 @@
     the weight gradient's bias column sums are a by-product of the TN GEMM;
   * dropout (p = 0.1 on three residual branches, the FFN hidden layer and both attention maps, tfm_decoder.py:365-380) is a
     counter-based hash of (seed, element index), regenerated in the backward instead of stored;
-  * the cross-attention core between the two halves of a layer is hh_xattn_fwd / hh_xattn_bwd on the K/V column slices that
-    `_MemorySide` (tfm_decoder.py of this package) projected for all layers at once.
+  * the cross-attention core between the two halves of a layer runs in MEMORY SPACE (round 5, csrc/mattn.hip): the projected query of
+    every head is mapped through that head's key rows of in_proj_weight (`ops.head_map_in`, one head-batched launch), attends over the
+    un-projected memory rows (`ops.mattn_fwd`), and the value rows / bias are applied to the 13 pooled rows (`ops.head_map_out`) -- the
+    memory side projects nothing.  The round-1..4 form (hh_xattn_fwd / hh_xattn_bwd on K/V column slices that `_MemorySide` projected
+    for all layers at once) is kept behind `Cross_Attention.kv_free = False`.
 """
 import torch
 from torch import nn
@@ -121,7 +124,8 @@ class QueryStack(torch.autograd.Function):
         qpos = f(query_embed).float()
         P = [[f(t) for t in params[l * NP:(l + 1) * NP]] for l in range(L)]
         M, Lk = holder.M, holder.L
-        kvv = holder.kv.view(B, M, 2 * Lk * C)
+        kv_free = holder.mem is not None                 # memory-space cross-attention (csrc/mattn.hip): no K/V projection of the memory
+        kvv = None if kv_free else holder.kv.view(B, M, 2 * Lk * C)
         tgt_all = torch.empty((L + 1, R, C), dtype=torch.float32, device=dev)
         tgt_all[0].zero_()
         saved = []
@@ -137,13 +141,24 @@ class QueryStack(torch.autograd.Function):
             tgt1 = ops.qgemm(o, wo_s, ops.NT, bias=bo_s, drop_p=p, drop_seed=sd("d1"), resid=x)
             _, cq, mean2, rstd2 = ops.layernorm_pos(tgt1, n2w, n2b, eps, qpos, save_stats=True)
             q = ops.qgemm(cq, wi_c[:C], ops.NT, bias=bi_c[:C], scale=0.125)                             # (norm2 + query_pos).Wq, scaled d^-1/2
-            k, v = kvv[:, :, l * C:(l + 1) * C], kvv[:, :, (Lk + l) * C:(Lk + l + 1) * C]
-            ca, lse = ops.xattn_fwd(q.view(B, Q, C), k, v, heads, p, sd("x"))
+            if kv_free:
+                # scores q_h.(mp Wk_h^T + bk_h) = (q_h Wk_h).mp + const: map the 13 rows of every head into memory space, attend over the
+                # un-projected rows, apply Wv_h / bv_h to the 13 pooled rows (tfm_decoder.py:438-441; csrc/mattn.hip)
+                qt = ops.head_map_in(q, wi_c[C:2 * C])                                                      # [R, heads * C]
+                pooled, lse, rsum = ops.mattn_fwd(qt, holder.mp, holder.mem, Q, p, sd("x"))
+                ca = ops.head_map_out(pooled, wi_c[2 * C:], bias=bi_c[2 * C:], rowscale=rsum if p > 0 else None)
+                xs = (qt, pooled, rsum)
+            else:
+                k, v = kvv[:, :, l * C:(l + 1) * C], kvv[:, :, (Lk + l) * C:(Lk + l + 1) * C]
+                ca, lse = ops.xattn_fwd(q.view(B, Q, C), k, v, heads, p, sd("x"))
+                xs = None
             tgt2 = ops.qgemm(ca.view(R, C), wo_c, ops.NT, bias=bo_c, drop_p=p, drop_seed=sd("d2"), resid=tgt1)
             e, mean3, rstd3 = ops.layernorm(tgt2, n3w, n3b, eps, out_dtype=torch.float32, save_stats=True)
             hid = ops.qgemm(e, w1, ops.NT, bias=b1, relu=True, drop_p=p, drop_seed=sd("ff"))
             ops.qgemm(hid, w2, ops.NT, bias=b2, drop_p=p, drop_seed=sd("d3"), resid=tgt2, out=tgt_all[l + 1])
-            saved.append((a, aq, mean1, rstd1, qkv, o, tgt1, cq, mean2, rstd2, q, ca, lse, tgt2, e, mean3, rstd3, hid))
+            if holder.keep:                              # test hook: which FFN units are active (the branch of the ReLU this step differentiates)
+                holder.relu_masks.append(hid > 0)
+            saved.append((a, aq, mean1, rstd1, qkv, o, tgt1, cq, mean2, rstd2, q, ca, lse, tgt2, e, mean3, rstd3, hid, xs))
         hs, dmean, drstd = ops.layernorm(tgt_all[1:].reshape(L * R, C), f(dnw), f(dnb), eps, out_dtype=torch.float32, save_stats=True)
         ctx.holder, ctx.dims, ctx.eps, ctx.p = holder, (L, B, Q, C, heads), eps, p
         ctx.P, ctx.saved, ctx.tgt_all, ctx.dec = P, saved, tgt_all, (f(dnw), dmean, drstd)
@@ -178,17 +193,21 @@ class QueryStack(torch.autograd.Function):
         ln_b = lambda l, k: sv(l, (1, 7, 13)[k]) if sunk else lnbuf[l * 3 + k, 1]
         dn_w, dn_b = (sinks[0].view, sinks[1].view) if sunk else (lnbuf[L * 3, 0], lnbuf[L * 3, 1])
         new = lambda l, i, *shape: sv(l, i) if sunk else torch.empty(shape, dtype=torch.float32, device=dev)
-        if h.dkv is None:
-            h.dkv = torch.empty_like(h.kv)
+        kv_free = h.mem is not None
         M, Lk = h.M, h.L
-        kvv, dkvv = h.kv.view(B, M, 2 * Lk * C), h.dkv.view(B, M, 2 * Lk * C)
+        if kv_free:
+            pdT, dsT, qt16, dp16 = h.bwd_buffers()
+        else:
+            if h.dkv is None:
+                h.dkv = torch.empty_like(h.kv)
+            kvv, dkvv = h.kv.view(B, M, 2 * Lk * C), h.dkv.view(B, M, 2 * Lk * C)
         keep = 1.0 / (1.0 - p) if p > 0 else 1.0
         grads = [None] * (L * NP)
         dqpos_parts = []
         g = None
         for l in reversed(range(L)):
             n1w, n1b, wi_s, bi_s, wo_s, bo_s, n2w, n2b, wi_c, bi_c, wo_c, bo_c, n3w, n3b, w1, b1, w2, b2 = ctx.P[l]
-            a, aq, mean1, rstd1, qkv, o, tgt1, cq, mean2, rstd2, q, ca, lse, tgt2, e, mean3, rstd3, hid = ctx.saved[l]
+            a, aq, mean1, rstd1, qkv, o, tgt1, cq, mean2, rstd2, q, ca, lse, tgt2, e, mean3, rstd3, hid, xs = ctx.saved[l]
             sd = lambda site: _seed(h.seed, l, site)
             x, tgt3 = ctx.tgt_all[l], ctx.tgt_all[l + 1]
             # decoder.norm of this layer's output (+ the gradient arriving from layer l + 1)
@@ -207,12 +226,25 @@ class QueryStack(torch.autograd.Function):
             dbo_c = new(l, 11, C)
             dwo_c = ops.qgemm(g2, ca.view(R, C), ops.TN, colsum=dbo_c, out=sv(l, 10) if sunk else None, **drop("d2"))
             dca = ops.qgemm(g2, wo_c, ops.NN, **drop("d2"))
-            k, v = kvv[:, :, l * C:(l + 1) * C], kvv[:, :, (Lk + l) * C:(Lk + l + 1) * C]
-            dk, dv = dkvv[:, :, l * C:(l + 1) * C], dkvv[:, :, (Lk + l) * C:(Lk + l + 1) * C]
-            dq = ops.xattn_bwd(q.view(B, Q, C), k, v, ca, lse, dca.view(B, Q, C), dk, dv, heads, p, sd("x")).view(R, C)
-            # query rows of the cross-attention in-projection; its key / value rows are written by _MemorySide (which also reports
-            # the parameter as final when both halves went straight into the arena)
-            ops.qgemm(dq, cq, ops.TN, a_scale=0.125, colsum=(sv(l, 9) if sunk else d_bi_c[l])[:C], out=(sv(l, 8) if sunk else d_wi_c[l])[:C])
+            gw_c, gb_c = (sv(l, 8), sv(l, 9)) if sunk else (d_wi_c[l], d_bi_c[l])       # gradient of this layer's packed [q; k; v] in-projection
+            if kv_free:
+                qt, pooled, rsum = xs
+                rs = rsum if p > 0 else None
+                # head output O_h = pooled_h Wv_h^T + rsum_h bv_h:  d pooled, d Wv (value rows), d bv as the TN product's column sums
+                dpooled = ops.head_map_in(dca, wi_c[2 * C:])
+                ops.head_map_wgrad(dca, pooled, gw_c[2 * C:], colsum=gb_c[2 * C:], rowscale=rs)
+                # attention core in memory space: d qt; Pd^T / dS^T of this layer for _MemorySideKVFree's batched d-memory GEMM
+                dqt = ops.mattn_bwd(qt, dpooled, lse, dca, ca, bi_c[2 * C:], h.mp, h.mem, Q, pdT, dsT, qt16, dp16, l * 128, p, sd("x"))
+                # qt_h = q_h Wk_h:  d q, d Wk (key rows); the key bias drops out of the softmax -- its gradient is exactly 0 (the rows stay zero)
+                dq = ops.head_map_out(dqt, wi_c[C:2 * C])
+                ops.head_map_wgrad(q, dqt, gw_c[C:2 * C])
+            else:
+                k, v = kvv[:, :, l * C:(l + 1) * C], kvv[:, :, (Lk + l) * C:(Lk + l + 1) * C]
+                dk, dv = dkvv[:, :, l * C:(l + 1) * C], dkvv[:, :, (Lk + l) * C:(Lk + l + 1) * C]
+                dq = ops.xattn_bwd(q.view(B, Q, C), k, v, ca, lse, dca.view(B, Q, C), dk, dv, heads, p, sd("x")).view(R, C)
+            # query rows of the cross-attention in-projection (K/V path: its key / value rows are written by _MemorySide, which also
+            # reports the parameter as final when both halves went straight into the arena)
+            ops.qgemm(dq, cq, ops.TN, a_scale=0.125, colsum=gb_c[:C], out=gw_c[:C])
             dcq = ops.qgemm(dq, wi_c[:C], ops.NN, a_scale=0.125)
             g1 = ops.layernorm_bwd_add(tgt1, n2w, mean2, rstd2, dcq, g2, ln_w(l, 1), ln_b(l, 1))
             # self-attention:  tgt1 = x + drop1(o.Wo^T + bo),  o = attn(q = k = aq.W[:2C], v = a.W[2C:]),  a = norm1(x), aq = a + qpos
@@ -237,9 +269,9 @@ class QueryStack(torch.autograd.Function):
             # everything is in the arena: report the parameters final (bucket all-reduces may start), except the cross-attention
             # in-projections, whose key / value rows _MemorySide.backward still has to write
             for i, s_ in enumerate(sinks):
-                if i < 2 or (i - 2) % NP not in (8, 9):
+                if kv_free or i < 2 or (i - 2) % NP not in (8, 9):
                     s_.done()
-            h.q_rows_sunk = True
+            h.q_rows_sunk = not kv_free
             return (dquery, torch.zeros(1, dtype=torch.float32, device=dev), None, None, None, None, None, None, None, *grads)
         return (dquery, torch.zeros(1, dtype=torch.float32, device=dev), lnbuf[L * 3, 0], lnbuf[L * 3, 1], None, None, None, None, None, *grads)
 

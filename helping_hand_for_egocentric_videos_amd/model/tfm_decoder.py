@@ -35,15 +35,35 @@ def _require_gpu(x, who):
 
 
 class _KVHolder:
-    """K/V of all layers [B*M, 2*L*C] bf16 (K columns first) and its gradient buffer."""
+    """What the memory side hands the six cross-attention layers, and what they hand back.
+
+    kv_free (default, round 5): `mem` = pre_norm(proj(x)) and `mp` = mem + pos, bf16 [B, M, C] -- the un-projected rows every layer and
+    head attends over (csrc/mattn.hip); the backward of the layers leaves Pd^T / dS^T (`pdT`, `dsT`: bf16 [B, L*128, M]) and the bf16
+    mapped queries / pooled-row gradients (`qt16`, `dp16`: bf16 [B, L*128, C]) for ONE batched GEMM in _MemorySideKVFree.backward.
+    Otherwise (the round-1..4 path, kept for A/B measurements and for M % 128 != 0): K/V of all layers [B*M, 2*L*C] bf16 (K columns
+    first) and its gradient buffer."""
 
     def __init__(self):
         self.kv = None
         self.dkv = None
+        self.mem = self.mp = None
+        self.pdT = self.dsT = self.qt16 = self.dp16 = None
         self.B = self.M = self.C = self.L = 0
         self.seed = 0
         self.keep, self.kept = False, None
+        self.relu_masks = []             # keep only: per layer, the active units of the FFN hidden layer [B*Q, ffn] (tests/test_step_gpu.py)
         self.q_rows_sunk = False         # QueryStack.backward wrote the query rows of every cross-attention in-projection gradient into the arena
+
+    def bwd_buffers(self):
+        """Pd^T / dS^T / bf16 operand rows of all layers, allocated by the first layer whose backward runs (every layer writes its own 128
+        rows -- all 16 query slots of all 8 heads, zeros beyond Q -- so nothing needs clearing)."""
+        if self.pdT is None:
+            dev, rows = self.mem.device, self.L * 128
+            self.pdT = torch.empty((self.B, rows, self.M), dtype=torch.bfloat16, device=dev)
+            self.dsT = torch.empty_like(self.pdT)
+            self.qt16 = torch.empty((self.B, rows, self.C), dtype=torch.bfloat16, device=dev)
+            self.dp16 = torch.empty_like(self.qt16)
+        return self.pdT, self.dsT, self.qt16, self.dp16
 
 
 class _MemorySide(torch.autograd.Function):
@@ -134,32 +154,55 @@ class _MemorySide(torch.autograd.Function):
         return (None, dw_proj, dg, db, dpos, None, None, *gw, *gb)
 
 
-class _XAttn(torch.autograd.Function):
-    """softmax(q.K^T).V of one layer on the holder's K/V column slices (q fp32 [B,Q,C], pre-scaled)."""
+class _MemorySideKVFree(torch.autograd.Function):
+    """features -> proj -> pre_norm -> (memory, memory + pos) and NOTHING else: no key / value projection of the M memory tokens
+    (tfm_decoder.py:438-441 evaluated in memory space, csrc/mattn.hip).  Returns a 1-element token the query stack consumes, so that
+    this node's backward runs after the layers' backward has left Pd^T / dS^T of every layer in the holder:
+        d memory = sum_layers Pd^T dpooled + dS^T qt          ONE batched TN GEMM over [6 x 128 rows] per clip
+        d pos    = sum_clips  dS^T qt                          one split-K TN GEMM over [B x 6 x 128 rows]
+    then the LayerNorm backward and the weight gradient of the memory projection as before."""
 
     @staticmethod
-    def forward(ctx, q, token, holder, layer, heads, dropout_p, seed):
-        B, M, C, L = holder.B, holder.M, holder.C, holder.L
-        kvv = holder.kv.view(B, M, 2 * L * C)
-        k, v = kvv[:, :, layer * C:(layer + 1) * C], kvv[:, :, (L + layer) * C:(L + layer + 1) * C]
-        q = q.contiguous()
-        out, lse = ops.xattn_fwd(q, k, v, heads, dropout_p, seed)
-        ctx.holder, ctx.layer, ctx.heads, ctx.p, ctx.seed = holder, layer, heads, dropout_p, seed
-        ctx.save_for_backward(q, out, lse)
-        return out
+    def forward(ctx, feat_b, w_proj, g_pre, b_pre, pos, holder, eps, L):
+        C = w_proj.shape[0]
+        BM = feat_b.shape[0]
+        M = pos.shape[0]
+        B = BM // M
+        mem0 = ops.gemm(feat_b, ops.to_bf16(w_proj.detach()), out_dtype=torch.float32)                   # [BM, C]
+        memory, mem_pos, mean, rstd = ops.layernorm_pos(mem0, g_pre.detach().float(), b_pre.detach().float(), eps,
+                                                        pos.detach().float().contiguous(), out_dtype=torch.bfloat16, save_stats=True)
+        holder.mem, holder.mp = memory.view(B, M, C), mem_pos.view(B, M, C)
+        holder.B, holder.M, holder.C, holder.L = B, M, C, L
+        ctx.holder = holder
+        ctx.param_objs = (w_proj, g_pre, b_pre)
+        ctx.save_for_backward(feat_b, mem0, mean, rstd, g_pre)
+        return torch.zeros(1, dtype=torch.float32, device=feat_b.device)
 
     @staticmethod
-    def backward(ctx, dout):
-        q, out, lse = ctx.saved_tensors
-        h, l = ctx.holder, ctx.layer
+    def backward(ctx, _gtoken):
+        feat_b, mem0, mean, rstd, g_pre = ctx.saved_tensors
+        h = ctx.holder
         B, M, C, L = h.B, h.M, h.C, h.L
-        if h.dkv is None:
-            h.dkv = torch.empty_like(h.kv)
-        kvv, dkvv = h.kv.view(B, M, 2 * L * C), h.dkv.view(B, M, 2 * L * C)
-        k, v = kvv[:, :, l * C:(l + 1) * C], kvv[:, :, (L + l) * C:(L + l + 1) * C]
-        dk, dv = dkvv[:, :, l * C:(l + 1) * C], dkvv[:, :, (L + l) * C:(L + l + 1) * C]
-        dq = ops.xattn_bwd(q, k, v, out, lse, dout.contiguous(), dk, dv, ctx.heads, ctx.p, ctx.seed)
-        return dq, torch.zeros(1, dtype=torch.float32, device=q.device), None, None, None, None, None
+        if h.pdT is None:                      # no cross-attention gradient reached us
+            dmem = torch.zeros((B * M, C), dtype=torch.float32, device=feat_b.device)
+            dpos = torch.zeros((M, C), dtype=torch.float32, device=feat_b.device)
+        else:
+            dmem = ops.gemm_tn_batched2(h.pdT, h.dp16, h.dsT, h.qt16).view(B * M, C)                     # d(memory) incl. the key path
+            dpos = ops.gemm_tn(h.dsT.view(B * L * 128, M), h.qt16.view(B * L * 128, C))                  # d(pos) = sum over clips of the key path
+        dmem0, dg, db = ops.layernorm_bwd(mem0, g_pre.detach().float(), mean, rstd, dmem)
+        dw_proj = ops.gemm_tn(ops.to_bf16(dmem0), feat_b)                                                  # [C, F]
+        if h.keep:
+            h.kept = {"mem": h.mem, "mp": h.mp, "dmem": dmem, "dpos": dpos, "relu_masks": h.relu_masks}        # test hook (Cross_Attention.debug_keep_kv)
+        h.mem = h.mp = h.pdT = h.dsT = h.qt16 = h.dp16 = None
+        sinks = [getattr(t, "_hh_sink", None) for t in ctx.param_objs]
+        if all(s is not None and s.armed() for s in sinks):
+            for s_ in sinks:
+                s_.claim()
+            torch._foreach_copy_([s_.view for s_ in sinks], [dw_proj, dg, db])
+            for s_ in sinks:
+                s_.done()
+            return (None, None, None, None, dpos, None, None, None)
+        return (None, dw_proj, dg, db, dpos, None, None, None)
 
 
 class _LinearBF16(torch.autograd.Function):
@@ -290,11 +333,6 @@ class TransformerDecoderLayer(nn.Module):
         o = (p @ v).transpose(1, 2).reshape(B, Q, C)
         return linear_x3(o, m.out_proj.weight, m.out_proj.bias)
 
-    def forward_tokens(self, tgt, qpos, token, holder, layer_idx):
-        """Batch-first forward_pre (tfm_decoder.py:430-461) on the holder's batched K/V: tgt, qpos [B,Q,C] fp32."""
-        p = self.p_attn if self.training else 0.0
-        return self._attend(tgt, qpos, lambda q: _XAttn.apply(q, token, holder, layer_idx, self.nhead, p, holder.seed + 7919 * layer_idx))
-
     def _attend(self, tgt, qpos, xattn):
         """forward_pre with sa_first (tfm_decoder.py:430-461) on batch-first fp32 [B,Q,C]; `xattn(q)` is the cross-attention core
         of this layer (q already projected and scaled)."""
@@ -386,16 +424,6 @@ class TransformerDecoder(nn.Module):
             return torch.stack(intermediate), [], []
         return output.unsqueeze(0), [], []
 
-    def forward_tokens(self, tgt, qpos, token, holder):
-        inter = []
-        for i, layer in enumerate(self.layers):
-            tgt = layer.forward_tokens(tgt, qpos, token, holder, i)
-            if self.return_intermediate:
-                inter.append(self.norm(tgt))
-        if self.return_intermediate:
-            return torch.stack(inter)                  # [L,B,Q,C]
-        return self.norm(tgt).unsqueeze(0)
-
 
 class Cross_Attention(nn.Module):
     """tfm_decoder.py:50-93."""
@@ -413,8 +441,11 @@ class Cross_Attention(nn.Module):
         self._reset_parameters()
         self.d_model, self.nhead = d_model, nhead
         self.dec_layers, self.enc_layers = num_decoder_layers, num_encoder_layers
-        self.use_query_stack = True
-        self.debug_keep_kv, self.last_holder = False, None        # tests: keep the batched K/V and their gradients after backward
+        # kv_free (default): the cross-attention runs in memory space (csrc/mattn.hip) -- no K/V projection of the memory tokens.  False:
+        # the round-1..4 path (one batched K/V in-projection for all layers + hh_xattn_*), kept for same-session A/B measurements; it is
+        # also what runs when the clip's token count is not a multiple of 128 (the batched d-memory GEMM's tile)
+        self.kv_free = True
+        self.debug_keep_kv, self.last_holder = False, None        # tests: keep the memory rows / K/V and their gradients after backward
         self._seed = None            # dropout-mask stream of the cross-attention kernels; see next_dropout_seed()
 
     def _reset_parameters(self):
@@ -440,16 +471,14 @@ class Cross_Attention(nn.Module):
         holder.keep = self.debug_keep_kv
         self.last_holder = holder if self.debug_keep_kv else None
         layers = self.decoder.layers
-        in_w = [l.multihead_attn.in_proj_weight for l in layers]
-        in_b = [l.multihead_attn.in_proj_bias for l in layers]
-        token = _MemorySide.apply(feat_b, w_proj, self.pre_norm.weight, self.pre_norm.bias, pos, holder,
-                                  self.pre_norm.eps, *in_w, *in_b)
-        if not self.use_query_stack:                  # A/B only: per-op autograd path (the round-1 structure; torch RNG dropout)
-            qp = query_embed.unsqueeze(0).expand(B, -1, -1)
-            hs = self.decoder.forward_tokens(torch.zeros_like(qp), qp, token, holder)
-            if not torch.is_grad_enabled():
-                holder.kv = None
-            return hs
+        kv_free = self.kv_free and pos.shape[0] % 128 == 0
+        if kv_free:
+            token = _MemorySideKVFree.apply(feat_b, w_proj, self.pre_norm.weight, self.pre_norm.bias, pos, holder, self.pre_norm.eps, len(layers))
+        else:
+            in_w = [l.multihead_attn.in_proj_weight for l in layers]
+            in_b = [l.multihead_attn.in_proj_bias for l in layers]
+            token = _MemorySide.apply(feat_b, w_proj, self.pre_norm.weight, self.pre_norm.bias, pos, holder,
+                                      self.pre_norm.eps, *in_w, *in_b)
         # the 13-row query side of all six layers + decoder.norm: one autograd node on libhh kernels (model/qside.py)
         p = layers[0].p_attn if self.training else 0.0
         norm = self.decoder.norm
@@ -457,7 +486,7 @@ class Cross_Attention(nn.Module):
         if not self.decoder.return_intermediate:
             hs = hs[-1:]
         if not torch.is_grad_enabled():
-            holder.kv = None
+            holder.kv = holder.mem = holder.mp = None
         return hs
 
     def forward(self, src, mask, query_embed, pos_embed):

@@ -482,6 +482,144 @@ def text_attention(qkv, S, L, heads):
     return out
 
 
+# ---- decoder cross-attention without the memory-side K/V projections (include/hh.h: hh_mattn_*, csrc/mattn.hip) -------------------
+MATTN_H, MATTN_C = 8, 512
+
+
+def _head_qgemm(mode, a, lda, sa, b, ldb, sb, c, ldc, sc, M, N, K, *, bias=None, sbias=0, rowscale=None, ld_rs=0, s_rs=0, colsum=None, scolsum=0):
+    o = QGemmOpts()
+    o.batch = MATTN_H
+    o.stride_a, o.stride_b, o.stride_c = int(sa), int(sb), int(sc)
+    o.bias = bias.data_ptr() if bias is not None else None
+    o.stride_bias = int(sbias)
+    o.rowscale = rowscale.data_ptr() if rowscale is not None else None
+    o.ld_rowscale, o.stride_rowscale = int(ld_rs), int(s_rs)
+    o.colsum = colsum.data_ptr() if colsum is not None else None
+    o.stride_colsum = int(scolsum)
+    _lib.check(_lib.lib().hh_qgemm_f32x3(_p(a), int(lda), _p(b), int(ldb), _p(c), int(ldc), int(M), int(N), int(K), int(mode), ctypes.byref(o), _stream()),
+               "hh_qgemm_f32x3(batched)")
+
+
+def _f32_2d(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("libhh ops need GPU tensors (got device %s); there is no CPU fallback" % t.device)
+        if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+            raise RuntimeError("head-batched qgemm: operands must be fp32, 2-D, unit inner stride, 16-byte aligned rows")
+
+
+def head_map_in(x, w, out=None):
+    """out[r, h, :] = x[r, 64 h : 64 h + 64] @ w[64 h : 64 h + 64, :]  for the 8 heads in ONE launch (hh_qgemm_f32x3, batched NN):
+    x fp32 [R, 512] (the head-major columns of a projected query / of a head-output gradient), w fp32 [512, 512] = the key / value rows
+    of nn.MultiheadAttention.in_proj_weight (row-strided view) -> fp32 [R, 8 * 512]: the rows mapped INTO memory space."""
+    _f32_2d(x, w, out)
+    R, H, C = x.shape[0], MATTN_H, MATTN_C
+    if x.shape[1] != H * 64 or tuple(w.shape) != (H * 64, C):
+        raise ValueError("head_map_in: x [R, 512], w [512, 512]")
+    if out is None:
+        out = torch.empty((R, H * C), dtype=torch.float32, device=x.device)
+    _head_qgemm(NN, x, x.stride(0), 64, w, w.stride(0), 64 * w.stride(0), out, out.stride(0), C, R, C, 64)
+    return out
+
+
+def head_map_out(y, w, bias=None, rowscale=None, out=None):
+    """out[r, 64 h + n] = y[r, h, :] . w[64 h + n, :] (+ bias[64 h + n] * rowscale[r, h])  (batched NT): y fp32 [R, 8 * 512] rows in memory
+    space (pooled rows / mapped-query gradients), w fp32 [512, 512] value / key rows of in_proj_weight -> fp32 [R, 512] head-major."""
+    _f32_2d(y, w, out, rowscale)
+    _chk(bias)
+    R, H, C = y.shape[0], MATTN_H, MATTN_C
+    if y.shape[1] != H * C or tuple(w.shape) != (H * 64, C):
+        raise ValueError("head_map_out: y [R, 8 * 512], w [512, 512]")
+    if out is None:
+        out = torch.empty((R, H * 64), dtype=torch.float32, device=y.device)
+    _head_qgemm(NT, y, y.stride(0), C, w, w.stride(0), 64 * w.stride(0), out, out.stride(0), 64, R, 64, C, bias=bias, sbias=64,
+                rowscale=rowscale if bias is not None else None, ld_rs=rowscale.stride(0) if rowscale is not None else 0, s_rs=1)
+    return out
+
+
+def head_map_wgrad(x, y, out, colsum=None, rowscale=None):
+    """out[64 h + m, :] = sum_r x[r, 64 h + m] y[r, h, :]  (batched TN; the key / value rows of d in_proj_weight), optionally
+    colsum[64 h + m] = sum_r x[r, 64 h + m] * rowscale[r, h] (the value-bias gradient).  x fp32 [R, 512], y fp32 [R, 8 * 512],
+    out fp32 [512, 512] (row-strided view)."""
+    _f32_2d(x, y, out, rowscale)
+    _chk(colsum)
+    R, H, C = x.shape[0], MATTN_H, MATTN_C
+    if x.shape[1] != H * 64 or y.shape != (R, H * C) or tuple(out.shape) != (H * 64, C):
+        raise ValueError("head_map_wgrad: x [R, 512], y [R, 8 * 512], out [512, 512]")
+    _head_qgemm(TN, x, x.stride(0), 64, y, y.stride(0), C, out, out.stride(0), 64 * out.stride(0), 64, C, R, colsum=colsum, scolsum=64,
+                rowscale=rowscale if colsum is not None else None, ld_rs=rowscale.stride(0) if rowscale is not None else 0, s_rs=1)
+    return out
+
+
+def mattn_slices(B, M, wanted=None):
+    """Key slices of hh_mattn_fwd / hh_mattn_bwd: two workgroups (of 8 waves, one per CU) per (clip, slice) -- enough slices to give every
+    CU one, at least four 32-key chunks per slice."""
+    if wanted is None:
+        wanted = min(max(1, (128 + B - 1) // max(B, 1)), max(1, (M // 32) // 4))
+    s = _lib.lib().hh_mattn_slices(int(M), int(wanted))
+    if s < 1:
+        raise ValueError("mattn: M must be a positive multiple of 32 (M=%d)" % M)
+    return s
+
+
+def _mattn_mem(mp, mem):
+    for t in (mp, mem):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 3 or t.stride(2) != 1 or t.shape[2] != MATTN_C or t.stride(0) != t.shape[1] * t.stride(1):
+            raise RuntimeError("mattn: mp / mem must be bf16 GPU tensors [B, M, 512] with unit column stride and dense batch stride")
+    if mp.shape != mem.shape or mp.stride(1) != mem.stride(1):
+        raise RuntimeError("mattn: mp and mem must share shape and row stride")
+
+
+def mattn_fwd(qt, mp, mem, Q, dropout_p=0.0, seed=0, slices=None):
+    """qt fp32 [B*Q, 8*512] (mapped queries), mp / mem bf16 [B, M, 512] -> (pooled fp32 [B*Q, 8*512], lse2 fp32 [B*Q, 8], rsum fp32 [B*Q, 8])."""
+    _chk(qt)
+    _mattn_mem(mp, mem)
+    B, M, _ = mp.shape
+    if qt.dtype != torch.float32 or tuple(qt.shape) != (B * Q, MATTN_H * MATTN_C):
+        raise ValueError("mattn_fwd: qt must be fp32 [B*Q, 8*512]")
+    S = mattn_slices(B, M, slices)
+    pooled = torch.empty_like(qt)
+    lse2 = torch.empty((B * Q, MATTN_H), dtype=torch.float32, device=qt.device)
+    rsum = torch.empty_like(lse2)
+    ws = _workspace("mattn_fwd", B, Q, S, device=qt.device) if S > 1 else None
+    _lib.check(_lib.lib().hh_mattn_fwd(_p(qt), _p(mp), _p(mem), mp.stride(1), _p(pooled), _p(lse2), _p(rsum), _p(ws), S, B, Q, M, MATTN_H, MATTN_C,
+                                       float(dropout_p), int(seed) & 0xFFFFFFFF, _stream()), "hh_mattn_fwd")
+    return pooled, lse2, rsum
+
+
+def mattn_bwd(qt, dpooled, lse2, dca, ca, bv, mp, mem, Q, pdT, dsT, qt16, dp16, row_off, dropout_p=0.0, seed=0, slices=None):
+    """Backward of mattn_fwd for one layer: returns dqt fp32 [B*Q, 8*512]; writes this layer's 128 rows (row_off + head*16 + query) of
+    pdT / dsT (bf16 [B, rows, M]) and of qt16 / dp16 (bf16 [B, rows, 512]) -- the operands of gemm_tn_batched2."""
+    _chk(qt, dpooled, lse2, dca, ca, bv, pdT, dsT, qt16, dp16)
+    _mattn_mem(mp, mem)
+    B, M, _ = mp.shape
+    rows = pdT.shape[1]
+    if pdT.dtype != torch.bfloat16 or tuple(pdT.shape) != (B, rows, M) or dsT.shape != pdT.shape or tuple(qt16.shape) != (B, rows, MATTN_C) or dp16.shape != qt16.shape:
+        raise ValueError("mattn_bwd: pdT / dsT bf16 [B, rows, M], qt16 / dp16 bf16 [B, rows, 512]")
+    S = mattn_slices(B, M, slices)
+    part = _workspace("mattn_bwd", B, Q, S, device=qt.device).view(S, B * Q, MATTN_H * MATTN_C)
+    _lib.check(_lib.lib().hh_mattn_bwd(_p(qt), _p(dpooled), _p(lse2), _p(dca), _p(ca), _p(bv), _p(mp), _p(mem), mp.stride(1), _p(part), S, _p(pdT), _p(dsT),
+                                       _p(qt16), _p(dp16), rows, int(row_off), B, Q, M, MATTN_H, MATTN_C, float(dropout_p), int(seed) & 0xFFFFFFFF,
+                                       _stream()), "hh_mattn_bwd")
+    return part[0] if S == 1 else part.sum(0)
+
+
+def gemm_tn_batched2(at, bt, at2=None, bt2=None):
+    """C[z] fp32 [M, N] = at[z]^T @ bt[z] (+ at2[z]^T @ bt2[z]):  at bf16 [batch, K, M], bt bf16 [batch, K, N], contiguous
+    (include/hh.h: hh_gemm_tn_bf16_batched2) -> fp32 [batch, M, N]."""
+    _chk(at, bt, at2, bt2)
+    Bn, K, M = at.shape
+    N = bt.shape[2]
+    if at.dtype != torch.bfloat16 or bt.dtype != torch.bfloat16 or tuple(bt.shape) != (Bn, K, N) or (at2 is not None and (at2.shape != at.shape or bt2.shape != bt.shape)):
+        raise ValueError("gemm_tn_batched2: at [batch, K, M], bt [batch, K, N] bf16 (second pair: same shapes)")
+    out = torch.empty((Bn, M, N), dtype=torch.float32, device=at.device)
+    _lib.check(_lib.lib().hh_gemm_tn_bf16_batched2(_p(at), _p(bt), _p(at2), _p(bt2), M, N, K * M, K * N, _p(out), M * N, M, N, K, Bn, _stream()),
+               "hh_gemm_tn_bf16_batched2")
+    return out
+
+
 def xattn_fwd(q, k, v, heads, dropout_p=0.0, seed=0, splits=None):
     """q fp32 [B,Q,C] (pre-scaled); k, v bf16 [B,M,C] views with a common row stride -> (out fp32 [B,Q,C], lse [B,h,Q]).
     `splits` > 1 cuts the keys into slices (one workgroup per (clip, head, slice)); the default does so only when B*heads leaves

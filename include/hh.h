@@ -114,6 +114,10 @@ int64_t hh_workspace_bytes_gemm_zstats(int64_t M, int N);      /* `z_partials` o
 int64_t hh_workspace_bytes_gemm_tn(int M, int N, int splits);
 int64_t hh_workspace_bytes_xattn_bwd(int B, int Q, int heads, int dq_splits);
 int64_t hh_workspace_bytes_xattn_fwd(int B, int Q, int heads, int splits);
+/*   mattn_fwd        : `workspace` of hh_mattn_fwd, slices > 1 (fp32 [slices, B*Q, 8, 512 + 4] partial pooled rows + statistics)
+ *   mattn_bwd        : `dqt_partials` of hh_mattn_bwd          (fp32 [slices, B*Q, 8 * 512]) */
+int64_t hh_workspace_bytes_mattn_fwd(int B, int Q, int slices);
+int64_t hh_workspace_bytes_mattn_bwd(int B, int Q, int slices);
 int64_t hh_workspace_bytes_attn_cls_partial(int B, int T, int n, int heads, int time_mode);
 
 /* ---- LayerNorm over the last dim (model/LaviLa.py:439,456 eps 1e-6 / 1e-5; tfm_decoder.py:57,375-377)
@@ -215,6 +219,12 @@ int hh_embed_ln_pre(const float* tok, const float* cls, const float* pos, const 
  * sum over the s-th token slice of At[k, m] -- the bias gradient of the nn.Linear whose dY is At -- as a by-product. */
 int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int64_t ldb, float* partials, float* colsum_partials, int M, int N,
                     int64_t K, int splits, hh_stream_t stream);
+/* batched two-pair form:  C_z [M, N] fp32 (dense, batch stride stride_c) = At_z^T Bt_z + At2_z^T Bt2_z  for z = 0 .. batch - 1; operand z
+ * of a pair sits at + z * stride_a / + z * stride_b elements; both pairs share lda / ldb / K; At2 = Bt2 = NULL: one pair.  No split-K (K
+ * is short here: the rows of hh_mattn_bwd's Pd^T / dS^T), K % 64 == 0 with two pairs.  The memory-side gradient of the decoder's
+ * cross-attention over all six layers (tfm_decoder.py:433-441 backward) in one launch. */
+int hh_gemm_tn_bf16_batched2(const void* At, const void* Bt, const void* At2, const void* Bt2, int64_t lda, int64_t ldb, int64_t stride_a,
+                             int64_t stride_b, float* C, int64_t stride_c, int M, int N, int64_t K, int batch, hh_stream_t stream);
 
 /* ---- divided space-time attention cores (model/LaviLa.py:246-283, attn() :194-198)
  * qkv bf16 [B, N=1+T*n, 3*D] (q|k|v, head-major inside D) or its head-major planes (qkv_layout: enum hh_qkv_layout), out bf16
@@ -255,6 +265,29 @@ int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_t ldkv, con
                  const float* dout, float* dq, int dq_splits, void* dk, void* dv, int64_t lddkv,
                  int B, int Q, int M, int heads, float dropout_p, uint32_t seed, hh_stream_t stream);
 
+/* ---- decoder cross-attention WITHOUT the memory-side K/V projections (round 5; tfm_decoder.py:433-441; csrc/mattn.hip).
+ * q_h . ((memory + pos) Wk_h^T + bk_h) = (q_h Wk_h) . (memory + pos) + const  and  sum_i p_i (memory_i Wv_h^T + bv_h) = (sum_i p_i memory_i) Wv_h^T
+ * + (sum_i p_i) bv_h:  the caller maps the query rows of every head into memory space (qt = q_h Wk_h: a head-batched hh_qgemm_f32x3),
+ * these kernels attend over the UN-projected rows, and the caller applies Wv_h / bv_h to the pooled rows.  d_model 512, 8 heads (the
+ * reference's decoder, tfm_decoder.py:51); Q <= 16; M % 32 == 0.
+ *   qt fp32 [B*Q, 8*512]: row (clip, query), columns head*512 + k (already scaled by d^-1/2);  mp = memory + pos, mem = memory: bf16 [B, M, ld]
+ *   forward:  pooled fp32 [B*Q, 8*512] = sum_i Pd[., i] mem[i, :],  Pd = dropout(softmax_i(qt . mp[i]));  lse2 fp32 [B*Q, 8] = log2 sum_i
+ *             2^(score_i log2 e) (for the backward);  rsum fp32 [B*Q, 8] = sum_i Pd (1 without dropout: the weight of the value bias).
+ *             The keys are cut into `slices` slices (one workgroup of 8 waves per (clip, 4 heads, slice)), merged by a second launch when
+ *             slices > 1 (workspace: hh_workspace_bytes_mattn_fwd).  hh_mattn_slices(M, wanted) = the slice count actually used.
+ *   backward: dqt_partials fp32 [slices, B*Q, 8*512] (the caller sums the planes) = sum_i dS[., i] mp[i, :] with dS = P o (dP - delta),
+ *             dP = mask/(1-p) o (dpooled . mem[i] + dca . bv), delta = dca . ca per head (dca / ca fp32 [B*Q, 512]: gradient and value of
+ *             the head outputs, bv fp32 [512] the layer's value bias);  pdT / dsT bf16 [B, rows_total, M]: rows [row_off, row_off + 128)
+ *             (row_off + head*16 + query) receive Pd^T and dS^T, keys contiguous -- the operands of hh_gemm_tn_bf16_batched2, which makes
+ *             d mem + d mp for all layers at once;  qt16 / dp16 (optional, bf16 [B, rows_total, 512]): the same rows of bf16(qt) / bf16(dpooled),
+ *             the other operands of that GEMM.  Same dropout mask as the forward for the same seed. */
+int hh_mattn_slices(int M, int slices);
+int hh_mattn_fwd(const float* qt, const void* mp, const void* mem, int64_t ld, float* pooled, float* lse2, float* rsum, float* workspace,
+                 int slices, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, hh_stream_t stream);
+int hh_mattn_bwd(const float* qt, const float* dpooled, const float* lse2, const float* dca, const float* ca, const float* bv,
+                 const void* mp, const void* mem, int64_t ld, float* dqt_partials, int slices, void* pdT, void* dsT, void* qt16, void* dp16,
+                 int rows_total, int row_off, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, hh_stream_t stream);
+
 /* ---- query side of the decoder (model/tfm_decoder.py:430-461 forward_pre on the 13 object queries, :208-233 heads, and the
  * txt_proj / obj_proj projections of run/train.py:124-125,187-189): fp32 operands, bf16 matrix cores at fp32-grade accuracy.
  * hh_qgemm_f32x3: C = epilogue(prologue(A) . B); every operand fp32; each fp32 value is split on the fly into bf16 hi + lo and
@@ -283,6 +316,15 @@ typedef struct hh_qgemm_opts {
     int32_t splitk;           /* > 1: the contraction is cut into that many slices whose partial products are added ATOMICALLY into C
                                  (and colsum): the caller zeroes them first; no epilogue options.  For long contractions with few
                                  output tiles (weight gradients of the box heads: 512 x 512 outputs over 6656 rows) */
+    /* round 5 -- batched form (the per-head maps of the K/V-projection-free cross-attention, hh_mattn_*): batch > 1 runs `batch`
+     * independent products in one launch; product z reads A + z * stride_a, B + z * stride_b, writes C + z * stride_c, and takes
+     * bias + z * stride_bias / colsum + z * stride_colsum / rowscale + z * stride_rowscale (strides in elements, multiples of 4 for the
+     * matrices and the bias).  No split-K, relu_mask or residual with it.
+     * rowscale (optional, batched or not): NT / NN -- the bias term becomes bias[n] * rowscale[m * ld_rowscale] (the value bias of an
+     * attention whose dropped probabilities no longer sum to one); TN -- colsum[m] = sum_k A[k, m] * rowscale[k * ld_rowscale]. */
+    int32_t batch;
+    int64_t stride_a, stride_b, stride_c, stride_bias, stride_colsum;
+    const float* rowscale; int64_t ld_rowscale, stride_rowscale;
 } hh_qgemm_opts;
 int hh_qgemm_f32x3(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, int mode,
                    const hh_qgemm_opts* opts, hh_stream_t stream);

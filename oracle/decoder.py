@@ -44,6 +44,13 @@ def mha_given_kv(q_in, K, V, sd, prefix, heads):
     return F.linear(o, sd[prefix + ".out_proj.weight"], sd[prefix + ".out_proj.bias"])
 
 
+def memory_rows(features, sd, cfg):
+    """(memory, pos) of ObjDecoder / Cross_Attention (tfm_decoder.py:200-205,86-88): memory = pre_norm(proj(x)) [B,M,C], pos [M,C]."""
+    B, T, n, _ = features.shape
+    memory = _ln(F.linear(features, sd["proj.weight"]).reshape(B, T * n, cfg.dec_dim), sd, "transformer.pre_norm")
+    return memory, pos_embed_3d(sd, T, n)
+
+
 def memory_kv(features, sd, cfg):
     """Memory side of ObjDecoder/Cross_Attention (tfm_decoder.py:200-205,86-88,438-441): features [B,T,n,F] ->
     (K, V) [L,B,M,C] with K_l = (pre_norm(proj(x)) + pos).Wk_l^T + bk_l and V_l = pre_norm(proj(x)).Wv_l^T + bv_l."""
@@ -59,19 +66,24 @@ def memory_kv(features, sd, cfg):
     return torch.stack(Ks), torch.stack(Vs)
 
 
-def decoder_layer(tgt, memory, pos, qpos, sd, b, heads, kv=None):
+def decoder_layer(tgt, memory, pos, qpos, sd, b, heads, kv=None, rows=None, relu_mask=None):
     """TransformerDecoderLayer.forward_pre, sa_first -- tfm_decoder.py:430-461 (all LN eps 1e-5).  kv = (K, V) of this layer
-    replaces the in-layer key/value projection of (memory + pos, memory)."""
+    replaces the in-layer key/value projection of (memory + pos, memory); rows = (memory, memory_plus_pos) replaces the two operands
+    of that projection (lets a test feed the oracle the very memory rows another implementation attends over); relu_mask [B,Q,ffn]
+    (bool) replaces the ReLU of the FFN by that fixed mask -- the branch of the piecewise-linear function another implementation took,
+    so that units whose pre-activation sits within rounding distance of the kink do not make two fp32-grade gradients differ."""
     a = _ln(tgt, sd, b + "norm1")
     tgt = tgt + mha(a + qpos, a + qpos, a, sd, b + "self_attn", heads)
     c = _ln(tgt, sd, b + "norm2")
     if kv is not None:
         tgt = tgt + mha_given_kv(c + qpos, kv[0], kv[1], sd, b + "multihead_attn", heads)
+    elif rows is not None:
+        tgt = tgt + mha(c + qpos, rows[1], rows[0], sd, b + "multihead_attn", heads)
     else:
         tgt = tgt + mha(c + qpos, memory + pos, memory, sd, b + "multihead_attn", heads)
     e = _ln(tgt, sd, b + "norm3")
-    ff = F.linear(F.relu(F.linear(e, sd[b + "linear1.weight"], sd[b + "linear1.bias"])),
-                  sd[b + "linear2.weight"], sd[b + "linear2.bias"])
+    h1 = F.linear(e, sd[b + "linear1.weight"], sd[b + "linear1.bias"])
+    ff = F.linear(F.relu(h1) if relu_mask is None else h1 * relu_mask.to(h1.dtype), sd[b + "linear2.weight"], sd[b + "linear2.bias"])
     return tgt + ff
 
 
@@ -98,13 +110,15 @@ def cross_attention_forward(src, mask, query_embed, pos_embed, sd, cfg, prefix="
     return torch.stack(inter), memory.transpose(1, 2).reshape(B, C, T, n)
 
 
-def objdecoder_forward(features, sd, cfg, compute_logits=True, kv=None):
+def objdecoder_forward(features, sd, cfg, compute_logits=True, kv=None, rows=None, relu_masks=None):
     """ObjDecoder.forward -- tfm_decoder.py:183-233 (+ Cross_Attention.forward :76-93,
     TransformerDecoder.forward :255-295).
 
     features [B,T,n,F] -> (out dict, hs [L,B,Q,C]).  out['pred_boxes'] [B*T,Q,4] (cx,cy,w,h),
     out['pred_logits'] [B*T,Q,classes+1], out['aux_outputs'] for layers 0..L-2.
     kv = (K, V) [L,B,M,C]: run the query side on these key/value projections (see mha_given_kv) instead of the memory side's.
+    rows = (memory, memory + pos) [B,M,C] each: run every layer's key / value projection on these rows instead of the memory side's.
+    relu_masks: per layer [B,Q,ffn] bool, see decoder_layer.
     """
     B, T, n, _ = features.shape
     C, heads, L = cfg.dec_dim, cfg.dec_heads, cfg.dec_layers
@@ -116,7 +130,7 @@ def objdecoder_forward(features, sd, cfg, compute_logits=True, kv=None):
     inter = []
     for l in range(L):
         tgt = decoder_layer(tgt, memory, pos, qpos, sd, f"transformer.decoder.layers.{l}.", heads,
-                            None if kv is None else (kv[0][l], kv[1][l]))
+                            None if kv is None else (kv[0][l], kv[1][l]), rows, None if relu_masks is None else relu_masks[l])
         inter.append(_ln(tgt, sd, "transformer.decoder.norm"))
     hs = torch.stack(inter)                                                   # [L,B,Q,C]
     Q = hs.shape[2]

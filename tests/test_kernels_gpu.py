@@ -552,6 +552,132 @@ def test_xattn_fwd_key_slices_equal_the_single_pass(B, M, splits):
         assert_close_bf16(dflt, ops.xattn_fwd(q, k, v, heads, splits=1)[0], 2e-5, "xattn default split")
 
 
+def _mattn_ref(qt, mp, mem, wv, bv, Q):
+    """fp64 reference of the memory-space cross-attention incl. the value projection: qt [B*Q, 8*512], mp / mem [B, M, 512] ->
+    (pooled [B*Q, 8*512], lse2 [B*Q, 8], ca [B*Q, 512])."""
+    B, M, C = mp.shape
+    H = 8
+    q4 = qt.view(B, Q, H, C)
+    s = torch.einsum("bqhc,bmc->bqhm", q4, mp)
+    p = torch.softmax(s, -1)
+    pooled = torch.einsum("bqhm,bmc->bqhc", p, mem)
+    lse2 = torch.logsumexp(s, -1) * 1.4426950408889634
+    ca = torch.einsum("bqhc,hnc->bqhn", pooled, wv.view(H, 64, C)) + bv.view(H, 64)
+    return pooled.reshape(B * Q, H * C), lse2.reshape(B * Q, H), ca.reshape(B * Q, H * 64)
+
+
+@pytest.mark.parametrize("B,Q,M,slices", [(2, 13, 4096, None), (3, 5, 1024, 1), (1, 16, 128, None), (1, 13, 18432, None), (2, 13, 1184, 3), (5, 13, 256, 2)])
+def test_mattn_fwd_bwd_vs_torch(B, Q, M, slices):
+    """hh_mattn_fwd / hh_mattn_bwd (cross-attention in memory space, d = 512: csrc/mattn.hip) + the batched d-memory GEMM against fp64
+    PyTorch on the same fp32 query-side values and bf16 memory rows.  Query-side operands enter the MFMAs as bf16 hi + lo pairs, so
+    pooled / lse2 / dqt are exact with respect to the stored rows (fp32-grade: <= 3e-5 of the scale); d mem / d mp go through bf16
+    Pd^T / dS^T (one rounding: 8e-3).  (1, 13, 18432): config 4's key count; (2, 13, 1184, 3): ragged last slice; (5, 13, 256, 2):
+    the clip count is not a multiple of the 8 workgroup-units a grid round holds."""
+    H, C = 8, 512
+    R = B * Q
+    qt = rnd(R, H * C, seed=1, scale=0.08)
+    mpm = bf(rnd(2, B, M, C, seed=2))
+    wv, bv = rnd(C, C, seed=3, scale=0.05), rnd(C, seed=4, scale=0.1)
+    G = rnd(R, C, seed=5)
+    mp, mem = mpm[0].to(DEV), mpm[1].to(DEV)
+    pooled, lse2, rsum = ops.mattn_fwd(qt.to(DEV), mp, mem, Q, slices=slices)
+    qr = qt.double().requires_grad_(True)
+    mpr, memr = mpm[0].double().requires_grad_(True), mpm[1].double().requires_grad_(True)
+    rp, rl, rca = _mattn_ref(qr, mpr, memr, wv.double(), bv.double(), Q)
+    assert_close_bf16(pooled, rp.detach(), 3e-5, "mattn pooled")
+    torch.testing.assert_close(lse2.cpu().double(), rl.detach(), rtol=0, atol=2e-4)
+    assert float((rsum.cpu() - 1).abs().max()) < 1e-5
+    # value projection + bias on the pooled rows (head-batched NT), then the backward chain
+    ca = ops.head_map_out(pooled, wv.to(DEV), bias=bv.to(DEV))
+    assert_close_bf16(ca, rca.detach(), 3e-5, "mattn ca")
+    (rca * G.double()).sum().backward()
+    dca = G.to(DEV)
+    dpooled = ops.head_map_in(dca, wv.to(DEV))
+    L = 2
+    rows = L * 128
+    pdT = torch.full((B, rows, M), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dsT = torch.full_like(pdT, float("nan"))
+    qt16 = torch.full((B, rows, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dp16 = torch.full_like(qt16, float("nan"))
+    for l in range(L):                                  # two "layers" with the same inputs: every row of the operand buffers gets written
+        dqt = ops.mattn_bwd(qt.to(DEV), dpooled, lse2, dca, ca, bv.to(DEV), mp, mem, Q, pdT, dsT, qt16, dp16, l * 128, slices=slices)
+    assert_close_bf16(dqt, qr.grad, 1e-4, "mattn dqt")
+    for t in (pdT, dsT, qt16, dp16):
+        assert torch.isfinite(t.float()).all()
+    assert float(pdT.view(B, L, H, 16, M)[:, :, :, Q:].abs().max() if Q < 16 else 0.0) == 0.0           # query slots beyond Q are zero rows
+    if M % 128 == 0:
+        dmem = ops.gemm_tn_batched2(pdT, dp16, dsT, qt16)                                                 # [B, M, C] = d mem + d mp, L times
+        assert_close_bf16(dmem, L * (mpr.grad + memr.grad), 8e-3, "mattn d(mem) + d(mp)")
+        dmp = ops.gemm_tn_batched2(dsT, qt16)
+        assert_close_bf16(dmp, L * mpr.grad, 8e-3, "mattn d(mp)")
+        one = ops.gemm_tn_batched2(pdT[:, :128].contiguous(), dp16[:, :128].contiguous())
+        assert_close_bf16(one, memr.grad, 8e-3, "mattn d(mem), one layer")
+
+
+def test_mattn_key_slices_and_dropout():
+    """Key slices (one workgroup pair per (clip, slice) + merge) against the single pass, with and without dropout -- the slices see the
+    same (seed, clip, head, query, key) mask; with dropout rsum is the kept probability mass, and the analytic d qt matches a central
+    finite difference of the (deterministic, same-mask) forward."""
+    B, Q, M, H, C = 2, 13, 2048, 8, 512
+    qt = rnd(B * Q, H * C, seed=7, scale=0.08).to(DEV)
+    mpm = bf(rnd(2, B, M, C, seed=8)).to(DEV)
+    mp, mem = mpm[0], mpm[1]
+    for p, seed in ((0.0, 0), (0.1, 4321)):
+        one = ops.mattn_fwd(qt, mp, mem, Q, p, seed, slices=1)
+        many = ops.mattn_fwd(qt, mp, mem, Q, p, seed, slices=16)
+        assert_close_bf16(many[0], one[0], 2e-5, "mattn slices p=%g" % p)
+        torch.testing.assert_close(many[1], one[1], rtol=0, atol=2e-5)
+        torch.testing.assert_close(many[2], one[2], rtol=1e-5, atol=1e-6)
+    pooled, lse2, rsum = ops.mattn_fwd(qt, mp, mem, Q, 0.1, 77)
+    assert 0.8 < float(rsum.mean()) < 1.2 and float((rsum - 1).abs().max()) > 1e-3
+    assert float((ops.mattn_fwd(qt, mp, mem, Q, 0.1, 78)[0] - pooled).abs().max()) > 0                    # another seed, another mask
+    # backward with dropout: finite difference along a random direction (value projection with bias: the rsum term is live)
+    wv, bv = rnd(C, C, seed=9, scale=0.05).to(DEV), rnd(C, seed=10, scale=0.1).to(DEV)
+    G = rnd(B * Q, C, seed=11).to(DEV)
+
+    def f(x):
+        po, _, rs = ops.mattn_fwd(x, mp, mem, Q, 0.1, 77)
+        return ops.head_map_out(po, wv, bias=bv, rowscale=rs)
+    ca = f(qt)
+    dpooled = ops.head_map_in(G, wv)
+    bufs = [torch.empty((B, 128, M), dtype=torch.bfloat16, device=DEV) for _ in range(2)] + [torch.empty((B, 128, C), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    dqt = ops.mattn_bwd(qt, dpooled, lse2, G, ca, bv, mp, mem, Q, *bufs, 0, 0.1, 77)
+    d = rnd(B * Q, H * C, seed=12).to(DEV)
+    eps = 2e-3
+    fd = float((((f(qt + eps * d) - f(qt - eps * d)) / (2 * eps)) * G).double().sum())
+    an = float((dqt * d).double().sum())
+    assert abs(fd - an) <= 0.03 * abs(fd) + 1e-3, (fd, an)
+
+
+def test_head_batched_qgemm_vs_torch():
+    """The three head-batched hh_qgemm_f32x3 forms of the memory-space cross-attention (ops.head_map_in / _out / _wgrad) on row-strided
+    views of a packed [q; k; v] in-projection, against fp64 PyTorch (fp32-grade: 2e-5)."""
+    R, H, C = 37, 8, 512
+    w3 = rnd(3 * C, C, seed=1, scale=0.05).to(DEV)
+    b3 = rnd(3 * C, seed=2, scale=0.1).to(DEV)
+    x = rnd(R, C, seed=3).to(DEV)
+    y = rnd(R, H * C, seed=4).to(DEV)
+    rs = (rnd(R, H, seed=5).abs() + 0.5).to(DEV)
+    wk, wv = w3[C:2 * C], w3[2 * C:]
+    got = ops.head_map_in(x, wk)
+    ref = torch.einsum("rhn,hnc->rhc", x.double().view(R, H, 64), wk.double().view(H, 64, C)).reshape(R, H * C)
+    assert_close_bf16(got, ref, 2e-5, "head_map_in")
+    got = ops.head_map_out(y, wv, bias=b3[2 * C:], rowscale=rs)
+    ref = torch.einsum("rhc,hnc->rhn", y.double().view(R, H, C), wv.double().view(H, 64, C)) + b3[2 * C:].double().view(H, 64) * rs.double()[:, :, None]
+    assert_close_bf16(got, ref.reshape(R, C), 2e-5, "head_map_out")
+    got = ops.head_map_out(y, wv)
+    assert_close_bf16(got, torch.einsum("rhc,hnc->rhn", y.double().view(R, H, C), wv.double().view(H, 64, C)).reshape(R, C), 2e-5, "head_map_out, no bias")
+    gw = torch.zeros((3 * C, C), dtype=torch.float32, device=DEV)
+    gb = torch.zeros(3 * C, dtype=torch.float32, device=DEV)
+    ops.head_map_wgrad(x, y, gw[2 * C:], colsum=gb[2 * C:], rowscale=rs)
+    ref = torch.einsum("rhn,rhc->hnc", x.double().view(R, H, 64), y.double().view(R, H, C)).reshape(C, C)
+    assert_close_bf16(gw[2 * C:], ref, 2e-5, "head_map_wgrad")
+    assert_close_bf16(gb[2 * C:], (x.double().view(R, H, 64) * rs.double()[:, :, None]).sum(0).reshape(C), 2e-5, "head_map_wgrad colsum")
+    assert float(gw[:2 * C].abs().max()) == 0 and float(gb[:2 * C].abs().max()) == 0
+    ops.head_map_wgrad(x, y, gw[C:2 * C], colsum=gb[C:2 * C])
+    assert_close_bf16(gb[C:2 * C], x.double().sum(0), 2e-5, "plain colsum")
+
+
 def test_match_boxes_bit_exact_and_losses():
     from helping_hand_for_egocentric_videos_amd import synth, TINY4
     from oracle import losses as OL
