@@ -57,12 +57,15 @@ def prof_enable(stride):
     _lib.check(_lib.lib().hh_prof_enable(int(stride)), "hh_prof_enable")
 
 
-def prof_read(name):
-    """-> (launches timed, launches seen, total ms, total algorithmic work) of one kernel class; synchronises on its events."""
+ROLES = {"decoder": 0, "vision_tower": 1, "text_tower": 2}      # include/hh.h: hh_prof_set_role (the part of the step the host was launching)
+
+
+def prof_read(name, role=-1):
+    """-> (launches timed, launches seen, total ms, total algorithmic work) of one kernel class (one role, or all: -1); synchronises on its events."""
     import ctypes
     from helping_hand_for_egocentric_videos_amd import _lib
     n, seen, ms, work = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
-    _lib.check(_lib.lib().hh_prof_read(PROF[name], ctypes.byref(n), ctypes.byref(seen), ctypes.byref(ms), ctypes.byref(work)), "hh_prof_read")
+    _lib.check(_lib.lib().hh_prof_read_role(PROF[name], int(role), ctypes.byref(n), ctypes.byref(seen), ctypes.byref(ms), ctypes.byref(work)), "hh_prof_read_role")
     return n.value, seen.value, ms.value, work.value
 
 
@@ -76,10 +79,11 @@ def prof_kernel_name(name):
 def prof_snapshot():
     snap = {k: prof_read(k) for k in PROF}
     snap["names"] = {k: prof_kernel_name(k) for k in PROF}
+    snap["roles"] = {r: {k: prof_read(k, i) for k in PROF} for r, i in ROLES.items()}
     return snap
 
 
-def pmc_traffic(kernel_substr, cfg_tag="", tag_order=("r4", "r3", "r2", "r1")):
+def pmc_traffic(kernel_substr, cfg_tag="", tag_order=("r5", "r4", "r3", "r2", "r1")):
     """HBM-side bytes per launch of a kernel from the COMMITTED PMC passes of the same configuration (profiles/<round>_[c4_]pmc_summary.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction); launch-weighted mean over the
     template instantiations whose name contains `kernel_substr`.  NOT measured in this run.  Returns (bytes, file) or (None, None)."""
@@ -95,7 +99,7 @@ def pmc_traffic(kernel_substr, cfg_tag="", tag_order=("r4", "r3", "r2", "r1")):
     return None, None
 
 
-def rocprof_committed(kernel_substr, cfg_tag="", pipelined=True, tag_order=("r4", "r3")):
+def rocprof_committed(kernel_substr, cfg_tag="", pipelined=True, tag_order=("r5", "r4", "r3")):
     """Average duration per launch (us) and launch count of the kernels whose name contains `kernel_substr` in the committed rocprofv3
     --kernel-trace --stats CSV of the same bench command (profiles/<round>_[c4_]{bench,unpipelined}_kernel_stats.csv).  -> dict or None."""
     import csv
@@ -270,12 +274,26 @@ def build(cfg, dev, world=1):
     return enc_sd, dec_sd, backbone, decoder
 
 
+def visual_ln_fold(backbone):
+    """What the tower's blocks actually packed (the module global can differ from it)."""
+    m = backbone.visual.ln_fold_packed()
+    return bool(LaviLa.LN_FOLD) if m is None else bool(m)
+
+
+def selfcheck_summary(sc):
+    if not sc:
+        return None
+    return {"clip0_encoder_bit_identical": sc.get("encoder_bit_identical_clips_before_last"), "matched_indices_equal": sc.get("matched_indices_equal"),
+            "hs_diff_over_scale": round(sc.get("hs_max_abs_diff_over_scale", 0.0), 6)}
+
+
 def barrier(world):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
 
 
+LAST_REGION = [0.0, 0.0]     # wall-clock bounds (time.time()) of the last timed region: the power samples are cut to it
 STATS_STEPS = 50     # per-step statistics are taken over at least this many steps: the K contract steps + extra ones run after the timed region
 
 
@@ -289,6 +307,7 @@ def timed_region(run, steps, warmup, world, timers, stats_steps=0):
     if timers:
         prof_enable(STRIDE)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    LAST_REGION[0] = time.time()
     t0 = time.perf_counter()
     ev[0].record()
     out = None
@@ -297,6 +316,7 @@ def timed_region(run, steps, warmup, world, timers, stats_steps=0):
         ev[i + 1].record()
     barrier(world)
     dt = time.perf_counter() - t0
+    LAST_REGION[1] = time.time()
     region = prof_snapshot() if timers else None
     extra = max(0, stats_steps - steps)
     for i in range(extra):
@@ -330,68 +350,88 @@ def rate(rec, key, scale):
     return (work / (ms * 1e-3) / scale, n, seen, ms) if n and ms > 0 else (None, n, seen, ms)
 
 
-def roofline_records(region, iso, dt_ms, pipelined, cfg, B):
-    """dt_ms: wall time of the whole timed region.  `roofline` (dominant kernel: the persistent GEMM, MFMA-bound) and `attention_roofline` (HBM-bound kernels) from the library's
-    own event timers.  Algorithmic work: 2*M*N*K of the full 256-row tiles per GEMM launch; 8*N*D bytes per clip and attention call
-    (q, k, v read + o written, bf16); bytes read + written for add+LayerNorm.  Kernel labels are what the
-    library dispatched (hh_prof_kernel_name), not names composed here."""
+def _stream_rec(rec, key, steps, scale=1e12):
+    """{achieved, launches, avg_launch_us, ms_per_step} of one (class, role) record set; None if nothing was timed.  ms_per_step = launches in
+    the region x mean launch time / steps: the time that class occupies ITS stream per step."""
+    ach, n, seen, ms = rate(rec, key, scale)
+    if ach is None:
+        return None
+    avg_us = ms * 1e3 / n
+    return {"achieved": round(ach, 1), "launches_in_region": seen, "launches_timed": n, "avg_launch_us": round(avg_us, 1),
+            "ms_per_step": round(seen * avg_us / 1e3 / max(steps, 1), 2)}
+
+
+def roofline_records(region, iso, dt_ms, pipelined, cfg, B, steps):
+    """dt_ms: wall time of the whole timed region of `steps` steps.  `roofline` = the dominant kernel (persistent GEMM, MFMA-bound) ON THE
+    VISION-TOWER STREAM: the launches the host issued inside SpaceTimeTransformer.forward_features (hh_prof_set_role) -- one serial stream, so
+    launches x mean launch time <= the region's wall time by construction (`stream_ms_per_step` <= `ms_per_step`).  The text tower (side
+    stream) and the decoder (main stream) run concurrently with it: their launches of the same kernel family are `by_stream`, the aggregate
+    over all three `by_stream.all` (NOT comparable with a step's time).  `attention_roofline`: the HBM-bound kernels of the tower.
+    Algorithmic work: 2*M*N*K of the full 256-row tiles per GEMM launch; 8*N*D bytes per clip and attention call."""
     roof, att = None, {}
     names = region.get("names", {})
+    roles = region.get("roles", {})
+    vis = roles.get("vision_tower", region)
     cfg_tag = "c4_" if (cfg.num_frames == 32 and cfg.img_size == 336) else ""
     have_profile = cfg_tag == "c4_" or (cfg.num_frames == 16 and cfg.img_size == 224)
-    ach, n, seen, ms = rate(region, "gemm256", 1e12)
-    if ach is not None:
+    main = _stream_rec(vis, "gemm256", steps)
+    if main is not None:
         traffic, src = pmc_traffic("gemm256w4p_kernel<true", cfg_tag) if have_profile else (None, None)
         alg_bytes = gemm_algorithmic_bytes(cfg, B, LaviLa.LN_FOLD)
-        roof = {"kernel": "gemm256w4p_kernel (persistent 256x256x64 bf16 MFMA GEMM: 4 waves x 128x128, one wave per SIMD, continuous half-tile LDS-DMA stream across tiles) -- every template instantiation, nothing else",
-                "last_dispatched": names.get("gemm256", ""),
-                "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": traffic, "traffic_from_committed_pmc": traffic,
-                "traffic_note": ("HBM-side bytes per launch, NOT measured in this run: launch-weighted mean over gemm256w4p_kernel<true, *> in the committed "
-                                 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration (profiles/%s; FETCH_SIZE doubled per the gfx950 correction)" % src) if src else None,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "algorithmic_bytes_note": ("A [M,K] + W [N,K] read once + C [M,N] written once, bf16, mean over the vision tower's six GEMMs per block (qkv x2, proj x2, fc1, fc2) "
-                                           "at M = %d" % (B * cfg.tokens)) + ("; LayerNorm fold: the branch-ending GEMMs read the fp32 residual rows, write z (bf16) and -- space proj, "
-                                           "fc2 -- the fp32 rows back instead of C" if LaviLa.LN_FOLD else ""),
-                "ln_fold": bool(LaviLa.LN_FOLD),
-                "ln_fold_note": ("norm3 / norm1 / norm2 of every block run INSIDE these launches (residual add, row statistics, in-place fp32 update in the producers' "
-                                 "epilogues; rstd / mean / gamma / beta applied algebraically in the consumers'): their time counts here, `achieved` still divides 2*M*N*K "
-                                 "by it.  --no-ln-fold runs the stand-alone add+LayerNorm kernels (A/B: profiles/r4_ln_fold_ab.json)") if LaviLa.LN_FOLD else None,
-                "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
-                "algorithmic_work": "2*M*N*K of the full 256-row tiles of each launch (DESIGN.md section 5)",
-                "launches_timed": n, "launches_in_region": seen,
-                "timing": "library-side HIP events recorded on the launch stream right before and right after the kernel launch (hh_prof_enable), every %dth launch.  Checked "
-                          "against rocprofv3 --kernel-trace in the SAME run (round 4: 511 vs 504 us per launch); `rocprofv3_committed` is the per-dispatch figure of the committed "
-                          "profile of this command (20 steps; the 5-step profiles of earlier rounds ended before the chip reached its steady clock and read ~8 %% low)" % STRIDE,
-                "avg_launch_us": round(ms * 1e3 / n, 1), "stream_time_over_step": round(ms * STRIDE / dt_ms, 3),
-                "region": "timed region (pipelined: decoder kernels of the previous step run beside it)" if pipelined else "timed region (un-pipelined)"}
+        step_ms = dt_ms / max(steps, 1)
+        roof = {"kernel": "gemm256w4p_kernel, vision-tower launches (persistent 256x256x64 bf16 MFMA GEMM, LayerNorms folded in)",
+                "bound": "mfma", "achieved": main["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(main["achieved"] / PEAK_BF16_TFLOPS, 4),
+                "launches_in_region": main["launches_in_region"], "launches_timed": main["launches_timed"], "avg_launch_us": main["avg_launch_us"],
+                "stream_ms_per_step": main["ms_per_step"], "ms_per_step": round(step_ms, 2), "stream_time_le_step": bool(main["ms_per_step"] <= step_ms),
+                "traffic": traffic, "traffic_source": ("committed PMC passes, profiles/%s (not measured in this run)" % src) if src else None,
+                "algorithmic_bytes_per_launch": alg_bytes, "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
+                "ln_fold": bool(LaviLa.LN_FOLD), "last_dispatched": names.get("gemm256", ""),
+                "region": "timed region, pipelined" if pipelined else "timed region, un-pipelined"}
+        by = {}
+        for r in ("text_tower", "decoder"):
+            rec = _stream_rec(roles.get(r, {}), "gemm256", steps) if r in roles else None
+            if rec is not None:
+                by[r] = rec
+        allr = _stream_rec(region, "gemm256", steps)
+        if allr is not None:
+            allr["frac"] = round(allr["achieved"] / PEAK_BF16_TFLOPS, 4)
+            allr["note"] = "three concurrent streams: ms_per_step here may exceed the step's wall time"
+            by["all"] = allr
+        o = _stream_rec(region, "gemm_other", steps)
+        if o is not None:
+            o["what"] = "row tails, 128x128 kernel, one-tile-per-block kernel (all streams; not part of `achieved`)"
+            by["other_gemm_kernels"] = o
+        roof["by_stream"] = by
         rp = rocprof_committed("gemm256w4p_kernel", cfg_tag, pipelined) if have_profile else None
         if rp is not None:
             roof["rocprofv3_committed"] = rp
         if iso is not None:
-            a2, n2, _, ms2 = rate(iso, "gemm256", 1e12)
-            if a2 is not None:
-                roof["isolated"] = {"achieved": round(a2, 1), "frac": round(a2 / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms2 * 1e3 / n2, 1),
-                                    "note": "same kernel over 2 un-pipelined steps outside the timed region (alone on the chip); compare with the un-pipelined rocprofv3 summary in profiles/"}
-        o, no, _, mso = rate(region, "gemm_other", 1e12)
-        if o is not None:
-            roof["other_gemm_kernels"] = {"what": "row tails (gemm_tail_kernel), 128x128 kernel, one-tile-per-block 256x256 kernel -- NOT part of `achieved`",
-                                          "achieved": round(o, 1), "unit": "TFLOP/s", "launches_timed": no, "avg_launch_us": round(mso * 1e3 / no, 1),
-                                          "stream_time_over_step": round(mso * STRIDE / dt_ms, 3)}
-    for key in ("space_attn", "time_attn", "add_ln"):
-        r, n, _, ms = rate(region, key, 1e9)
-        if r is None:
+            i2 = _stream_rec(iso.get("roles", {}).get("vision_tower", iso), "gemm256", 2)
+            if i2 is not None:
+                roof["isolated"] = {"achieved": i2["achieved"], "frac": round(i2["achieved"] / PEAK_BF16_TFLOPS, 4), "avg_launch_us": i2["avg_launch_us"],
+                                    "note": "2 un-pipelined steps outside the timed region: the tower alone on the chip"}
+        roof["notes"] = {
+            "timing": "library-side HIP events on the launch stream around every %dth launch of the class and role (hh_prof_enable / hh_prof_set_role); "
+                      "agrees with rocprofv3 --kernel-trace of the same run (round 4: 511 vs 504 us)" % STRIDE,
+            "work": "2*M*N*K of the full 256-row tiles of each launch; norm3 / norm1 / norm2 of every block run inside these launches (DESIGN.md 4.6), "
+                    "their time counts here",
+            "bytes": "A [M,K] + W [N,K] read, C [M,N] written, bf16, mean over the six GEMMs of a block at M = %d; the branch-ending GEMMs read the fp32 "
+                     "residual rows and write z (bf16) / the fp32 rows instead of C" % (B * cfg.tokens)}
+    for key in ("space_attn", "time_attn"):
+        rec = _stream_rec(vis, key, steps, 1e9)
+        if rec is None:
             continue
-        att[key] = {"kernel": names.get(key, "") or key, "bound": "hbm", "achieved": round(r, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(r / PEAK_HBM_GBS, 4),
-                    "launches_timed": n, "avg_launch_us": round(ms * 1e3 / n, 1), "stream_time_over_step": round(ms * STRIDE / dt_ms, 3)}
+        att[key] = dict(rec, kernel=names.get(key, "") or key, bound="hbm", peak=PEAK_HBM_GBS, unit="GB/s", frac=round(rec["achieved"] / PEAK_HBM_GBS, 4))
         if iso is not None:
-            r2, n2, _, ms2 = rate(iso, key, 1e9)
-            if r2 is not None:
-                att[key]["isolated"] = {"achieved": round(r2, 1), "frac": round(r2 / PEAK_HBM_GBS, 4), "avg_launch_us": round(ms2 * 1e3 / n2, 1)}
+            i2 = _stream_rec(iso.get("roles", {}).get("vision_tower", iso), key, 2, 1e9)
+            if i2 is not None:
+                att[key]["isolated"] = {"achieved": i2["achieved"], "frac": round(i2["achieved"] / PEAK_HBM_GBS, 4), "avg_launch_us": i2["avg_launch_us"]}
+    tx = _stream_rec(roles.get("text_tower", {}), "add_ln", steps, 1e9) if "text_tower" in roles else None
+    if tx is not None:
+        att["text_tower_add_ln"] = dict(tx, bound="hbm", unit="GB/s", note="side-stream kernel of the TEXT tower (the vision tower has no stand-alone LayerNorm pass); stretched by CU starvation in the step")
     if att:
-        att["note"] = ("algorithmic bytes (8*N*D per attention call and clip, N = %d tokens, D = %d; bytes read + written for add+LayerNorm) / event time of the "
-                       "kernel alone; `isolated` = un-pipelined steps; `kernel` = the instantiation the library dispatched last (hh_prof_kernel_name); "
-                       "`stream_time_over_step` = the class's time on its stream / wall time of a step (three streams run concurrently: these do not sum to 1)" % (cfg.tokens, cfg.embed_dim))
+        att["note"] = ("vision-tower launches: algorithmic bytes (8*N*D per attention call and clip, N = %d tokens, D = %d) / event time of the kernel alone; "
+                       "`isolated` = un-pipelined steps" % (cfg.tokens, cfg.embed_dim))
     return roof, (att or None)
 
 
@@ -404,8 +444,12 @@ def bench_train(cfg, backbone, decoder, B, steps, warmup, world, rank, dev, args
         prof_enable(0)
     # (profiling runs pass --no-kernel-timers: no extra statistics steps under rocprofv3)
     dt, per, region, out = timed_region(run, steps, warmup, world, timers, stats_steps=STATS_STEPS if (want_iso and timers) else 0)
+    bounds = tuple(LAST_REGION)
     if timers:
         prof_enable(0)          # (the extra statistics steps are not part of the kernel-timer region: the snapshot was taken before them)
+    phases = None
+    if timers and want_iso and world == 1:
+        phases = phase_times(ts, batch, run, pipelined)
     iso = None
     if timers and pipelined and want_iso:
         # outside the timed region: two un-pipelined steps, so that every kernel is also timed alone on the chip (no decoder kernels
@@ -419,7 +463,43 @@ def bench_train(cfg, backbone, decoder, B, steps, warmup, world, rank, dev, args
         iso = prof_snapshot()
     if timers:
         prof_enable(0)
-    return ts, batch, dt, per, region, iso, out
+    return ts, batch, dt, per, region, iso, out, phases, bounds
+
+
+def phase_times(ts, batch, run, pipelined, reps=3):
+    """Outside the timed region: the two halves of a step alone on the chip, and the decoder half inside the pipelined step -- so that
+    "work hidden on another stream is still paid for in energy"  can be read off the bench line:
+      towers_alone_ms    frozen vision + text towers of one batch (TrainStep.encode), nothing else running
+      decoder_alone_ms   decoder forward / losses / backward / AdamW of one batch whose towers were computed before
+      decoder_in_step_ms the same span on the main stream inside the pipelined steady state (the next batch's towers run beside it)"""
+    def span(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+    rec = {}
+    with torch.no_grad():
+        span(lambda: ts.encode(batch["video"], batch["text"]))
+        rec["towers_alone_ms"] = round(min(span(lambda: ts.encode(batch["video"], batch["text"])) for _ in range(reps)), 2)
+    alone = []
+    for _ in range(reps + 1):
+        ts.prefetch(batch)
+        torch.cuda.synchronize()
+        alone.append(span(lambda: ts.step(batch)))
+    rec["decoder_alone_ms"] = round(min(alone[1:]), 2)
+    if pipelined:
+        ts.span_log = []
+        for _ in range(reps + 2):
+            run()
+        torch.cuda.synchronize()
+        spans = [a.elapsed_time(b) for a, b in ts.span_log if b is not None][2:]
+        ts.span_log = None
+        if spans:
+            rec["decoder_in_step_ms"] = round(sum(spans) / len(spans), 2)
+    return rec
 
 
 def main():
@@ -510,9 +590,7 @@ def main():
         metric = "train clips/sec (%d-frame %dp, nq=%d)" % (cfg.num_frames, cfg.img_size, cfg.num_queries)
         if power:
             power.start()
-        w0 = time.time()
-        ts, batch, dt, per, region, iso, out = bench_train(cfg, backbone, decoder, B, args.steps, args.warmup, world, rank, dev, args, timers)
-        w1 = time.time()
+        ts, batch, dt, per, region, iso, out, phases, (w0, w1) = bench_train(cfg, backbone, decoder, B, args.steps, args.warmup, world, rank, dev, args, timers)
     else:
         items = args.mcq_items
         mcq = synth.make_mcq_item(cfg, items, seed=1000 + rank)
@@ -524,13 +602,12 @@ def main():
         metric = "EgoMCQ fwd clips/sec (%d-frame %dp)" % (cfg.num_frames, cfg.img_size)
         if power:
             power.start()
-        w0 = time.time()
         dt, per, region, out = timed_region(run, args.steps, args.warmup, world, timers)
-        w1 = time.time()
-        iso = None
+        w0, w1 = LAST_REGION
+        iso = phases = None
         if timers:
             prof_enable(0)
-    power_rec = power.stop(w0 + 0.3 * (w1 - w0), w1) if power else None      # skip the warm-up third of the bracket
+    power_rec = power.stop(w0 + 0.15 * (w1 - w0), w1) if power else None      # the timed region itself (its first 15 % left out: the chip settles into its steady power state)
     dts = torch.tensor([dt], device=dev, dtype=torch.float64)
     per_rank = None
     if world > 1:
@@ -610,8 +687,8 @@ def main():
         torch.cuda.empty_cache()
         _, _, bb4, dec4 = build(C4, dev)
         B4, k4 = 4, 10
-        ts4, batch4, dt4, per4, region4, iso4, out4 = bench_train(C4, bb4, dec4, B4, k4, 3, 1, rank, dev, args, timers)
-        roof4, att4 = roofline_records(region4, iso4, dt4 * 1e3, not args.no_pipeline, C4, B4) if region4 is not None else (None, None)
+        ts4, batch4, dt4, per4, region4, iso4, out4, phases4, _ = bench_train(C4, bb4, dec4, B4, k4, 3, 1, rank, dev, args, timers)
+        roof4, att4 = roofline_records(region4, iso4, dt4 * 1e3, not args.no_pipeline, C4, B4, k4) if region4 is not None else (None, None)
         c4_rec = {"metric": "train clips/sec (32-frame 336p, nq=12)", "value": round(B4 * k4 / dt4, 2), "unit": "clips/s", "ms_per_step": round(dt4 / k4 * 1e3, 2),
                   "steps": k4, "warmup": 3, "step_stats": step_stats(per4, drop_first=not args.no_pipeline),
                   "config": {"workload": "C4: 32-frame 336p (N = 18 433 tokens / clip), nq=12, frozen TimeSformer-L + object-query decoder train step",
@@ -622,20 +699,29 @@ def main():
 
     if rank == 0:
         dt_ms = dt * 1e3
-        roof, att = roofline_records(region, iso, dt_ms, not args.no_pipeline, cfg, clips_per_step) if region is not None else (None, None)
+        roof, att = roofline_records(region, iso, dt_ms, not args.no_pipeline, cfg, clips_per_step, args.steps) if region is not None else (None, None)
         if roof is not None and clock is not None:
             clock["frac_of_clock_limited_peak"] = round(roof["achieved"] / clock["clock_limited_peak"], 4)
             roof["sustained_clock"] = clock
         train = args.workload == "train"
         tf = step_tflop_per_clip(cfg, train)
+        if roof is not None:
+            # (the driver keeps `roofline` and `config` of the line: the cross-checks that must survive sit in there as plain numbers)
+            roof["end_to_end_mfma_frac"] = round(value * tf / (world * PEAK_BF16_TFLOPS), 4)
+            if power_rec:
+                roof["power_w_mean"] = power_rec.get("package_power_w_mean")
+                roof["power_cap_w"] = 1400
+            if phases:
+                roof.update(phases)
         line = {"metric": metric, "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": "%s, frozen TimeSformer-L + object-query decoder %s" % (cfg_name, "train step" if train else "EgoMCQ forward"),
                            "clips_per_gpu": clips_per_step, "pipelined_encoder": bool(train and not args.no_pipeline),
                            "global_clips": clips_per_step * world, "parallelism": "dp%d" % world,
-                           "resident_batch_reused": True, "materialize_logits": False, "ln_fold": bool(LaviLa.LN_FOLD),
-                           "step_tflop_per_clip": round(tf, 2)},
+                           "resident_batch_reused": True, "materialize_logits": False, "ln_fold": visual_ln_fold(backbone),
+                           "decoder_kv_free": bool(decoder.transformer.kv_free), "step_tflop_per_clip": round(tf, 2),
+                           "selfcheck": selfcheck_summary(selfcheck)},
                 "step_stats": step_stats(per, drop_first=bool(train and not args.no_pipeline)),
                 "end_to_end_mfma_frac": round(value * tf / (world * PEAK_BF16_TFLOPS), 4),
                 "roofline": roof}

@@ -39,6 +39,8 @@ SIGNATURES = {
     "hh_prof_enable": [c_int],
     "hh_prof_kernel_name": [c_int],
     "hh_prof_read": [c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
+    "hh_prof_set_role": [c_int],
+    "hh_prof_read_role": [c_int, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
     "hh_workspace_bytes_gemm_splitk": [c_i64, c_int, c_int],
     "hh_workspace_bytes_gemm_tn": [c_int, c_int, c_int],
     "hh_workspace_bytes_gemm_zstats": [c_i64, c_int],

@@ -126,12 +126,14 @@ extern "C" int64_t hh_workspace_bytes_attn_cls_partial(int B, int T, int n, int 
 // an instrumented kernel class is bracketed by two hipEvents recorded on ITS launch stream, with nothing but that kernel between
 // them -- so the sum of the elapsed times is comparable with rocprofv3's per-kernel durations (a torch-side bracket around
 // hh_gemm_bf16 also contains the row-tail launch and the host gaps).  Off by default: the launch sites then pay one relaxed load.
-struct ProfRec { int klass; hipEvent_t e0, e1; double work; };
+struct ProfRec { int klass, role; hipEvent_t e0, e1; double work; };
+#define HH_PROF_ROLES 4
+static std::atomic<int> g_prof_role{0};         // hh_prof_set_role: which part of the step the host is launching (0 = decoder / loss / optimizer, 1 = vision tower, 2 = text tower)
 static std::atomic<int> g_prof_stride{0};
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
-static long long g_prof_seen[HH_PROF_CLASSES];
+static long long g_prof_seen[HH_PROF_CLASSES][HH_PROF_ROLES];
 static std::atomic<const char*> g_prof_name[HH_PROF_CLASSES];     // kernel (template instantiation) last dispatched per class while profiling was on
 static int g_prof_gen = 0;                       // bumped by every hh_prof_enable: a scope opened before the call must not touch the new records
 static const size_t HH_PROF_MAX_RECS = 1u << 16; // bound on the records (and events) kept while profiling stays enabled; later launches are only counted
@@ -146,9 +148,10 @@ static hipEvent_t prof_event() {
 HHProfScope::HHProfScope(int klass, double work, hipStream_t s) : rec_(-1), gen_(0), stream_(s) {
     const int stride = g_prof_stride.load(std::memory_order_relaxed);
     if (stride <= 0 || klass < 0 || klass >= HH_PROF_CLASSES) return;
+    const int role = g_prof_role.load(std::memory_order_relaxed);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if ((g_prof_seen[klass]++ % stride) != 0 || g_prof_recs.size() >= HH_PROF_MAX_RECS) return;
-    ProfRec r{klass, prof_event(), prof_event(), work};
+    if ((g_prof_seen[klass][role]++ % stride) != 0 || g_prof_recs.size() >= HH_PROF_MAX_RECS) return;      // every stride-th launch of the class IN THIS ROLE
+    ProfRec r{klass, role, prof_event(), prof_event(), work};
     hipEventRecord(r.e0, s);
     g_prof_recs.push_back(r);
     rec_ = (int)g_prof_recs.size() - 1;
@@ -180,27 +183,43 @@ extern "C" int hh_prof_enable(int stride) {
     for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
     g_prof_recs.clear();
     ++g_prof_gen;
-    for (int i = 0; i < HH_PROF_CLASSES; ++i) g_prof_seen[i] = 0;
+    for (int i = 0; i < HH_PROF_CLASSES; ++i)
+        for (int j = 0; j < HH_PROF_ROLES; ++j) g_prof_seen[i][j] = 0;
     if (stride > 0)
         for (int i = 0; i < HH_PROF_CLASSES; ++i) g_prof_name[i].store(nullptr, std::memory_order_relaxed);
     g_prof_stride.store(stride, std::memory_order_relaxed);
     return HH_OK;
 }
 
+extern "C" int hh_prof_set_role(int role) {
+    HH_REQUIRE(role >= 0 && role < HH_PROF_ROLES, HH_ERR_SHAPE, "hh_prof_set_role: role must be in [0, %d)", HH_PROF_ROLES);
+    g_prof_role.store(role, std::memory_order_relaxed);
+    return HH_OK;
+}
+
+extern "C" int hh_prof_read_role(int klass, int role, int64_t* launches_timed, int64_t* launches_seen, double* total_ms, double* total_work);
+
 extern "C" int hh_prof_read(int klass, int64_t* launches_timed, int64_t* launches_seen, double* total_ms, double* total_work) {
-    HH_REQUIRE(klass >= 0 && klass < HH_PROF_CLASSES && launches_timed && launches_seen && total_ms && total_work, HH_ERR_SHAPE,
+    return hh_prof_read_role(klass, -1, launches_timed, launches_seen, total_ms, total_work);
+}
+
+extern "C" int hh_prof_read_role(int klass, int role, int64_t* launches_timed, int64_t* launches_seen, double* total_ms, double* total_work) {
+    HH_REQUIRE(klass >= 0 && klass < HH_PROF_CLASSES && role >= -1 && role < HH_PROF_ROLES && launches_timed && launches_seen && total_ms && total_work, HH_ERR_SHAPE,
                "hh_prof_read: bad arguments");
     std::lock_guard<std::mutex> lk(g_prof_mu);
     int64_t n = 0;
     double ms = 0.0, work = 0.0;
     for (auto& r : g_prof_recs) {
-        if (r.klass != klass) continue;
+        if (r.klass != klass || (role >= 0 && r.role != role)) continue;
         hipError_t e = hipEventSynchronize(r.e1);
         float t = 0.f;
         if (e == hipSuccess) e = hipEventElapsedTime(&t, r.e0, r.e1);
         HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_prof_read: %s", hipGetErrorString(e));
         ms += t; work += r.work; ++n;
     }
-    *launches_timed = n; *launches_seen = g_prof_seen[klass]; *total_ms = ms; *total_work = work;
+    long long seen = 0;
+    for (int j = 0; j < HH_PROF_ROLES; ++j)
+        if (role < 0 || role == j) seen += g_prof_seen[klass][j];
+    *launches_timed = n; *launches_seen = seen; *total_ms = ms; *total_work = work;
     return HH_OK;
 }

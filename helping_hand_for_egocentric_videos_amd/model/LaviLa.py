@@ -322,6 +322,10 @@ class SpaceTimeTransformer(nn.Module):
     @torch.no_grad()
     def forward_features(self, x, use_checkpoint=False, cls_at_last=True, out_dtype=torch.float32):
         """LaviLa.py:537-573.  The tower is frozen in this path (run/train.py:89,109-110): no autograd graph."""
+        with ops.prof_role(ops.PROF_ROLE_VISION):
+            return self._forward_features(x, out_dtype)
+
+    def _forward_features(self, x, out_dtype):
         _require_gpu(x, "SpaceTimeTransformer")
         B, T = x.shape[:2]
         if T > self.num_frames:
@@ -406,7 +410,7 @@ class CLIP(nn.Module):
             raise NotImplementedError("CLIP.encode_text: the text tower is frozen on the hot path (run/train.py:89 freezes the backbone; optim_policy, "
                                       "utils/train_utils.py:42-43, gives it no optimizer group); a trainable text tower has no libhh backward and there is "
                                       "no stock-op fallback -- call under torch.no_grad() or freeze the parameters")
-        with torch.no_grad():
+        with torch.no_grad(), ops.prof_role(ops.PROF_ROLE_TEXT):
             x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]
             x = self.transformer.forward_frozen(x)
             x = ops.layernorm(x, self.ln_final.weight.detach().float(), self.ln_final.bias.detach().float(), self.ln_final.eps,

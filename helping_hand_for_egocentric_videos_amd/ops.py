@@ -57,6 +57,24 @@ def set_tuning(name, value):
     _lib.check(_lib.lib().hh_set_tuning(name.encode(), int(value)), "hh_set_tuning")
 
 
+PROF_ROLE_DECODER, PROF_ROLE_VISION, PROF_ROLE_TEXT = 0, 1, 2
+
+
+class prof_role:
+    """`with ops.prof_role(ops.PROF_ROLE_VISION): ...` -- names the part of the step whose kernels the host launches inside the block, for
+    the library's per-kernel timers (include/hh.h: hh_prof_set_role).  Costs one relaxed store; never changes results."""
+
+    def __init__(self, role):
+        self.role = int(role)
+
+    def __enter__(self):
+        _lib.lib().hh_prof_set_role(self.role)
+
+    def __exit__(self, *exc):
+        _lib.lib().hh_prof_set_role(PROF_ROLE_DECODER)
+        return False
+
+
 def set_stream_cu_budget(stream, n_cus):
     """Persistent one-workgroup-per-CU kernels launched on `stream` use `n_cus` workgroups (0 = all CUs); include/hh.h:
     hh_stream_set_cu_budget."""

@@ -60,6 +60,7 @@ class TrainStep:
         self._zeroed_idx = None
         self._row_base = None                          # cached arange(rows) * context_length of the caption matrix
         self.text_on_side_stream = True               # False: both towers on one stream (bench.py's kernel-alone timing steps)
+        self.span_log = None                           # a list: every step appends (start, end) device events of its decoder / loss / optimizer span on the main stream (bench.py)
         backbone.eval()                               # run/train.py:89
 
     # ------------------------------------------------------------------ forward
@@ -129,6 +130,10 @@ class TrainStep:
         B, T = video.shape[:2]
         W, _ = world()
         grid, tmap = self._encoded(batch)
+        if self.span_log is not None:                  # (after the main stream's wait for this batch's towers: the span holds no tower time)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.span_log.append([ev, None])
         if next_batch is not None:
             self.prefetch(next_batch)
         det, hs, _, _ = self.decoder(grid)
@@ -217,6 +222,10 @@ class TrainStep:
                              self.lr, *self.betas, self.eps, self.wd, zero_grads=zero_grads)
         a.grads_clean = bool(zero_grads)
         a.sink_armed = False                                    # until the next zero_grad()
+        if self.span_log and self.span_log[-1][1] is None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.span_log[-1][1] = ev
 
 
     # ------------------------------------------------------------------ optimizer state (checkpoint exchange with the reference)

@@ -97,6 +97,12 @@ enum hh_prof_class {
 };
 int hh_prof_enable(int stride);
 int hh_prof_read(int klass, int64_t* launches_timed, int64_t* launches_seen, double* total_ms, double* total_work);
+/* roles (round 5): the host names the part of the step it is launching -- 0 = decoder / losses / optimizer (default), 1 = vision tower,
+ * 2 = text tower -- and every timed launch carries the role current at its launch; the stride applies per (class, role).  The three
+ * parts run on three concurrent streams in the pipelined step: only the sums of ONE role are comparable with a step's wall time.
+ * hh_prof_read_role(klass, role, ...) sums one role's records (role -1 = all roles = hh_prof_read). */
+int hh_prof_set_role(int role);
+int hh_prof_read_role(int klass, int role, int64_t* launches_timed, int64_t* launches_seen, double* total_ms, double* total_work);
 /* the kernel (template instantiation, spelled as rocprofv3 --kernel-trace prints it) that the LAST launch of the class dispatched since
  * hh_prof_enable(stride > 0); "" if none.  A static string owned by the library. */
 const char* hh_prof_kernel_name(int klass);
