@@ -283,7 +283,7 @@ def visual_ln_fold(backbone):
 def selfcheck_summary(sc):
     if not sc:
         return None
-    return {"clip0_encoder_bit_identical": sc.get("encoder_bit_identical_clips_before_last"), "matched_indices_equal": sc.get("matched_indices_equal"),
+    return {"clip0_encoder_bit_identical": sc.get("encoder_bit_identical_clips_before_last"), "matched_frames_equal": sc.get("matched_frames_equal_fraction"),
             "hs_diff_over_scale": round(sc.get("hs_max_abs_diff_over_scale", 0.0), 6)}
 
 
@@ -523,6 +523,7 @@ def main():
     ap.add_argument("--kv-proj", action="store_true", help="A/B: the decoder's round-1..4 cross-attention (one K/V in-projection of all memory tokens for the six layers + hh_xattn_*) "
                                                            "instead of the memory-space attention (csrc/mattn.hip)")
     ap.add_argument("--token-major-qkv", action="store_true", help="A/B: the QKV projections write nn.Linear's token-major [B*N, 3D] instead of head-major planes")
+    ap.add_argument("--time-proj-fp32", action="store_true", help="A/B: the time projection's epilogue re-reads the fp32 residual rows (round 4) instead of z3 = bf16(x)")
     ap.add_argument("--no-ln-fold", action="store_true", help="A/B: norm1 / norm2 as stand-alone fused add+LayerNorm kernels instead of folded into the GEMMs around them")
     ap.add_argument("--space-16q", action="store_true", help="A/B: space attention on the 16-query-block kernel instead of the joint-block kernel")
     ap.add_argument("--gemm-tail", type=int, default=None, help="A/B: hh_set_tuning('gemm_tail', v): 1 (default) = row tails of <= 64 rows inside the persistent kernel, 2 = always the separate tail kernel, 0 = the 128x128 kernel; same results")
@@ -557,6 +558,8 @@ def main():
 
     if args.no_ln_fold:
         LaviLa.LN_FOLD = False
+    if args.time_proj_fp32:
+        LaviLa.TIME_PROJ_READS_Z3 = False
     cfg, cfg_name = CONFIGS[args.config]
     B = args.batch or {"c2": 32, "c4": 4, "c1": 2}[args.config]
     torch.manual_seed(0)

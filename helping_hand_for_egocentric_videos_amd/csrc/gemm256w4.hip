@@ -520,13 +520,21 @@ __device__ __forceinline__ void w4p_store_rows_direct(const GemmParams& p, int64
 // z and z^2 over its 32 columns (the four lanes of a row are 16 apart: two cross-lane adds), and sends z -- and C = bf16(value), unless
 // skip_c -- through the wave's LDS scratch to 4-rows-x-256-B stores.  The (sum, sum of squares) of the wave's 128 columns go to
 // z_partials[row][n0 / 128 + wc]; gemm.hip's finalize pass adds the N / 128 slices in a fixed order.
-template <int IDX, int TR = 256>
+// RB (round 5, EPI 7): the residual rows are bf16 (the z = bf16(x) this block's norm3 consumed; the time branch's z1 only feeds norm1): ONE
+// 16-byte load per 8 columns instead of two -- kept raw in xa[j] (bit pattern), widened where the group is consumed; xb is unused.
+template <int IDX, int TR = 256, bool RB = false>
 __device__ __forceinline__ void w4p_zload(const float* xw0, unsigned xlo, f32x4 (&xa)[4], f32x4 (&xb)[4], int64_t ldx) {
-    const float* r = xw0 + (int64_t)w4_rowoff<TR>(IDX) * ldx + xlo;       // (wave-uniform base + the lane's 32-bit offset: see the write-back below)
+    if constexpr (RB) {
+        const bf16_t* r = (const bf16_t*)xw0 + (int64_t)w4_rowoff<TR>(IDX) * ldx + xlo;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        xa[j] = *(const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64);
-        xb[j] = *(const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64 + 4);
+        for (int j = 0; j < 4; ++j) xa[j] = *(const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64);      // 8 bf16 = 16 bytes, not yet widened
+    } else {
+        const float* r = xw0 + (int64_t)w4_rowoff<TR>(IDX) * ldx + xlo;       // (wave-uniform base + the lane's 32-bit offset: see the write-back below)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xa[j] = *(const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64);
+            xb[j] = *(const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64 + 4);
+        }
     }
 }
 __device__ __forceinline__ void w4p_lds_rows(char* scr, int frow, int fq, int l15, int l4, const f32x4 (&a)[4], const f32x4 (&b)[4], u32x4 (&rd)[4]) {
@@ -538,7 +546,7 @@ __device__ __forceinline__ void w4p_lds_rows(char* scr, int frow, int fq, int l1
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int r = 4 * q + l4; rd[q] = *(const u32x4*)(scr + r * 256 + ((l15 ^ r) << 4)); }
 }
-template <int IDX, int TR = 256>
+template <int IDX, int TR = 256, bool RB = false>
 __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw0, bf16_t* zw0, float* part0, char* scr,
                                                  int frow, int fq, int l15, int l4, const float* bias_l, float* xw0, unsigned xoff, unsigned xlo, unsigned coff,
                                                  unsigned zoff, f32x4 (&xa)[4], f32x4 (&xb)[4], f32x4 (&xna)[4], f32x4 (&xnb)[4]) {
@@ -566,12 +574,16 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw
     f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        a[j] += xa[j]; b[j] += xb[j];
+        if constexpr (RB) {
+            const u32x4 r = __builtin_bit_cast(u32x4, xa[j]);
+            a[j] += (f32x4){bf16_lo_to_f32(r[0]), bf16_hi_to_f32(r[0]), bf16_lo_to_f32(r[1]), bf16_hi_to_f32(r[1])};
+            b[j] += (f32x4){bf16_lo_to_f32(r[2]), bf16_hi_to_f32(r[2]), bf16_lo_to_f32(r[3]), bf16_hi_to_f32(r[3])};
+        } else { a[j] += xa[j]; b[j] += xb[j]; }
         s4 += a[j]; s4 += b[j];
         q4 += a[j] * a[j]; q4 += b[j] * b[j];
     }
-    if constexpr (IDX + 2 < w4_groups<TR>()) w4p_zload<IDX + 2, TR>(xw0, xlo, xa, xb, p.e.z_ldr);      // (xa / xb are consumed: re-targeted right away)
-    if (p.e.z_update) {
+    if constexpr (IDX + 2 < w4_groups<TR>()) w4p_zload<IDX + 2, TR, RB>(xw0, xlo, xa, xb, p.e.z_ldr);      // (xa / xb are consumed: re-targeted right away)
+    if (!RB && p.e.z_update) {
         // x <- x + branch in place (the rows this lane loaded xa / xb from).  Straight from the MFMA layout a store instruction would
         // cover 16 rows x 4 pieces of 16 B at a 32-B stride (measured: fc2 + 228 us per launch, most of it these 64 stores per tile);
         // through the wave's LDS scratch -- one 64-column half (16 rows x 256 B, the bf16 image's geometry and swizzle) at a time -- the
@@ -602,7 +614,7 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw
     bf16_t* zw = zw0 + (int64_t)w4_rowoff<TR>(IDX) * p.e.z_ldc;
 #pragma unroll
     for (int q = 0; q < 4; ++q) *(u32x4*)(zw + (int64_t)(4 * q) * p.e.z_ldc + zoff) = rd[q];
-    if constexpr (IDX + 1 < w4_groups<TR>()) w4p_store_tile_z<IDX + 1, TR>(p, cw0, zw0, part0, scr, frow, fq, l15, l4, bias_l, xw0, xoff, xlo, coff, zoff, xna, xnb, xa, xb);
+    if constexpr (IDX + 1 < w4_groups<TR>()) w4p_store_tile_z<IDX + 1, TR, RB>(p, cw0, zw0, part0, scr, frow, fq, l15, l4, bias_l, xw0, xoff, xlo, coff, zoff, xna, xnb, xa, xb);
 }
 
 // Dynamic tile walk: per stream slot (runtime.cpp: hh_stream_slot) 8 per-XCD tile counters + the count of finished workgroups; the last
@@ -620,10 +632,13 @@ __device__ unsigned g_w4_tile_cnt[32][16];
 template <bool OUT_BF16, int EPI, int TR = 256>
 __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
     static_assert(TR == 256 || (TR == 224 && OUT_BF16 && (EPI == 0 || EPI == 4)), "224-row tiles: bf16 bias-only and LayerNorm-fold producer epilogues");
+    constexpr bool PRODUCER = EPI == 4 || EPI == 7;          // LayerNorm fold, producer side; 7 = with bf16 residual rows (z_resid_dtype HH_BF16)
+    constexpr bool CONSUMER = EPI == 5 || EPI == 6;
+    constexpr bool RB = EPI == 7;
     constexpr int WROWS = TR == 224 ? 112 : 64;              // tile row of wave row 1's first A-lo row
     // global_store_dwordx4 per wave and tile in the epilogue that are younger than every load of it (checked in the ISA); the producer
     // side of the LayerNorm fold (EPI 4) waits for its residual loads group by group: only the last group's z stores are certain to trail
-    constexpr int STORES = EPI == 4 ? 4 : OUT_BF16 ? 4 * w4_groups<TR>() : 64;
+    constexpr int STORES = PRODUCER ? 4 : OUT_BF16 ? 4 * w4_groups<TR>() : 64;
     constexpr int VM_ST = 24 + STORES > 63 ? 63 : 24 + STORES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -686,7 +701,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
     const int64_t hiA = (TR == 224 ? 64 : 128) * p.lda * 2, hiW = 64 * p.ldw * 2;
 
     float* bias_s = (float*)(smem + 2 * W4_BUF);
-    if constexpr (EPI < 5) {
+    if constexpr (!CONSUMER) {
         for (int i = tid * 4; i < p.N; i += 256 * 4)
             *(f32x4*)(bias_s + i) = p.e.bias ? *(const f32x4*)(p.e.bias + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -747,7 +762,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
     }
 #define W4_STAGE(BUF, SLOT, VOFF, PTR) do { w4_dma<W4_IMM(BUF, SLOT)>(s.VOFF[0], s.PTR, s.wave_lds); w4_dma<W4_IMM(BUF, SLOT) + 1024>(s.VOFF[1], s.PTR, s.wave_lds);   \
         w4_dma<W4_IMM(BUF, SLOT) + 2048>(s.VOFF[2], s.PTR, s.wave_lds); w4_dma<W4_IMM(BUF, SLOT) + 3072>(s.VOFF[3], s.PTR, s.wave_lds); s.PTR += 128; } while (0)
-    if constexpr (EPI >= 5) ln_prefetch(0, m0, n0);                      // (older than every DMA of the ring: the prologue's waits cover it)
+    if constexpr (CONSUMER) ln_prefetch(0, m0, n0);                      // (older than every DMA of the ring: the prologue's waits cover it)
     W4_STAGE(0, W4_ALO, aoff, pAL); W4_STAGE(0, W4_BLO, woff, pWL); W4_STAGE(0, W4_BHI, woff, pWH); W4_STAGE(0, W4_AHI, aoff, pAH);
     W4_STAGE(1, W4_ALO, aoff, pAL); W4_STAGE(1, W4_BLO, woff, pWL); W4_STAGE(1, W4_BHI, woff, pWH); W4_STAGE(1, W4_AHI, aoff, pAH);
     asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                   // A-lo(0), W-lo(0) landed (6 half-tiles younger)
@@ -801,7 +816,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
             s.nAL = nA; s.nAH = nA + hiA; s.nWL = nW; s.nWH = nW + hiW;
             // its epilogue record, into the other LDS record (this tile's is read in the epilogue below); it lands -- and every wave's
             // counted wait + barrier of the next edges publishes it -- a whole main loop before it is read
-            if constexpr (EPI >= 5) ln_prefetch((tile_i + 1) & 1, nm0, nn0);
+            if constexpr (CONSUMER) ln_prefetch((tile_i + 1) & 1, nm0, nn0);
         }
         asm volatile("" : "+s"(s.nAL), "+s"(s.nAH), "+s"(s.nWL), "+s"(s.nWH));
         if (has_next) { w4_iter<W4V_REBASE, VM_ST, TR>(s); w4_iter<W4V_MID, VM_ST, TR>(s); }
@@ -829,7 +844,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
             stamp(3);
             W4Ln ln;
             f32x2 st0 = {1.f, 0.f};
-            if constexpr (EPI >= 5) {
+            if constexpr (CONSUMER) {
                 const float* rec = (const float*)(smem + 2 * W4_BUF + (tile_i & 1) * W4_LNREC);     // this tile's record (LDS)
                 const int cl = wc * 128 + 8 * fq;                                   // the lane's first column inside the tile
                 ln.bias_l = rec + cl;
@@ -842,11 +857,11 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
                     ln.cs_v[j][1] = *(const f32x4*)(rec + 256 + cj + 4);
                 }
             }
-            if constexpr (EPI == 4) {
+            if constexpr (PRODUCER) {
                 char* scr = smem + 2 * W4_BUF + p.N * 4 + wave * 4096;
                 const int64_t row0 = m0 + wr * WROWS;                     // first of the wave's rows; n0 + wc * 128: its first column (all uniform)
                 const int col0 = n0 + wc * 128;
-                float* xw0 = (float*)e.z_resid + row0 * e.z_ldr + col0;
+                float* xw0 = RB ? (float*)((bf16_t*)e.z_resid + row0 * e.z_ldr + col0) : (float*)e.z_resid + row0 * e.z_ldr + col0;      // (RB: really a bf16 pointer)
                 bf16_t* cw0 = (bf16_t*)p.C + row0 * p.ldc + col0;
                 bf16_t* zw0 = (bf16_t*)e.z_out + row0 * e.z_ldc + col0;
                 float* part0 = e.z_partials + (row0 * (int64_t)(p.N >> 7) + ((n0 >> 7) + wc)) * 2;
@@ -859,9 +874,9 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
                 const unsigned coff = l4u * (unsigned)p.ldc + 8u * l15u, zoff = l4u * (unsigned)e.z_ldc + 8u * l15u;      // store phase, bf16 rows
                 const unsigned xlo = l15u * (unsigned)e.z_ldr + 8u * l4u;                     // MFMA layout: row frow = lane & 15, columns 8 fq
                 f32x4 xa[4], xb[4], xna[4], xnb[4];
-                w4p_zload<0, TR>(xw0, xlo, xa, xb, e.z_ldr);
-                w4p_zload<1, TR>(xw0, xlo, xna, xnb, e.z_ldr);
-                w4p_store_tile_z<0, TR>(p, cw0, zw0, part0, scr, frow_, fq_, l15, l4, bias_z, xw0, xoff, xlo, coff, zoff, xa, xb, xna, xnb);
+                w4p_zload<0, TR, RB>(xw0, xlo, xa, xb, e.z_ldr);
+                w4p_zload<1, TR, RB>(xw0, xlo, xna, xnb, e.z_ldr);
+                w4p_store_tile_z<0, TR, RB>(p, cw0, zw0, part0, scr, frow_, fq_, l15, l4, bias_z, xw0, xoff, xlo, coff, zoff, xa, xb, xna, xnb);
             } else if constexpr (OUT_BF16 && EPI != 2 && EPI != 6) {
                 // through this wave's 4 KB of LDS: a lane finishes 4 x 16 B of one row (MFMA layout), the wave then stores 4 rows x 256 B
                 // per instruction.  A store instruction covering 16 rows x 64 B takes ~270 cycles on the CU's store path, 4 rows x 256 B
@@ -894,7 +909,7 @@ static int g_w4_ln_ext = 1;         // hh_set_tuning("gemm_ln_w4", 0): keep Laye
 void hh_gemm256w4p_set_ln_ext(int v) { g_w4_ln_ext = v; }
 int hh_gemm256w4p_ln_epi(const hh_gemm_epilogue& e) {
     if (e.c_dtype != HH_BF16) return -1;
-    if (e.z_out) return (e.ln_stats == nullptr && e.act == HH_ACT_NONE && e.colscale_cols == 0 && e.c_block_stride == 0) ? 4 : -1;
+    if (e.z_out) return (e.ln_stats == nullptr && e.act == HH_ACT_NONE && e.colscale_cols == 0 && e.c_block_stride == 0) ? (e.z_resid_dtype == HH_BF16 ? 7 : 4) : -1;
     if (e.ln_stats) {                        // (callers check N >= 2048: the two epilogue records live where the N-float bias vector is)
         if (e.act == HH_ACT_NONE && e.colscale_cols > 0 && e.colscale_cols % 128 == 0) return 5;
         if (e.act == HH_ACT_QUICKGELU && e.colscale_cols == 0) return 6;
@@ -920,7 +935,7 @@ int hh_gemm256w4p_launch(const GemmParams& p, int epi, unsigned pg, hipStream_t 
     if (!attr_done) {
 #define ATTRP(BF, E) hipFuncSetAttribute((const void*)gemm256w4p_kernel<BF, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096))
         ATTRP(true, 0); ATTRP(false, 0); ATTRP(true, 1); ATTRP(false, 1); ATTRP(true, 2); ATTRP(false, 2); ATTRP(true, 3); ATTRP(false, 3);
-        ATTRP(true, 4); ATTRP(true, 5); ATTRP(true, 6);
+        ATTRP(true, 4); ATTRP(true, 5); ATTRP(true, 6); ATTRP(true, 7);
 #undef ATTRP
         hipFuncSetAttribute((const void*)gemm256w4p_kernel<true, 0, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096));
         hipFuncSetAttribute((const void*)gemm256w4p_kernel<true, 4, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096));
@@ -937,7 +952,7 @@ int hh_gemm256w4p_launch(const GemmParams& p, int epi, unsigned pg, hipStream_t 
     }
     if (epi >= 4) {
         if (!bf) { hh_set_error("hh_gemm_bf16: the LayerNorm-fold epilogues of the persistent kernel write bf16"); return HH_ERR_UNSUPPORTED; }
-        if (epi == 4) LAUNCHP(true, 4); else if (epi == 5) LAUNCHP(true, 5); else LAUNCHP(true, 6);
+        if (epi == 4) LAUNCHP(true, 4); else if (epi == 5) LAUNCHP(true, 5); else if (epi == 6) LAUNCHP(true, 6); else LAUNCHP(true, 7);
         g_w4_ts_last = true;
         return hh_check_launch("hh_gemm_bf16(256x256 persistent, 4 waves, LayerNorm fold)");
     }

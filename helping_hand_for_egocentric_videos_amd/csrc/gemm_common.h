@@ -56,7 +56,11 @@ __device__ __forceinline__ void gemm_store4(const hh_gemm_epilogue& e, char* Cba
     }
     if (e.resid) v += *(const f32x4*)(e.resid + orow * e.ldr + n);
     if (e.z_out) {
-        const f32x4 z = *(const f32x4*)(e.z_resid + orow * e.z_ldr + n) + v;
+        f32x4 z;
+        if (e.z_resid_dtype == HH_BF16) {
+            const u32x2 r = *(const u32x2*)((const bf16_t*)e.z_resid + orow * e.z_ldr + n);
+            z = (f32x4){bf16_lo_to_f32(r[0]), bf16_hi_to_f32(r[0]), bf16_lo_to_f32(r[1]), bf16_hi_to_f32(r[1])} + v;
+        } else z = *(const f32x4*)((const float*)e.z_resid + orow * e.z_ldr + n) + v;
         if (e.z_update) *(f32x4*)((float*)e.z_resid + orow * e.z_ldr + n) = z;      // x <- x + branch, in place (this lane read the same 16 bytes)
         u32x2 o = {pack_bf16(z[0], z[1]), pack_bf16(z[2], z[3])};
         *(u32x2*)((bf16_t*)e.z_out + orow * e.z_ldc + n) = o;

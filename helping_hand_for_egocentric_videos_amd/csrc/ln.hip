@@ -31,10 +31,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
                                                      const float* __restrict__ beta, TOUT* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      int64_t rows, int cols, float eps,
-                                                     TOUT* __restrict__ y2, const float* __restrict__ pos, int pos_rows) {
+                                                     TOUT* __restrict__ y2, const float* __restrict__ pos, int pos_rows,
+                                                     TOUT* __restrict__ y_cls = nullptr, int split_n = 0) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    // split_n > 0 (hh_layernorm_split_cls_fwd): rows are clips of split_n tokens whose first is the CLS token -- it goes to y_cls[clip],
+    // the other split_n - 1 rows of a clip follow each other in y (the decoder's [B, T*n, D] grid, model/tfm_decoder.py:200-205)
+    if (split_n > 0) {
+        const int64_t clip = row / split_n, t = row % split_n;
+        y = t == 0 ? y_cls + clip * cols - row * cols : y - (clip + 1) * (int64_t)cols;      // (both then indexed with row * cols below)
+    }
     float v[NV][4];
     load_row<NV, TIN>(x + row * cols, cols, lane, v);
     float s = 0.f;
@@ -312,16 +319,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIN* __restrict__ x, 
 
 template <int NV>
 static int ln_fwd_dispatch(const void* x, int xd, const float* g, const float* b, void* y, int yd, float* mo, float* ro,
-                           int64_t rows, int cols, float eps, hipStream_t s, void* y2 = nullptr, const float* pos = nullptr, int pos_rows = 1) {
+                           int64_t rows, int cols, float eps, hipStream_t s, void* y2 = nullptr, const float* pos = nullptr, int pos_rows = 1,
+                           void* y_cls = nullptr, int split_n = 0) {
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if (xd == HH_F32 && yd == HH_BF16)
-        hipLaunchKernelGGL((ln_fwd_kernel<NV, float, bf16_t>), grid, block, 0, s, (const float*)x, g, b, (bf16_t*)y, mo, ro, rows, cols, eps, (bf16_t*)y2, pos, pos_rows);
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, float, bf16_t>), grid, block, 0, s, (const float*)x, g, b, (bf16_t*)y, mo, ro, rows, cols, eps, (bf16_t*)y2, pos, pos_rows, (bf16_t*)y_cls, split_n);
     else if (xd == HH_F32 && yd == HH_F32)
-        hipLaunchKernelGGL((ln_fwd_kernel<NV, float, float>), grid, block, 0, s, (const float*)x, g, b, (float*)y, mo, ro, rows, cols, eps, (float*)y2, pos, pos_rows);
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, float, float>), grid, block, 0, s, (const float*)x, g, b, (float*)y, mo, ro, rows, cols, eps, (float*)y2, pos, pos_rows, (float*)y_cls, split_n);
     else if (xd == HH_BF16 && yd == HH_BF16)
-        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, g, b, (bf16_t*)y, mo, ro, rows, cols, eps, (bf16_t*)y2, pos, pos_rows);
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, g, b, (bf16_t*)y, mo, ro, rows, cols, eps, (bf16_t*)y2, pos, pos_rows, (bf16_t*)y_cls, split_n);
     else
-        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, float>), grid, block, 0, s, (const bf16_t*)x, g, b, (float*)y, mo, ro, rows, cols, eps, (float*)y2, pos, pos_rows);
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, float>), grid, block, 0, s, (const bf16_t*)x, g, b, (float*)y, mo, ro, rows, cols, eps, (float*)y2, pos, pos_rows, (float*)y_cls, split_n);
     return hh_check_launch("hh_layernorm_fwd");
 }
 
@@ -337,6 +345,22 @@ extern "C" int hh_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
     if (nv <= 2) return ln_fwd_dispatch<2>(x, x_dtype, gamma, beta, y, y_dtype, mean_out, rstd_out, rows, cols, eps, s);
     if (nv <= 4) return ln_fwd_dispatch<4>(x, x_dtype, gamma, beta, y, y_dtype, mean_out, rstd_out, rows, cols, eps, s);
     return ln_fwd_dispatch<8>(x, x_dtype, gamma, beta, y, y_dtype, mean_out, rstd_out, rows, cols, eps, s);
+}
+
+extern "C" int hh_layernorm_split_cls_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y_patches, void* y_cls, int y_dtype,
+                                          int64_t clips, int tokens_per_clip, int cols, float eps, hh_stream_t stream) {
+    HH_REQUIRE(clips >= 0 && tokens_per_clip >= 2 && cols > 0 && cols % 8 == 0 && cols <= 2048, HH_ERR_SHAPE,
+               "hh_layernorm_split_cls_fwd: cols=%d must be a multiple of 8 and <= 2048, tokens_per_clip >= 2", cols);
+    HH_REQUIRE((x_dtype == HH_F32 || x_dtype == HH_BF16) && (y_dtype == HH_F32 || y_dtype == HH_BF16), HH_ERR_DTYPE, "hh_layernorm_split_cls_fwd: bad dtype");
+    if (clips == 0) return HH_OK;
+    HH_REQUIRE(y_patches != nullptr && y_cls != nullptr && HH_ALIGNED16(x) && HH_ALIGNED16(y_patches) && HH_ALIGNED16(y_cls) && HH_ALIGNED16(gamma) && HH_ALIGNED16(beta), HH_ERR_ALIGN,
+               "hh_layernorm_split_cls_fwd: pointers must be non-NULL and 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t rows = clips * tokens_per_clip;
+    const int nv = (cols + 255) / 256;
+    if (nv <= 2) return ln_fwd_dispatch<2>(x, x_dtype, gamma, beta, y_patches, y_dtype, nullptr, nullptr, rows, cols, eps, s, nullptr, nullptr, 1, y_cls, tokens_per_clip);
+    if (nv <= 4) return ln_fwd_dispatch<4>(x, x_dtype, gamma, beta, y_patches, y_dtype, nullptr, nullptr, rows, cols, eps, s, nullptr, nullptr, 1, y_cls, tokens_per_clip);
+    return ln_fwd_dispatch<8>(x, x_dtype, gamma, beta, y_patches, y_dtype, nullptr, nullptr, rows, cols, eps, s, nullptr, nullptr, 1, y_cls, tokens_per_clip);
 }
 
 extern "C" int hh_layernorm_pos_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, void* y_plus_pos, int y_dtype,

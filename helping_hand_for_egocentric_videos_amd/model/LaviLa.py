@@ -97,6 +97,7 @@ QKV_HEAD_MAJOR_PLANES = True       # False: the QKV projection writes nn.Linear'
 # The flag is read when a block packs its weights; a block whose pack was made under the other setting re-packs on its next use
 # (SpaceTimeBlock.packed), and `SpaceTimeTransformer.ln_fold_packed()` reports what the tower actually runs (bench.py records that).
 LN_FOLD = True
+TIME_PROJ_READS_Z3 = True          # False: the time projection's epilogue reads the fp32 residual rows (round 4; A/B measurements)
 
 
 class VarAttention(nn.Module):
@@ -218,7 +219,9 @@ class SpaceTimeBlock(nn.Module):
             else:
                 z3, st3 = pending
             a = self.timeattn.core(z3, pk["time"], B, T, n, "time", ln=(st3, pk["qkv_n3"]))                     # qkv(LN3(x))
-            _, z1, st1 = ops.gemm(a, pk["time"]["wproj"], pk["time"]["bproj"], z=(x, eps1, False))              # z1 = x + t
+            # z1 = x + t feeds norm1 and nothing else (LaviLa.py:372-384: the space residual goes on x): the time projection adds its
+            # result to z3 = bf16(x) -- the 2-byte rows this block's norm3 just consumed -- instead of re-reading the 4-byte fp32 stream
+            _, z1, st1 = ops.gemm(a, pk["time"]["wproj"], pk["time"]["bproj"], z=(z3 if TIME_PROJ_READS_Z3 else x, eps1, False))
             a = self.attn.core(z1, pk["space"], B, T, n, "space", ln=(st1, pk["qkv_n1"]))                        # qkv(LN1(x + t))
             _, z2, st2 = ops.gemm(a, pk["space"]["wproj"], pk["space"]["bproj"], z=(x, eps2, False, True))      # x <- x + s; z2
             wf, cs, bf = pk["fc1_n2"]
@@ -320,12 +323,15 @@ class SpaceTimeTransformer(nn.Module):
         return self._pack
 
     @torch.no_grad()
-    def forward_features(self, x, use_checkpoint=False, cls_at_last=True, out_dtype=torch.float32):
-        """LaviLa.py:537-573.  The tower is frozen in this path (run/train.py:89,109-110): no autograd graph."""
+    def forward_features(self, x, use_checkpoint=False, cls_at_last=True, out_dtype=torch.float32, split_cls=False):
+        """LaviLa.py:537-573.  The tower is frozen in this path (run/train.py:89,109-110): no autograd graph.
+        split_cls (keyword-only in spirit; the reference has no such argument): return (x_cls [B, D], patch rows [B, T*n, D]) with the
+        patch rows contiguous -- what the decoder takes (run/train.py:115: image_feature_map[:, 1:]) -- instead of the [B, 1+T*n, D] map;
+        the final LayerNorm writes them there directly, no strided copy of the feature map."""
         with ops.prof_role(ops.PROF_ROLE_VISION):
-            return self._forward_features(x, out_dtype)
+            return self._forward_features(x, out_dtype, split_cls)
 
-    def _forward_features(self, x, out_dtype):
+    def _forward_features(self, x, out_dtype, split_cls):
         _require_gpu(x, "SpaceTimeTransformer")
         B, T = x.shape[:2]
         if T > self.num_frames:
@@ -338,17 +344,27 @@ class SpaceTimeTransformer(nn.Module):
         else:
             patches = ops.patch_im2col(x.float().contiguous(), self.patch_embed.patch_size[0], self.patch_embed.kpad())
         tok = ops.gemm(patches, pk["wpatch"], out_dtype=torch.float32)
-        xs = ops.embed_ln_pre(tok, pk["cls"], pk["pos"], pk["tmp"], *pk["ln_pre"][:2], B, T, n, pk["ln_pre"][2])
+        fold = bool(LN_FOLD) and len(self.blocks) > 0
+        pending = None
+        if fold:      # z = bf16(x) and its row statistics for block 0's folded norm3 ride in the same pass (no cast + hh_ln_rowstats launches)
+            xs, z0, st0 = ops.embed_ln_pre(tok, pk["cls"], pk["pos"], pk["tmp"], *pk["ln_pre"][:2], B, T, n, pk["ln_pre"][2], z_eps=self.blocks[0].norm3.eps)
+            pending = (z0, st0)
+        else:
+            xs = ops.embed_ln_pre(tok, pk["cls"], pk["pos"], pk["tmp"], *pk["ln_pre"][:2], B, T, n, pk["ln_pre"][2])
         del patches, tok
         xs = xs.view(B * (1 + T * n), D)
-        pending = None
         for blk in self.blocks:
             pending = blk.fused(xs, B, T, n, pending)
         if pending is None or "qkv_n1" in self.blocks[0].packed():       # (with the fold xs already holds the full residual stream)
+            if split_cls:
+                cls, pat = ops.layernorm_split_cls(xs, *pk["norm"], clips=B, out_dtype=out_dtype)
+                return self.pre_logits(cls), pat
             out = ops.layernorm(xs, *pk["norm"], out_dtype=out_dtype)
         else:
             out = ops.add_layernorm(xs, pending[0], *pk["norm"], write_x=False, out_dtype=out_dtype, delta2=pending[1])
         out = out.view(B, 1 + T * n, D)                                                      # norm evaluated once (A5)
+        if split_cls:
+            return self.pre_logits(out[:, 0]), out[:, 1:].contiguous()
         return self.pre_logits(out[:, 0]), out
 
     def forward(self, x, use_checkpoint=False):

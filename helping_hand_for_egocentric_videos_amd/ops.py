@@ -305,8 +305,8 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
         x, eps, keep_c = z[:3]
         update = bool(z[3]) if len(z) > 3 else False
         _chk(x)
-        if x.dtype != torch.float32 or tuple(x.shape) != (M, N) or out_dtype != torch.bfloat16:
-            raise TypeError("gemm: z=(x, eps, keep_c) needs x fp32 [M, N] and a bf16 output")
+        if x.dtype not in (torch.float32, torch.bfloat16) or tuple(x.shape) != (M, N) or out_dtype != torch.bfloat16 or (update and x.dtype != torch.float32):
+            raise TypeError("gemm: z=(x, eps, keep_c[, update]) needs x fp32 [M, N] (bf16 allowed without update: a branch that only feeds a LayerNorm) and a bf16 output")
         zt = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
         st = torch.empty((M, 2), dtype=torch.float32, device=a.device)
     if out is None:
@@ -317,7 +317,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
     if z is not None:
         part = _workspace("gemm_zstats", M, N, device=a.device)
         e.z_resid, e.z_ldr, e.z_out, e.z_ldc, e.z_stats, e.z_partials = x.data_ptr(), N, zt.data_ptr(), N, st.data_ptr(), part.data_ptr()
-        e.z_eps, e.skip_c, e.z_update = float(eps), int(not keep_c), int(update)
+        e.z_eps, e.skip_c, e.z_update, e.z_resid_dtype = float(eps), int(not keep_c), int(update), _dt(x)
         e.bias = bias.data_ptr() if bias is not None else None
         e.colscale, e.c_dtype = 1.0, BF16
         cbuf = out if keep_c else zt                               # (a valid pointer even when C is skipped)
@@ -405,13 +405,35 @@ def patch_im2col_u8(video, patch, kpad, mean=NORM_MEAN, std=NORM_STD):
     return out
 
 
-def embed_ln_pre(tok, cls, pos, temporal, gamma, beta, B, T, n, eps=1e-5):
+def embed_ln_pre(tok, cls, pos, temporal, gamma, beta, B, T, n, eps=1e-5, z_eps=None):
+    """x fp32 [B, 1+T*n, D] = ln_pre(cat[cls, tok] + pos + temporal) (LaviLa.py:548-559).  z_eps (the next LayerNorm's eps): also returns
+    z = bf16(x) [rows, D] and its row statistics fp32 [rows, 2] -- the operands of the first block's folded norm3 -- from the same pass."""
     _chk(tok, cls, pos, temporal, gamma, beta)
     D = tok.shape[-1]
     x = torch.empty((B, 1 + T * n, D), dtype=torch.float32, device=tok.device)
+    z = st = None
+    if z_eps is not None:
+        z = torch.empty((B * (1 + T * n), D), dtype=torch.bfloat16, device=tok.device)
+        st = torch.empty((B * (1 + T * n), 2), dtype=torch.float32, device=tok.device)
     _lib.check(_lib.lib().hh_embed_ln_pre(_p(tok), _p(cls), _p(pos), _p(temporal), _p(gamma), _p(beta), _p(x), B, T, n, D,
-                                          float(eps), _stream()), "hh_embed_ln_pre")
-    return x
+                                          float(eps), _p(z), _p(st), float(z_eps or 0.0), _stream()), "hh_embed_ln_pre")
+    return x if z_eps is None else (x, z, st)
+
+
+def layernorm_split_cls(x, gamma, beta, eps, clips, out_dtype=torch.bfloat16):
+    """LayerNorm of `clips` clips of N = rows / clips token rows each, CLS first: -> (cls [clips, D], patches [clips, N - 1, D]) -- the
+    tower's final norm written straight into the decoder's grid (include/hh.h: hh_layernorm_split_cls_fwd)."""
+    _chk(x, gamma, beta)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    if clips <= 0 or rows % clips or rows // clips < 2:
+        raise ValueError("layernorm_split_cls: %d rows do not split into %d clips of >= 2 tokens" % (rows, clips))
+    N = rows // clips
+    ycls = torch.empty((clips, cols), dtype=out_dtype, device=x.device)
+    ypat = torch.empty((clips, N - 1, cols), dtype=out_dtype, device=x.device)
+    _lib.check(_lib.lib().hh_layernorm_split_cls_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(ypat), _p(ycls), _dt(ypat), clips, N, cols, float(eps), _stream()),
+               "hh_layernorm_split_cls_fwd")
+    return ycls, ypat
 
 
 def gemm_tn(at, bt, splits=None, colsum=False):

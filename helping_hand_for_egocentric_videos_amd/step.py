@@ -90,11 +90,10 @@ class TrainStep:
         with torch.no_grad():
             with torch.cuda.stream(side):
                 _, tmap = self.backbone.encode_text(text, apply_project=False, want_cls=False)
-            _, fmap = self.backbone.visual.forward_features(video, out_dtype=torch.bfloat16)
+            _, pat = self.backbone.visual.forward_features(video, out_dtype=torch.bfloat16, split_cls=True)      # patch rows, contiguous
         cur.wait_stream(side)
         tmap.record_stream(cur)
-        grid = fmap[:, 1:].reshape(B, T, n, fmap.shape[-1])
-        return grid, tmap
+        return pat.view(B, T, n, pat.shape[-1]), tmap
 
     def prefetch(self, batch):
         """Start the frozen towers of `batch` on the encoder stream (software pipelining across steps: the frozen encoder
@@ -344,12 +343,18 @@ def first_clips_check(ts, batch, k=2):
         f = lambda t: t.float()
         scale = lambda t: float(f(t).abs().max().clamp_min(1e-30))
         idx_equal = all(bool(torch.equal(mb[key][:k * T], ms[key])) for key in ("pred_idx", "tgt_idx", "n", "count"))
+        same = torch.ones(k * T, dtype=torch.bool, device=pb.device)
+        for key in ("pred_idx", "tgt_idx"):
+            same &= (mb[key][:k * T].reshape(k * T, -1) == ms[key].reshape(k * T, -1)).all(1)
         rec = {"clips_compared": k, "batch": int(batch["video"].shape[0]),
                "encoder_bit_identical_clips_before_last": bool(k < 2 or torch.equal(gb[:k - 1], gs[:k - 1])),
                "encoder_last_clip_max_abs_diff_over_scale": float((f(gb[k - 1]) - f(gs[k - 1])).abs().max()) / scale(gs[k - 1]),
                "hs_max_abs_diff_over_scale": float((f(hb[:, :k]) - f(hs_)).abs().max()) / scale(hs_),
                "pred_boxes_max_abs_diff": float((pb[:k * T] - ps).abs().max()),
                "matched_indices_equal": idx_equal,
+               # (matching is bit-exact on IDENTICAL boxes; these two runs' boxes differ by pred_boxes_max_abs_diff, which may flip a frame whose
+               # two best assignments are tied to within that -- the loss below, each side with its own matching, then still agrees)
+               "matched_frames_equal_fraction": float(same.float().mean()),
                "hand_box_loss_first_clips_rel_diff": abs(float(lb) - float(ls)) / max(abs(float(ls)), 1e-30)}
         return rec
     finally:
@@ -380,10 +385,10 @@ def mcq_forward(backbone, decoder, video, text, cfg):
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             _, tmap = backbone.encode_text(text, apply_project=False)
-        _, fmap = backbone.visual.forward_features(video.flatten(0, 1), out_dtype=torch.bfloat16)
+        _, fmap = backbone.visual.forward_features(video.flatten(0, 1), out_dtype=torch.bfloat16, split_cls=True)      # patch rows [q*5, T*n, D]
         cur.wait_stream(side)
         tmap.record_stream(cur)
-        _, hs, _, _ = decoder(fmap[:, 1:].reshape(q * 5, T, n, fmap.shape[-1]))
+        _, hs, _, _ = decoder(fmap.view(q * 5, T, n, fmap.shape[-1]))
         te = decoder.txt_proj(tmap[torch.arange(q, device=text.device), text.float().argmax(-1)])
         ve = decoder.obj_proj(hs[-1])[:, -1].view(q, 5, -1)
         return sim_matrix(te[:, None], ve)[:, 0]
@@ -413,7 +418,7 @@ class McqScorer:
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             _, tmap = self.backbone.encode_text(text, apply_project=False)
-        _, fmap = self.backbone.visual.forward_features(video.flatten(0, 1), out_dtype=torch.bfloat16)
+        _, fmap = self.backbone.visual.forward_features(video.flatten(0, 1), out_dtype=torch.bfloat16, split_cls=True)      # patch rows [q*5, T*n, D]
         cur.wait_stream(side)
         tmap.record_stream(cur)
         return fmap, tmap
@@ -448,7 +453,7 @@ class McqScorer:
         was = decoder.materialize_logits
         decoder.materialize_logits = False
         try:
-            _, hs, _, _ = decoder(fmap[:, 1:].reshape(q * 5, T, n, fmap.shape[-1]))
+            _, hs, _, _ = decoder(fmap.view(q * 5, T, n, fmap.shape[-1]))
             te = decoder.txt_proj(tmap[torch.arange(q, device=text.device), text.float().argmax(-1)])
             ve = decoder.obj_proj(hs[-1])[:, -1].view(q, 5, -1)
             return sim_matrix(te[:, None], ve)[:, 0]

@@ -178,7 +178,7 @@ typedef struct hh_gemm_epilogue {
      *   No resid / remap / split-K with it. */
     const float* ln_stats;    /* fp32 [M, 2] = (rstd, -rstd * mean) per row of A, or NULL */
     const float* ln_colsum;   /* fp32 [N]: sum_k float(W[n, k]) of the bf16 operand actually multiplied */
-    const float* z_resid;     /* fp32 [M, z_ldr] */
+    const void* z_resid;      /* fp32 [M, z_ldr] (bf16 with z_resid_dtype = HH_BF16) */
     int64_t z_ldr;
     void* z_out;              /* bf16 [M, z_ldc], or NULL (producer side off) */
     int64_t z_ldc;
@@ -188,6 +188,9 @@ typedef struct hh_gemm_epilogue {
     int skip_c;               /* != 0 with z_out: C is not written (a branch nobody adds to the residual stream: the time branch, LaviLa.py:372-384) */
     int z_update;             /* != 0 with z_out: z (fp32, before its bf16 rounding) is also written back to z_resid IN PLACE -- the residual
                                  stream update x <- x + branch (LaviLa.py:384,388) happens in the producing GEMM's epilogue */
+    int z_resid_dtype;        /* HH_F32 (0, default) or HH_BF16 (round 5): z_resid holds bf16 rows -- the producer that only feeds a LayerNorm
+                                 (the time branch: z1 = x + t goes to norm1 alone, LaviLa.py:372) reads the 2-byte z = bf16(x) its own block's
+                                 norm3 consumed instead of the 4-byte fp32 stream; no z_update with it */
 } hh_gemm_epilogue;
 
 int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
@@ -213,10 +216,11 @@ int hh_patch_im2col(const float* video, void* patches, int64_t frames, int H, in
 int hh_patch_im2col_u8(const uint8_t* video, void* patches, int64_t frames, int H, int W, int P, int Kpad,
                        int channels_last, const float* mean3, const float* std3, hh_stream_t stream);
 /* x[b,0,:]   = LN(cls + pos[0]) ; x[b,1+f*n+p,:] = LN(tok[(b*T+f)*n+p,:] + pos[1+p] + temporal[f])  (eps, ln_pre)
- * tok fp32 [B*T*n, D]; x fp32 [B, 1+T*n, D] */
+ * tok fp32 [B*T*n, D]; x fp32 [B, 1+T*n, D].  z_out / z_stats (optional, both or neither): z = bf16(x) [rows, D] and its row statistics
+ * (rstd, -rstd * mean) fp32 [rows, 2] with eps z_eps -- the operands of the first block's folded LayerNorm (hh_gemm_epilogue.ln_stats). */
 int hh_embed_ln_pre(const float* tok, const float* cls, const float* pos, const float* temporal,
                     const float* gamma, const float* beta, float* x, int B, int T, int n, int D, float eps,
-                    hh_stream_t stream);
+                    void* z_out, float* z_stats, float z_eps, hh_stream_t stream);
 
 /* ---- weight-gradient GEMM in its natural layout (backward of the nn.Linear layers of tfm_decoder.py:156,438-441):
  * partials[s, m, n] (fp32, [splits, M, N]) = sum over the s-th token slice of At[k, m] * Bt[k, n]; At bf16 [K, M] (row stride lda),
@@ -340,6 +344,11 @@ int hh_qgemm_f32x3(const float* A, int64_t lda, const float* B, int64_t ldb, flo
 int hh_qself_attn_fwd(const float* qkv, float* out, int B, int Q, int heads, float dropout_p, uint32_t seed, hh_stream_t stream);
 int hh_qself_attn_bwd(const float* qkv, const float* dout, float* dqkv, int B, int Q, int heads, float dropout_p, uint32_t seed,
                       hh_stream_t stream);
+/* LayerNorm of clips of `tokens_per_clip` rows whose first row is the CLS token (the tower's final norm, LaviLa.py:572): the CLS rows go to
+ * y_cls [clips, cols], the other rows, clip after clip, to y_patches [clips * (tokens_per_clip - 1), cols] -- the decoder's [B, T*n, D] grid
+ * (tfm_decoder.py:200-205) without a strided copy of the feature map. */
+int hh_layernorm_split_cls_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y_patches, void* y_cls, int y_dtype,
+                               int64_t clips, int tokens_per_clip, int cols, float eps, hh_stream_t stream);
 /* LayerNorm with a second output y_plus_pos = LN(x) + pos[row % pos_rows] (pos fp32 [pos_rows, cols]): the operands of an attention
  * whose keys / queries carry a positional embedding and whose values do not (tfm_decoder.py:431-441: q = k = x + query_pos, v = x;
  * key = memory + pos, value = memory) come out of ONE pass.  Same dtypes / limits as hh_layernorm_fwd. */

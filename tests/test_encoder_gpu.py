@@ -224,6 +224,22 @@ def test_oracle_full_width_t16_vs_reference_checksums():
     np.testing.assert_allclose(float(x.double().abs().sum()), float(g["x_abs_sum"]), rtol=1e-6)
 
 
+def test_split_cls_feature_map_equals_the_sliced_one():
+    """forward_features(split_cls=True) (what TrainStep.encode / the EgoMCQ scorer take: the final norm writes the patch rows straight into
+    the decoder's grid, and block 0's z / statistics come out of the embedding pass) == the [B, 1+T*n, D] map, sliced -- bit for bit."""
+    cfg = TINY16
+    sd = synth.encoder_state(cfg, seed=8, with_text=False)
+    video = synth.make_batch(cfg, 3, seed=8)["video"].cuda()
+    vis = LaviLa.build_backbone(cfg, None).visual
+    vis.load_state_dict({k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}, strict=True)
+    vis = vis.cuda()
+    for dt in (torch.float32, torch.bfloat16):
+        c0, full = vis.forward_features(video, out_dtype=dt)
+        c1, pat = vis.forward_features(video, out_dtype=dt, split_cls=True)
+        assert pat.is_contiguous() and pat.shape == (3, cfg.tokens - 1, cfg.embed_dim)
+        assert torch.equal(c0, c1) and torch.equal(pat, full[:, 1:])
+
+
 def test_module_api_shapes_and_standalone_forms():
     cfg = TINY4
     sd = synth.encoder_state(cfg, seed=2)

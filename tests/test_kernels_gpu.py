@@ -354,6 +354,28 @@ def test_patch_embed_front_end():
                          sd["visual.ln_pre.bias"].to(DEV), B, T, n)
     ref = OE.embed_tokens(video, sd, cfg)
     torch.testing.assert_close(x.cpu(), ref, rtol=2e-2, atol=2e-2)      # bf16 patch GEMM operands
+    # the same pass can also emit z = bf16(x) and its row statistics for the first block's folded LayerNorm (round 5)
+    x2, z, st = ops.embed_ln_pre(tok, sd["visual.cls_token"].view(-1).to(DEV), sd["visual.pos_embed"][0].contiguous().to(DEV),
+                                 sd["visual.temporal_embed"][0].contiguous().to(DEV), sd["visual.ln_pre.weight"].to(DEV),
+                                 sd["visual.ln_pre.bias"].to(DEV), B, T, n, z_eps=1e-6)
+    assert torch.equal(x2, x) and torch.equal(z, x.view(-1, D).to(torch.bfloat16))
+    torch.testing.assert_close(st, ops.ln_rowstats(z, 1e-6), rtol=1e-5, atol=1e-6)
+    zf = z.float()
+    rstd = (zf.var(1, unbiased=False) + 1e-6).rsqrt()
+    torch.testing.assert_close(st[:, 0], rstd, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(st[:, 1], -rstd * zf.mean(1), rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("clips,N,cols,xdt,ydt", [(3, 1025, 1024, torch.float32, torch.bfloat16), (2, 5, 128, torch.float32, torch.float32), (1, 2, 512, torch.bfloat16, torch.bfloat16)])
+def test_layernorm_split_cls(clips, N, cols, xdt, ydt):
+    """hh_layernorm_split_cls_fwd: the tower's final LayerNorm writes the CLS rows and the patch rows to two dense tensors (the decoder's
+    grid needs no strided copy of the feature map): bit-identical to hh_layernorm_fwd followed by the slicing."""
+    x = (rnd(clips * N, cols, seed=1) * 2 + 0.3).to(xdt).to(DEV)
+    g, b = (rnd(cols, seed=2) * 0.1 + 1).to(DEV), (rnd(cols, seed=3) * 0.1).to(DEV)
+    full = ops.layernorm(x, g, b, 1e-6, out_dtype=ydt).view(clips, N, cols)
+    cls, pat = ops.layernorm_split_cls(x, g, b, 1e-6, clips, out_dtype=ydt)
+    assert cls.shape == (clips, cols) and pat.shape == (clips, N - 1, cols) and pat.is_contiguous()
+    assert torch.equal(cls, full[:, 0]) and torch.equal(pat, full[:, 1:])
 
 
 @pytest.mark.parametrize("channels_last", [False, True])
@@ -1078,6 +1100,29 @@ def test_gemm_ln_fold_producer(M, N, K, keep_c):
     # the statistics are those of z up to its bf16 rounding (rows of 128 ... 1024 values: ~2^-9 / sqrt(N) on the moments)
     assert ((st[:, 0] - rstd) / rstd).abs().max().item() <= 2e-3
     assert (st[:, 1] + rstd * mean).abs().max().item() <= 4e-3 * (1.0 + (rstd * mean).abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", LN_FOLD_SHAPES + [(256 * 33 + 7, 1024, 4096)])
+def test_gemm_ln_fold_producer_with_bf16_residual_rows(M, N, K):
+    """z_resid_dtype = HH_BF16 (round 5): the producer adds its result to bf16 rows -- the time projection reads z3 = bf16(x), the rows its
+    block's norm3 consumed, instead of the fp32 stream (LaviLa.py:372: z1 = x + t only feeds norm1).  On the persistent kernel
+    (gemm256w4p_kernel<true, 7, 256>), its in-kernel row tail and the generic kernels: z == bf16(float(xb) + A W^T + b) computed by the
+    fp32-residual instantiation on the widened rows, bit for bit; the bf16 rows are only read; z_update with them is refused."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K + 3)
+    a = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    xb = (torch.randn(M, N, device=DEV, generator=g) * 2.0 + 0.3).to(torch.bfloat16)
+    x0 = xb.clone()
+    c, z, st = ops.gemm(a, w, bias, z=(xb, 1e-6, False))
+    assert c is None and torch.equal(xb, x0)
+    _, z_ref, st_ref = ops.gemm(a, w, bias, z=(xb.float(), 1e-6, False))
+    assert torch.equal(z, z_ref)
+    torch.testing.assert_close(st, st_ref, rtol=1e-6, atol=1e-7)
+    c2, z2, _ = ops.gemm(a, w, bias, z=(xb, 1e-6, True))
+    assert torch.equal(z2, z) and torch.equal(c2, ops.gemm(a, w, bias))
+    with pytest.raises(TypeError):
+        ops.gemm(a, w, bias, z=(xb, 1e-6, False, True))
 
 
 @pytest.mark.parametrize("M,N,K", [(4097, 3072, 1024), (300, 384, 128), (33, 256, 512), (256 * 40 + 32, 3072, 1024), (256 * 20, 4096, 1024),
