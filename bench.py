@@ -287,6 +287,25 @@ def selfcheck_summary(sc):
             "hs_diff_over_scale": round(sc.get("hs_max_abs_diff_over_scale", 0.0), 6)}
 
 
+def count_collectives(fn):
+    """Run fn() with torch.distributed's collective entry points wrapped: -> {name: calls} (this process)."""
+    names = ("all_reduce", "all_gather", "all_gather_into_tensor", "broadcast", "reduce_scatter_tensor", "all_to_all_single", "reduce", "all_gather_object")
+    n, orig = {}, {}
+    for k in names:
+        orig[k] = getattr(dist, k)
+
+        def wrapped(*a, _k=k, **kw):
+            n[_k] = n.get(_k, 0) + 1
+            return orig[_k](*a, **kw)
+        setattr(dist, k, wrapped)
+    try:
+        fn()
+    finally:
+        for k, f in orig.items():
+            setattr(dist, k, f)
+    return n
+
+
 def barrier(world):
     if world > 1:
         dist.barrier()
@@ -631,9 +650,21 @@ def main():
         ts.comm.active = True
         t2 = torch.tensor([dt2], device=dev, dtype=torch.float64)
         dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        # COUNTED, per rank: the collectives one more pipelined step issues (torch.distributed's entry points wrapped for its duration);
+        # must be 1 packed all-gather + one all-reduce per gradient bucket + 1 flag all-reduce on every rank
+        counted = count_collectives(lambda: ts.step(batch, next_batch=None if args.no_pipeline else batch))
+        barrier(world)
+        want = {"all_gather_into_tensor": 1, "all_reduce": len(ts.arena.buckets) + 1}
+        mine = torch.tensor([counted.get("all_gather_into_tensor", 0), counted.get("all_reduce", 0), sum(counted.values())], device=dev, dtype=torch.int64)
+        allc = torch.empty((world, 3), device=dev, dtype=torch.int64)
+        dist.all_gather_into_tensor(allc, mine)
+        per_rank_counts = allc.tolist()
+        assert all(r == [want["all_gather_into_tensor"], want["all_reduce"], want["all_gather_into_tensor"] + want["all_reduce"]] for r in per_rank_counts), \
+            ("collectives per step differ from 1 + #buckets + 1", per_rank_counts, want)
         comm_rec = {"ms_per_step_without_gradient_allreduce": round(float(t2) / k2 * 1e3, 2), "steps": k2,
                     "allreduce_exposed_ms": round(dt / args.steps * 1e3 - float(t2) / k2 * 1e3, 2),
                     "collectives_per_step": {"all_gather": 1, "all_reduce_gradient_buckets": len(ts.arena.buckets), "all_reduce_flags": 1},
+                    "collectives_counted_per_rank": {"[all_gather_into_tensor, all_reduce, total] per rank": per_rank_counts, "asserted": "1 + #buckets + 1 on every rank"},
                     "gradient_bytes_per_step": int(ts.arena.total * 4)}
 
     # the line's own parity bit: clips 0-1 of the benchmarked batch against the same two clips run as a batch of 2 (after the timed region)

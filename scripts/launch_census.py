@@ -20,7 +20,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
 ev = prof.events()
 kern = [e for e in ev if e.device_type == torch.autograd.DeviceType.CUDA]
 ours = ("gemm", "attn", "ln_", "add_ln", "xattn", "adamw", "match", "lsap", "box_loss", "transpose_kernel", "cast_f32", "im2col", "embed_ln", "qgemm", "qself", "cls_combine", "colsum", "merge", "tail",
-        "rownorm", "egonce", "masked_ce", "tv_accuracy")
+        "rownorm", "egonce", "masked_ce", "tv_accuracy", "mattn", "text_flags", "box_tail")
 stock = [k for k in kern if not any(o in k.name for o in ours)]
 print("device launches in the step: %d, stock (non-libhh): %d" % (len(kern), len(stock)))
 # attribute every stock kernel to the innermost aten op (CPU event) that launched it and to the first repo frame of its stack

@@ -192,4 +192,8 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     import math
     assert comm["ms_per_step_without_gradient_allreduce"] > 0 and math.isfinite(float(comm["allreduce_exposed_ms"]))
     assert comm["collectives_per_step"]["all_reduce_gradient_buckets"] >= 1 and comm["gradient_bytes_per_step"] > 0
+    # counted, not stated: every rank issued 1 packed all-gather + one all-reduce per bucket + the flag all-reduce in a step
+    counted = list(comm["collectives_counted_per_rank"].values())[0]
+    nb = comm["collectives_per_step"]["all_reduce_gradient_buckets"]
+    assert counted == [[1, nb + 1, nb + 2]] * 2, counted
     assert "cpu_baseline" not in line and "c4" not in line          # rank-0-at-N=1-only records

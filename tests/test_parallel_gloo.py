@@ -156,6 +156,88 @@ def test_two_ranks_equal_one_rank_on_concatenated_batch():
     torch.testing.assert_close(ret["params"], arena.params, rtol=1e-4, atol=1e-5)
 
 
+class _Sleep(torch.autograd.Function):
+    """Identity whose backward stalls the host: a rank that falls behind in the middle of its backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, seconds):
+        ctx.seconds = seconds
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        import time
+        time.sleep(ctx.seconds)
+        return g, None
+
+
+def _skew_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        model = Toy()
+        arena = FlatArena(model, bucket_bytes=512)
+        comm = BucketedAllReduce(arena)
+        full = make_data(4, 11)
+        b = 4 // world
+        local = {k: (v[rank * b:(rank + 1) * b] if v.shape[0] == 4 else v[rank * b * 5:(rank + 1) * b * 5]) for k, v in full.items()}
+        state, order, losses = None, [], []
+        orig = dist.all_reduce
+
+        def logged(t, *a, **kw):
+            order.append(int(t.numel()))
+            return orig(t, *a, **kw)
+        for it in range(3):
+            arena.zero_grad()
+            # the SLOW rank alternates: rank 1 stalls 200 ms inside its backward (between the head gradients and the projection's) in
+            # steps 0 and 2, rank 0 in step 1 -- the other rank's buckets are ready long before, its collectives wait for the peer
+            slow = rank == (1 if it != 1 else 0)
+            ve, te, boxes = model(local["feats"], local["texts"])
+            if slow:
+                ve = _Sleep.apply(ve, 0.2)
+            gve, gte, pf, vv, nv, sums = gather_contrastive(ve, te, local["pad"], local["verb"], local["noun"], counts=torch.tensor([float(boxes.shape[0])]))
+            Bg = gve.shape[0]
+            nce, _ = OL.egonce(OL.sim_matrix(gte, gve), OL.sim_matrix(vv, vv), OL.sim_matrix(nv, nv), pf[:, None].repeat(1, Bg))
+            loss = nce + (boxes - local["tgt"]).abs().sum() / normaliser(sums)[0]
+            dist.all_reduce = logged
+            try:
+                loss.backward()
+                comm.finish()
+            finally:
+                dist.all_reduce = orig
+            # the global loss terms are the same numbers on every rank (computed on the gathered batch)
+            losses.append(float(nce.detach()))
+            grads = {n: p.grad.clone() for n, p in arena.entries}
+            state = OS.adamw_update({n: p.data for n, p in arena.entries}, grads, state, lr=1e-2, wd=1e-2)
+        sizes = [int(e - s_) for s_, e, _ in arena.buckets]
+        per_step = len(sizes) + 1
+        assert len(order) == 3 * per_step, (order, sizes)
+        for it in range(3):                       # strictly in arena order on every rank and in every step, the flags last
+            assert order[it * per_step:(it + 1) * per_step - 1] == sizes, (rank, it, order, sizes)
+            assert order[(it + 1) * per_step - 1] == len(arena.names)
+        gathered = [torch.empty_like(arena.params) for _ in range(world)]
+        dist.all_gather(gathered, arena.params.clone())
+        assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged under skew"
+        gl = [None] * world
+        dist.all_gather_object(gl, losses)
+        assert all(l == gl[0] for l in gl), gl              # identical per-rank loss dicts after 3 steps
+        if rank == 0:
+            ret["ok"] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_skew_does_not_reorder_or_hang_the_collectives():
+    """One rank sleeps 200 ms inside its backward (alternating ranks over 3 steps): the bucket all-reduces still go out strictly in
+    arena order on both ranks, followed by the flag all-reduce; nothing hangs; parameters and the global loss terms stay identical on
+    both ranks (run/train.py:126-140, box_utils.py:218-222 are what this data-parallel layer replaces)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_skew_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret.get("ok")
+
+
 def test_arena_groups_follow_the_reference_optim_policy():
     model = Toy()
     arena = FlatArena(model)
