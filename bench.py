@@ -656,9 +656,9 @@ def main():
         barrier(world)
         want = {"all_gather_into_tensor": 1, "all_reduce": len(ts.arena.buckets) + 1}
         mine = torch.tensor([counted.get("all_gather_into_tensor", 0), counted.get("all_reduce", 0), sum(counted.values())], device=dev, dtype=torch.int64)
-        allc = torch.empty((world, 3), device=dev, dtype=torch.int64)
+        allc = torch.empty(world * 3, device=dev, dtype=torch.int64)
         dist.all_gather_into_tensor(allc, mine)
-        per_rank_counts = allc.tolist()
+        per_rank_counts = allc.view(world, 3).tolist()
         assert all(r == [want["all_gather_into_tensor"], want["all_reduce"], want["all_gather_into_tensor"] + want["all_reduce"]] for r in per_rank_counts), \
             ("collectives per step differ from 1 + #buckets + 1", per_rank_counts, want)
         comm_rec = {"ms_per_step_without_gradient_allreduce": round(float(t2) / k2 * 1e3, 2), "steps": k2,

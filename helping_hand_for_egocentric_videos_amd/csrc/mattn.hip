@@ -241,12 +241,41 @@ __device__ __forceinline__ bool ma_unit(const MaCommon& p, int& b, int& hg, int&
     return true;
 }
 
+// Slice hand-off without a merge launch: every workgroup of a (clip, head group) stores its partial rows, then takes a ticket; the one whose
+// ticket is the last folds all slices.  Producer / consumer forms of MI355X_MICROARCH.md (inter-workgroup visibility): every storing wave
+// waits vmcnt(0), workgroup barrier, ONE lane releases at agent scope + waits + takes the ticket (agent-scope atomic); the last arriver's
+// lane acquires at agent scope + waits, a barrier publishes that to its other waves, plain loads follow.  The counter is reset by the last
+// arriver (kernels of one stream never overlap; one table row per launch stream: runtime.cpp hh_stream_slot).
+#define MA_TICKET_UNITS 4096
+__device__ unsigned g_ma_ticket[32][MA_TICKET_UNITS];
+
+__device__ __forceinline__ bool ma_last_arriver(unsigned* ticket, unsigned total, int* lds_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev + 1u == total;
+        if (last) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *lds_flag = last;
+    }
+    __syncthreads();
+    return *lds_flag != 0;
+}
+
 struct MaFwd {
     MaCommon c;
     const float* qt;          // [B*Q, H*C] fp32: row (clip, query), column head * 512 + k
-    float* o_part;            // [slices][B*Q, H*C]: un-normalised partial pooled rows (slices == 1: the final, normalised rows)
+    float* o_part;            // [slices][B*Q, H*C]: un-normalised partial pooled rows (slices == 1: unused)
     float* st_part;           // [slices][B*Q, H][4]: running maximum (base-2 logits), sum of p, sum of dropped p, -
-    float* lse2; float* rsum; // slices == 1 only: [B*Q, H] final statistics
+    float* pooled;            // [B*Q, H*C] final, normalised rows
+    float* lse2; float* rsum; // [B*Q, H] final statistics
+    int slot;                 // ticket table row of the launch stream
 };
 
 __global__ __launch_bounds__(512) void mattn_fwd_kernel(MaFwd p) {
@@ -323,47 +352,46 @@ __global__ __launch_bounds__(512) void mattn_fwd_kernel(MaFwd p) {
     l_run += __shfl_xor(l_run, 32, 64);
     rs_run += __shfl_xor(rs_run, 16, 64);
     rs_run += __shfl_xor(rs_run, 32, 64);
-    if (ql >= Q) return;
-    const int64_t r = (int64_t)b * Q + ql;
+    const bool live = ql < Q;
+    const int64_t r = (int64_t)b * Q + (live ? ql : 0);
     const bool final_ = p.c.slices == 1;
     const float sc = final_ ? 1.f / l_run : 1.f;
-    float* orow = p.o_part + ((int64_t)slice * p.c.B * Q + r) * (MA_H * MA_C) + head * MA_C + 256 * dh + 4 * g;
+    if (live) {
+        float* orow = (final_ ? p.pooled : p.o_part + (int64_t)slice * p.c.B * Q * (MA_H * MA_C)) + r * (MA_H * MA_C) + head * MA_C + 256 * dh + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < 16; ++dt) *(f32x4*)(orow + 16 * dt) = o[dt] * sc;
-    if (dh == 0 && g == 0) {
-        if (final_) {
-            p.lse2[r * MA_H + head] = m_run + __builtin_amdgcn_logf(l_run);      // v_log_f32 is base 2
-            p.rsum[r * MA_H + head] = rs_run * sc;
-        } else {
-            *(f32x4*)(p.st_part + (((int64_t)slice * p.c.B * Q + r) * MA_H + head) * 4) = (f32x4){m_run, l_run, rs_run, 0.f};
+        for (int dt = 0; dt < 16; ++dt) *(f32x4*)(orow + 16 * dt) = o[dt] * sc;
+        if (dh == 0 && g == 0) {
+            if (final_) {
+                p.lse2[r * MA_H + head] = m_run + __builtin_amdgcn_logf(l_run);      // v_log_f32 is base 2
+                p.rsum[r * MA_H + head] = rs_run * sc;
+            } else {
+                *(f32x4*)(p.st_part + (((int64_t)slice * p.c.B * Q + r) * MA_H + head) * 4) = (f32x4){m_run, l_run, rs_run, 0.f};
+            }
         }
     }
-}
-
-// pooled[r, h, :] = sum_s 2^(m_s - m) O_s[r, h, :] / L,  L = sum_s 2^(m_s - m) l_s,  lse2 = m + log2 L,  rsum likewise
-__global__ __launch_bounds__(128) void mattn_fwd_merge_kernel(const float* __restrict__ o_part, const float* __restrict__ st_part, float* __restrict__ pooled,
-                                                              float* __restrict__ lse2, float* __restrict__ rsum, int64_t rows_h, int slices) {
-    const int64_t rh = blockIdx.x;                       // (row, head)
-    const int tid = threadIdx.x;
-    float m = -INFINITY;
-    for (int s = 0; s < slices; ++s) m = fmaxf(m, st_part[((int64_t)s * rows_h + rh) * 4]);
-    float L = 0.f, RS = 0.f;
-    for (int s = 0; s < slices; ++s) {
-        const f32x4 st = *(const f32x4*)(st_part + ((int64_t)s * rows_h + rh) * 4);
-        const float w = __builtin_amdgcn_exp2f(st[0] - m);
-        L += w * st[1];
-        RS += w * st[2];
-    }
-    const float inv = 1.f / L;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < slices; ++s) {
-        const float w = __builtin_amdgcn_exp2f(st_part[((int64_t)s * rows_h + rh) * 4] - m);
-        acc += *(const f32x4*)(o_part + ((int64_t)s * rows_h + rh) * MA_C + 4 * tid) * w;
-    }
-    *(f32x4*)(pooled + rh * MA_C + 4 * tid) = acc * inv;
-    if (tid == 0) {
-        lse2[rh] = m + __builtin_amdgcn_logf(L);
-        rsum[rh] = RS * inv;
+    if (final_) return;
+    // ---- the last of this (clip, head group)'s `slices` workgroups folds them:  pooled = sum_s 2^(m_s - m) O_s / L,  L = sum_s 2^(m_s - m) l_s
+    int* flag = (int*)(smem + MA_XOFF);
+    if (!ma_last_arriver(&g_ma_ticket[p.slot][b * 2 + hg], (unsigned)p.c.slices, flag)) return;
+    const int64_t plane = (int64_t)p.c.B * Q * MA_H;                // (row, head) pairs per slice
+    for (int qh = 0; qh < Q * 4; ++qh) {
+        const int64_t rh = ((int64_t)b * Q + qh / 4) * MA_H + 4 * hg + (qh & 3);
+        float m = -INFINITY;
+        for (int s_ = 0; s_ < p.c.slices; ++s_) m = fmaxf(m, p.st_part[(s_ * plane + rh) * 4]);
+        float L = 0.f, RS = 0.f, acc = 0.f;
+        for (int s_ = 0; s_ < p.c.slices; ++s_) {
+            const f32x4 st = *(const f32x4*)(p.st_part + (s_ * plane + rh) * 4);
+            const float w = __builtin_amdgcn_exp2f(st[0] - m);
+            L += w * st[1];
+            RS += w * st[2];
+            acc += w * p.o_part[(s_ * plane + rh) * MA_C + tid];
+        }
+        const float inv = 1.f / L;
+        p.pooled[rh * MA_C + tid] = acc * inv;
+        if (tid == 0) {
+            p.lse2[rh] = m + __builtin_amdgcn_logf(L);
+            p.rsum[rh] = RS * inv;
+        }
     }
 }
 
@@ -401,7 +429,7 @@ extern "C" int hh_mattn_slices(int M, int slices) {
 
 extern "C" int64_t hh_workspace_bytes_mattn_fwd(int B, int Q, int slices) {
     if (B < 0 || Q <= 0 || Q > 16 || slices < 1) return -1;
-    if (slices == 1) return 16;
+    if (slices <= 1) return 16;
     return (int64_t)slices * B * Q * MA_H * (MA_C + 4) * 4;
 }
 
@@ -420,10 +448,12 @@ extern "C" int hh_mattn_fwd(const float* qt, const void* mp, const void* mem, in
     ma_drop_params(dropout_p, &p.c.drop_thresh, &p.c.drop_scale);
     p.c.seed = seed;
     HH_REQUIRE(p.c.slices == 1 || workspace != nullptr, HH_ERR_SHAPE, "hh_mattn_fwd: slices > 1 needs hh_workspace_bytes_mattn_fwd() bytes of workspace");
-    p.qt = qt; p.lse2 = lse2; p.rsum = rsum;
+    p.qt = qt; p.pooled = pooled; p.lse2 = lse2; p.rsum = rsum;
     const int64_t rows_h = (int64_t)B * Q * MA_H;
-    if (p.c.slices == 1) { p.o_part = pooled; p.st_part = nullptr; }
-    else { p.o_part = workspace; p.st_part = workspace + (int64_t)p.c.slices * rows_h * MA_C; }
+    p.o_part = workspace;
+    p.st_part = p.c.slices == 1 ? nullptr : workspace + (int64_t)p.c.slices * rows_h * MA_C;
+    p.slot = hh_stream_slot((hipStream_t)stream);
+    HH_REQUIRE(p.c.slices == 1 || (p.slot >= 0 && 2 * B <= MA_TICKET_UNITS), HH_ERR_UNSUPPORTED, "hh_mattn_fwd: key slices need a ticket row (<= 32 launch streams, B <= %d)", MA_TICKET_UNITS / 2);
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute((const void*)mattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MA_XOFF + 8 * 2048);
@@ -436,8 +466,6 @@ extern "C" int hh_mattn_fwd(const float* qt, const void* mp, const void* mem, in
         HHProfScope prof(HH_PROF_XATTN_FWD, 4.0 * (double)B * M * MA_C, s);                  // mp and mem rows, bf16, once
         hipLaunchKernelGGL(mattn_fwd_kernel, dim3(grid), dim3(512), MA_XOFF + 8 * 2048, s, p);
     }
-    if (p.c.slices > 1)
-        hipLaunchKernelGGL(mattn_fwd_merge_kernel, dim3((unsigned)rows_h), dim3(128), 0, s, p.o_part, p.st_part, pooled, lse2, rsum, rows_h, p.c.slices);
     return hh_check_launch("hh_mattn_fwd");
 }
 
@@ -459,7 +487,9 @@ struct MaBwd {
     const float* dca;         // [B*Q, C'] gradient of the attention output (C' = H * 64 columns, head-major)
     const float* ca;          // [B*Q, C'] the attention output itself (delta = sum_n dca * ca over a head's 64 columns)
     const float* bv;          // [C'] value bias of the layer (cb = sum_n dca * bv)
-    float* dqt_part;          // [slices][B*Q, H*C]
+    float* dqt_part;          // [slices][B*Q, H*C] (slices > 1)
+    float* dqt;               // [B*Q, H*C] final
+    int slot;
     bf16_t* pdT; bf16_t* dsT; // [B, rows_total, M] bf16; this layer's rows start at row_off
     bf16_t* qt16; bf16_t* dp16; // [B, rows_total, C] bf16 copies of qt / dpooled (rows as above; slice 0 writes them), or NULL
     int rows_total, row_off;
@@ -562,24 +592,38 @@ __global__ __launch_bounds__(512) void mattn_bwd_kernel(MaBwd p) {
         ma_pool<0>(A, sh, sl, acc);
         ma_addr_flip(A);
     }
-    if (!live) return;
-    float* orow = p.dqt_part + ((int64_t)slice * p.c.B * Q + r) * (MA_H * MA_C) + head * MA_C + 256 * dh + 4 * g;
+    const bool final_ = p.c.slices == 1;
+    if (live) {
+        float* orow = (final_ ? p.dqt : p.dqt_part + (int64_t)slice * p.c.B * Q * (MA_H * MA_C)) + r * (MA_H * MA_C) + head * MA_C + 256 * dh + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < 16; ++dt) *(f32x4*)(orow + 16 * dt) = acc[dt];
+        for (int dt = 0; dt < 16; ++dt) *(f32x4*)(orow + 16 * dt) = acc[dt];
+    }
+    if (final_) return;
+    // the last of this (clip, head group)'s workgroups adds the slices' planes in a fixed order (see ma_last_arriver)
+    int* flag = (int*)(smem + MA_XOFF);
+    if (!ma_last_arriver(&g_ma_ticket[p.slot][b * 2 + hg], (unsigned)p.c.slices, flag)) return;
+    const int64_t plane = (int64_t)p.c.B * Q * (MA_H * MA_C);
+    for (int qh = 0; qh < Q * 4; ++qh) {
+        const int64_t at = ((int64_t)b * Q + qh / 4) * (MA_H * MA_C) + (4 * hg + (qh & 3)) * MA_C + tid;
+        float a_ = 0.f;
+        for (int s_ = 0; s_ < p.c.slices; ++s_) a_ += p.dqt_part[s_ * plane + at];
+        p.dqt[at] = a_;
+    }
 }
 
 extern "C" int64_t hh_workspace_bytes_mattn_bwd(int B, int Q, int slices) {
     if (B < 0 || Q <= 0 || Q > 16 || slices < 1) return -1;
+    if (slices == 1) return 16;
     return (int64_t)slices * B * Q * MA_H * MA_C * 4;
 }
 
 extern "C" int hh_mattn_bwd(const float* qt, const float* dpooled, const float* lse2, const float* dca, const float* ca, const float* bv,
-                            const void* mp, const void* mem, int64_t ld, float* dqt_partials, int slices, void* pdT, void* dsT, void* qt16, void* dp16,
+                            const void* mp, const void* mem, int64_t ld, float* dqt, float* workspace, int slices, void* pdT, void* dsT, void* qt16, void* dp16,
                             int rows_total, int row_off, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, hh_stream_t stream) {
     int rc = ma_check("hh_mattn_bwd", B, Q, M, heads, C, ld, slices);
     if (rc) return rc;
     HH_REQUIRE(HH_ALIGNED16(qt) && HH_ALIGNED16(dpooled) && HH_ALIGNED16(dca) && HH_ALIGNED16(ca) && HH_ALIGNED16(bv) && HH_ALIGNED16(mp) && HH_ALIGNED16(mem) &&
-               HH_ALIGNED16(dqt_partials) && HH_ALIGNED16(pdT) && HH_ALIGNED16(dsT) && HH_ALIGNED16(qt16) && HH_ALIGNED16(dp16), HH_ERR_ALIGN,
+               HH_ALIGNED16(dqt) && HH_ALIGNED16(workspace) && HH_ALIGNED16(pdT) && HH_ALIGNED16(dsT) && HH_ALIGNED16(qt16) && HH_ALIGNED16(dp16), HH_ERR_ALIGN,
                "hh_mattn_bwd: pointers must be 16-byte aligned");
     HH_REQUIRE(pdT != nullptr && dsT != nullptr && (qt16 == nullptr) == (dp16 == nullptr), HH_ERR_SHAPE, "hh_mattn_bwd: pdT / dsT are required; qt16 and dp16 come together");
     HH_REQUIRE(rows_total >= row_off + MA_H * 16 && row_off >= 0 && row_off % 16 == 0, HH_ERR_SHAPE, "hh_mattn_bwd: the layer's 128 rows [row_off, row_off + 128) must lie inside rows_total");
@@ -589,10 +633,12 @@ extern "C" int hh_mattn_bwd(const float* qt, const float* dpooled, const float* 
     p.c.mp = (const bf16_t*)mp; p.c.mem = (const bf16_t*)mem; p.c.ld = ld; p.c.B = B; p.c.Q = Q; p.c.M = M;
     p.c.slices = slices;
     ma_slicing(M, &p.c.slices, &p.c.keys_per_slice);
-    HH_REQUIRE(p.c.slices == slices, HH_ERR_SHAPE, "hh_mattn_bwd: pass slices = hh_mattn_slices(M, wanted) (got %d, usable %d): the caller sums that many partial planes", slices, p.c.slices);
+    HH_REQUIRE(p.c.slices == 1 || workspace != nullptr, HH_ERR_SHAPE, "hh_mattn_bwd: slices > 1 needs hh_workspace_bytes_mattn_bwd() bytes of workspace");
+    p.slot = hh_stream_slot((hipStream_t)stream);
+    HH_REQUIRE(p.c.slices == 1 || (p.slot >= 0 && 2 * B <= MA_TICKET_UNITS), HH_ERR_UNSUPPORTED, "hh_mattn_bwd: key slices need a ticket row (<= 32 launch streams, B <= %d)", MA_TICKET_UNITS / 2);
     ma_drop_params(dropout_p, &p.c.drop_thresh, &p.c.drop_scale);
     p.c.seed = seed;
-    p.qt = qt; p.dpooled = dpooled; p.lse2 = lse2; p.dca = dca; p.ca = ca; p.bv = bv; p.dqt_part = dqt_partials;
+    p.qt = qt; p.dpooled = dpooled; p.lse2 = lse2; p.dca = dca; p.ca = ca; p.bv = bv; p.dqt_part = workspace; p.dqt = dqt;
     p.pdT = (bf16_t*)pdT; p.dsT = (bf16_t*)dsT; p.qt16 = (bf16_t*)qt16; p.dp16 = (bf16_t*)dp16; p.rows_total = rows_total; p.row_off = row_off;
     static bool attr_done = false;
     if (!attr_done) {

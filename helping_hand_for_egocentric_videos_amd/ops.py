@@ -639,11 +639,12 @@ def mattn_bwd(qt, dpooled, lse2, dca, ca, bv, mp, mem, Q, pdT, dsT, qt16, dp16, 
     if pdT.dtype != torch.bfloat16 or tuple(pdT.shape) != (B, rows, M) or dsT.shape != pdT.shape or tuple(qt16.shape) != (B, rows, MATTN_C) or dp16.shape != qt16.shape:
         raise ValueError("mattn_bwd: pdT / dsT bf16 [B, rows, M], qt16 / dp16 bf16 [B, rows, 512]")
     S = mattn_slices(B, M, slices)
-    part = _workspace("mattn_bwd", B, Q, S, device=qt.device).view(S, B * Q, MATTN_H * MATTN_C)
-    _lib.check(_lib.lib().hh_mattn_bwd(_p(qt), _p(dpooled), _p(lse2), _p(dca), _p(ca), _p(bv), _p(mp), _p(mem), mp.stride(1), _p(part), S, _p(pdT), _p(dsT),
+    dqt = torch.empty_like(qt)
+    ws = _workspace("mattn_bwd", B, Q, S, device=qt.device) if S > 1 else None
+    _lib.check(_lib.lib().hh_mattn_bwd(_p(qt), _p(dpooled), _p(lse2), _p(dca), _p(ca), _p(bv), _p(mp), _p(mem), mp.stride(1), _p(dqt), _p(ws), S, _p(pdT), _p(dsT),
                                        _p(qt16), _p(dp16), rows, int(row_off), B, Q, M, MATTN_H, MATTN_C, float(dropout_p), int(seed) & 0xFFFFFFFF,
                                        _stream()), "hh_mattn_bwd")
-    return part[0] if S == 1 else part.sum(0)
+    return dqt
 
 
 def gemm_tn_batched2(at, bt, at2=None, bt2=None):

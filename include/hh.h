@@ -121,7 +121,7 @@ int64_t hh_workspace_bytes_gemm_tn(int M, int N, int splits);
 int64_t hh_workspace_bytes_xattn_bwd(int B, int Q, int heads, int dq_splits);
 int64_t hh_workspace_bytes_xattn_fwd(int B, int Q, int heads, int splits);
 /*   mattn_fwd        : `workspace` of hh_mattn_fwd, slices > 1 (fp32 [slices, B*Q, 8, 512 + 4] partial pooled rows + statistics)
- *   mattn_bwd        : `dqt_partials` of hh_mattn_bwd          (fp32 [slices, B*Q, 8 * 512]) */
+ *   mattn_bwd        : `workspace` of hh_mattn_bwd, slices > 1  (fp32 [slices, B*Q, 8 * 512]) */
 int64_t hh_workspace_bytes_mattn_fwd(int B, int Q, int slices);
 int64_t hh_workspace_bytes_mattn_bwd(int B, int Q, int slices);
 int64_t hh_workspace_bytes_attn_cls_partial(int B, int T, int n, int heads, int time_mode);
@@ -283,9 +283,10 @@ int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_t ldkv, con
  *   qt fp32 [B*Q, 8*512]: row (clip, query), columns head*512 + k (already scaled by d^-1/2);  mp = memory + pos, mem = memory: bf16 [B, M, ld]
  *   forward:  pooled fp32 [B*Q, 8*512] = sum_i Pd[., i] mem[i, :],  Pd = dropout(softmax_i(qt . mp[i]));  lse2 fp32 [B*Q, 8] = log2 sum_i
  *             2^(score_i log2 e) (for the backward);  rsum fp32 [B*Q, 8] = sum_i Pd (1 without dropout: the weight of the value bias).
- *             The keys are cut into `slices` slices (one workgroup of 8 waves per (clip, 4 heads, slice)), merged by a second launch when
- *             slices > 1 (workspace: hh_workspace_bytes_mattn_fwd).  hh_mattn_slices(M, wanted) = the slice count actually used.
- *   backward: dqt_partials fp32 [slices, B*Q, 8*512] (the caller sums the planes) = sum_i dS[., i] mp[i, :] with dS = P o (dP - delta),
+ *             The keys are cut into `slices` slices (one workgroup of 8 waves per (clip, 4 heads, slice)); with slices > 1 the partial rows
+ *             go through `workspace` (hh_workspace_bytes_mattn_fwd) and the LAST workgroup of a (clip, 4 heads) to finish folds them in the
+ *             same launch (agent-scope release / ticket / acquire; fixed summation order).  hh_mattn_slices(M, wanted) = the slice count used.
+ *   backward: dqt fp32 [B*Q, 8*512] = sum_i dS[., i] mp[i, :] (slices folded the same way; workspace: hh_workspace_bytes_mattn_bwd) with dS = P o (dP - delta),
  *             dP = mask/(1-p) o (dpooled . mem[i] + dca . bv), delta = dca . ca per head (dca / ca fp32 [B*Q, 512]: gradient and value of
  *             the head outputs, bv fp32 [512] the layer's value bias);  pdT / dsT bf16 [B, rows_total, M]: rows [row_off, row_off + 128)
  *             (row_off + head*16 + query) receive Pd^T and dS^T, keys contiguous -- the operands of hh_gemm_tn_bf16_batched2, which makes
@@ -295,7 +296,7 @@ int hh_mattn_slices(int M, int slices);
 int hh_mattn_fwd(const float* qt, const void* mp, const void* mem, int64_t ld, float* pooled, float* lse2, float* rsum, float* workspace,
                  int slices, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, hh_stream_t stream);
 int hh_mattn_bwd(const float* qt, const float* dpooled, const float* lse2, const float* dca, const float* ca, const float* bv,
-                 const void* mp, const void* mem, int64_t ld, float* dqt_partials, int slices, void* pdT, void* dsT, void* qt16, void* dp16,
+                 const void* mp, const void* mem, int64_t ld, float* dqt, float* workspace, int slices, void* pdT, void* dsT, void* qt16, void* dp16,
                  int rows_total, int row_off, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, hh_stream_t stream);
 
 /* ---- query side of the decoder (model/tfm_decoder.py:430-461 forward_pre on the 13 object queries, :208-233 heads, and the

@@ -671,6 +671,40 @@ def test_mattn_key_slices_and_dropout():
     assert abs(fd - an) <= 0.03 * abs(fd) + 1e-3, (fd, an)
 
 
+def test_mattn_slice_handoff_is_bit_stable_under_uneven_load():
+    """The key slices of hh_mattn_fwd / hh_mattn_bwd are folded by the LAST workgroup of a (clip, head group) to finish (agent-scope
+    release -> ticket -> acquire, csrc/mattn.hip: ma_last_arriver) -- an inter-workgroup hand-off, which fails under uneven load if a
+    fence is missing.  40 rounds beside a stream of large GEMMs (the tower beside the decoder, as in the pipelined step), consumer
+    caches warm: every word of pooled / lse2 / dqt must equal the first round's (fixed summation order) and the single-slice result to
+    fp32 re-association."""
+    B, Q, M, H, C = 6, 13, 4096, 8, 512
+    qt = rnd(B * Q, H * C, seed=21, scale=0.08).to(DEV)
+    mpm = bf(rnd(2, B, M, C, seed=22)).to(DEV)
+    mp, mem = mpm[0], mpm[1]
+    wv, bv = rnd(C, C, seed=23, scale=0.05).to(DEV), rnd(C, seed=24, scale=0.1).to(DEV)
+    G = rnd(B * Q, C, seed=25).to(DEV)
+    bufs = [torch.empty((B, 128, M), dtype=torch.bfloat16, device=DEV) for _ in range(2)] + [torch.empty((B, 128, C), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    a = bf(rnd(8192, 1024, seed=26)).to(DEV)
+    w = bf(rnd(4096, 1024, seed=27, scale=0.05)).to(DEV)
+    side = torch.cuda.Stream()
+    one = ops.mattn_fwd(qt, mp, mem, Q, slices=1)
+    first = None
+    for it in range(40):
+        with torch.cuda.stream(side):
+            for _ in range(1 + it % 3):
+                ops.gemm(a, w)
+        pooled, lse2, rsum = ops.mattn_fwd(qt, mp, mem, Q, slices=16)
+        ca = ops.head_map_out(pooled, wv, bias=bv)
+        dqt = ops.mattn_bwd(qt, ops.head_map_in(G, wv), lse2, G, ca, bv, mp, mem, Q, *bufs, 0, slices=8)
+        cur = (pooled.clone(), lse2.clone(), dqt.clone())
+        if first is None:
+            first = cur
+            assert_close_bf16(pooled, one[0], 2e-5, "slices vs single pass")
+        else:
+            assert all(torch.equal(x, y) for x, y in zip(cur, first)), it
+    torch.cuda.synchronize()
+
+
 def test_head_batched_qgemm_vs_torch():
     """The three head-batched hh_qgemm_f32x3 forms of the memory-space cross-attention (ops.head_map_in / _out / _wgrad) on row-strided
     views of a packed [q; k; v] in-projection, against fp64 PyTorch (fp32-grade: 2e-5)."""
