@@ -373,25 +373,47 @@ __global__ __launch_bounds__(512) void mattn_fwd_kernel(MaFwd p) {
     // ---- the last of this (clip, head group)'s `slices` workgroups folds them:  pooled = sum_s 2^(m_s - m) O_s / L,  L = sum_s 2^(m_s - m) l_s
     int* flag = (int*)(smem + MA_XOFF);
     if (!ma_last_arriver(&g_ma_ticket[p.slot][b * 2 + hg], (unsigned)p.c.slices, flag)) return;
+    // (all 512 threads work on independent loads: first the slices' statistics -> per-(query, head) weights in LDS, then every thread folds
+    // 13 float4 of the 52 x 512 output values over the slices; a serial loop over (query, head) x slice cost ~100 us of load latency)
     const int64_t plane = (int64_t)p.c.B * Q * MA_H;                // (row, head) pairs per slice
-    for (int qh = 0; qh < Q * 4; ++qh) {
-        const int64_t rh = ((int64_t)b * Q + qh / 4) * MA_H + 4 * hg + (qh & 3);
+    const int S = p.c.slices, NP = Q * 4;
+    float* wtab = (float*)smem;                                      // [NP <= 64][S <= 64] weights 2^(m_s - m) / L   (the stages are dead by now)
+    float* stat = wtab + 64 * 64;                                    // [NP][S][4] raw statistics (64 KB at most)
+    for (int e = tid; e < NP * S; e += 512) {
+        const int pr = e / S, s_ = e % S;
+        const int64_t rh = ((int64_t)b * Q + pr / 4) * MA_H + 4 * hg + (pr & 3);
+        *(f32x4*)(stat + 4 * e) = *(const f32x4*)(p.st_part + (s_ * plane + rh) * 4);
+    }
+    __syncthreads();
+    if (tid < NP) {
         float m = -INFINITY;
-        for (int s_ = 0; s_ < p.c.slices; ++s_) m = fmaxf(m, p.st_part[(s_ * plane + rh) * 4]);
-        float L = 0.f, RS = 0.f, acc = 0.f;
-        for (int s_ = 0; s_ < p.c.slices; ++s_) {
-            const f32x4 st = *(const f32x4*)(p.st_part + (s_ * plane + rh) * 4);
-            const float w = __builtin_amdgcn_exp2f(st[0] - m);
-            L += w * st[1];
-            RS += w * st[2];
-            acc += w * p.o_part[(s_ * plane + rh) * MA_C + tid];
+        for (int s_ = 0; s_ < S; ++s_) m = fmaxf(m, stat[4 * (tid * S + s_)]);
+        float L = 0.f, RS = 0.f;
+        for (int s_ = 0; s_ < S; ++s_) {
+            const float w = __builtin_amdgcn_exp2f(stat[4 * (tid * S + s_)] - m);
+            L += w * stat[4 * (tid * S + s_) + 1];
+            RS += w * stat[4 * (tid * S + s_) + 2];
+            wtab[tid * S + s_] = w;
         }
         const float inv = 1.f / L;
-        p.pooled[rh * MA_C + tid] = acc * inv;
-        if (tid == 0) {
-            p.lse2[rh] = m + __builtin_amdgcn_logf(L);
-            p.rsum[rh] = RS * inv;
+        for (int s_ = 0; s_ < S; ++s_) wtab[tid * S + s_] *= inv;
+        const int64_t rh = ((int64_t)b * Q + tid / 4) * MA_H + 4 * hg + (tid & 3);
+        p.lse2[rh] = m + __builtin_amdgcn_logf(L);
+        p.rsum[rh] = RS * inv;
+    }
+    __syncthreads();
+    for (int v = tid; v < NP * 128; v += 512) {                     // float4 v of the [NP][512] block
+        const int pr = v >> 7;
+        const int64_t at = (((int64_t)b * Q + pr / 4) * MA_H + 4 * hg + (pr & 3)) * MA_C + 4 * (v & 127);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int s_ = 0;
+        for (; s_ + 4 <= S; s_ += 4) {
+            const f32x4 a0 = *(const f32x4*)(p.o_part + (s_ + 0) * plane * MA_C + at), a1 = *(const f32x4*)(p.o_part + (s_ + 1) * plane * MA_C + at);
+            const f32x4 a2 = *(const f32x4*)(p.o_part + (s_ + 2) * plane * MA_C + at), a3 = *(const f32x4*)(p.o_part + (s_ + 3) * plane * MA_C + at);
+            acc += a0 * wtab[pr * S + s_]; acc += a1 * wtab[pr * S + s_ + 1]; acc += a2 * wtab[pr * S + s_ + 2]; acc += a3 * wtab[pr * S + s_ + 3];
         }
+        for (; s_ < S; ++s_) acc += *(const f32x4*)(p.o_part + s_ * plane * MA_C + at) * wtab[pr * S + s_];
+        *(f32x4*)(p.pooled + at) = acc;
     }
 }
 
@@ -407,7 +429,7 @@ static int ma_check(const char* what, int B, int Q, int M, int heads, int C, int
     HH_REQUIRE(heads == MA_H && C == MA_C, HH_ERR_UNSUPPORTED, "%s: built for the reference decoder's d_model 512 / 8 heads (tfm_decoder.py:51) (heads=%d C=%d)", what, heads, C);
     HH_REQUIRE(B >= 0 && Q > 0 && Q <= 16 && M > 0 && M % MA_KC == 0, HH_ERR_SHAPE, "%s: need 0 < Q <= 16 and M %% 32 == 0 (Q=%d M=%d)", what, Q, M);
     HH_REQUIRE(ld >= MA_C && ld % 8 == 0, HH_ERR_SHAPE, "%s: memory leading dimension %lld too small / unaligned", what, (long long)ld);
-    HH_REQUIRE(slices >= 1 && slices <= 256, HH_ERR_SHAPE, "%s: slices must be in [1, 256]", what);
+    HH_REQUIRE(slices >= 1 && slices <= 64, HH_ERR_SHAPE, "%s: slices must be in [1, 64] (the fold keeps their statistics in LDS)", what);
     return HH_OK;
 }
 
@@ -603,11 +625,19 @@ __global__ __launch_bounds__(512) void mattn_bwd_kernel(MaBwd p) {
     int* flag = (int*)(smem + MA_XOFF);
     if (!ma_last_arriver(&g_ma_ticket[p.slot][b * 2 + hg], (unsigned)p.c.slices, flag)) return;
     const int64_t plane = (int64_t)p.c.B * Q * (MA_H * MA_C);
-    for (int qh = 0; qh < Q * 4; ++qh) {
-        const int64_t at = ((int64_t)b * Q + qh / 4) * (MA_H * MA_C) + (4 * hg + (qh & 3)) * MA_C + tid;
-        float a_ = 0.f;
-        for (int s_ = 0; s_ < p.c.slices; ++s_) a_ += p.dqt_part[s_ * plane + at];
-        p.dqt[at] = a_;
+    const int S = p.c.slices;
+    for (int v = tid; v < Q * 4 * 128; v += 512) {                  // float4 v of this (clip, head group)'s [Q * 4][512] block: independent loads
+        const int pr = v >> 7;
+        const int64_t at = ((int64_t)b * Q + pr / 4) * (MA_H * MA_C) + (4 * hg + (pr & 3)) * MA_C + 4 * (v & 127);
+        f32x4 a_ = {0.f, 0.f, 0.f, 0.f};
+        int s_ = 0;
+        for (; s_ + 4 <= S; s_ += 4) {
+            const f32x4 a0 = *(const f32x4*)(p.dqt_part + (s_ + 0) * plane + at), a1 = *(const f32x4*)(p.dqt_part + (s_ + 1) * plane + at);
+            const f32x4 a2 = *(const f32x4*)(p.dqt_part + (s_ + 2) * plane + at), a3 = *(const f32x4*)(p.dqt_part + (s_ + 3) * plane + at);
+            a_ += a0; a_ += a1; a_ += a2; a_ += a3;
+        }
+        for (; s_ < S; ++s_) a_ += *(const f32x4*)(p.dqt_part + s_ * plane + at);
+        *(f32x4*)(p.dqt + at) = a_;
     }
 }
 

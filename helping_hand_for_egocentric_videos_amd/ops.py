@@ -597,7 +597,7 @@ def mattn_slices(B, M, wanted=None):
     """Key slices of hh_mattn_fwd / hh_mattn_bwd: two workgroups (of 8 waves, one per CU) per (clip, slice) -- enough slices to give every
     CU one, at least four 32-key chunks per slice."""
     if wanted is None:
-        wanted = min(max(1, (128 + B - 1) // max(B, 1)), max(1, (M // 32) // 4))
+        wanted = min(max(1, (128 + B - 1) // max(B, 1)), max(1, (M // 32) // 4), 64)
     s = _lib.lib().hh_mattn_slices(int(M), int(wanted))
     if s < 1:
         raise ValueError("mattn: M must be a positive multiple of 32 (M=%d)" % M)
