@@ -55,34 +55,22 @@ __device__ __forceinline__ bool ma_keep(unsigned seed, unsigned bh, unsigned qq,
 
 __device__ __forceinline__ unsigned ma_lds_u32(const char* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
 
+// LDS reads are ordinary (compiler-visible) loads: the compiler places its own lgkmcnt waits and interleaves reads and MFMAs.  Only the
+// LDS-DMA is inline asm -- hipcc turns every wait into vmcnt(0) once it has seen the global_load_lds BUILTIN (attn_space.hip), but it does
+// not look inside asm; the DMA's completion is ordered by this file's explicit vmcnt(0) + s_barrier (memory clobbers).
+typedef __attribute__((address_space(3))) const u32x4* ma_lds_v4;
+typedef __attribute__((address_space(3))) const f32x4* ma_lds_f4;
+typedef __attribute__((address_space(3))) ma_s16x4* ma_lds_s4;
 template <int OFF>
-__device__ __forceinline__ bf16x8 ma_rd128(unsigned a) {
-    u32x4 r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
-    return __builtin_bit_cast(bf16x8, r);
-}
+__device__ __forceinline__ bf16x8 ma_rd128(unsigned a) { return __builtin_bit_cast(bf16x8, *(ma_lds_v4)(size_t)(a + OFF)); }
 template <int OFF>
-__device__ __forceinline__ f32x4 ma_rd128f(unsigned a) {
-    f32x4 r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
-    return r;
-}
-// (the value is an MFMA result: an LDS instruction that reads the destination of an 8-pass MFMA needs 11 wait states after it, and the
-// compiler's hazard recogniser does not look inside inline asm -- without the s_nops the write stored the accumulator of an MFMA still in flight)
+__device__ __forceinline__ f32x4 ma_rd128f(unsigned a) { return *(ma_lds_f4)(size_t)(a + OFF); }
 template <int OFF>
-__device__ __forceinline__ void ma_wr128f(unsigned a, f32x4 v) {
-    asm volatile("s_nop 7\n\ts_nop 7\n\tds_write_b128 %0, %1 offset:%2" :: "v"(a), "v"(v), "n"(OFF) : "memory");
-}
+__device__ __forceinline__ void ma_wr128f(unsigned a, f32x4 v) { *(__attribute__((address_space(3))) f32x4*)(size_t)(a + OFF) = v; }
 template <int OFF>
 __device__ __forceinline__ bf16x4 ma_tr4(unsigned a) {
-    ma_s16x4 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
-    return __builtin_bit_cast(bf16x4, r);
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((ma_lds_s4)(size_t)(a + OFF)));
 }
-// counted LDS waits that "touch" the registers they make valid, so that no consumer is scheduled above them
-#define MA_LGKM4(N, A, B, C, D) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(A), "+v"(B), "+v"(C), "+v"(D) : "n"(N))
-#define MA_LGKM8(N, A, B, C, D, E, F, G, H) asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(A), "+v"(B), "+v"(C), "+v"(D), "+v"(E), "+v"(F), "+v"(G), "+v"(H) : "n"(N))
-#define MA_LGKM2(N, A, B) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(A), "+v"(B) : "n"(N))
 #define MA_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define MA_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define MA_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -92,6 +80,21 @@ __device__ __forceinline__ void ma_dma_row(const bf16_t* src, unsigned voff, uns
     // (s_nop 4: the scalar operands may come straight out of a v_readfirstlane -- VALU writes SGPR -> VMEM reads it needs 5 wait states, and
     // the compiler's hazard recogniser does not look inside inline asm; scripts/check_isa_hazards.py)
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src), "s"(dst) : "memory");
+}
+
+// reductions over the four 16-lane groups of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same query): two register swaps on the
+// vector unit (v_permlane16_swap / v_permlane32_swap) instead of two ds_bpermute round trips through the LDS crossbar
+__device__ __forceinline__ float ma_max_groups(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float ma_sum_groups(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 struct MaCommon {
@@ -167,7 +170,6 @@ __device__ __forceinline__ void ma_scores(const MaAddr& A, const bf16x8 (&hi)[8]
         bf16x8 f5 = kt == 0 ? ma_rd128<HALF_OFF + 256>(a1) : ma_rd128<HALF_OFF + 16384 + 256>(a1);
         bf16x8 f6 = kt == 0 ? ma_rd128<HALF_OFF + 256>(a2) : ma_rd128<HALF_OFF + 16384 + 256>(a2);
         bf16x8 f7 = kt == 0 ? ma_rd128<HALF_OFF + 256>(a3) : ma_rd128<HALF_OFF + 16384 + 256>(a3);
-        MA_LGKM4(4, f0, f1, f2, f3);
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, hi[0], acc[kt], 0, 0, 0);
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, lo[0], acc[kt], 0, 0, 0);
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, hi[1], acc[kt], 0, 0, 0);
@@ -176,7 +178,6 @@ __device__ __forceinline__ void ma_scores(const MaAddr& A, const bf16x8 (&hi)[8]
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f2, lo[2], acc[kt], 0, 0, 0);
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f3, hi[3], acc[kt], 0, 0, 0);
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f3, lo[3], acc[kt], 0, 0, 0);
-        MA_LGKM4(0, f4, f5, f6, f7);
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f4, hi[4], acc[kt], 0, 0, 0);
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f4, lo[4], acc[kt], 0, 0, 0);
         acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f5, hi[5], acc[kt], 0, 0, 0);
@@ -211,14 +212,12 @@ __device__ __forceinline__ void ma_pool(const MaAddr& A, const bf16x8& ph, const
                 a3 = ma_tr4<HALF_OFF + 256>(t[4 * quad + 3]); b3 = ma_tr4<HALF_OFF + 16384 + 256>(t[4 * quad + 3]);
             }
             const int dt = 8 * half + 4 * quad;
-            MA_LGKM4(4, a0, b0, a1, b1);
             const bf16x8 v0 = {a0[0], a0[1], a0[2], a0[3], b0[0], b0[1], b0[2], b0[3]};
             const bf16x8 v1 = {a1[0], a1[1], a1[2], a1[3], b1[0], b1[1], b1[2], b1[3]};
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, ph, o[dt], 0, 0, 0);
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pl, o[dt], 0, 0, 0);
             o[dt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, ph, o[dt + 1], 0, 0, 0);
             o[dt + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pl, o[dt + 1], 0, 0, 0);
-            MA_LGKM4(0, a2, b2, a3, b3);
             const bf16x8 v2 = {a2[0], a2[1], a2[2], a2[3], b2[0], b2[1], b2[2], b2[3]};
             const bf16x8 v3 = {a3[0], a3[1], a3[2], a3[3], b3[0], b3[1], b3[2], b3[3]};
             o[dt + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v2, ph, o[dt + 2], 0, 0, 0);
@@ -227,6 +226,17 @@ __device__ __forceinline__ void ma_pool(const MaAddr& A, const bf16x8& ph, const
             o[dt + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v3, pl, o[dt + 3], 0, 0, 0);
         }
     }
+}
+
+// the same in four parts (row 4 w + I of both halves: 2 DMAs each), so that the issue of a stage's 8 DMAs -- 600 cycles per wave when they go
+// out back to back, 1600 for the waves that lose the arbitration (scripts/mattn_timeline.hip) -- is spread over the phases of a chunk
+template <int I>
+__device__ __forceinline__ void ma_stage_part(const MaCommon& p, int b, int k0, int wave, unsigned lane16, unsigned stage_lds) {
+    const int kr = 4 * wave + I;
+    const int64_t row = ((int64_t)b * p.M + k0 + kr) * p.ld;
+    const unsigned voff = lane16 ^ (unsigned)(32 * (kr & 7));
+    ma_dma_row(p.mp + row, voff, stage_lds + kr * MA_ROWB);
+    ma_dma_row(p.mem + row, voff, stage_lds + MA_HALF + kr * MA_ROWB);
 }
 
 // workgroup index -> (clip, head group, key slice); the two head groups of a (clip, slice) unit are blockIdx b and b + 8: the same
@@ -268,6 +278,19 @@ __device__ __forceinline__ bool ma_last_arriver(unsigned* ticket, unsigned total
     return *lds_flag != 0;
 }
 
+// scripts/mattn_timeline.hip compiles this file with -DMA_TIMELINE: workgroup 0's waves then add up the shader cycles of the phases of a
+// chunk (the product build contains none of this)
+#ifdef MA_TIMELINE
+__device__ unsigned long long g_ma_tl[8][8];
+#define MA_TL_DECL unsigned long long tl_t = __builtin_readcyclecounter(); unsigned long long tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define MA_TL(I) do { const unsigned long long n_ = __builtin_readcyclecounter(); tl_acc[I] += n_ - tl_t; tl_t = n_; } while (0)
+#define MA_TL_FLUSH() do { if (blockIdx.x == 0 && lane == 0) for (int i_ = 0; i_ < 8; ++i_) g_ma_tl[wave][i_] = tl_acc[i_]; } while (0)
+#else
+#define MA_TL_DECL
+#define MA_TL(I)
+#define MA_TL_FLUSH()
+#endif
+
 struct MaFwd {
     MaCommon c;
     const float* qt;          // [B*Q, H*C] fp32: row (clip, query), column head * 512 + k
@@ -305,18 +328,28 @@ __global__ __launch_bounds__(512) void mattn_fwd_kernel(MaFwd p) {
     const unsigned xme = lds0 + MA_XOFF + wave * 2048 + lane * 16, xpartner = lds0 + MA_XOFF + (wave ^ 1) * 2048 + lane * 16;
     const unsigned bh = (unsigned)(b * MA_H + head);
 
+    MA_TL_DECL;
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);        // the second-dispatched half loses every issue arbitration otherwise (MI355X_MICROARCH.md, two waves per SIMD)
     for (int c = 0; c < nchunks; ++c) {
         MA_WAIT_VM0();                                   // this wave's rows of chunk c have landed
+        MA_TL(0);
         MA_BARRIER();                                    // everyone's have; everyone has left chunk c - 1 (its stage is free)
-        if (c + 1 < nchunks) ma_stage(p.c, b, k_begin + (c + 1) * MA_KC, wave, voff, lds0 + ((c + 1) & 1) * MA_STAGE);
+        MA_TL(1);
+        const bool more = c + 1 < nchunks;                 // (wave-uniform)
+        const int kn = k_begin + (c + 1) * MA_KC;
+        const unsigned sn = lds0 + ((c + 1) & 1) * MA_STAGE;
+        if (more) ma_stage_part<0>(p.c, b, kn, wave, voff, sn);
+        MA_TL(2);
         f32x4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         ma_scores<0>(A, qh, qlo, s);
         ma_wr128f<0>(xme, s[0]);
         ma_wr128f<1024>(xme, s[1]);
+        if (more) ma_stage_part<1>(p.c, b, kn, wave, voff, sn);
         MA_WAIT_LGKM0();
+        MA_TL(3);
         MA_BARRIER();
+        MA_TL(4);
         f32x4 x0 = ma_rd128f<0>(xpartner), x1 = ma_rd128f<1024>(xpartner);
-        MA_LGKM2(0, x0, x1);
         s[0] += x0;
         s[1] += x1;
         // online softmax in base 2 (this lane: query ql, keys 4 g + r of both key tiles)
@@ -324,8 +357,8 @@ __global__ __launch_bounds__(512) void mattn_fwd_kernel(MaFwd p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { t[r] = s[0][r] * MA_LOG2E; t[4 + r] = s[1][r] * MA_LOG2E; }
         float mx = fmaxf(fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])), fmaxf(fmaxf(t[4], t[5]), fmaxf(t[6], t[7])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = ma_max_groups(mx);
+        if (more) ma_stage_part<2>(p.c, b, kn, wave, voff, sn);
         const float m_new = fmaxf(m_run, mx);
         if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull) {              // rescale only when some row's maximum moved
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -345,13 +378,15 @@ __global__ __launch_bounds__(512) void mattn_fwd_kernel(MaFwd p) {
             rs_run += pv;
             ma_split_hl(pv, ph[j], pl[j]);
         }
+        if (more) ma_stage_part<3>(p.c, b, kn, wave, voff, sn);
+        MA_TL(5);
         ma_pool<MA_HALF>(A, ph, pl, o);
         ma_addr_flip(A);
+        MA_TL(6);
     }
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
-    rs_run += __shfl_xor(rs_run, 16, 64);
-    rs_run += __shfl_xor(rs_run, 32, 64);
+    MA_TL_FLUSH();
+    l_run = ma_sum_groups(l_run);
+    rs_run = ma_sum_groups(rs_run);
     const bool live = ql < Q;
     const int64_t r = (int64_t)b * Q + (live ? ql : 0);
     const bool final_ = p.c.slices == 1;
@@ -552,10 +587,8 @@ __global__ __launch_bounds__(512) void mattn_bwd_kernel(MaBwd p) {
             const f32x4 bb = *(const f32x4*)(bvp + e);
             cb += dv[0] * bb[0] + dv[1] * bb[1] + dv[2] * bb[2] + dv[3] * bb[3];
         }
-        delta += __shfl_xor(delta, 16, 64);
-        delta += __shfl_xor(delta, 32, 64);
-        cb += __shfl_xor(cb, 16, 64);
-        cb += __shfl_xor(cb, 32, 64);
+        delta = ma_sum_groups(delta);
+        cb = ma_sum_groups(cb);
     }
     const float lse = live ? p.lse2[r * MA_H + head] : 0.f;
     // bf16 copies of this head's qt / dpooled rows for the batched d-memory GEMM (hi halves = the rounded values; zero rows beyond Q)
@@ -574,21 +607,26 @@ __global__ __launch_bounds__(512) void mattn_bwd_kernel(MaBwd p) {
     const unsigned bh = (unsigned)(b * MA_H + head);
     bf16_t* outT = (dh == 0 ? p.pdT : p.dsT) + ((int64_t)b * p.rows_total + p.row_off + head * 16 + ql) * p.c.M;
 
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);        // (as in the forward)
     for (int c = 0; c < nchunks; ++c) {
         MA_WAIT_VM0();
         MA_BARRIER();
-        if (c + 1 < nchunks) ma_stage(p.c, b, k_begin + (c + 1) * MA_KC, wave, voff, lds0 + ((c + 1) & 1) * MA_STAGE);
+        const bool more = c + 1 < nchunks;                 // the next stage's 8 DMAs go out two at a time between the phases (see ma_stage_part)
+        const int kn = k_begin + (c + 1) * MA_KC;
+        const unsigned sn = lds0 + ((c + 1) & 1) * MA_STAGE;
+        if (more) ma_stage_part<0>(p.c, b, kn, wave, voff, sn);
         f32x4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dp[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         ma_scores<0>(A, qh, qlo, s);
         ma_wr128f<0>(xme, s[0]);
         ma_wr128f<1024>(xme, s[1]);
+        if (more) ma_stage_part<1>(p.c, b, kn, wave, voff, sn);
         ma_scores<MA_HALF>(A, dh_, dlo, dp);
         ma_wr128f<2048>(xme, dp[0]);
         ma_wr128f<3072>(xme, dp[1]);
+        if (more) ma_stage_part<2>(p.c, b, kn, wave, voff, sn);
         MA_WAIT_LGKM0();
         MA_BARRIER();
         f32x4 x0 = ma_rd128f<0>(xpartner), x1 = ma_rd128f<1024>(xpartner), x2 = ma_rd128f<2048>(xpartner), x3 = ma_rd128f<3072>(xpartner);
-        MA_LGKM4(0, x0, x1, x2, x3);
         s[0] += x0; s[1] += x1; dp[0] += x2; dp[1] += x3;
         bf16x8 sh, sl;
         bf16x4 st0, st1;                                  // what this wave stores: Pd (dim-half 0) or dS (dim-half 1), keys 4 g .. of each key tile
@@ -611,6 +649,7 @@ __global__ __launch_bounds__(512) void mattn_bwd_kernel(MaBwd p) {
         }
         *(bf16x4*)(outT + kbase) = st0;
         *(bf16x4*)(outT + kbase + 16) = st1;
+        if (more) ma_stage_part<3>(p.c, b, kn, wave, voff, sn);
         ma_pool<0>(A, sh, sl, acc);
         ma_addr_flip(A);
     }
