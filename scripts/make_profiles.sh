@@ -49,7 +49,7 @@ L += [""] + stats("prof_u", TAG + "_unpipelined", "Same build, un-pipelined step
 # ---- steady state of the un-pipelined run: the dispatches between the first and the last optimizer launch (adamw_arena_kernel = one per step), so
 # that the process's start-up (weight packing, copies, fills) does not count as "per step"
 LIBHH = ("gemm", "attn", "ln_", "add_ln", "embed", "im2col", "cast_", "transpose", "qgemm", "qself", "xattn", "lsap", "match_boxes", "box_", "rownorm", "egonce",
-         "masked_ce", "tv_accuracy", "adamw", "cls_combine", "text_flags", "_Z13ln_fwd", "accuracy", "gather_rows", "word_", "dropout_")
+         "masked_ce", "tv_accuracy", "adamw", "cls_combine", "text_flags", "_Z13ln_fwd", "accuracy", "gather_rows", "word_", "dropout_", "mattn")
 tf = glob.glob(R + "/gpurun_out/prof_u/**/*kernel_trace.csv", recursive=True)
 if tf:
     tr = sorted(csv.DictReader(open(tf[0])), key=lambda r: int(r["Start_Timestamp"]))
@@ -79,7 +79,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if row["Counter_Name"] == c:
                 agg[row["Kernel_Name"]] += float(row["Counter_Value"]); cnt[row["Kernel_Name"]] += 1
     val[c] = (agg, cnt)
-names = [k for k in val["FETCH_SIZE"][0] if any(t in k for t in ("gemm", "attn", "ln_", "add_ln", "xattn", "transpose", "embed", "im2col"))]
+names = [k for k in val["FETCH_SIZE"][0] if any(t in k for t in ("gemm", "attn", "ln_", "add_ln", "xattn", "mattn", "transpose", "embed", "im2col"))]
 js, rows = {}, []
 for k in names:
     n = val["FETCH_SIZE"][1][k]
@@ -112,7 +112,7 @@ S = ["# " + TAG + " -- matrix-core and VALU utilisation per kernel (rocprofv3 --
      "| kernel | launches | MFMA busy % | VALU busy % | MFMA GFLOP / launch | SQ_INSTS_VALU / launch (M) |", "|---|---|---|---|---|---|"]
 rows = []
 for k, c in agg.items():
-    if not any(t in k for t in ("gemm", "attn", "ln_", "add_ln", "xattn")) or c["SQ_BUSY_CU_CYCLES"] <= 0: continue
+    if not any(t in k for t in ("gemm", "attn", "ln_", "add_ln", "xattn", "mattn")) or c["SQ_BUSY_CU_CYCLES"] <= 0: continue
     busy = 4.0 * c["SQ_BUSY_CU_CYCLES"]
     rows.append((c["SQ_VALU_MFMA_BUSY_CYCLES"], "| %s | %d | %.1f | %.1f | %.1f | %.1f |" % (k[:80].replace("|", "/"), cnt[k], 100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / busy,
                  100 * 4.0 * c["SQ_ACTIVE_INST_VALU"] / busy, 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_BF16"] / max(cnt[k], 1) / 1e9, c["SQ_INSTS_VALU"] / max(cnt[k], 1) / 1e6)))
