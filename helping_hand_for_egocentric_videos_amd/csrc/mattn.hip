@@ -29,8 +29,8 @@
 // Bank model of MI355X_MICROARCH.md: 16-B chunk c of row r lives at position c ^ (2 (r & 7)); both the row reads (16 keys x 4
 // chunks per instruction) and the transposed reads (8 rows x 32 B per half wave) are conflict-free with it.
 //
-// hipcc and LDS-DMA (see attn_space.hip): the DMA, every LDS access of the main loop and every wait are opaque inline asm; the
-// compiler sees no vector-memory dependency it could turn into vmcnt(0).
+// hipcc and LDS-DMA (see attn_space.hip): only the DMA and its waits are inline asm (below: ma_dma_row); the LDS reads are ordinary loads the
+// compiler schedules -- it never sees the global_load_lds builtin, so it has no reason to turn its own waits into vmcnt(0).
 #include "common.h"
 
 typedef short ma_s16x4 __attribute__((ext_vector_type(4)));

@@ -8,8 +8,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "0":
     LaviLa.LN_FOLD = False
 for kv in sys.argv[2:]:
     k, v = kv.split("=")
-    if k == "streams": LaviLa.TOWER_STREAMS = int(v)
-    else: ops.set_tuning(k, int(v))
+    ops.set_tuning(k, int(v))
 cfg = C2
 bb = LaviLa.build_backbone(cfg, synth.encoder_state(cfg, seed=0))
 video = synth.make_batch(cfg, 32, seed=1)["video"].cuda()
