@@ -722,11 +722,13 @@ __device__ __forceinline__ void spacep_chunk(unsigned k0a, unsigned k1a, unsigne
         }
     }
     // the V^T fragments of this chunk's key pair: requested now, consumed after the exponentials
-    bf16x4 a0 = sp_tr4_raw<0>(v0a), a1 = sp_tr4_raw<0>(v1a), a2 = sp_tr4_raw<0>(v2a), a3 = sp_tr4_raw<0>(v3a);
+    // (v1a = v0a + 8 and v3a = v2a + 8 at every call site: the second 8-byte halves are read through the immediate offset)
+    (void)v1a; (void)v3a;
+    bf16x4 a0 = sp_tr4_raw<0>(v0a), a1 = sp_tr4_raw<8>(v0a), a2 = sp_tr4_raw<0>(v2a), a3 = sp_tr4_raw<8>(v2a);
     // second key tile of the pair; a single-tile chunk re-reads the first (its probabilities are 0, the operand only has to be finite
     // -- a register COPY of a0 here would be taken before the read has landed)
     constexpr int OB = NT == 2 ? 2048 : 0;
-    bf16x4 b0 = sp_tr4_raw<OB>(v0a), b1 = sp_tr4_raw<OB>(v1a), b2 = sp_tr4_raw<OB>(v2a), b3 = sp_tr4_raw<OB>(v3a);
+    bf16x4 b0 = sp_tr4_raw<OB>(v0a), b1 = sp_tr4_raw<OB + 8>(v0a), b2 = sp_tr4_raw<OB>(v2a), b3 = sp_tr4_raw<OB + 8>(v2a);
     if (FIRST) {
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
@@ -904,221 +906,7 @@ __global__ __launch_bounds__(64 * NWV, WPS) void space_attnp_kernel(const bf16_t
 }
 
 
-// ---- persistent workgroups with cross-problem prefetch (round 4; n = 256, config 2).  A (clip, frame, head) problem spends 38 % of its
-// workgroup's life waiting for its K / V / Q rows and the two workgroups of a CU fall into step.  Here a workgroup walks
-// its problems p, p + gridDim, ... and the NEXT problem's rows stream in BEHIND the current one: the key rows are used in order, so
-// once every wave has passed the first third of the keys, that third of the K / V tiles is dead -- one workgroup barrier later the
-// next problem's first segment is LDS-DMA'd over it, and so on for the second and last segment; the next Q rows go into the Q registers
-// as soon as the last chunk has used them.  A problem's start then waits for ONE vmcnt(0) whose loads were issued a segment or more
-// earlier.  What made the rows die early: (1) the CLS query's partial over the frame's keys no longer runs at the end over all keys but
-// per segment -- waves 0..2 take one two-tile chunk of it each, as one more (16-column, replicated) query block of the same chunk routine; (2) the rare
-// running-maximum redo (a score 2^127 above the block's reference) cannot count on resident keys any more: a workgroup-wide flag sends
-// such a problem down a slow path that re-stages its K / V, redoes the blocks and the CLS partial with the resident-tile routines and
-// restarts the stream.  Every LDS-DMA is inline asm here (the compiler must not know: see the progressive kernel above).
 #define NWMAX 12        // most waves per workgroup of any variant (CLS scratch records)
-__device__ __forceinline__ void sp_dma16(const bf16_t* src, unsigned lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(lds_wave_base) : "memory");
-}
-template <int NWV, int P0, int CNT>
-__device__ __forceinline__ void spacepp_stage_seg(unsigned ks, unsigned vs, const bf16_t* base, const bf16_t* q_ptr, int64_t ld, int64_t ws, int n,
-                                                  int lane, int wave) {
-    static_assert(CNT % NWV == 0, "every wave stages the same number of pieces");
-#pragma unroll
-    for (int r = 0; r < CNT / NWV; ++r) {
-        const int pc = P0 + wave + r * NWV, row = pc * 8 + (lane >> 3);
-        const bf16_t* src = (row < n) ? q_ptr + (int64_t)row * ld : base;
-        sp_dma16(src + ws + ((lane & 7) ^ kswz(row)) * 8, ks + (unsigned)pc * 1024u);
-    }
-#pragma unroll
-    for (int r = 0; r < CNT / NWV; ++r) {
-        const int pc = P0 + wave + r * NWV, row = pc * 8 + (lane >> 3);
-        const bf16_t* src = (row < n) ? q_ptr + (int64_t)row * ld : base;
-        sp_dma16(src + 2 * ws + ((lane & 7) ^ vswz(row)) * 8, vs + (unsigned)pc * 1024u);
-    }
-}
-
-template <int JB, int NWV>
-__global__ __launch_bounds__(64 * NWV, 2) void space_attnpp_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                   float* __restrict__ cls_partial, int B, int T, int heads, int layout, int nprob) {
-    constexpr int NQB = 16, n = NQB * 16, nt = NQB + 1, KP = ((n + 1 + 31) / 32) * 32, SEG = 12;      // 3 segments of 12 pieces = 96 key rows
-    static_assert(NWV * JB == NQB && 3 * SEG == KP / 8 && NWV >= 3, "n = 256: 4 waves x 4 joint blocks, 36 pieces");
-    constexpr int E0 = SEG / 4, E1 = 2 * SEG / 4, NCH = NQB / 2;                                        // chunk indices of the segment starts; plain chunks
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;
-    char* Vs = smem + (size_t)KP * 128;
-    float* scratch = (float*)(smem + (size_t)KP * 256);
-    // two words, alternating by problem (an LDS-typed pointer: as a generic `volatile int*` the accesses came out as flat_load / flat_store)
-    volatile __attribute__((address_space(3))) int* flag =
-        (volatile __attribute__((address_space(3))) int*)(smem + (size_t)KP * 256 + (size_t)NWMAX * CLS_REC * 4);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int D = heads * 64;
-    const int N = 1 + T * n;
-    const int64_t ld = layout ? 64 : 3 * (int64_t)D;
-    const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
-    const int c = lane & 15, g = lane >> 4;
-    const int gb = wave * JB;
-    const unsigned ks_u = sp_lds_u32(Ks), vs_u = sp_lds_u32(Vs);
-    const int kz = (c & 7) ^ (c >> 3), trq = c >> 2, trp = c & 3, vz = ((trq >> 1) & 1) << 2;
-    const unsigned kb0 = sp_lds_u32(Ks + c * 128 + ((g ^ kz) << 4));
-    const unsigned kb1 = sp_lds_u32(Ks + c * 128 + (((g + 4) ^ kz) << 4));
-    const unsigned vb0 = sp_lds_u32(Vs + (4 * g + trq) * 128 + (((2 * trp) ^ vz) << 4));
-    const unsigned vb1 = vb0 + 8;
-    const unsigned vb2 = sp_lds_u32(Vs + (4 * g + trq) * 128 + (((2 * trp + 1) ^ vz) << 4));
-    const unsigned vb3 = vb2 + 8;
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    if (tid < 2) flag[tid] = 0;
-
-    int p = blockIdx.x;
-    int head = p % heads, f = (p / heads) % T, b = p / (heads * T);
-    const bf16_t* base = qkv + (int64_t)b * N * ld + head * hs;
-    const bf16_t* q_ptr = base + (int64_t)(1 + f * n) * ld;
-    bf16x8 q[JB][2], qc[1][2];
-    // (`ln`: an OPAQUE copy of the lane index -- the per-lane address terms of the staging / Q loads are loop-invariant, and hoisted out of
-    // the problem loop they stay live across it: 50+ registers, spilled)
-    auto load_q = [&](const bf16_t* bs, const bf16_t* qp, int ln) {
-        const int c_ = ln & 15, g_ = ln >> 4;
-#pragma unroll
-        for (int j = 0; j < JB; ++j) {
-            const bf16_t* qrow = qp + (int64_t)((gb + j) * 16 + c_) * ld + 8 * g_;
-            q[j][0] = sp_gld128_raw(qrow);
-            q[j][1] = sp_gld128_raw(qrow + 32);
-        }
-        qc[0][0] = sp_gld128_raw(bs + 8 * g_);                           // the CLS query of the clip and head (row 0 of the clip), replicated
-        qc[0][1] = sp_gld128_raw(bs + 8 * g_ + 32);
-    };
-    auto touch_q = [&]() {
-        asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[2][0]), "+v"(q[2][1]), "+v"(q[3][0]), "+v"(q[3][1]));
-        asm volatile("" : "+v"(qc[0][0]), "+v"(qc[0][1]));
-    };
-    load_q(base, q_ptr, lane);
-    spacepp_stage_seg<NWV, 0, SEG>(ks_u, vs_u, base, q_ptr, ld, ws, n, lane, wave);
-    spacepp_stage_seg<NWV, SEG, SEG>(ks_u, vs_u, base, q_ptr, ld, ws, n, lane, wave);
-    spacepp_stage_seg<NWV, 2 * SEG, SEG>(ks_u, vs_u, base, q_ptr, ld, ws, n, lane, wave);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    touch_q();
-    __builtin_amdgcn_s_barrier();
-
-#define SPP_CHUNK(CI, FIRST_) do { const unsigned off_ = (unsigned)(CI) * 4096u;                                                    \
-        spacep_chunk<JB, 2, false, FIRST_>(kb0 + off_, kb1 + off_, vb0 + off_, vb1 + off_, vb2 + off_, vb3 + off_, q, lane, o, ol, m_ref); } while (0)
-#define SPP_CLS(CI, FIRST_) do { const unsigned off_ = (unsigned)(CI) * 4096u;                                                      \
-        spacep_chunk<1, 2, false, FIRST_>(kb0 + off_, kb1 + off_, vb0 + off_, vb1 + off_, vb2 + off_, vb3 + off_, qc, lane, co, col, cm); } while (0)
-    for (int it = 0;; ++it) {
-        const int pn = p + (int)gridDim.x;
-        const bool has_next = pn < nprob;
-        const int nhead = pn % heads, nf = (pn / heads) % T, nb = pn / (heads * T);
-        const bf16_t* nbase = qkv + (int64_t)nb * N * ld + nhead * hs;
-        const bf16_t* nq_ptr = nbase + (int64_t)(1 + nf * n) * ld;
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        f32x4 o[JB][4], ol[JB], co[1][4], col[1];
-        float m_ref[JB], cm[1];
-#pragma unroll
-        for (int j = 0; j < JB; ++j) {
-            ol[j] = z4;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[j][dt] = z4;
-        }
-        col[0] = z4; cm[0] = -INFINITY;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) co[0][dt] = z4;
-        // ---- segment 0 (key rows 0..95): chunks 0..2; the CLS query's partial over it: wave 0
-        SPP_CHUNK(0, true);
-        for (int ci = 1; ci < E0; ++ci) SPP_CHUNK(ci, false);
-        if (wave == 0) SPP_CLS(0, true); else if (wave == 1) SPP_CLS(1, true); else if (wave == 2) SPP_CLS(2, true);                             // (one chunk per wave: a whole segment on one wave put three more
-                                                                         //  chunk latencies in front of the barrier -- 285 vs 251 us)
-        __builtin_amdgcn_s_barrier();                                    // every wave is done with segment 0 of K / V
-        if (has_next) spacepp_stage_seg<NWV, 0, SEG>(ks_u, vs_u, nbase, nq_ptr, ld, ws, n, ln, wave);
-        // ---- segment 1: chunks 3..5; CLS partial: wave 1
-        for (int ci = E0; ci < E1; ++ci) SPP_CHUNK(ci, false);
-        if (wave == 0) SPP_CLS(E0, false); else if (wave == 1) SPP_CLS(E0 + 1, false); else if (wave == 2) SPP_CLS(E0 + 2, false);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" : "+v"(ln));
-        if (has_next) spacepp_stage_seg<NWV, SEG, SEG>(ks_u, vs_u, nbase, nq_ptr, ld, ws, n, ln, wave);
-        // ---- segment 2: chunks 6..7 and the CLS key's tile; CLS partial: wave 2 (the CLS key itself is counted by frame 0 only)
-        for (int ci = E1; ci < NCH; ++ci) SPP_CHUNK(ci, false);
-        {
-            const unsigned off = (unsigned)NCH * 4096u;
-            spacep_chunk<JB, 1, true, false>(kb0 + off, kb1 + off, vb0 + off, vb1 + off, vb2 + off, vb3 + off, q, lane, o, ol, m_ref);
-            if (wave == 0) SPP_CLS(E1, false);
-            else if (wave == 1) SPP_CLS(E1 + 1, false);
-            else if (wave == 2 && f == 0) spacep_chunk<1, 1, true, false>(kb0 + off, kb1 + off, vb0 + off, vb1 + off, vb2 + off, vb3 + off, qc, lane, co, col, cm);
-        }
-        // ---- overflow of a block's (or the CLS partial's) reference maximum -> the whole workgroup takes the slow path
-        bool bad = wave < 3 && !(col[0][0] <= 3.0e38f);
-#pragma unroll
-        for (int j = 0; j < JB; ++j) bad = bad || !(ol[j][0] <= 3.0e38f);
-        if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) flag[it & 1] = 1;
-        {   // this wave's CLS partial record (wave 3: neutral)
-            float* wrec = scratch + wave * CLS_REC;
-            if (c == 0) {
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) *(f32x4*)(wrec + 4 + 16 * g + 4 * dt) = wave < 3 ? co[0][dt] : z4;
-                if (g == 0) { wrec[0] = wave < 3 ? cm[0] : -INFINITY; wrec[1] = wave < 3 ? col[0][0] : 0.f; }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                    // segment 2 is dead; records and flag are visible
-        const bool redo_any = flag[it & 1] != 0;
-        float* rec = cls_partial ? cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC : nullptr;
-        if (!redo_any) {
-            if (has_next) {
-                asm volatile("" : "+v"(ln));
-                spacepp_stage_seg<NWV, 2 * SEG, SEG>(ks_u, vs_u, nbase, nq_ptr, ld, ws, n, ln, wave);
-                load_q(nbase, nq_ptr, ln);                               // (the Q registers are free: no redo)
-            }
-            asm volatile("" : "+v"(ln));
-            const int cs_ = ln & 15, gs_ = ln >> 4;
-#pragma unroll
-            for (int j = 0; j < JB; ++j) {
-                bf16_t* op = out + ((int64_t)b * N + 1 + f * n + (gb + j) * 16 + cs_) * D + head * 64 + 16 * gs_;
-                space_store_block(o[j], ol[j][0], op, cs_, D);
-            }
-            if (rec != nullptr && tid < 64) space16_cls_merge<NWV>(scratch, rec, tid);
-        } else {
-            // slow path: the next problem's segments 0 / 1 are landing on this problem's keys -- drain, re-stage THIS problem, redo with
-            // the resident-tile routines (running maximum), then restart the stream
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            spacepp_stage_seg<NWV, 0, SEG>(ks_u, vs_u, base, q_ptr, ld, ws, n, lane, wave);
-            spacepp_stage_seg<NWV, SEG, SEG>(ks_u, vs_u, base, q_ptr, ld, ws, n, lane, wave);
-            spacepp_stage_seg<NWV, 2 * SEG, SEG>(ks_u, vs_u, base, q_ptr, ld, ws, n, lane, wave);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            // (every block of the problem again, with the running maximum -- the fast path's accumulators are not kept alive for this:
-            // their registers are what the slow path would otherwise spill)
-#pragma unroll
-            for (int j = 0; j < JB; ++j) {
-                bf16_t* op = out + ((int64_t)b * N + 1 + f * n + (gb + j) * 16 + c) * D + head * 64 + 16 * g;
-                f32x4 o2[4] = {z4, z4, z4, z4};
-                float m_run = -INFINITY, l_run = 0.f;
-                const bf16x8 qj[2] = {q[j][0], q[j][1]};
-                for (int t = 0; t + 1 < nt; ++t) space16_chunk<1, false>(Ks, Vs, qj, t, lane, o2, m_run, l_run);
-                space16_chunk<1, true>(Ks, Vs, qj, nt - 1, lane, o2, m_run, l_run);
-                space_store_block(o2, l_run, op, c, D);
-            }
-            __syncthreads();
-            if (rec != nullptr) space16_cls_partial<NWV>(Ks, Vs, scratch, base, rec, n, f == 0, tid, lane, wave);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (has_next) {
-                spacepp_stage_seg<NWV, 0, SEG>(ks_u, vs_u, nbase, nq_ptr, ld, ws, n, lane, wave);
-                spacepp_stage_seg<NWV, SEG, SEG>(ks_u, vs_u, nbase, nq_ptr, ld, ws, n, lane, wave);
-                spacepp_stage_seg<NWV, 2 * SEG, SEG>(ks_u, vs_u, nbase, nq_ptr, ld, ws, n, lane, wave);
-                load_q(nbase, nq_ptr, lane);
-            }
-        }
-        if (!has_next) break;
-        if (tid == 0) flag[(it + 1) & 1] = 0;                            // (nobody reads or sets the other word before the next problem's last barrier)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the next problem's K / V / Q (issued a segment or more ago) and this one's stores
-        touch_q();
-        __builtin_amdgcn_s_barrier();
-        p = pn; head = nhead; f = nf; b = nb; base = nbase; q_ptr = nq_ptr;
-    }
-#undef SPP_CHUNK
-#undef SPP_CLS
-}
-
 
 // merge G partial records per (clip, head) into out row 0:  o = sum_g o_g e^{m_g - m} / sum_g l_g e^{m_g - m}
 __global__ __launch_bounds__(64) void cls_combine_kernel(const float* __restrict__ partial, int G, bf16_t* __restrict__ out,
@@ -1204,26 +992,6 @@ extern "C" int hh_space_attn_fwd(const void* qkv, int qkv_layout, void* out, flo
             hh_prof_note_kernel(HH_PROF_SPACE_ATTN, "space_attnp_kernel<3, 12, 3, 36, 12, 24, 24, 16>");
             hipLaunchKernelGGL(kp, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * 12), lds16, (hipStream_t)stream,
                                (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, heads, qkv_layout);
-            return hh_check_launch("hh_space_attn_fwd");
-        }
-        if (!dbg && nqb == 16 && (want == 4 || want == 0) && hh_tuning_space_prog() == 3) {
-            // n = 256: persistent workgroups, the next problem's K / V / Q stream in behind the current one (space_attnpp_kernel)
-            typedef void (*kernpp_t)(const bf16_t*, bf16_t*, float*, int, int, int, int, int);
-            const kernpp_t kpp = (kernpp_t)space_attnpp_kernel<4, 4>;
-            static size_t attrpp = 0;
-            if (lds16 > attrpp) {
-                hipError_t e = hipFuncSetAttribute((const void*)kpp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
-                HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds16);
-                attrpp = lds16;
-            }
-            const int64_t nprob = (int64_t)B * T * heads;
-            int ncu = 0, dev = 0;
-            hipGetDevice(&dev);
-            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-            const int64_t grid = nprob < 2 * (int64_t)ncu ? nprob : 2 * (int64_t)ncu;          // two workgroups per CU (LDS)
-            hh_prof_note_kernel(HH_PROF_SPACE_ATTN, "space_attnpp_kernel<4, 4>");
-            hipLaunchKernelGGL(kpp, dim3((unsigned)grid), dim3(64 * 4), lds16, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, heads,
-                               qkv_layout, (int)nprob);
             return hh_check_launch("hh_space_attn_fwd");
         }
         if (!dbg && nqb == 16 && (want == 4 || want == 0) && hh_tuning_space_prog() == 2) {

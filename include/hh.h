@@ -58,8 +58,8 @@ int hh_version(void);
  *                   0 = always the 16-query-block kernel;  "space_waves" waves per workgroup of the joint kernel: 0 (default) = automatic (12 waves x
  *                   3 blocks when K / V fill the LDS, i.e. one workgroup per CU, and n / 16 divides by 36 -- config 4's n = 576 --, else 4), 4 / 12 =
  *                   force where the shape divides;  "space_prog" 1 (default) = K / V staged progressively (compute starts on the first key
- *                   segment while the rest is in flight) where a specialised kernel exists: n = 576; 0 = off; 2 = also n = 256 (experiment); 3 = n = 256 on
- *                   the persistent cross-problem-prefetch kernel (space_attnpp_kernel; slower, kept as a recorded experiment);
+ *                   segment while the rest is in flight) where a specialised kernel exists: n = 576; 0 = off; 2 = also n = 256 (experiment: within
+ *                   +-0.1 % at step level).  (Round 4's persistent cross-problem-prefetch variant, value 3, was slower and is removed: DESIGN.md 4.2);
  *                   "space_debug" 0 / 1 / 2: full kernel / memory traffic only / no staging
  *   "gemm256_debug_ts", "gemm256_debug_nostore": diagnostics (timeline recording; skip the epilogue stores) */
 int hh_set_tuning(const char* name, int value);

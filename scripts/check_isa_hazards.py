@@ -2,7 +2,8 @@
 (v_readlane_b32 = the reload of a spilled SGPR, v_readfirstlane_b32) and read as the ADDRESS of a vector-memory instruction that sits
 inside an inline-asm statement less than 5 instructions later (gfx9: VALU writes SGPR -> VMEM reads that SGPR needs 5 wait states; the
 compiler's hazard recogniser pads its own instructions but does not parse inline asm).  Round 4: the persistent GEMM's tile-counter
-atomic read a stale pointer this way once SGPR pressure made the compiler spill it (memory access fault).
+atomic read a stale pointer this way once SGPR pressure made the compiler spill it (memory access fault).  Also checked: (2) compiler
+traffic into asm-owned accumulator registers, (3) destinations of asm-issued loads touched before a vmcnt wait (see scan()).
 
     python scripts/check_isa_hazards.py [file.hip ...]        (default: every csrc/*.hip that contains inline-asm VMEM with an "s" operand)
 Exit code 1 and a listing if a hazard is found."""
@@ -57,6 +58,26 @@ def scan(path):
         if "gemm256w4p_kernel" in func and not in_asm:
             if re.match(r"v_accvgpr_write_b32 a\d+, v\d+", t) or re.match(r"(global|buffer|ds)_(load|read)\S* a\[", t) or re.match(r"v_accvgpr_mov", t):
                 bad.append((func, ln, t, ln, "compiler-generated write into the asm-owned accumulator registers (VGPR spill to AGPR)", 0))
+    # (3) a vector load issued by INLINE ASM (opaque to the compiler: it believes the destination is valid when the statement "returns")
+    # whose destination registers are read, written or copied by any instruction before the next s_waitcnt that names vmcnt: the register
+    # allocator is free to move such a value, and a copy taken before the load has landed is garbage (round 5: whole waves of wrong space
+    # attention outputs, timing-dependent -- the Q fragments, loaded long before the wait that makes them valid)
+    for k, (ln, t, in_asm, func) in enumerate(insts):
+        m = in_asm and re.match(r"global_load_dword(x\d)? (v\[(\d+):(\d+)\]|v(\d+)),", t)
+        if not m:
+            continue
+        lo, hi = (int(m.group(3)), int(m.group(4))) if m.group(3) else (int(m.group(5)), int(m.group(5)))
+        for ln2, t2, in_asm2, func2 in insts[k + 1:k + 1 + 2000]:
+            # (a linear walk of the fall-through path: it ends at the wait, at an unconditional branch or at the end of the function)
+            if func2 != func or (t2.startswith("s_waitcnt") and "vmcnt" in t2) or t2.startswith(("s_branch", "s_endpgm", "s_setpc")):
+                break
+            regs = set()
+            for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", t2):
+                regs.update(range(int(a), int(b) + 1))
+            regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", t2))
+            if any(lo <= r <= hi for r in regs):
+                bad.append((func, ln, t, ln2, t2 + "   <- touches the destination of an asm load that no vmcnt wait has made valid", 0))
+                break
     for k, (ln, t, _, func) in enumerate(insts):
         m = re.match(r"v_(readlane|readfirstlane)_b32 (s\d+)", t)
         if not m:
@@ -76,7 +97,7 @@ def scan(path):
 
 
 def main(argv):
-    files = argv or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and re.search(r'asm volatile\([^;]*(global_|buffer_)[^;]*"s"\(', open(os.path.join(CSRC, f)).read(), re.S)]
+    files = argv or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and re.search(r'asm volatile\([^;]*(global_|buffer_)[^;]*"(s|=v)"\(', open(os.path.join(CSRC, f)).read(), re.S)]
     total = 0
     for f in files:
         bad = scan(device_asm(f))

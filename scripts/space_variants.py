@@ -1,5 +1,5 @@
 """Space attention at the headline shape (B = 32, T = 16, n = 256, 16 heads, head-major planes), one variant per process argument:
-1 = joint-block kernel (default), 2 = progressive staging (3 segments), 3 = persistent workgroups with cross-problem prefetch.
+1 = joint-block kernel (default), 2 = progressive staging (3 segments)  (3 = round 4's persistent variant: removed in round 5).
 Runs 12 calls; meant to sit under `rocprofv3 --pmc ... --kernel-trace` for the per-variant SQ / traffic counters."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

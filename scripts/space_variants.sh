@@ -22,7 +22,7 @@ def t(reps=20):
     for _ in range(reps): ops.divided_attention(planes, B, T, n, heads, "space")
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for prog in (1, 3, 1, 3, 2):
+for prog in (1, 2, 1, 2):
     ops.set_tuning("space_prog", prog)
     print("space_prog=%d: %.1f us per call (space kernel + cls_combine, back to back)" % (prog, t()))
 PY

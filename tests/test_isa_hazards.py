@@ -1,7 +1,8 @@
 """Static check of the compiled kernels for a hazard the compiler cannot see (CPU test: hipcc cross-compiles gfx950 assembly here):
 an SGPR reloaded by a VALU instruction (v_readlane_b32: a spilled pointer) and used as the address of a vector-memory instruction INSIDE
 an inline-asm statement fewer than 5 wait states later.  Found in round 4 as a memory access fault of the persistent GEMM's tile-counter
-atomic; scripts/check_isa_hazards.py scans every file whose inline asm issues VMEM with a scalar address."""
+atomic; scripts/check_isa_hazards.py scans every file whose inline asm issues VMEM with a scalar address or loads into VGPRs (round 5: a
+fragment loaded by inline asm and copied / spilled by the compiler before the wait that makes it valid)."""
 import os
 import shutil
 import subprocess
@@ -19,3 +20,6 @@ def test_no_sgpr_reload_to_inline_asm_vmem_hazard():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_isa_hazards.py")], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "gemm256w4.hip: 0 hazard(s)" in r.stdout, r.stdout
+    # round 5: destinations of asm-issued vector loads (the Q fragments of the progressive space-attention kernel) are not touched -- copied,
+    # spilled, overwritten -- before a vmcnt wait has made them valid
+    assert "attn_space.hip: 0 hazard(s)" in r.stdout and "mattn.hip: 0 hazard(s)" in r.stdout, r.stdout

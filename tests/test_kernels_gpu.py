@@ -1213,60 +1213,6 @@ def test_text_flags_vs_torch():
     assert torch.equal(pad.cpu(), ((text != 0).sum(-1) != 2).float())
 
 
-@pytest.mark.parametrize("B,T,heads", [(1, 2, 2), (3, 6, 16), (32, 16, 16), (2, 1, 1)])
-def test_space_attention_persistent_kernel_n256(B, T, heads):
-    """space_attnpp_kernel (hh_set_tuning("space_prog", 3); n = 256): persistent workgroups whose next problem streams in behind the
-    current one.  Patch rows bit-identical to the joint-block kernel (same chunk arithmetic); the CLS rows -- whose partial is now taken
-    segment by segment by waves 0..2 instead of tile-interleaved over 4 waves -- to fp32 re-association; all vs the fp32 reference.
-    The grids cover 1 problem per workgroup (4, 2), several with a ragged last round (288 over ... workgroups) and the headline 8192."""
-    n = 256
-    N, D = 1 + T * n, heads * 64
-    qkv = rnd(B * N, 3 * D, seed=B + T)
-    qkv[:, :D] *= 0.6 * ops.LOG2E
-    qkv = bf(qkv).to(DEV)
-    base = ops.divided_attention(qkv, B, T, n, heads, "space")
-    try:
-        ops.set_tuning("space_prog", 3)
-        pp = ops.divided_attention(qkv, B, T, n, heads, "space")
-        pp2 = ops.divided_attention(qkv, B, T, n, heads, "space")
-        planes = qkv.view(B * N, 3 * heads, 64).transpose(0, 1).contiguous()
-        pp_planes = ops.divided_attention(planes, B, T, n, heads, "space")
-    finally:
-        ops.set_tuning("space_prog", 1)
-    assert torch.equal(pp, pp2) and torch.equal(pp, pp_planes)                       # run-to-run and across qkv layouts
-    a, b = pp.view(B, N, D), base.view(B, N, D)
-    assert torch.equal(a[:, 1:], b[:, 1:])                                           # patch rows: the same bits
-    assert_close_bf16(a[:, 0], b[:, 0], 8e-3, "CLS rows, persistent vs joint kernel")
-    if B * T * heads <= 512:
-        assert_close_bf16(pp, _ref_divided(qkv.cpu(), B, T, n, heads, "space"), 1.2e-2, "attn-space-persistent")
-
-
-def test_space_attention_persistent_kernel_slow_path():
-    """A score 2^127 above a block's reference maximum sends the whole (clip, frame, head) problem of the persistent kernel down its slow
-    path (re-stage the problem's keys over the next problem's prefetched ones, running-maximum redo, restart the stream): the problems
-    before and after it in the same workgroup's walk must be untouched."""
-    B, T, n, heads = 40, 16, 256, 1                                                 # 640 problems over 512 workgroups: 128 of them walk two
-    N, D = 1 + T * n, heads * 64
-    qkv = rnd(B * N, 3 * D, seed=5)
-    qkv[:, :D] *= 0.3
-    for b_, f_ in ((0, 3), (1, 0), (33, 5)):                                        # problems in the first and in the second round
-        r0 = b_ * N + 1 + f_ * n
-        q0 = qkv[r0 + 40, :64].clone()
-        qkv[r0 + 200, D:D + 64] = q0 * (160.0 / float(q0 @ q0))                     # key 200: logit ~ +160 for query 40
-    qkv[:, :D] *= ops.LOG2E
-    qkv = bf(qkv)
-    try:
-        ops.set_tuning("space_prog", 3)
-        out = ops.divided_attention(qkv.to(DEV), B, T, n, heads, "space")
-    finally:
-        ops.set_tuning("space_prog", 1)
-    ref = _ref_divided(qkv, B, T, n, heads, "space")
-    assert torch.isfinite(out.float()).all()
-    assert_close_bf16(out, ref, 1.2e-2, "attn-space-persistent-redo")
-    err = (out.float().cpu() - ref).abs().amax(1)
-    assert (err / (ref.abs().amax(1) + 1e-3)).max() < 5e-2
-
-
 def test_round4_entry_points_accept_empty_inputs():
     """M = 0 / no captions: the LayerNorm-fold GEMMs, hh_ln_rowstats and hh_text_flags return empty results instead of failing on the
     null data pointer of an empty tensor."""
