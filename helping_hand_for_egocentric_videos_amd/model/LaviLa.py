@@ -428,9 +428,8 @@ class CLIP(nn.Module):
                                       "no stock-op fallback -- call under torch.no_grad() or freeze the parameters")
         with torch.no_grad(), ops.prof_role(ops.PROF_ROLE_TEXT):
             x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]
-            x = self.transformer.forward_frozen(x)
-            x = ops.layernorm(x, self.ln_final.weight.detach().float(), self.ln_final.bias.detach().float(), self.ln_final.eps,
-                              out_dtype=torch.float32)
+            x = self.transformer.forward_frozen(x, final_ln=(self.ln_final.weight.detach().float(), self.ln_final.bias.detach().float(),
+                                                             self.ln_final.eps), owns_x=True)
         if not want_cls and not apply_project:          # (the training step gathers the EOT rows itself, run/train.py:124: four launches saved)
             return None, x
         x_cls = x[torch.arange(x.shape[0], device=x.device), text.float().argmax(dim=-1)]      # (ids < 2^24: exact; the int64 ArgMax reduce is 20x slower)

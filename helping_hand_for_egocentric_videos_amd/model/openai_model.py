@@ -71,9 +71,11 @@ class Transformer(nn.Module):
         return self._pack
 
     @torch.no_grad()
-    def forward_frozen(self, x: torch.Tensor):
+    def forward_frozen(self, x: torch.Tensor, final_ln=None, owns_x=False):
         """Inference path for frozen weights on the GPU: x fp32 [S, L, W] (batch-first) -> fp32 [S, L, W].
-        Same maths as forward() (pre-LN causal MHA + QuickGELU MLP), bf16 GEMM operands, fp32 residual stream."""
+        Same maths as forward() (pre-LN causal MHA + QuickGELU MLP), bf16 GEMM operands, fp32 residual stream.
+        final_ln = (weight, bias, eps): also apply that LayerNorm (CLIP.ln_final) -- fused with the last block's residual add, so the
+        stream's last update and the normalisation are one pass; owns_x: x is a temporary of the caller and may be updated in place."""
         from .. import ops
         S, L, W = x.shape
         h, d = self.heads, W // self.heads
@@ -82,7 +84,9 @@ class Transformer(nn.Module):
         if d != 64 or L > 80:
             raise NotImplementedError("Transformer.forward_frozen: the causal attention core (hh_text_attn_fwd) takes head dim 64 and context <= 80 "
                                       "(CLIP's 12 x 64, 77); there is no stock-op fallback")
-        xs = x.reshape(S * L, W).float().contiguous().clone()
+        xs = x.reshape(S * L, W).float().contiguous()
+        if xs.data_ptr() == x.data_ptr() and not owns_x:      # the residual stream is updated in place: never the caller's own tensor
+            xs = xs.clone()
         pending = None                        # bf16 branch output not yet added to the fp32 residual stream (as in SpaceTimeBlock.fused)
         for pk in self.packed():
             xn = ops.layernorm(xs, *pk["ln1"]) if pending is None else ops.add_layernorm(xs, pending, *pk["ln1"], write_x=True)
@@ -91,6 +95,11 @@ class Transformer(nn.Module):
             a = ops.gemm(o, pk["wout"], pk["bout"])                                                        # bf16 branch
             hid = ops.gemm(ops.add_layernorm(xs, a, *pk["ln2"], write_x=True), pk["wfc"], pk["bfc"], act=ops.ACT_QUICKGELU)
             pending = ops.gemm(hid, pk["wpr"], pk["bpr"])
+        if final_ln is not None:
+            g, b, eps = final_ln
+            y = ops.layernorm(xs, g, b, eps, out_dtype=torch.float32) if pending is None else \
+                ops.add_layernorm(xs, pending, g, b, eps, write_x=False, out_dtype=torch.float32)
+            return y.view(S, L, W)
         if pending is not None:
             xs += pending.float()
         return xs.view(S, L, W)

@@ -33,7 +33,7 @@ class _LinearX3(torch.autograd.Function):
     is the bias gradient.  x [..., K] fp32, w [N, K] (a row-strided view is fine), b [N] or None."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, sink_ok=False):
         K = x.shape[-1]
         x2 = x.detach().reshape(-1, K)
         if x2.dtype != torch.float32 or x2.stride(-1) != 1 or x2.stride(0) % 4:
@@ -53,6 +53,9 @@ class _LinearX3(torch.autograd.Function):
         y = ops.qgemm(x2, wd, ops.NT, bias=bd, relu=relu)
         ctx.save_for_backward(x2, wd, y if relu else None)
         ctx.has_bias, ctx.relu, ctx.xshape, ctx.N, ctx.K = b is not None, relu, x.shape, N, K
+        # the Parameters themselves: their gradient sinks (parallel._GradSink) -- only where the caller vouches that this node is the
+        # parameters' ONLY consumer in a step (sink_ok: the _GradSink precondition; txt_proj, e.g., runs twice per step)
+        ctx.param_objs = (w, b) if sink_ok else (None, None)
         return (y if Np == N else y[:, :N]).reshape(*x.shape[:-1], N)
 
     @staticmethod
@@ -63,7 +66,7 @@ class _LinearX3(torch.autograd.Function):
         if N != ctx.N:
             dz = torch.nn.functional.pad(dz, (0, N - ctx.N))
         if ctx.relu:
-            dz = dz * (y > 0)
+            dz = torch.ops.aten.threshold_backward(dz.float(), y, 0.0)       # dz * (y > 0) in one launch
         dz = dz.float().contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -72,30 +75,49 @@ class _LinearX3(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             rows, K = x2.shape
             tiles = ((N + 63) // 64) * ((K + 63) // 64)
-            if rows >= 2048 and tiles < 256:          # long contraction, few output tiles (box heads: 6656 rows): split-K, atomic accumulate
+            split = max(2, min(32, rows // 256, 512 // tiles)) if rows >= 2048 and tiles < 256 else 1    # long contraction, few output tiles (box heads: 6656 rows): split-K, atomic accumulate
+            # Gradient sinks (parallel._GradSink): inside a TrainStep a weight / bias that is an nn.Parameter with exactly this one consumer
+            # owns a zeroed slice of the flat gradient arena -- the weight-gradient GEMM (and its bias by-product) write there, no zero
+            # fill, no AccumulateGrad add per parameter.  Views of a parameter (frame_proj's column halves) have no sink and go through autograd.
+            sw, sb = (getattr(t, "_hh_sink", None) for t in ctx.param_objs)
+            sunk = (sw is not None and sw.armed() and ctx.needs_input_grad[1] and (N, K) == (ctx.N, ctx.K) and sw.view.shape == (N, K)
+                    and sw.view.data_ptr() % 16 == 0
+                    and (not ctx.has_bias or (sb is not None and sb.armed() and ctx.needs_input_grad[2] and sb.view.data_ptr() % 16 == 0)))
+            if sunk:
+                sw.claim()
+                if ctx.has_bias:
+                    sb.claim()
+                ops.qgemm(dz, x2, ops.TN, colsum=sb.view if ctx.has_bias else None, out=sw.view, splitk=split)
+                sw.done()
+                if ctx.has_bias:
+                    sb.done()
+                return dx, None, None, None, None
+            if split > 1:
                 buf = torch.zeros(N * K + N, dtype=torch.float32, device=dz.device)
                 dw, db = buf[:N * K].view(N, K), (buf[N * K:] if ctx.has_bias else None)
-                ops.qgemm(dz, x2, ops.TN, colsum=db, out=dw, splitk=max(2, min(32, rows // 256, 512 // tiles)))
+                ops.qgemm(dz, x2, ops.TN, colsum=db, out=dw, splitk=split)
             else:
                 db = torch.empty(N, dtype=torch.float32, device=dz.device) if ctx.has_bias else None
                 dw = ops.qgemm(dz, x2, ops.TN, colsum=db)
             if dw.shape != (ctx.N, ctx.K):
                 dw = dw[:ctx.N, :ctx.K]
                 db = None if db is None else db[:ctx.N]
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear_x3(x, w, b=None, relu=False):
-    return _LinearX3.apply(x, w, b, relu)
+def linear_x3(x, w, b=None, relu=False, sink_ok=False):
+    return _LinearX3.apply(x, w, b, relu, sink_ok)
 
 
 class LinearX3(nn.Linear):
-    """nn.Linear (same parameters / state_dict keys) whose GPU forward and backward run on hh_qgemm_f32x3."""
+    """nn.Linear (same parameters / state_dict keys) whose GPU forward and backward run on hh_qgemm_f32x3.
+    `single_use = True` (set by the owner, e.g. ObjDecoder for its box / object heads): the module is applied ONCE per training step, so
+    its weight gradients may be written straight into the flat gradient arena (parallel._GradSink)."""
 
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("LinearX3: the product path runs on libhh HIP kernels only (got a %s tensor)" % x.device)
-        return _LinearX3.apply(x, self.weight, self.bias, False)
+        return _LinearX3.apply(x, self.weight, self.bias, False, getattr(self, "single_use", False))
 
 
 # parameters of one TransformerDecoderLayer in the order QueryStack receives them
@@ -163,6 +185,7 @@ class QueryStack(torch.autograd.Function):
         ctx.holder, ctx.dims, ctx.eps, ctx.p = holder, (L, B, Q, C, heads), eps, p
         ctx.P, ctx.saved, ctx.tgt_all, ctx.dec = P, saved, tgt_all, (f(dnw), dmean, drstd)
         ctx.param_objs = (dnw, dnb) + tuple(params)             # the Parameters themselves: their gradient sinks (parallel._GradSink), if any
+        ctx.query_obj = query_embed
         return hs.view(L, B, Q, C)
 
     @staticmethod
@@ -263,7 +286,17 @@ class QueryStack(torch.autograd.Function):
             if not sunk:
                 grads[l * NP:(l + 1) * NP] = [lnbuf[l * 3, 0], lnbuf[l * 3, 1], dwi_s, dbi_s, dwo_s, dbo_s, lnbuf[l * 3 + 1, 0], lnbuf[l * 3 + 1, 1],
                                               d_wi_c[l], d_bi_c[l], dwo_c, dbo_c, lnbuf[l * 3 + 2, 0], lnbuf[l * 3 + 2, 1], dw1, db1, dw2, db2]
-        dquery = torch.stack(dqpos_parts).sum(0).view(B, Q, C).sum(0)
+        # d query_embed = sum over layers (two uses each) and clips: ONE reduction, written into the parameter's arena slice when it has an
+        # armed sink (query_embed.weight enters only this node)
+        qsink = getattr(ctx.query_obj, "_hh_sink", None)
+        parts = torch.stack(dqpos_parts).view(-1, Q, C)
+        if sunk and qsink is not None and qsink.armed() and qsink.view.shape == (Q, C):
+            qsink.claim()
+            torch.sum(parts, dim=0, out=qsink.view)
+            qsink.done()
+            dquery = None
+        else:
+            dquery = parts.sum(0)
         ctx.saved = ctx.tgt_all = None
         if sunk:
             # everything is in the arena: report the parameters final (bucket all-reduces may start), except the cross-attention

@@ -277,6 +277,69 @@ def _draw_seed():
     return int(torch.randint(0, 0x7FFFFFFF, (1,)).item())
 
 
+class _PosEmbed3D(torch.autograd.Function):
+    """construct_3d_pos_embed (tfm_decoder.py:138-143) as ONE node: pos[t * n + i] = pos_embed[0, 1 + i] + temporal_embed[0, t] -- one
+    broadcast add forward; backward = two reductions written straight into the parameters' slices of the gradient arena
+    (parallel._GradSink; the CLS row of pos_embed and the frames behind T get no gradient: their arena rows stay zero).  The stock-op
+    chain it replaces (repeat, repeat_interleave, add; RepeatBackward / ExpandBackward sums, slice fills and copies, two
+    AccumulateGrad adds) was 9 launches per step."""
+
+    @staticmethod
+    def forward(ctx, pos_embed, temporal_embed, T):
+        n, C = pos_embed.shape[1] - 1, pos_embed.shape[2]
+        ctx.param_objs, ctx.dims = (pos_embed, temporal_embed), (T, n, C)
+        return (pos_embed.detach()[0, 1:].unsqueeze(0) + temporal_embed.detach()[0, :T].unsqueeze(1)).view(T * n, C)
+
+    @staticmethod
+    def backward(ctx, d):
+        T, n, C = ctx.dims
+        d3 = d.reshape(T, n, C)
+        pe, te = ctx.param_objs
+        sinks = [getattr(t, "_hh_sink", None) for t in ctx.param_objs]
+        if all(s is not None and s.armed() for s in sinks):
+            for s_ in sinks:
+                s_.claim()
+            torch.sum(d3, dim=0, out=sinks[0].view[0, 1:])
+            torch.sum(d3, dim=1, out=sinks[1].view[0, :T])
+            for s_ in sinks:
+                s_.done()
+            return None, None, None
+        dpe, dte = torch.zeros_like(pe), torch.zeros_like(te)
+        torch.sum(d3, dim=0, out=dpe[0, 1:])
+        torch.sum(d3, dim=1, out=dte[0, :T])
+        return dpe, dte, None
+
+
+class _SplitCols(torch.autograd.Function):
+    """w [N, 2C] -> (w[:, :C], w[:, C:]) for the decomposed frame conditioning (ObjDecoder.forward); backward writes the two column
+    halves' gradients into the parameter's slice of the gradient arena (two copies instead of SliceBackward's zero-fill + copy per
+    half, their sum and the AccumulateGrad add)."""
+
+    @staticmethod
+    def forward(ctx, w, C):
+        ctx.param_objs, ctx.C = (w,), C
+        wd = w.detach()
+        return wd[:, :C], wd[:, C:]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        C = ctx.C
+        (w,) = ctx.param_objs
+        sink = getattr(w, "_hh_sink", None)
+        if sink is not None and sink.armed() and g1 is not None and g2 is not None:
+            sink.claim()
+            sink.view[:, :C].copy_(g1)
+            sink.view[:, C:].copy_(g2)
+            sink.done()
+            return None, None
+        dw = torch.zeros_like(w)
+        if g1 is not None:
+            dw[:, :C] = g1
+        if g2 is not None:
+            dw[:, C:] = g2
+        return dw, None
+
+
 class MLP(nn.Module):
     """Simple multi-layer perceptron (tfm_decoder.py:96-108)."""
 
@@ -288,7 +351,8 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = linear_x3(x, layer.weight, layer.bias, relu=i < self.num_layers - 1)             # ReLU in the GEMM epilogue
+            x = linear_x3(x, layer.weight, layer.bias, relu=i < self.num_layers - 1,             # ReLU in the GEMM epilogue
+                          sink_ok=getattr(self, "single_use", False))
         return x
 
 
@@ -522,6 +586,7 @@ class ObjDecoder(nn.Module):
         self.hidden_dim = hidden_dim
         self.class_embed = LinearX3(hidden_dim, num_classes + 1)
         self.bbox_embed = MLP(hidden_dim, hidden_dim, 4, 3)
+        self.bbox_embed.single_use = True             # applied once per step (forward below): weight gradients go straight into the arena
         self.query_embed = nn.Embedding(num_queries, hidden_dim)
         self.pred_traj = pred_traj
         self.n_decode = 1
@@ -553,20 +618,23 @@ class ObjDecoder(nn.Module):
 
     def init_obj_model(self):
         self.obj_proj = nn.Sequential(LinearX3(self.hidden_dim, self.hidden_dim), nn.ReLU(), LinearX3(self.hidden_dim, 256))
+        for m in self.obj_proj:
+            if isinstance(m, LinearX3):
+                m.single_use = True                   # step.py applies obj_proj once per step; txt_proj runs twice (captions, nouns): no sinks
 
     def forward(self, features, use_checkpoint=False):
         _require_gpu(features, "ObjDecoder")
         B, T, n, Fd = features.shape
         C = self.hidden_dim
         feat_b = ops.to_bf16(features.detach().reshape(B * T * n, Fd).contiguous())
-        pos = self.construct_3d_pos_embed(T).view(T * n, C)
+        pos = _PosEmbed3D.apply(self.pos_embed, self.temporal_embed, T)          # == construct_3d_pos_embed(T).view(T * n, C)
         hs = self.transformer.forward_tokens(feat_b, self.proj.weight, pos, self.query_embed.weight, B)     # [L,B,Q,C]
         L, _, Q, _ = hs.shape
         full = self.materialize_logits
         if self.pred_traj and T == self.num_frames:
-            w = self.frame_proj.weight
-            base = linear_x3(hs if full else hs[-1:], w[:, :C])                                              # [l,B,Q,C]
-            fr = linear_x3(self.frame_index.weight[:T], w[:, C:], self.frame_proj.bias)                     # [T,C]
+            w_hs, w_fr = _SplitCols.apply(self.frame_proj.weight, C)
+            base = linear_x3(hs if full else hs[-1:], w_hs)                                                  # [l,B,Q,C]
+            fr = linear_x3(self.frame_index.weight[:T], w_fr, self.frame_proj.bias)                         # [T,C]
             cond = (base[:, :, None] + fr[None, None, :, None, :]).flatten(1, 2)                             # [l,B*T,Q,C]
         else:
             cond = hs if full else hs[-1:]

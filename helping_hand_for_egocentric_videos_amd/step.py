@@ -167,7 +167,9 @@ class TrainStep:
         cnt2 = torch.empty((2, hand.shape[0]), dtype=torch.int32, device=hand.device)      # both box types' per-frame target counts
         mh = matcher.match_raw(det["pred_boxes"], 0, 2, hand, count_out=cnt2[0])
         mo = matcher.match_raw(det["pred_boxes"], 2, nq - 2, objb, count_out=cnt2[1])
-        counts = torch.cat([cnt2.sum(1), (batch["nouns"] != 0).sum().reshape(1)]).float()
+        counts = torch.empty(3, dtype=torch.float32, device=hand.device)          # (three launches instead of sum / ne / sum / cat / cast)
+        torch.sum(cnt2, dim=1, dtype=torch.float32, out=counts[:2])
+        torch.sum(batch["nouns"] != 0, dim=tuple(range(batch["nouns"].dim())), dtype=torch.float32, out=counts[2])
         ve, te, pf, vv, nv, sums = gather_contrastive(video_embeds, text_embeds, pad_flag, batch["verb_vec"], noun_vec,
                                                       force=self.force_comm, counts=counts)
         norm = normaliser(sums)                                                     # clamp(global / W, 1) x 3
@@ -189,7 +191,7 @@ class TrainStep:
                                                     match=mo, return_loss_dict=True)
         noun_embeds = self.decoder.txt_proj(batch["all_nouns"])
         word = self.word(noun_embeds, obj[:, :-1], batch["nouns"], count=sums[2] / W if W > 1 else None)
-        total = nce + lh + lo + 0.5 * word                                          # run/train.py:149,183,191
+        total = torch.add(nce + lh + lo, word, alpha=0.5)                           # nce + lh + lo + 0.5 * word, run/train.py:149,183,191
         return {"total_loss": total, "nce_loss": nce.detach(), "box_loss_hand": lh.detach(), "box_loss_obj": lo.detach(),
                 "word_loss": word.detach(), "acc_vt": acc_vt, "acc_tv": acc_tv, "match_hand": mh, "match_obj": mo,
                 "pred_boxes": det["pred_boxes"], "hs": hs,

@@ -15,7 +15,8 @@ batch = {k: v.to(dev) for k, v in synth.make_batch(cfg, B, seed=1).items()}
 ts = TrainStep(cfg, bb, dec)
 for _ in range(3): ts.step(batch)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     ts.step(batch); torch.cuda.synchronize()
 ev = prof.events()
 kern = [e for e in ev if e.device_type == torch.autograd.DeviceType.CUDA]
@@ -31,8 +32,16 @@ for e in cpu:
     n = sum(1 for k in e.kernels if not any(o in k.name for o in ours))
     if not n or any(c.kernels for c in e.cpu_children):
         continue
-    where = next((s for s in (e.stack or []) if REPO in s and "scripts/" not in s), "autograd engine / no python frame")
-    where = where.replace(REPO + "/", "").split(": ")[0] if ": " in where else where.replace(REPO + "/", "")
+    # python stacks are not recorded for ops issued by the autograd engine: name the autograd node (or "forward") from the CPU parent chain
+    where, par = "forward", e.cpu_parent
+    while par is not None:
+        if par.name.startswith("autograd::engine::evaluate_function: "):
+            where = par.name.split(": ", 1)[1]
+            break
+        par = par.cpu_parent
+    py = next((s for s in (e.stack or []) if REPO in s and "scripts/" not in s), "")
+    if py:
+        where += " @ " + py.replace(REPO + "/", "").split(": ")[0]
     by[(e.name, str(e.input_shapes)[:70], where[:90])] += n
-for (name, shp, where), n in by.most_common(70):
+for (name, shp, where), n in by.most_common(120):
     print("%4d  %-28s %-70s %s" % (n, name, shp, where))
