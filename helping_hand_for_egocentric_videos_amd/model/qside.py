@@ -186,14 +186,22 @@ class QueryStack(torch.autograd.Function):
         ctx.P, ctx.saved, ctx.tgt_all, ctx.dec = P, saved, tgt_all, (f(dnw), dmean, drstd)
         ctx.param_objs = (dnw, dnb) + tuple(params)             # the Parameters themselves: their gradient sinks (parallel._GradSink), if any
         ctx.query_obj = query_embed
-        return hs.view(L, B, Q, C)
+        # Two outputs: all layers' normalised outputs [L,B,Q,C] and -- a separate tensor -- the LAST layer's, which is all the fast path
+        # consumes (heads, obj_proj): its consumers' gradients then arrive as one [B,Q,C] tensor instead of two zero-filled [L,B,Q,C]
+        # SelectBackward / SliceBackward temporaries and their sum, and the decoder.norm backward of the layers nobody read is skipped
+        ctx.set_materialize_grads(False)
+        hs = hs.view(L, B, Q, C)
+        return hs, hs[L - 1].clone()
 
     @staticmethod
-    def backward(ctx, dhs):
+    def backward(ctx, dhs, dlast):
         L, B, Q, C, heads = ctx.dims
         R, p, h = B * Q, ctx.p, ctx.holder
-        dev = dhs.device
-        dhs = dhs.contiguous().view(L, R, C)
+        dev = ctx.tgt_all.device
+        dhs = None if dhs is None else dhs.contiguous().view(L, R, C)
+        dlast = None if dlast is None else dlast.contiguous().view(R, C)
+        if dhs is None and dlast is None:
+            dlast = torch.zeros((R, C), dtype=torch.float32, device=dev)
         dnw, dmean, drstd = ctx.dec
         F_ = ctx.P[0][14].shape[0]
         # Gradient sinks: inside a TrainStep every parameter of this node owns a zeroed slice of the flat gradient arena
@@ -235,7 +243,13 @@ class QueryStack(torch.autograd.Function):
             x, tgt3 = ctx.tgt_all[l], ctx.tgt_all[l + 1]
             # decoder.norm of this layer's output (+ the gradient arriving from layer l + 1)
             sl = slice(l * R, (l + 1) * R)
-            g = ops.layernorm_bwd_add(tgt3, dnw, dmean[sl], drstd[sl], dhs[l], g, dn_w, dn_b, out=g)
+            dy = None if dhs is None else dhs[l]
+            if l == L - 1 and dlast is not None:
+                dy = dlast if dy is None else dy + dlast
+            if dy is not None:
+                g = ops.layernorm_bwd_add(tgt3, dnw, dmean[sl], drstd[sl], dy, g, dn_w, dn_b, out=g)
+            elif g is None:                              # (nobody read the last layer: nothing flows into it)
+                g = torch.zeros((R, C), dtype=torch.float32, device=dev)
             drop = lambda site: dict(a_drop_p=p, a_drop_seed=sd(site), a_drop_ld=C) if p > 0 else {}
             # FFN:  tgt3 = tgt2 + drop3(hid.W2^T + b2),  hid = drop(relu(e.W1^T + b1)),  e = norm3(tgt2)
             db2 = new(l, 17, C)

@@ -189,16 +189,20 @@ class _MemorySideKVFree(torch.autograd.Function):
         else:
             dmem = ops.gemm_tn_batched2(h.pdT, h.dp16, h.dsT, h.qt16).view(B * M, C)                     # d(memory) incl. the key path
             dpos = ops.gemm_tn(h.dsT.view(B * L * 128, M), h.qt16.view(B * L * 128, C))                  # d(pos) = sum over clips of the key path
-        dmem0, dg, db = ops.layernorm_bwd(mem0, g_pre.detach().float(), mean, rstd, dmem)
-        dw_proj = ops.gemm_tn(ops.to_bf16(dmem0), feat_b)                                                  # [C, F]
+        # gradient sinks (parallel._GradSink): the LayerNorm reductions accumulate into, and the projection's split-K partials are summed
+        # into, the parameters' (zeroed) slices of the gradient arena -- no zero fills, no copies, no AccumulateGrad adds
+        sinks = [getattr(t, "_hh_sink", None) for t in ctx.param_objs]
+        sunk = all(s is not None and s.armed() for s in sinks)
+        if sunk:
+            for s_ in sinks:
+                s_.claim()
+        dmem0, dg, db = ops.layernorm_bwd(mem0, g_pre.detach().float(), mean, rstd, dmem, dg=sinks[1].view if sunk else None,
+                                          db=sinks[2].view if sunk else None)
+        dw_proj = ops.gemm_tn(ops.to_bf16(dmem0), feat_b, out=sinks[0].view if sunk else None)             # [C, F]
         if h.keep:
             h.kept = {"mem": h.mem, "mp": h.mp, "dmem": dmem, "dpos": dpos, "relu_masks": h.relu_masks}        # test hook (Cross_Attention.debug_keep_kv)
         h.mem = h.mp = h.pdT = h.dsT = h.qt16 = h.dp16 = None
-        sinks = [getattr(t, "_hh_sink", None) for t in ctx.param_objs]
-        if all(s is not None and s.armed() for s in sinks):
-            for s_ in sinks:
-                s_.claim()
-            torch._foreach_copy_([s_.view for s_ in sinks], [dw_proj, dg, db])
+        if sunk:
             for s_ in sinks:
                 s_.done()
             return (None, None, None, None, dpos, None, None, None)
@@ -308,6 +312,28 @@ class _PosEmbed3D(torch.autograd.Function):
         torch.sum(d3, dim=0, out=dpe[0, 1:])
         torch.sum(d3, dim=1, out=dte[0, :T])
         return dpe, dte, None
+
+
+class _SplitRows(torch.autograd.Function):
+    """y [R, N] -> (y[:n], y[n:]): two row blocks of one GEMM's output (step.py projects captions and nouns through txt_proj in one call);
+    backward = one concatenation instead of two zero-filled SliceBackward temporaries and their sum."""
+
+    @staticmethod
+    def forward(ctx, y, n):
+        ctx.n, ctx.shape = n, y.shape
+        ctx.set_materialize_grads(False)
+        yd = y.detach()
+        return yd[:n], yd[n:]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        n, shape = ctx.n, ctx.shape
+        if g1 is None and g2 is None:
+            return None, None
+        ref = g1 if g1 is not None else g2
+        g1 = ref.new_zeros((n,) + tuple(shape[1:])) if g1 is None else g1
+        g2 = ref.new_zeros((shape[0] - n,) + tuple(shape[1:])) if g2 is None else g2
+        return torch.cat([g1, g2]), None
 
 
 class _SplitCols(torch.autograd.Function):
@@ -546,9 +572,10 @@ class Cross_Attention(nn.Module):
         # the 13-row query side of all six layers + decoder.norm: one autograd node on libhh kernels (model/qside.py)
         p = layers[0].p_attn if self.training else 0.0
         norm = self.decoder.norm
-        hs = QueryStack.apply(query_embed, token, norm.weight, norm.bias, holder, B, self.nhead, norm.eps, p, *stack_params(layers))
+        hs, last = QueryStack.apply(query_embed, token, norm.weight, norm.bias, holder, B, self.nhead, norm.eps, p, *stack_params(layers))
         if not self.decoder.return_intermediate:
-            hs = hs[-1:]
+            hs = last[None]
+        hs._hh_last = last                        # == hs[-1] as a tensor of its own (QueryStack's second output): see ObjDecoder.forward / step.py
         if not torch.is_grad_enabled():
             holder.kv = holder.mem = holder.mp = None
         return hs
@@ -618,9 +645,6 @@ class ObjDecoder(nn.Module):
 
     def init_obj_model(self):
         self.obj_proj = nn.Sequential(LinearX3(self.hidden_dim, self.hidden_dim), nn.ReLU(), LinearX3(self.hidden_dim, 256))
-        for m in self.obj_proj:
-            if isinstance(m, LinearX3):
-                m.single_use = True                   # step.py applies obj_proj once per step; txt_proj runs twice (captions, nouns): no sinks
 
     def forward(self, features, use_checkpoint=False):
         _require_gpu(features, "ObjDecoder")
@@ -631,13 +655,15 @@ class ObjDecoder(nn.Module):
         hs = self.transformer.forward_tokens(feat_b, self.proj.weight, pos, self.query_embed.weight, B)     # [L,B,Q,C]
         L, _, Q, _ = hs.shape
         full = self.materialize_logits
+        last = getattr(hs, "_hh_last", None)                      # the last layer's output as QueryStack's own second output (== hs[-1])
+        last1 = hs[-1:] if last is None else last[None]
         if self.pred_traj and T == self.num_frames:
             w_hs, w_fr = _SplitCols.apply(self.frame_proj.weight, C)
-            base = linear_x3(hs if full else hs[-1:], w_hs)                                                  # [l,B,Q,C]
+            base = linear_x3(hs if full else last1, w_hs)                                                    # [l,B,Q,C]
             fr = linear_x3(self.frame_index.weight[:T], w_fr, self.frame_proj.bias)                         # [T,C]
             cond = (base[:, :, None] + fr[None, None, :, None, :]).flatten(1, 2)                             # [l,B*T,Q,C]
         else:
-            cond = hs if full else hs[-1:]
+            cond = hs if full else last1
             if self.pred_traj and torch.is_grad_enabled():
                 # the trajectory branch is skipped for this clip length (on every rank alike: the shape decides): tell the gradient
                 # buckets now, or frame_index / frame_proj would hold back every all-reduce until the end of backward (parallel.py)
@@ -658,7 +684,7 @@ class ObjDecoder(nn.Module):
                 out['aux_outputs'] = self._set_aux_loss(outputs_class, outputs_coord)
         else:
             with torch.no_grad():
-                am = self.class_embed(hs[-1]).argmax(-1)                                                     # [B,Q]
+                am = self.class_embed(last1[0]).argmax(-1)                                                   # [B,Q]
                 out['pred_logits_argmax'] = am[:, None].expand(-1, T, -1).flatten(0, 1) if expand_t else am
             out['pred_logits'] = None
             out['num_classes'] = self.class_embed.out_features

@@ -118,13 +118,15 @@ def add_layernorm(x, delta, gamma, beta, eps, write_x=True, out_dtype=torch.bflo
     return y
 
 
-def layernorm_bwd(x, gamma, mean, rstd, dy):
-    _chk(x, gamma, mean, rstd, dy)
+def layernorm_bwd(x, gamma, mean, rstd, dy, dg=None, db=None):
+    """-> (dx, dgamma, dbeta).  dg / db: fp32 [cols] buffers the weight / bias gradients are ACCUMULATED into (zero on entry for a plain
+    gradient -- e.g. a parameter's slice of the zeroed gradient arena); fresh zeroed buffers by default."""
+    _chk(x, gamma, mean, rstd, dy, dg, db)
     cols = x.shape[-1]
     rows = x.numel() // cols
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    dg = torch.zeros(cols, dtype=torch.float32, device=x.device)
-    db = torch.zeros(cols, dtype=torch.float32, device=x.device)
+    dg = torch.zeros(cols, dtype=torch.float32, device=x.device) if dg is None else dg
+    db = torch.zeros(cols, dtype=torch.float32, device=x.device) if db is None else db
     L = _lib.lib()
     _lib.check(L.hh_layernorm_bwd(_p(x), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dx), _p(dg), _p(db), rows, cols,
                                   _stream()), "hh_layernorm_bwd")
@@ -436,9 +438,9 @@ def layernorm_split_cls(x, gamma, beta, eps, clips, out_dtype=torch.bfloat16):
     return ycls, ypat
 
 
-def gemm_tn(at, bt, splits=None, colsum=False):
+def gemm_tn(at, bt, splits=None, colsum=False, out=None):
     """Weight-gradient GEMM: at bf16 [K, M], bt bf16 [K, N] (token-major, row-strided views allowed) -> fp32 [M, N] = at^T @ bt.
-    Split-K over the tokens; the partial tiles are summed here.  colsum=True also returns sum_k at[k, :] (fp32 [M]: the bias
+    Split-K over the tokens; the partial tiles are summed here (into `out`, fp32 [M, N], when given).  colsum=True also returns sum_k at[k, :] (fp32 [M]: the bias
     gradient when `at` is dY), accumulated by the same kernel from the A fragments it already holds."""
     for t_ in (at, bt):
         if not t_.is_cuda:
@@ -457,7 +459,13 @@ def gemm_tn(at, bt, splits=None, colsum=False):
     cs = torch.empty((splits, M), dtype=torch.float32, device=at.device) if colsum else None
     _lib.check(_lib.lib().hh_gemm_tn_bf16(_p(at), at.stride(0), _p(bt), bt.stride(0), _p(part), _p(cs), M, N, K, int(splits), _stream()),
                "hh_gemm_tn_bf16")
-    out = part[0] if splits == 1 else part.sum(0)
+    if out is not None:                              # the partial tiles are summed (or the single one copied) into the caller's buffer
+        if splits == 1:
+            out.copy_(part[0])
+        else:
+            torch.sum(part, dim=0, out=out)
+    else:
+        out = part[0] if splits == 1 else part.sum(0)
     if colsum:
         return out, (cs[0] if splits == 1 else cs.sum(0))
     return out

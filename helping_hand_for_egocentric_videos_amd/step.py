@@ -10,7 +10,7 @@ No host synchronisation inside the step: every scalar in the returned dict is a 
 import torch
 
 from . import ops
-from .model import box_utils
+from .model import box_utils, tfm_decoder
 from .model.loss import EgoNCE, WordContrastiveLoss
 from .model.metric import compute_tv_accuracy, sim_matrix
 from .parallel import BucketedAllReduce, FlatArena, gather_contrastive, no_decay, normaliser, world
@@ -39,6 +39,13 @@ class TrainStep:
         self.cfg, self.backbone, self.decoder = cfg, backbone, decoder
         self.criterion = build_criterion().to(next(decoder.parameters()).device)
         self.nce, self.word = EgoNCE(), WordContrastiveLoss()
+        # losses() applies obj_proj and txt_proj exactly once per step: their weight gradients may go straight into the gradient arena
+        # (qside.LinearX3.single_use; the _GradSink precondition)
+        from .model.qside import LinearX3
+        for seq in (decoder.obj_proj, decoder.txt_proj):
+            for m in seq:
+                if isinstance(m, LinearX3):
+                    m.single_use = True
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         decoder.materialize_logits = not fast_heads
         self.arena = FlatArena(decoder, bucket_bytes, late=finishes_last)
@@ -150,8 +157,11 @@ class TrainStep:
             rows = torch.where(bad[:, None], torch.full((), float("nan"), dtype=rows.dtype, device=rows.device), rows)
         else:
             rows = tmap.reshape(-1, tmap.shape[-1]).index_select(0, self._row_base[1] + eot)
-        text_embeds = self.decoder.txt_proj(rows)
-        obj = self.decoder.obj_proj(hs[-1])                                        # [B,Q,256]
+        # captions' EOT rows and the noun vocabulary through txt_proj in ONE call (run/train.py:126,186 apply it twice: the same Linear, so
+        # the same numbers; one weight-gradient GEMM whose result goes straight into the gradient arena)
+        text_embeds, noun_embeds = tfm_decoder._SplitRows.apply(self.decoder.txt_proj(torch.cat([rows, batch["all_nouns"].to(rows.dtype)])), rows.shape[0])
+        hs_last = getattr(hs, "_hh_last", None)                                    # QueryStack's second output (== hs[-1], a tensor of its own)
+        obj = self.decoder.obj_proj(hs[-1] if hs_last is None else hs_last)        # [B,Q,256]
         video_embeds = obj[:, -1]
         if self._zeroed_idx is None or self._zeroed_idx.device != text.device:
             self._zeroed_idx = torch.tensor(ZEROED_NOUNS, device=text.device)              # once: a Python-list index is an H2D copy + sync per step
@@ -189,7 +199,6 @@ class TrainStep:
                                                     match=mh, return_loss_dict=True)
             lo, mo, do = box_utils.compute_box_loss("obj_boxes", self.criterion, det, objb, None, None, n_queries=nq, num_boxes=norm[1],
                                                     match=mo, return_loss_dict=True)
-        noun_embeds = self.decoder.txt_proj(batch["all_nouns"])
         word = self.word(noun_embeds, obj[:, :-1], batch["nouns"], count=sums[2] / W if W > 1 else None)
         total = torch.add(nce + lh + lo, word, alpha=0.5)                           # nce + lh + lo + 0.5 * word, run/train.py:149,183,191
         return {"total_loss": total, "nce_loss": nce.detach(), "box_loss_hand": lh.detach(), "box_loss_obj": lo.detach(),
