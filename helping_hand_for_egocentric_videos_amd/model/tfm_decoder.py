@@ -336,6 +336,51 @@ class _SplitRows(torch.autograd.Function):
         return torch.cat([g1, g2]), None
 
 
+class _SplitLastQuery(torch.autograd.Function):
+    """obj [B, Q, E] -> (obj[:, :Q-1], obj[:, Q-1]): the object queries' embeddings and the video query's (run/train.py:131-133);
+    backward = one concatenation instead of SelectBackward / SliceBackward zero fills, copies and their sum."""
+
+    @staticmethod
+    def forward(ctx, obj):
+        ctx.shape = obj.shape
+        ctx.set_materialize_grads(False)
+        od = obj.detach()
+        return od[:, :-1], od[:, -1]
+
+    @staticmethod
+    def backward(ctx, g_rest, g_last):
+        B, Q, E = ctx.shape
+        if g_rest is None and g_last is None:
+            return None
+        ref = g_rest if g_rest is not None else g_last
+        g_rest = ref.new_zeros((B, Q - 1, E)) if g_rest is None else g_rest
+        g_last = ref.new_zeros((B, E)) if g_last is None else g_last
+        return torch.cat([g_rest, g_last[:, None]], dim=1)
+
+
+class _FirstRows(torch.autograd.Function):
+    """w[:T] of a parameter whose only use in the step this is (frame_index.weight, tfm_decoder.py:196-203); backward copies the rows'
+    gradient into the parameter's slice of the gradient arena (the other rows stay zero) instead of zero fill + copy + AccumulateGrad."""
+
+    @staticmethod
+    def forward(ctx, w, T):
+        ctx.param_objs, ctx.T = (w,), T
+        return w.detach()[:T]
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.param_objs
+        sink = getattr(w, "_hh_sink", None)
+        if sink is not None and sink.armed():
+            sink.claim()
+            sink.view[:ctx.T].copy_(g)
+            sink.done()
+            return None, None
+        dw = torch.zeros_like(w)
+        dw[:ctx.T] = g
+        return dw, None
+
+
 class _SplitCols(torch.autograd.Function):
     """w [N, 2C] -> (w[:, :C], w[:, C:]) for the decomposed frame conditioning (ObjDecoder.forward); backward writes the two column
     halves' gradients into the parameter's slice of the gradient arena (two copies instead of SliceBackward's zero-fill + copy per
@@ -660,7 +705,7 @@ class ObjDecoder(nn.Module):
         if self.pred_traj and T == self.num_frames:
             w_hs, w_fr = _SplitCols.apply(self.frame_proj.weight, C)
             base = linear_x3(hs if full else last1, w_hs)                                                    # [l,B,Q,C]
-            fr = linear_x3(self.frame_index.weight[:T], w_fr, self.frame_proj.bias)                         # [T,C]
+            fr = linear_x3(_FirstRows.apply(self.frame_index.weight, T), w_fr, self.frame_proj.bias)       # [T,C]
             cond = (base[:, :, None] + fr[None, None, :, None, :]).flatten(1, 2)                             # [l,B*T,Q,C]
         else:
             cond = hs if full else last1
@@ -673,7 +718,8 @@ class ObjDecoder(nn.Module):
                     if sink is not None:
                         sink.arena.declare_unused([sink.name])
         outputs_coord = self.bbox_embed(cond).sigmoid()
-        out = {'pred_boxes': outputs_coord[-1]}
+        # (one layer only on the fast path: a view, not a select -- SelectBackward would zero-fill a [1, ...] temporary and copy into it)
+        out = {'pred_boxes': outputs_coord[-1] if outputs_coord.shape[0] != 1 else outputs_coord.view(outputs_coord.shape[1:])}
         expand_t = self.pred_traj and T == self.num_frames
         if full:
             outputs_class = self.class_embed(hs)

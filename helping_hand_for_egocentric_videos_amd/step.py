@@ -162,7 +162,7 @@ class TrainStep:
         text_embeds, noun_embeds = tfm_decoder._SplitRows.apply(self.decoder.txt_proj(torch.cat([rows, batch["all_nouns"].to(rows.dtype)])), rows.shape[0])
         hs_last = getattr(hs, "_hh_last", None)                                    # QueryStack's second output (== hs[-1], a tensor of its own)
         obj = self.decoder.obj_proj(hs[-1] if hs_last is None else hs_last)        # [B,Q,256]
-        video_embeds = obj[:, -1]
+        obj_rest, video_embeds = tfm_decoder._SplitLastQuery.apply(obj)             # obj[:, :-1], obj[:, -1]
         if self._zeroed_idx is None or self._zeroed_idx.device != text.device:
             self._zeroed_idx = torch.tensor(ZEROED_NOUNS, device=text.device)              # once: a Python-list index is an H2D copy + sync per step
         noun_vec = batch["noun_vec"].clone().index_fill_(1, self._zeroed_idx, 0)
@@ -199,7 +199,7 @@ class TrainStep:
                                                     match=mh, return_loss_dict=True)
             lo, mo, do = box_utils.compute_box_loss("obj_boxes", self.criterion, det, objb, None, None, n_queries=nq, num_boxes=norm[1],
                                                     match=mo, return_loss_dict=True)
-        word = self.word(noun_embeds, obj[:, :-1], batch["nouns"], count=sums[2] / W if W > 1 else None)
+        word = self.word(noun_embeds, obj_rest, batch["nouns"], count=sums[2] / W if W > 1 else None)
         total = torch.add(nce + lh + lo, word, alpha=0.5)                           # nce + lh + lo + 0.5 * word, run/train.py:149,183,191
         return {"total_loss": total, "nce_loss": nce.detach(), "box_loss_hand": lh.detach(), "box_loss_obj": lo.detach(),
                 "word_loss": word.detach(), "acc_vt": acc_vt, "acc_tv": acc_tv, "match_hand": mh, "match_obj": mo,
