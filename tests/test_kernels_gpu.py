@@ -1136,6 +1136,40 @@ def test_gemm_ln_fold_producer(M, N, K, keep_c):
     assert (st[:, 1] + rstd * mean).abs().max().item() <= 4e-3 * (1.0 + (rstd * mean).abs().max().item())
 
 
+@pytest.mark.parametrize("offset_sigma", [10.0, 50.0])
+def test_gemm_ln_fold_producer_statistics_with_a_large_row_mean(offset_sigma):
+    """rows inside persistent-GEMM tiles get their statistics from one-pass fp32 partial sums of the UNROUNDED z, the row tail
+    from a two-pass over the bf16 z -- measure both against fp64 statistics of the bf16 z the consumer multiplies, on rows whose mean is
+    10 / 50 sigma.  What this pins: the one-pass variance loses ~(mean/sigma)^2 2^-24 relative (1.5e-4 at 50 sigma) -- far below the
+    2^-9 mean/sigma that rounding z itself costs (the fold's real caveat); tile rows and tail rows agree within that."""
+    M, N, K = 256 * 40 + 40, 1024, 1024                                 # 40 x 4 tiles on the persistent kernel + a 40-row tail (in-kernel)
+    g = torch.Generator(device=DEV).manual_seed(int(offset_sigma))
+    a = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.02).to(torch.bfloat16)
+    bias = torch.zeros(N, device=DEV)
+    x = torch.randn(M, N, device=DEV, generator=g) + offset_sigma        # sigma ~ 1.2 (x + branch), mean = offset
+    eps = 1e-6
+    _, z, st = ops.gemm(a, w, bias, z=(x, eps, False))
+    zd = z.double()
+    mean, var = zd.mean(1), zd.var(1, unbiased=False)
+    rstd = (var + eps).rsqrt()
+    e_rstd = ((st[:, 0].double() - rstd) / rstd).abs()
+    e_mean = ((-st[:, 1].double() / st[:, 0].double()) - mean).abs() / var.sqrt()        # error of the mean in units of sigma
+    tile, tail = slice(0, 256 * 40), slice(256 * 40, M)
+    record("ln_fold_stats_offset_%d_sigma" % int(offset_sigma), "tile rows: rstd rel error vs fp64 statistics of bf16 z", float(e_rstd[tile].max()), 4e-2)
+    record("ln_fold_stats_offset_%d_sigma" % int(offset_sigma), "tail rows: rstd rel error vs fp64 statistics of bf16 z", float(e_rstd[tail].max()), 1e-5)
+    record("ln_fold_stats_offset_%d_sigma" % int(offset_sigma), "tile rows: mean error / sigma", float(e_mean[tile].max()), 2e-2)
+    # tile rows: statistics of the unrounded z differ from those of bf16(z) by the rounding of z (2^-9 offset per element, averaged over the row)
+    assert float(e_rstd[tile].max()) <= 4e-2 and float(e_mean[tile].max()) <= 2e-2
+    assert float(e_rstd[tail].max()) <= 1e-5 and float(e_mean[tail].max()) <= 1e-5
+    # and against the statistics of the unrounded fp32 z (what the one-pass sums see): the cancellation itself, (mean / sigma)^2 2^-24
+    zr = (x.double() + a.double() @ w.double().t())
+    r2 = (zr.var(1, unbiased=False) + eps).rsqrt()
+    e_cancel = ((st[tile, 0].double() - r2[tile]) / r2[tile]).abs().max().item()
+    record("ln_fold_stats_offset_%d_sigma" % int(offset_sigma), "tile rows: rstd rel error vs fp64 statistics of the unrounded z (one-pass cancellation)", e_cancel, 1e-3)
+    assert e_cancel <= 1e-3
+
+
 @pytest.mark.parametrize("M,N,K", LN_FOLD_SHAPES + [(256 * 33 + 7, 1024, 4096)])
 def test_gemm_ln_fold_producer_with_bf16_residual_rows(M, N, K):
     """z_resid_dtype = HH_BF16 (round 5): the producer adds its result to bf16 rows -- the time projection reads z3 = bf16(x), the rows its
