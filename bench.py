@@ -441,6 +441,16 @@ def roofline_records(region, iso, dt_ms, pipelined, cfg, B, steps):
         if rec is None:
             continue
         att[key] = dict(rec, kernel=names.get(key, "") or key, bound="hbm", peak=PEAK_HBM_GBS, unit="GB/s", frac=round(rec["achieved"] / PEAK_HBM_GBS, 4))
+        if key == "space_attn":
+            # the same launches against the matrix cores: QK^T + PV flops of a call (n frame keys + the CLS key per query).  At n = 576 keys per
+            # frame (config 4) the kernel sits right of the ridge (~290 flop per byte): the HBM fraction above understates it
+            T_ = cfg.num_frames
+            n_ = (cfg.tokens - 1) // T_
+            heads_ = cfg.embed_dim // 64
+            fl = 4.0 * B * T_ * heads_ * n_ * (n_ + 1) * 64
+            att[key]["mfma_view"] = {"tflops_achieved": round(fl / (rec["avg_launch_us"] * 1e-6) / 1e12, 1),
+                                     "frac_of_dense_peak": round(fl / (rec["avg_launch_us"] * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                     "flop_per_algorithmic_byte": round(fl / (8.0 * B * cfg.tokens * cfg.embed_dim), 1)}
         if iso is not None:
             i2 = _stream_rec(iso.get("roles", {}).get("vision_tower", iso), key, 2, 1e9)
             if i2 is not None:
