@@ -675,9 +675,11 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
     }
     p.Mt = (int)((p.M + p.tile_rows - 1) / p.tile_rows);
     p.Nt = p.N / 256;
-    // m-tiles per XCD-local group (scripts/gemm_group_bench.py with the four-barrier kernel): 16 for the short-K GEMMs up to 12 n-tiles
-    // (proj 1084 -> 1122, qkv 1181 -> 1201 TFLOP/s), 8 otherwise (fc1, fc2); "gemm256_group" overrides
-    const int GROUP = g_group > 0 ? g_group : ((p.N / 256 <= 12 && p.K <= 1024) ? 16 : 8);
+    // m-tiles per XCD-local group: 8 (8 m-tiles x 4 n-tiles per round and XCD).  Rounds 1-4 walked the short-K GEMMs up to 12 n-tiles (qkv,
+    // proj) 16 x 2 (measured on the plain four-barrier kernel: proj 1084 -> 1122, qkv 1181 -> 1201 TFLOP/s); with the LayerNorm fold in their
+    // epilogues 8 x 4 fetches 1289 instead of 2342 MiB per qkv launch and runs 1127 vs 1106 TFLOP/s alone (profiles/r5_gemm_group_fetch.md),
+    // and the step gains +1.1 ... +1.7 % in three same-session A/Bs (profiles/r5_ab_gemm_group.txt); "gemm256_group" overrides
+    const int GROUP = g_group > 0 ? g_group : 8;
     p.group_m = GROUP;
     p.debug_nostore = g_nostore;
     p.debug_ts = g_debug_ts == 1;

@@ -4,12 +4,18 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from helping_hand_for_egocentric_videos_amd import ops
 G = int(sys.argv[1]); which = sys.argv[2] if len(sys.argv) > 2 else "qkv"
+fold = len(sys.argv) > 3 and sys.argv[3] == "fold"          # consumer side of the LayerNorm fold (EPI 5 / 6: per-tile epilogue record by LDS-DMA)
 M = 32 * 4097
 N, K, kw = {"qkv": (3072, 1024, dict(colscale=0.125, colscale_cols=1024)), "fc1": (4096, 1024, dict(act=ops.ACT_QUICKGELU))}[which]
 g = torch.Generator(device="cuda").manual_seed(0)
 a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
 w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
 bias = torch.randn(N, device="cuda", generator=g)
+if fold:
+    stats = torch.stack([torch.rand(M, device="cuda", generator=g) + 0.5, torch.randn(M, device="cuda", generator=g) * 0.1], 1).contiguous()
+    kw["ln"] = (stats, torch.randn(N, device="cuda", generator=g))
+    if which == "qkv":
+        kw["col_blocked"] = True
 ops.set_tuning("gemm256_group", G)
 for _ in range(12): ops.gemm(a, w, bias, **kw)
 torch.cuda.synchronize()
@@ -17,4 +23,4 @@ e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
 e0.record()
 for _ in range(10): ops.gemm(a, w, bias, **kw)
 e1.record(); torch.cuda.synchronize()
-print("RESULT %s G=%d: %.1f us per call, %.1f TFLOP/s" % (which, G, e0.elapsed_time(e1) * 100, 2.0 * M * N * K / (e0.elapsed_time(e1) / 10) / 1e9))
+print("RESULT %s%s G=%d: %.1f us per call, %.1f TFLOP/s" % (which, " (fold consumer)" if fold else "", G, e0.elapsed_time(e1) * 100, 2.0 * M * N * K / (e0.elapsed_time(e1) / 10) / 1e9))

@@ -4,15 +4,16 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/gemm_group_fetch.md
-echo "# Persistent GEMM: XCD tile walk vs L2-side fetch traffic (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction), M = 32 x 4097 rows" > $OUT
+echo "# Persistent GEMM (${1:-plain} epilogue): XCD tile walk vs L2-side fetch traffic (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction), M = 32 x 4097 rows" > $OUT
 echo "" >> $OUT
 echo "| GEMM | G (m-tiles x n-tiles per round and XCD) | FETCH MiB / launch | x operand bytes | TFLOP/s (same process, timers off) |" >> $OUT
 echo "|---|---|---|---|---|" >> $OUT
+MODE=${1:-plain}          # "fold": the consumer side of the LayerNorm fold (what the step runs since round 4)
 for which in qkv fc1; do
 for G in 4 8 16 32; do
   rm -rf $R/gpurun_out/pmc_g
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_g -- python3 $R/scripts/gemm_group_fetch.py $G $which > $R/gpurun_out/pmc_g.log 2>&1
-  TF=$(python3 $R/scripts/gemm_group_fetch.py $G $which 2>/dev/null | grep RESULT | sed -e 's/.*call, //')
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_g -- python3 $R/scripts/gemm_group_fetch.py $G $which $MODE > $R/gpurun_out/pmc_g.log 2>&1
+  TF=$(python3 $R/scripts/gemm_group_fetch.py $G $which $MODE 2>/dev/null | grep RESULT | sed -e 's/.*call, //')
   python3 - "$which" "$G" "$TF" >> $OUT <<'PY'
 import csv, glob, os, sys
 which, G, tf = sys.argv[1], int(sys.argv[2]), sys.argv[3]
