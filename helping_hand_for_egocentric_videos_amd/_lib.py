@@ -16,7 +16,7 @@ class GemmEpilogue(ctypes.Structure):
                 ("act", c_int), ("c_dtype", c_int), ("remap_group", c_i64), ("remap_skip", c_i64),
                 ("remap_offset", c_i64), ("splitk", c_int), ("split_stride", c_i64), ("c_block_stride", c_i64),
                 ("ln_stats", c_vp), ("ln_colsum", c_vp), ("z_resid", c_vp), ("z_ldr", c_i64), ("z_out", c_vp), ("z_ldc", c_i64),
-                ("z_stats", c_vp), ("z_partials", c_vp), ("z_eps", c_float), ("skip_c", c_int), ("z_update", c_int), ("z_resid_dtype", c_int)]
+                ("z_stats", c_vp), ("z_partials", c_vp), ("z_eps", c_float), ("skip_c", c_int), ("z_update", c_int), ("z_resid_dtype", c_int), ("walk_reverse", c_int)]
 
 
 class QGemmOpts(ctypes.Structure):

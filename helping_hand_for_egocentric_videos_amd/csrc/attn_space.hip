@@ -549,9 +549,11 @@ __global__ __launch_bounds__(64 * NWV, WPS) void space_attnj_kernel(const bf16_t
     const int D = heads * 64;
     const int N = 1 + T * n;
     // qkv layout (include/hh.h, hh_qkv_layout): element (row, which, head, d) at row * ld + which * ws + head * hs + d
+    const int rev = layout >> 1;                       // (bit 1, HH_QKV_WALK_REVERSE: the problems last to first)
+    layout &= 1;
     const int64_t ld = layout ? 64 : 3 * (int64_t)D;
     const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
-    int bid = blockIdx.x;
+    int bid = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
     const int head = bid % heads; bid /= heads;
     const int f = bid % T;
     const int b = bid / T;
@@ -953,6 +955,8 @@ int hh_tuning_space_prog();
 
 extern "C" int hh_space_attn_fwd(const void* qkv, int qkv_layout, void* out, float* cls_partial, int B, int T, int n, int heads,
                                  hh_stream_t stream) {
+    const int walk_rev = qkv_layout & HH_QKV_WALK_REVERSE;          // (bit 1: the joint-block kernel takes it in the same argument)
+    qkv_layout &= ~HH_QKV_WALK_REVERSE;
     HH_REQUIRE(qkv_layout == HH_QKV_TOKEN_MAJOR || qkv_layout == HH_QKV_HEAD_MAJOR, HH_ERR_SHAPE, "hh_space_attn_fwd: bad qkv_layout");
     HH_REQUIRE(B >= 0 && T > 0 && heads > 0 && n > 0 && n % 32 == 0, HH_ERR_SHAPE, "hh_space_attn_fwd: n=%d must be a multiple of 32", n);
     HH_REQUIRE(HH_ALIGNED16(qkv) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_space_attn_fwd: pointers must be 16-byte aligned");
@@ -1022,7 +1026,7 @@ extern "C" int hh_space_attn_fwd(const void* qkv, int qkv_layout, void* out, flo
         hh_prof_note_kernel(HH_PROF_SPACE_ATTN, nw == 12 ? "space_attnj_kernel<3, 2, false, 12, 3>" : jb == 4 ? (dbg ? "space_attnj_kernel<4, 2, true, 4, 2> (debug)" : "space_attnj_kernel<4, 2, false, 4, 2>")
                                                 : jb == 3 ? "space_attnj_kernel<3, 2, false, 4, 2>" : "space_attnj_kernel<2, 6, false, 4, 2>");
         hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * nw), lds16, (hipStream_t)stream,
-                           (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP, dbg, qkv_layout);
+                           (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, n, heads, KP, dbg, qkv_layout | walk_rev);
         return hh_check_launch("hh_space_attn_fwd");
     }
     hh_prof_note_kernel(HH_PROF_SPACE_ATTN, "space_attn16_kernel");

@@ -64,11 +64,14 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
     const int D = heads * 64;
     const int N = 1 + T * n;
     // qkv layout (include/hh.h, hh_qkv_layout): element (row, which, head, d) at row * ld + which * ws + head * hs + d
+    const int rev = layout >> 1;                       // (bit 1 of the layout argument, HH_QKV_WALK_REVERSE: the problems last to first)
+    layout &= 1;
     const int64_t ld = layout ? 64 : 3 * (int64_t)D;
     const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
     const int groups = (n + P - 1) / P;
     int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     if (wid >= (int64_t)B * heads * groups) return;
+    if (rev) wid = (int64_t)B * heads * groups - 1 - wid;
     const int pg = (int)(wid % groups); wid /= groups;
     const int head = (int)(wid % heads);
     const int b = (int)(wid / heads);
@@ -258,11 +261,14 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
     const int D = heads * 64;
     const int N = 1 + T * n;
     // qkv layout (include/hh.h, hh_qkv_layout): element (row, which, head, d) at row * ld + which * ws + head * hs + d
+    const int rev = layout >> 1;                       // (bit 1 of the layout argument, HH_QKV_WALK_REVERSE: the problems last to first)
+    layout &= 1;
     const int64_t ld = layout ? 64 : 3 * (int64_t)D;
     const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
     const int groups = (n + P - 1) / P;
     int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     if (wid >= (int64_t)B * heads * groups) return;
+    if (rev) wid = (int64_t)B * heads * groups - 1 - wid;
     const int pg = (int)(wid % groups); wid /= groups;
     const int head = (int)(wid % heads);
     const int b = (int)(wid / heads);
@@ -450,6 +456,8 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
 
 extern "C" int hh_time_attn_fwd(const void* qkv, int qkv_layout, void* out, float* cls_partial, int B, int T, int n, int heads,
                                 hh_stream_t stream) {
+    const int walk_rev = qkv_layout & HH_QKV_WALK_REVERSE;          // (bit 1: the kernels take it in the same argument)
+    qkv_layout &= ~HH_QKV_WALK_REVERSE;
     HH_REQUIRE(qkv_layout == HH_QKV_TOKEN_MAJOR || qkv_layout == HH_QKV_HEAD_MAJOR, HH_ERR_SHAPE, "hh_time_attn_fwd: bad qkv_layout");
     HH_REQUIRE(B >= 0 && n > 0 && heads > 0, HH_ERR_SHAPE, "hh_time_attn_fwd: bad shape");
     HH_REQUIRE(T == 1 || T == 2 || T == 4 || T == 8 || T == 16 || T == 32, HH_ERR_UNSUPPORTED,
@@ -469,7 +477,7 @@ extern "C" int hh_time_attn_fwd(const void* qkv, int qkv_layout, void* out, floa
     }
     const unsigned wg = (unsigned)((blocks + 3) / 4);           // one wave per record, four waves per workgroup
 #define LAUNCHM(TT) do { hh_prof_note_kernel(HH_PROF_TIME_ATTN, "time_attn_mfma_kernel<" #TT ">"); \
-                         hipLaunchKernelGGL(time_attn_mfma_kernel<TT>, dim3(wg), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout); } while (0)
+                         hipLaunchKernelGGL(time_attn_mfma_kernel<TT>, dim3(wg), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout | walk_rev); } while (0)
     switch (T) {
         case 1: LAUNCHM(1); break;
         case 2: LAUNCHM(2); break;

@@ -593,6 +593,7 @@ static int g_space_prog = 1;       // 1 = progressive K / V staging where a spec
 int hh_tuning_space_prog() { return g_space_prog; }
 
 
+
 extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "gemm256") && value >= 0 && value <= 5) { g_mode = value; return HH_OK; }
     if (name && !strcmp(name, "gemm_tail") && value >= 0 && value <= 2) { g_tail = value; return HH_OK; }
@@ -681,6 +682,7 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
     // and the step gains +1.1 ... +1.7 % in three same-session A/Bs (profiles/r5_ab_gemm_group.txt); "gemm256_group" overrides
     const int GROUP = g_group > 0 ? g_group : 8;
     p.group_m = GROUP;
+    p.rev_m = p.e.walk_reverse != 0;
     p.debug_nostore = g_nostore;
     p.debug_ts = g_debug_ts == 1;
     const int per_xcd_mt = (p.Mt + 7) / 8;

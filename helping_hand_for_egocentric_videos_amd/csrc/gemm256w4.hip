@@ -17,6 +17,22 @@
 // A half-tile is re-staged right after the barrier that follows its last read and is consumed seven quadrants later: seven
 // half-tile DMAs (4 instructions per wave each) are in flight after each staging call, one counted s_waitcnt vmcnt(24) + one s_barrier per quadrant.
 #include "gemm_common.h"
+// epilogue traffic (C / z / residual rows: streamed once per launch) with the non-temporal cache policy when HH_EPI_NT is defined: it should
+// not evict the A / W panels the tile walk keeps in L2 (experiment, round 5)
+#ifdef HH_EPI_NT
+#define W4_ST(P, V) __builtin_nontemporal_store((V), (P))
+#define W4_LD(P) __builtin_nontemporal_load(P)
+#else
+#define W4_ST(P, V) (*(P) = (V))
+#define W4_LD(P) (*(P))
+#endif
+#if defined(HH_EPI_NT) || defined(HH_EPI_NTX)      // NTX: only the fp32 residual rows (read and written once per producer launch)
+#define W4_STX(P, V) __builtin_nontemporal_store((V), (P))
+#define W4_LDX(P) __builtin_nontemporal_load(P)
+#else
+#define W4_STX(P, V) (*(P) = (V))
+#define W4_LDX(P) (*(P))
+#endif
 
 #define W4_HT 16384
 #define W4_BUF 65536
@@ -476,7 +492,7 @@ __device__ __forceinline__ void w4p_store_tile(const GemmParams& p, bf16_t* cptr
     if constexpr (IDX > 0) {                                           // the previous group's rows (its LDS reads were issued before this group's arithmetic)
         const int64_t r0 = rowbase + w4_rowoff<TR>(IDX - 1) + l4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *(u32x4*)(cptr + (r0 + 4 * q) * p.ldc) = (*prev)[q];
+        for (int q = 0; q < 4; ++q) W4_ST((u32x4*)(cptr + (r0 + 4 * q) * p.ldc), (*prev)[q]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) *(u32x4*)(scr + frow * 256 + (((j * 4 + fq) ^ frow) << 4)) = o[j];      // chunk = 8 nh + 4 jj + fq = 4 j + fq
@@ -487,7 +503,7 @@ __device__ __forceinline__ void w4p_store_tile(const GemmParams& p, bf16_t* cptr
     else {
         const int64_t r0 = rowbase + w4_rowoff<TR>(IDX) + l4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *(u32x4*)(cptr + (r0 + 4 * q) * p.ldc) = rd[q];
+        for (int q = 0; q < 4; ++q) W4_ST((u32x4*)(cptr + (r0 + 4 * q) * p.ldc), rd[q]);
     }
 }
 // straight from the MFMA layout (a store instruction covers 16 rows x 64 B of bf16): fp32 output, and the QuickGELU epilogue, whose
@@ -506,10 +522,10 @@ __device__ __forceinline__ void w4p_store_rows_direct(const GemmParams& p, int64
     for (int j = 0; j < 4; ++j) {
         if constexpr (OUT_BF16) {
             u32x4 o = {pack_bf16(a[j][0], a[j][1]), pack_bf16(a[j][2], a[j][3]), pack_bf16(b[j][0], b[j][1]), pack_bf16(b[j][2], b[j][3])};
-            *(u32x4*)((bf16_t*)p.C + orow * p.ldc + ccol[j]) = o;
+            W4_ST((u32x4*)((bf16_t*)p.C + orow * p.ldc + ccol[j]), o);
         } else {
-            *(f32x4*)((float*)p.C + orow * p.ldc + ccol[j]) = a[j];
-            *(f32x4*)((float*)p.C + orow * p.ldc + ccol[j] + 4) = b[j];
+            W4_ST((f32x4*)((float*)p.C + orow * p.ldc + ccol[j]), a[j]);
+            W4_ST((f32x4*)((float*)p.C + orow * p.ldc + ccol[j] + 4), b[j]);
         }
     }
     if constexpr (IDX + 1 < 8) w4p_store_rows_direct<OUT_BF16, EPI, IDX + 1>(p, rowbase, sc, bias_v, ccol, ln, st_next);
@@ -527,13 +543,13 @@ __device__ __forceinline__ void w4p_zload(const float* xw0, unsigned xlo, f32x4 
     if constexpr (RB) {
         const bf16_t* r = (const bf16_t*)xw0 + (int64_t)w4_rowoff<TR>(IDX) * ldx + xlo;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xa[j] = *(const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64);      // 8 bf16 = 16 bytes, not yet widened
+        for (int j = 0; j < 4; ++j) xa[j] = W4_LDX((const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64));      // 8 bf16 = 16 bytes, not yet widened
     } else {
         const float* r = xw0 + (int64_t)w4_rowoff<TR>(IDX) * ldx + xlo;       // (wave-uniform base + the lane's 32-bit offset: see the write-back below)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            xa[j] = *(const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64);
-            xb[j] = *(const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64 + 4);
+            xa[j] = W4_LDX((const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64));
+            xb[j] = W4_LDX((const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64 + 4));
         }
     }
 }
@@ -569,7 +585,7 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw
         w4p_lds_rows(scr, frow, fq, l15, l4, a, b, rd);
         bf16_t* cw = cw0 + (int64_t)w4_rowoff<TR>(IDX) * p.ldc;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *(u32x4*)(cw + (int64_t)(4 * q) * p.ldc + coff) = rd[q];
+        for (int q = 0; q < 4; ++q) W4_ST((u32x4*)(cw + (int64_t)(4 * q) * p.ldc + coff), rd[q]);
     }
     f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -602,7 +618,7 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw
             for (int q = 0; q < 4; ++q) {
                 const int r = 4 * q + l4;
                 const f32x4 v = *(const f32x4*)(scr + r * 256 + ((l15 ^ r) << 4));
-                *(f32x4*)(xw + (int64_t)(4 * q) * p.e.z_ldr + h * 64 + xoff) = v;
+                W4_STX((f32x4*)(xw + (int64_t)(4 * q) * p.e.z_ldr + h * 64 + xoff), v);
             }
         }
     }
@@ -613,7 +629,7 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw
     w4p_lds_rows(scr, frow, fq, l15, l4, a, b, rd);
     bf16_t* zw = zw0 + (int64_t)w4_rowoff<TR>(IDX) * p.e.z_ldc;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *(u32x4*)(zw + (int64_t)(4 * q) * p.e.z_ldc + zoff) = rd[q];
+    for (int q = 0; q < 4; ++q) W4_ST((u32x4*)(zw + (int64_t)(4 * q) * p.e.z_ldc + zoff), rd[q]);
     if constexpr (IDX + 1 < w4_groups<TR>()) w4p_store_tile_z<IDX + 1, TR, RB>(p, cw0, zw0, part0, scr, frow, fq, l15, l4, bias_l, xw0, xoff, xlo, coff, zoff, xna, xnb, xa, xb);
 }
 
@@ -662,7 +678,8 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
         int kg, nt_i, mi;
         if (d < gfull * per) { kg = d / per; const int r = d % per; nt_i = r / GROUP; mi = r % GROUP; }
         else { const int r = d - gfull * per; kg = gfull; nt_i = r / grem; mi = r % grem; }
-        m0 = (int64_t)(xcd + 8 * (kg * GROUP + mi)) * TR;
+        const int mt = xcd + 8 * (kg * GROUP + mi);
+        m0 = (int64_t)(p.rev_m ? p.Mt - 1 - mt : mt) * TR;
         n0 = nt_i * 256;
     };
     unsigned* tcnt = g_w4_tile_cnt[p.tile_slot];

@@ -11,6 +11,7 @@ struct GemmParams {
     int debug_nostore;        // timing experiments only
     int debug_ts;             // persistent 256x256 kernel: record the per-tile timeline (debug)
     int group_m;              // 256x256 kernel: m-tiles per XCD-local group
+    int rev_m;                // persistent 4-wave kernel: walk the m-tiles last to first (hh_gemm_epilogue.walk_reverse)
     int skew_iters;           // 256x256 kernel: start-time skew quantum (0 = off)
     int tile_rows;            // persistent 4-wave kernel: 256, or 224 (gemm256w4.hip: whole rounds where 256-row tiles leave a partial one; opt-in)
     int skew_phases;          // persistent 4-wave kernel: 0 = the quantum times (workgroup index in its XCD) & 31, P > 0 = times (index % P)

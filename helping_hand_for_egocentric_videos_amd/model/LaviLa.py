@@ -98,6 +98,8 @@ QKV_HEAD_MAJOR_PLANES = True       # False: the QKV projection writes nn.Linear'
 # (SpaceTimeBlock.packed), and `SpaceTimeTransformer.ln_fold_packed()` reports what the tower actually runs (bench.py records that).
 LN_FOLD = True
 TIME_PROJ_READS_Z3 = True          # False: the time projection's epilogue reads the fp32 residual rows (round 4; A/B measurements)
+# every large kernel of a tower block walks its rows opposite to its predecessor (SpaceTimeBlock.fused); False: all first to last (rounds 1-4)
+WALK_ALTERNATE = True
 
 
 class VarAttention(nn.Module):
@@ -132,7 +134,7 @@ class VarAttention(nn.Module):
     def _mode(einops_to):
         return "space" if einops_to.replace(" ", "") == "(bf)nd" else "time"
 
-    def core(self, xn, pk, B, T, n, mode, ln=None):
+    def core(self, xn, pk, B, T, n, mode, ln=None, rev_gemm=False, rev_attn=False):
         """xn bf16 [B*N, D] (already normalised) -> attention output bf16 [B*N, D] (before proj).
         ln=(stats, folded operands): xn holds UN-normalised rows z and the LayerNorm is applied inside the qkv GEMM."""
         D = xn.shape[1]
@@ -140,11 +142,11 @@ class VarAttention(nn.Module):
         qscale = self.scale * (ops.LOG2E if mode == "space" else 1.0)
         # head-major planes [3*heads, B*N, 64]: a head's rows are contiguous 128-byte lines for the attention kernels (ops.gemm col_blocked)
         if ln is None:
-            qkv = ops.gemm(xn, pk["wqkv"], pk["bqkv"], colscale=qscale, colscale_cols=D, col_blocked=QKV_HEAD_MAJOR_PLANES)
+            qkv = ops.gemm(xn, pk["wqkv"], pk["bqkv"], colscale=qscale, colscale_cols=D, col_blocked=QKV_HEAD_MAJOR_PLANES, reverse=rev_gemm)
         else:
             stats, (wf, cs, bf) = ln
-            qkv = ops.gemm(xn, wf, bf, colscale=qscale, colscale_cols=D, col_blocked=QKV_HEAD_MAJOR_PLANES, ln=(stats, cs))
-        return ops.divided_attention(qkv, B, T, n, self.num_heads, mode)
+            qkv = ops.gemm(xn, wf, bf, colscale=qscale, colscale_cols=D, col_blocked=QKV_HEAD_MAJOR_PLANES, ln=(stats, cs), reverse=rev_gemm)
+        return ops.divided_attention(qkv, B, T, n, self.num_heads, mode, reverse=rev_attn)
 
     def forward(self, x, einops_from, einops_to, einops_dims):
         """x [B, 1+T*n, D] -> proj(attention(x)) [B, N, D] fp32.  einops strings as the reference passes them
@@ -218,15 +220,21 @@ class SpaceTimeBlock(nn.Module):
                 st3 = ops.ln_rowstats(z3, eps3)
             else:
                 z3, st3 = pending
-            a = self.timeattn.core(z3, pk["time"], B, T, n, "time", ln=(st3, pk["qkv_n3"]))                     # qkv(LN3(x))
+            # Walk direction (round 5): every large kernel of the block walks its rows OPPOSITE to its predecessor, so that it starts on the
+            # rows that were written last -- the part of its input still in the 256 MB Infinity Cache (a kernel that starts where its
+            # predecessor started evicts exactly what it is about to need): time qkv up, time attention down, time proj up, space qkv
+            # down, space attention up, space proj down, fc1 up, fc2 down -- eight kernels, so the pattern repeats block after block.
+            # Same tiles, same arithmetic, bit-identical results (+0.6 % clips/s, profiles/r5_ab_walk.txt).
+            alt = WALK_ALTERNATE
+            a = self.timeattn.core(z3, pk["time"], B, T, n, "time", ln=(st3, pk["qkv_n3"]), rev_gemm=False, rev_attn=alt)   # qkv(LN3(x))
             # z1 = x + t feeds norm1 and nothing else (LaviLa.py:372-384: the space residual goes on x): the time projection adds its
             # result to z3 = bf16(x) -- the 2-byte rows this block's norm3 just consumed -- instead of re-reading the 4-byte fp32 stream
             _, z1, st1 = ops.gemm(a, pk["time"]["wproj"], pk["time"]["bproj"], z=(z3 if TIME_PROJ_READS_Z3 else x, eps1, False))
-            a = self.attn.core(z1, pk["space"], B, T, n, "space", ln=(st1, pk["qkv_n1"]))                        # qkv(LN1(x + t))
-            _, z2, st2 = ops.gemm(a, pk["space"]["wproj"], pk["space"]["bproj"], z=(x, eps2, False, True))      # x <- x + s; z2
+            a = self.attn.core(z1, pk["space"], B, T, n, "space", ln=(st1, pk["qkv_n1"]), rev_gemm=alt, rev_attn=False)     # qkv(LN1(x + t))
+            _, z2, st2 = ops.gemm(a, pk["space"]["wproj"], pk["space"]["bproj"], z=(x, eps2, False, True), reverse=alt)   # x <- x + s; z2
             wf, cs, bf = pk["fc1_n2"]
             h = ops.gemm(z2, wf, bf, act=ops.ACT_QUICKGELU, ln=(st2, cs))                                        # fc1(LN2(x))
-            _, z3n, st3n = ops.gemm(h, pk["w2"], pk["b2"], z=(x, eps3, False, True))                             # x <- x + m; next z3
+            _, z3n, st3n = ops.gemm(h, pk["w2"], pk["b2"], z=(x, eps3, False, True), reverse=alt)                 # x <- x + m; next z3
             return z3n, st3n
         if pending is None:
             xn = ops.layernorm(x, *pk["n3"])

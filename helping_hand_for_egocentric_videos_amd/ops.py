@@ -250,7 +250,7 @@ def fold_layernorm_into_linear(weight, bias, gamma, beta):
 
 
 def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, resid=None, colscale=1.0,
-         colscale_cols=0, remap=None, out_rows=None, splitk=1, col_blocked=False, ln=None, z=None):
+         colscale_cols=0, remap=None, out_rows=None, splitk=1, col_blocked=False, ln=None, z=None, reverse=False):
     """C = epilogue(A @ W^T).  a bf16 [M,K], w bf16 [N,K] (nn.Linear weight layout), bias fp32 [N].
 
     LayerNorm fold (include/hh.h):  ln=(stats fp32 [M,2], colsum fp32 [N]) -- consumer side: `a` holds un-normalised rows, `w` / `bias`
@@ -261,6 +261,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
     remap=(group, skip, offset) scatters output row m to m + (m//group)*skip + offset (token-major scatter).
     col_blocked=True returns C as N/64 planes [N/64, M, 64] (plane j = columns 64j .. 64j+63; include/hh.h c_block_stride):
     the QKV projection written this way is the head-major buffer of divided_attention.
+    reverse: the persistent kernel walks its m-tiles last to first (hh_gemm_epilogue.walk_reverse; same results).
     """
     _chk(bias)
     for t in (a, w, resid, out):                     # 2-D operands may be row-strided views (unit inner stride)
@@ -295,6 +296,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
         e = GemmEpilogue()
         e.bias = bias.data_ptr() if bias is not None else None
         e.colscale, e.colscale_cols, e.act, e.c_dtype, e.c_block_stride = float(colscale), int(colscale_cols), int(act), _dt(planes), M * 64
+        e.walk_reverse = int(bool(reverse))
         if ln is not None:
             _set_ln(e, ln, M, N, bias)
         _lib.check(_lib.lib().hh_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(planes), 64, M, N, K, ctypes.byref(e), _stream()),
@@ -314,6 +316,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
     if out is None:
         out = torch.empty((out_rows if out_rows is not None else M, N), dtype=out_dtype, device=a.device) if keep_c else None
     e = GemmEpilogue()
+    e.walk_reverse = int(bool(reverse))
     if ln is not None:
         _set_ln(e, ln, M, N, bias)
     if z is not None:
@@ -483,11 +486,12 @@ def attention_q_scale(mode, head_dim=64):
 QKV_TOKEN_MAJOR, QKV_HEAD_MAJOR = 0, 1                  # include/hh.h: enum hh_qkv_layout
 
 
-def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
+def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True, reverse=False):
     """qkv bf16 (q pre-scaled by attention_q_scale(mode)), token-major [B*N, 3D] or head-major planes [3*heads, B*N, 64]
     (gemm(..., col_blocked=True)) -> bf16 [B*N, D].  Rows 1.. come from the space/time kernel; the CLS row
     (query 0 attends all N keys) is folded into the same kernels as per-group partials + hh_cls_combine
-    (fold_cls=False runs the stand-alone hh_cls_attn_fwd pass instead)."""
+    (fold_cls=False runs the stand-alone hh_cls_attn_fwd pass instead).  reverse: walk the problems last to first (HH_QKV_WALK_REVERSE; same
+    results -- see SpaceTimeBlock.fused)."""
     _chk(qkv, out)
     N = 1 + T * n
     D = heads * 64
@@ -511,9 +515,9 @@ def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True):
     else:
         _lib.check(L.hh_cls_attn_fwd(_p(qkv), lay, _p(out), B, N, heads, int(mode == "space"), _stream()), "hh_cls_attn_fwd")
     if mode == "space":
-        _lib.check(L.hh_space_attn_fwd(_p(qkv), lay, _p(out), _p(part), B, T, n, heads, _stream()), "hh_space_attn_fwd")
+        _lib.check(L.hh_space_attn_fwd(_p(qkv), lay | (2 if reverse else 0), _p(out), _p(part), B, T, n, heads, _stream()), "hh_space_attn_fwd")
     else:
-        _lib.check(L.hh_time_attn_fwd(_p(qkv), lay, _p(out), _p(part), B, T, n, heads, _stream()), "hh_time_attn_fwd")
+        _lib.check(L.hh_time_attn_fwd(_p(qkv), lay | (2 if reverse else 0), _p(out), _p(part), B, T, n, heads, _stream()), "hh_time_attn_fwd")
     if fold_cls:
         _lib.check(L.hh_cls_combine(_p(part), G, _p(out), B, N, heads, _stream()), "hh_cls_combine")
     return out

@@ -31,6 +31,10 @@ enum hh_act { HH_ACT_NONE = 0, HH_ACT_QUICKGELU = 1, HH_ACT_RELU = 2 };
  *   HH_QKV_HEAD_MAJOR : ((which * heads + head) * R + row) * 64 + d                (3*heads planes of [R, 64]: a head's rows are
  *                       contiguous 128-byte lines; written by hh_gemm_bf16 with c_block_stride = R * 64) */
 enum hh_qkv_layout { HH_QKV_TOKEN_MAJOR = 0, HH_QKV_HEAD_MAJOR = 1 };
+/* OR-ed into the qkv_layout argument of hh_space_attn_fwd / hh_time_attn_fwd (round 5): walk the (clip, ...) problems LAST TO FIRST.  Same
+ * results; a kernel that starts on the rows its predecessor wrote last finds them in the 256 MB Infinity Cache (hh_gemm_epilogue.walk_reverse
+ * is the GEMM side).  Honoured by the kernels of the benchmarked shapes (n = 256 joint-block space kernel, T <= 16 time kernel); others ignore it. */
+#define HH_QKV_WALK_REVERSE 2
 
 int hh_version(void);
 /* Performance knobs for A/B measurements (never change results).  Together with the per-stream CU budget below this is the
@@ -191,6 +195,9 @@ typedef struct hh_gemm_epilogue {
     int z_resid_dtype;        /* HH_F32 (0, default) or HH_BF16 (round 5): z_resid holds bf16 rows -- the producer that only feeds a LayerNorm
                                  (the time branch: z1 = x + t goes to norm1 alone, LaviLa.py:372) reads the 2-byte z = bf16(x) its own block's
                                  norm3 consumed instead of the 4-byte fp32 stream; no z_update with it */
+    int walk_reverse;         /* != 0 (round 5): the persistent kernel walks its m-tiles last to first (same tiles, same arithmetic, same results):
+                                 the tower alternates the direction from kernel to kernel so that each one starts on the rows its predecessor
+                                 wrote last -- the part of its input still in the Infinity Cache (model/LaviLa.py: SpaceTimeBlock.fused) */
 } hh_gemm_epilogue;
 
 int hh_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,

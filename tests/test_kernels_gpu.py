@@ -1247,6 +1247,36 @@ def test_text_flags_vs_torch():
     assert torch.equal(pad.cpu(), ((text != 0).sum(-1) != 2).float())
 
 
+def test_walk_direction_does_not_change_results():
+    """Round 5: hh_gemm_epilogue.walk_reverse / HH_QKV_WALK_REVERSE make a kernel walk its m-tiles / (clip, ...) problems last to first, so that
+    it starts on the rows its predecessor wrote last (model/LaviLa.py: SpaceTimeBlock.fused alternates the direction).  Same tiles, same
+    arithmetic: every output -- C, head-major planes, z, the in-place residual update, row statistics, attention rows incl. the folded CLS
+    rows -- is bit-identical, on the persistent kernel with an in-kernel row tail."""
+    M, N, K = 256 * 40 + 32, 1024, 1024
+    g = torch.Generator(device=DEV).manual_seed(5)
+    a = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    x = torch.randn(M, N, device=DEV, generator=g)
+    stats = torch.stack([torch.rand(M, device=DEV, generator=g) + 0.5, torch.randn(M, device=DEV, generator=g) * 0.1], 1).contiguous()
+    cs = torch.randn(N, device=DEV, generator=g)
+    for kw in (dict(), dict(act=ops.ACT_QUICKGELU, ln=(stats, cs)), dict(colscale=0.125, colscale_cols=256, col_blocked=True, ln=(stats, cs))):
+        assert torch.equal(ops.gemm(a, w, bias, **kw), ops.gemm(a, w, bias, reverse=True, **kw)), kw
+    for zargs in ((x, 1e-6, False), (x.to(torch.bfloat16), 1e-6, False)):
+        f, r = ops.gemm(a, w, bias, z=zargs), ops.gemm(a, w, bias, z=zargs, reverse=True)
+        assert torch.equal(f[1], r[1]) and torch.equal(f[2], r[2])
+    x1, x2 = x.clone(), x.clone()
+    f, r = ops.gemm(a, w, bias, z=(x1, 1e-6, False, True)), ops.gemm(a, w, bias, z=(x2, 1e-6, False, True), reverse=True)
+    assert torch.equal(x1, x2) and torch.equal(f[1], r[1]) and torch.equal(f[2], r[2])
+    B, T, n, heads = 3, 16, 256, 4
+    Nn, D = 1 + T * n, heads * 64
+    qkv = bf(rnd(B * Nn, 3 * D, seed=9) * 0.5).to(DEV)
+    planes = qkv.view(B * Nn, 3 * heads, 64).transpose(0, 1).contiguous()
+    for mode in ("space", "time"):
+        for t in (qkv, planes):
+            assert torch.equal(ops.divided_attention(t, B, T, n, heads, mode), ops.divided_attention(t, B, T, n, heads, mode, reverse=True)), mode
+
+
 def test_round4_entry_points_accept_empty_inputs():
     """M = 0 / no captions: the LayerNorm-fold GEMMs, hh_ln_rowstats and hh_text_flags return empty results instead of failing on the
     null data pointer of an empty tensor."""
