@@ -6,12 +6,16 @@ from helping_hand_for_egocentric_videos_amd import ops
 G = int(sys.argv[1]); which = sys.argv[2] if len(sys.argv) > 2 else "qkv"
 fold = len(sys.argv) > 3 and sys.argv[3] == "fold"          # consumer side of the LayerNorm fold (EPI 5 / 6: per-tile epilogue record by LDS-DMA)
 M = 32 * 4097
-N, K, kw = {"qkv": (3072, 1024, dict(colscale=0.125, colscale_cols=1024)), "fc1": (4096, 1024, dict(act=ops.ACT_QUICKGELU))}[which]
+N, K, kw = {"qkv": (3072, 1024, dict(colscale=0.125, colscale_cols=1024)), "fc1": (4096, 1024, dict(act=ops.ACT_QUICKGELU)),
+            "proj": (1024, 1024, dict()), "fc2": (1024, 4096, dict())}[which]
 g = torch.Generator(device="cuda").manual_seed(0)
 a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
 w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
 bias = torch.randn(N, device="cuda", generator=g)
-if fold:
+if fold and which in ("proj", "fc2"):         # producer side: x <- x + A W^T + b in place, z and its row statistics
+    xres = torch.randn(M, N, device="cuda", generator=g)
+    kw["z"] = (xres, 1e-6, False, True)
+elif fold:
     stats = torch.stack([torch.rand(M, device="cuda", generator=g) + 0.5, torch.randn(M, device="cuda", generator=g) * 0.1], 1).contiguous()
     kw["ln"] = (stats, torch.randn(N, device="cuda", generator=g))
     if which == "qkv":
