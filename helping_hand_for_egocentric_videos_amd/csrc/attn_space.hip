@@ -821,9 +821,11 @@ __global__ __launch_bounds__(64 * NWV, WPS) void space_attnp_kernel(const bf16_t
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = heads * 64;
     const int N = 1 + T * n;
+    const int rev = layout >> 1;                       // (bit 1, HH_QKV_WALK_REVERSE: the problems last to first)
+    layout &= 1;
     const int64_t ld = layout ? 64 : 3 * (int64_t)D;
     const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
-    int bid = blockIdx.x;
+    int bid = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
     const int head = bid % heads; bid /= heads;
     const int f = bid % T;
     const int b = bid / T;
@@ -995,7 +997,7 @@ extern "C" int hh_space_attn_fwd(const void* qkv, int qkv_layout, void* out, flo
             }
             hh_prof_note_kernel(HH_PROF_SPACE_ATTN, "space_attnp_kernel<3, 12, 3, 36, 12, 24, 24, 16>");
             hipLaunchKernelGGL(kp, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * 12), lds16, (hipStream_t)stream,
-                               (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, heads, qkv_layout);
+                               (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, heads, qkv_layout | walk_rev);
             return hh_check_launch("hh_space_attn_fwd");
         }
         if (!dbg && nqb == 16 && (want == 4 || want == 0) && hh_tuning_space_prog() == 2) {

@@ -472,7 +472,7 @@ extern "C" int hh_time_attn_fwd(const void* qkv, int qkv_layout, void* out, floa
     HHProfScope prof(HH_PROF_TIME_ATTN, 8.0 * B * (1.0 + (double)T * n) * heads * 64, s);
     if (T == 32) {
         hh_prof_note_kernel(HH_PROF_TIME_ATTN, "time_attn_mfma32_kernel");
-        hipLaunchKernelGGL(time_attn_mfma32_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout);
+        hipLaunchKernelGGL(time_attn_mfma32_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout | walk_rev);
         return hh_check_launch("hh_time_attn_fwd(T=32)");
     }
     const unsigned wg = (unsigned)((blocks + 3) / 4);           // one wave per record, four waves per workgroup

@@ -33,7 +33,7 @@ enum hh_act { HH_ACT_NONE = 0, HH_ACT_QUICKGELU = 1, HH_ACT_RELU = 2 };
 enum hh_qkv_layout { HH_QKV_TOKEN_MAJOR = 0, HH_QKV_HEAD_MAJOR = 1 };
 /* OR-ed into the qkv_layout argument of hh_space_attn_fwd / hh_time_attn_fwd (round 5): walk the (clip, ...) problems LAST TO FIRST.  Same
  * results; a kernel that starts on the rows its predecessor wrote last finds them in the 256 MB Infinity Cache (hh_gemm_epilogue.walk_reverse
- * is the GEMM side).  Honoured by the kernels of the benchmarked shapes (n = 256 joint-block space kernel, T <= 16 time kernel); others ignore it. */
+ * is the GEMM side).  Honoured by the joint-block space kernels (n = 256, n = 576) and the MFMA time kernels; the generic 16-query space kernel ignores it. */
 #define HH_QKV_WALK_REVERSE 2
 
 int hh_version(void);

@@ -1268,13 +1268,13 @@ def test_walk_direction_does_not_change_results():
     x1, x2 = x.clone(), x.clone()
     f, r = ops.gemm(a, w, bias, z=(x1, 1e-6, False, True)), ops.gemm(a, w, bias, z=(x2, 1e-6, False, True), reverse=True)
     assert torch.equal(x1, x2) and torch.equal(f[1], r[1]) and torch.equal(f[2], r[2])
-    B, T, n, heads = 3, 16, 256, 4
-    Nn, D = 1 + T * n, heads * 64
-    qkv = bf(rnd(B * Nn, 3 * D, seed=9) * 0.5).to(DEV)
-    planes = qkv.view(B * Nn, 3 * heads, 64).transpose(0, 1).contiguous()
-    for mode in ("space", "time"):
-        for t in (qkv, planes):
-            assert torch.equal(ops.divided_attention(t, B, T, n, heads, mode), ops.divided_attention(t, B, T, n, heads, mode, reverse=True)), mode
+    for B, T, n, heads in ((3, 16, 256, 4), (2, 32, 576, 2), (2, 4, 256, 3)):              # config 2's kernels, config 4's, a small T
+        Nn, D = 1 + T * n, heads * 64
+        qkv = bf(rnd(B * Nn, 3 * D, seed=9) * 0.5).to(DEV)
+        planes = qkv.view(B * Nn, 3 * heads, 64).transpose(0, 1).contiguous()
+        for mode in ("space", "time"):
+            for t in (qkv, planes):
+                assert torch.equal(ops.divided_attention(t, B, T, n, heads, mode), ops.divided_attention(t, B, T, n, heads, mode, reverse=True)), (mode, T, n)
 
 
 def test_round4_entry_points_accept_empty_inputs():
