@@ -918,7 +918,13 @@ __global__ __launch_bounds__(64) void cls_combine_kernel(const float* __restrict
     const int head = blockIdx.x % heads, b = blockIdx.x / heads, d = threadIdx.x;
     const float* rec = partial + ((int64_t)b * heads + head) * G * CLS_REC;
     const float LOG2E = 1.4426950408889634f;
-    // statistics: lane g owns record g (G <= 64 per pass) -> the G dependent scalar loads of a serial loop become one wave max / sum
+    // statistics: lane g owns record g (G <= 64 per pass) -> the G dependent scalar loads of a serial loop become one wave max / sum.
+    // The first 16 records' o columns are requested together with the statistics (they do not depend on them; only their weights do):
+    // one memory round trip instead of two for the space kernel's G = 16 (round 5: 18.9 -> see profiles)
+    constexpr int PRE = 16;
+    float opre[PRE];
+#pragma unroll
+    for (int g = 0; g < PRE; ++g) opre[g] = g < G ? rec[g * CLS_REC + 4 + d] : 0.f;
     float m = -INFINITY;
     for (int g0 = 0; g0 < G; g0 += 64) m = fmaxf(m, wave_max(g0 + d < G ? rec[(g0 + d) * CLS_REC] : -INFINITY));
     float l = 0.f, o = 0.f;
@@ -927,8 +933,14 @@ __global__ __launch_bounds__(64) void cls_combine_kernel(const float* __restrict
         const float e = ok ? __builtin_amdgcn_exp2f((rec[(g0 + d) * CLS_REC] - m) * LOG2E) : 0.f;
         l += wave_sum(ok ? rec[(g0 + d) * CLS_REC + 1] * e : 0.f);
         const int cnt = min(64, G - g0);
+        int g = 0;
+        if (g0 == 0) {
+#pragma unroll
+            for (; g < PRE; ++g)
+                if (g < cnt) o += opre[g] * __shfl(e, g, 64);
+        }
 #pragma unroll 8
-        for (int g = 0; g < cnt; ++g) o += rec[(g0 + g) * CLS_REC + 4 + d] * __shfl(e, g, 64);     // independent coalesced loads
+        for (; g < cnt; ++g) o += rec[(g0 + g) * CLS_REC + 4 + d] * __shfl(e, g, 64);     // independent coalesced loads
     }
     out[(int64_t)b * N * heads * 64 + head * 64 + d] = (bf16_t)(o / l);
 }
