@@ -140,7 +140,15 @@ __global__ __launch_bounds__(256) void ln_fold_stats_kernel(const float* __restr
         if (row >= rows_part) return;
         const f32x2* p = (const f32x2*)partials + row * slices;
         float s = 0.f, q = 0.f;
-        for (int i = 0; i < slices; ++i) { const f32x2 v = p[i]; s += v[0]; q += v[1]; }
+        if (slices == 8) {                          // (N = 1024: the tower's producers) all eight 8-byte slots requested at once -- as four 16-byte loads --
+            f32x4 v[4];                             // and added in the same order as the loop below: one memory round trip instead of eight
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ((const f32x4*)p)[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s += v[i][0]; q += v[i][1]; s += v[i][2]; q += v[i][3]; }
+        } else {
+            for (int i = 0; i < slices; ++i) { const f32x2 v = p[i]; s += v[0]; q += v[1]; }
+        }
         const float inv_cols = 1.f / (float)cols;
         const float mean = s * inv_cols;
         const float rstd = rsqrtf(fmaxf(q * inv_cols - mean * mean, 0.f) + eps);
