@@ -919,9 +919,10 @@ __global__ __launch_bounds__(64) void cls_combine_kernel(const float* __restrict
     const float* rec = partial + ((int64_t)b * heads + head) * G * CLS_REC;
     const float LOG2E = 1.4426950408889634f;
     // statistics: lane g owns record g (G <= 64 per pass) -> the G dependent scalar loads of a serial loop become one wave max / sum.
-    // The first 16 records' o columns are requested together with the statistics (they do not depend on them; only their weights do):
-    // one memory round trip instead of two for the space kernel's G = 16 (round 5: 18.9 -> see profiles)
-    constexpr int PRE = 16;
+    // The first 32 records' o columns are requested together with the statistics (they do not depend on them; only their weights do):
+    // one memory round trip instead of two (round 5: 14.1 -> 8.2 us per launch alone, 18.9 -> 16.6 us in the step, where the records come
+    // from HBM rather than L2)
+    constexpr int PRE = 32;                       // (space: G = T = 16, time: G = n T / 128 = 32 at the headline shape)
     float opre[PRE];
 #pragma unroll
     for (int g = 0; g < PRE; ++g) opre[g] = g < G ? rec[g * CLS_REC + 4 + d] : 0.f;
