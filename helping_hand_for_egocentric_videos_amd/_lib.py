@@ -16,7 +16,7 @@ class GemmEpilogue(ctypes.Structure):
                 ("act", c_int), ("c_dtype", c_int), ("remap_group", c_i64), ("remap_skip", c_i64),
                 ("remap_offset", c_i64), ("splitk", c_int), ("split_stride", c_i64), ("c_block_stride", c_i64),
                 ("ln_stats", c_vp), ("ln_colsum", c_vp), ("z_resid", c_vp), ("z_ldr", c_i64), ("z_out", c_vp), ("z_ldc", c_i64),
-                ("z_stats", c_vp), ("z_partials", c_vp), ("z_eps", c_float), ("skip_c", c_int), ("z_update", c_int), ("z_resid_dtype", c_int), ("walk_reverse", c_int)]
+                ("z_stats", c_vp), ("z_partials", c_vp), ("z_eps", c_float), ("skip_c", c_int), ("z_update", c_int), ("z_resid_dtype", c_int), ("z_resid_lo", c_vp), ("walk_reverse", c_int)]
 
 
 class QGemmOpts(ctypes.Structure):
@@ -65,8 +65,8 @@ SIGNATURES = {
     "hh_transpose_to_bf16": [c_vp, c_int, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp],
     "hh_patch_im2col": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp],
     "hh_patch_im2col_u8": [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_vp],
-    "hh_embed_ln_pre": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, c_vp, c_vp, c_float, c_vp],
-    "hh_layernorm_split_cls_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_float, c_vp],
+    "hh_embed_ln_pre": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_float, c_vp, c_vp, c_float, c_vp, c_vp],
+    "hh_layernorm_split_cls_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_int, c_float, c_vp, c_vp],
     "hh_space_attn_fwd": [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "hh_time_attn_fwd": [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "hh_cls_combine": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp],

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
                                                        const float* __restrict__ pos, const float* __restrict__ temporal,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ x, int B, int T, int n, int D, float eps,
-                                                       bf16_t* __restrict__ z, float* __restrict__ zstats, float z_eps) {
+                                                       bf16_t* __restrict__ z, float* __restrict__ zstats, float z_eps, bf16_t* __restrict__ z_lo) {
     const int lane = threadIdx.x & 63;
     const int64_t N = 1 + (int64_t)T * n;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -140,10 +140,14 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
         f32x4 g = *(const f32x4*)(gamma + c), bb = *(const f32x4*)(beta + c), o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + bb[j];
-        *(f32x4*)(x + row * D + c) = o;
+        if (x != nullptr) *(f32x4*)(x + row * D + c) = o;
         if (z != nullptr) {                       // (kept for the second pass below: the bf16 rounding of the row the first block's fold multiplies)
             const u32x2 zz = {pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3])};
             *(u32x2*)(z + row * D + c) = zz;
+            if (z_lo != nullptr) {                // bf16 pair stream: x = z + z_lo
+                const u32x2 ll = {pack_bf16(o[0] - bf16_lo_to_f32(zz[0]), o[1] - bf16_hi_to_f32(zz[0])), pack_bf16(o[2] - bf16_lo_to_f32(zz[1]), o[3] - bf16_hi_to_f32(zz[1]))};
+                *(u32x2*)(z_lo + row * D + c) = ll;
+            }
             v[i][0] = bf16_lo_to_f32(zz[0]); v[i][1] = bf16_hi_to_f32(zz[0]); v[i][2] = bf16_lo_to_f32(zz[1]); v[i][3] = bf16_hi_to_f32(zz[1]);
         }
     }
@@ -203,20 +207,22 @@ extern "C" int hh_patch_im2col_u8(const uint8_t* video, void* patches, int64_t f
 
 extern "C" int hh_embed_ln_pre(const float* tok, const float* cls, const float* pos, const float* temporal,
                                const float* gamma, const float* beta, float* x, int B, int T, int n, int D, float eps,
-                               void* z_out, float* z_stats, float z_eps, hh_stream_t stream) {
+                               void* z_out, float* z_stats, float z_eps, void* z_lo, hh_stream_t stream) {
+    HH_REQUIRE(z_lo == nullptr || (z_out != nullptr && HH_ALIGNED16(z_lo)), HH_ERR_SHAPE, "hh_embed_ln_pre: z_lo (bf16 pair stream) comes with z_out");
+    HH_REQUIRE(x != nullptr || z_lo != nullptr, HH_ERR_SHAPE, "hh_embed_ln_pre: x may be NULL only with the bf16 pair outputs (z_out, z_lo)");
     HH_REQUIRE((z_out == nullptr) == (z_stats == nullptr) && (z_out == nullptr || (HH_ALIGNED16(z_out) && (((uintptr_t)z_stats) & 7) == 0 && z_eps > 0.f)), HH_ERR_SHAPE,
                "hh_embed_ln_pre: z_out and z_stats come together (16- / 8-byte aligned, z_eps > 0)");
     HH_REQUIRE(B >= 0 && T > 0 && n > 0 && D > 0 && D % 8 == 0 && D <= 2048, HH_ERR_SHAPE, "hh_embed_ln_pre: D=%d must be a multiple of 8, <= 2048", D);
     HH_REQUIRE(HH_ALIGNED16(tok) && HH_ALIGNED16(cls) && HH_ALIGNED16(pos) && HH_ALIGNED16(temporal) && HH_ALIGNED16(gamma) &&
-               HH_ALIGNED16(beta) && HH_ALIGNED16(x), HH_ERR_ALIGN, "hh_embed_ln_pre: pointers must be 16-byte aligned");
+               HH_ALIGNED16(beta) && (x == nullptr || HH_ALIGNED16(x)), HH_ERR_ALIGN, "hh_embed_ln_pre: pointers must be 16-byte aligned");
     if (B == 0) return HH_OK;
     const int64_t rows = (int64_t)B * (1 + (int64_t)T * n);
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int nv = (D + 255) / 256;
-    if (nv <= 1) hipLaunchKernelGGL(embed_ln_kernel<1>, grid, block, 0, s, tok, cls, pos, temporal, gamma, beta, x, B, T, n, D, eps, (bf16_t*)z_out, z_stats, z_eps);
-    else if (nv <= 2) hipLaunchKernelGGL(embed_ln_kernel<2>, grid, block, 0, s, tok, cls, pos, temporal, gamma, beta, x, B, T, n, D, eps, (bf16_t*)z_out, z_stats, z_eps);
-    else if (nv <= 4) hipLaunchKernelGGL(embed_ln_kernel<4>, grid, block, 0, s, tok, cls, pos, temporal, gamma, beta, x, B, T, n, D, eps, (bf16_t*)z_out, z_stats, z_eps);
-    else hipLaunchKernelGGL(embed_ln_kernel<8>, grid, block, 0, s, tok, cls, pos, temporal, gamma, beta, x, B, T, n, D, eps, (bf16_t*)z_out, z_stats, z_eps);
+    if (nv <= 1) hipLaunchKernelGGL(embed_ln_kernel<1>, grid, block, 0, s, tok, cls, pos, temporal, gamma, beta, x, B, T, n, D, eps, (bf16_t*)z_out, z_stats, z_eps, (bf16_t*)z_lo);
+    else if (nv <= 2) hipLaunchKernelGGL(embed_ln_kernel<2>, grid, block, 0, s, tok, cls, pos, temporal, gamma, beta, x, B, T, n, D, eps, (bf16_t*)z_out, z_stats, z_eps, (bf16_t*)z_lo);
+    else if (nv <= 4) hipLaunchKernelGGL(embed_ln_kernel<4>, grid, block, 0, s, tok, cls, pos, temporal, gamma, beta, x, B, T, n, D, eps, (bf16_t*)z_out, z_stats, z_eps, (bf16_t*)z_lo);
+    else hipLaunchKernelGGL(embed_ln_kernel<8>, grid, block, 0, s, tok, cls, pos, temporal, gamma, beta, x, B, T, n, D, eps, (bf16_t*)z_out, z_stats, z_eps, (bf16_t*)z_lo);
     return hh_check_launch("hh_embed_ln_pre");
 }

@@ -268,6 +268,11 @@ static int gemm_bf16_impl(const void* A, int64_t lda, const void* W, int64_t ldw
             HH_REQUIRE(epi->z_resid != nullptr && epi->z_stats != nullptr && epi->act == HH_ACT_NONE && epi->colscale_cols == 0 && !cblk &&
                        epi->ln_stats == nullptr && epi->c_dtype == HH_BF16, HH_ERR_UNSUPPORTED,
                        "hh_gemm_bf16: z_out needs z_resid and z_stats, a bf16 row-major C, and no activation / column scale / ln_stats");
+            if (epi->z_resid_lo != nullptr)
+                HH_REQUIRE(epi->z_resid_dtype == HH_BF16 && epi->z_update != 0 && epi->z_out == epi->z_resid && epi->z_ldr == epi->z_ldc && epi->skip_c != 0 &&
+                           HH_ALIGNED16(epi->z_resid_lo), HH_ERR_UNSUPPORTED,
+                           "hh_gemm_bf16: z_resid_lo (bf16 pair stream) needs z_resid_dtype = HH_BF16, z_update, skip_c, z_out == z_resid and z_ldr == z_ldc");
+            else
             HH_REQUIRE((epi->z_resid_dtype == HH_F32 || (epi->z_resid_dtype == HH_BF16 && epi->z_update == 0 && epi->z_ldr % 8 == 0)), HH_ERR_UNSUPPORTED,
                        "hh_gemm_bf16: z_resid_dtype must be HH_F32, or HH_BF16 without z_update (z_ldr %% 8 == 0)");
             HH_REQUIRE(epi->z_ldr >= N && epi->z_ldc >= N && epi->z_ldr % 4 == 0 && epi->z_ldc % 8 == 0 && N <= 2048 && HH_ALIGNED16(epi->z_resid) &&

@@ -709,9 +709,9 @@ int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
                 const int slot = g_dynamic ? hh_stream_slot(s) : -1;
                 p.dynamic = slot >= 0;
                 p.tile_slot = slot >= 0 ? slot : 0;      // (N: bias vector + epilogue scratch share the 32 KB of LDS the ring leaves)
-                static const char* const w4p_names[16] = {"gemm256w4p_kernel<false, 0, 256>", "gemm256w4p_kernel<true, 0, 256>", "gemm256w4p_kernel<false, 1, 256>", "gemm256w4p_kernel<true, 1, 256>",
+                static const char* const w4p_names[18] = {"gemm256w4p_kernel<false, 0, 256>", "gemm256w4p_kernel<true, 0, 256>", "gemm256w4p_kernel<false, 1, 256>", "gemm256w4p_kernel<true, 1, 256>",
                                                           "gemm256w4p_kernel<false, 2, 256>", "gemm256w4p_kernel<true, 2, 256>", "gemm256w4p_kernel<false, 3, 256>", "gemm256w4p_kernel<true, 3, 256>",
-                                                          "", "gemm256w4p_kernel<true, 4, 256>", "", "gemm256w4p_kernel<true, 5, 256>", "", "gemm256w4p_kernel<true, 6, 256>", "", "gemm256w4p_kernel<true, 7, 256>"};
+                                                          "", "gemm256w4p_kernel<true, 4, 256>", "", "gemm256w4p_kernel<true, 5, 256>", "", "gemm256w4p_kernel<true, 6, 256>", "", "gemm256w4p_kernel<true, 7, 256>", "", "gemm256w4p_kernel<true, 8, 256>"};
                 hh_prof_note_kernel(HH_PROF_GEMM256, p.tile_rows == 224 ? (epi == 4 ? "gemm256w4p_kernel<true, 4, 224>" : "gemm256w4p_kernel<true, 0, 224>") : w4p_names[epi * 2 + (bf ? 1 : 0)]);
                 int rc = hh_gemm256w4p_launch(p, epi, pg, s);
                 if (tail_done) *tail_done = p.tail_rows > 0;

@@ -538,12 +538,18 @@ __device__ __forceinline__ void w4p_store_rows_direct(const GemmParams& p, int64
 // z_partials[row][n0 / 128 + wc]; gemm.hip's finalize pass adds the N / 128 slices in a fixed order.
 // RB (round 5, EPI 7): the residual rows are bf16 (the z = bf16(x) this block's norm3 consumed; the time branch's z1 only feeds norm1): ONE
 // 16-byte load per 8 columns instead of two -- kept raw in xa[j] (bit pattern), widened where the group is consumed; xb is unused.
-template <int IDX, int TR = 256, bool RB = false>
-__device__ __forceinline__ void w4p_zload(const float* xw0, unsigned xlo, f32x4 (&xa)[4], f32x4 (&xb)[4], int64_t ldx) {
-    if constexpr (RB) {
+// RM: residual mode -- 0 = fp32 rows, 1 = bf16 rows (EPI 7), 2 = bf16 PAIR hi + lo (EPI 8: xa = 16 raw bytes of hi, xb = 16 raw bytes of lo)
+template <int IDX, int TR = 256, int RM = 0>
+__device__ __forceinline__ void w4p_zload(const float* xw0, const bf16_t* xl0, unsigned xlo, f32x4 (&xa)[4], f32x4 (&xb)[4], int64_t ldx) {
+    if constexpr (RM != 0) {
         const bf16_t* r = (const bf16_t*)xw0 + (int64_t)w4_rowoff<TR>(IDX) * ldx + xlo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) xa[j] = W4_LDX((const f32x4*)(r + (j & 1) * 32 + (j >> 1) * 64));      // 8 bf16 = 16 bytes, not yet widened
+        if constexpr (RM == 2) {
+            const bf16_t* q = xl0 + (int64_t)w4_rowoff<TR>(IDX) * ldx + xlo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xb[j] = W4_LDX((const f32x4*)(q + (j & 1) * 32 + (j >> 1) * 64));
+        }
     } else {
         const float* r = xw0 + (int64_t)w4_rowoff<TR>(IDX) * ldx + xlo;       // (wave-uniform base + the lane's 32-bit offset: see the write-back below)
 #pragma unroll
@@ -562,10 +568,11 @@ __device__ __forceinline__ void w4p_lds_rows(char* scr, int frow, int fq, int l1
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int r = 4 * q + l4; rd[q] = *(const u32x4*)(scr + r * 256 + ((l15 ^ r) << 4)); }
 }
-template <int IDX, int TR = 256, bool RB = false>
+template <int IDX, int TR = 256, int RM = 0>
 __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw0, bf16_t* zw0, float* part0, char* scr,
-                                                 int frow, int fq, int l15, int l4, const float* bias_l, float* xw0, unsigned xoff, unsigned xlo, unsigned coff,
+                                                 int frow, int fq, int l15, int l4, const float* bias_l, float* xw0, bf16_t* xl0, unsigned xoff, unsigned xlo, unsigned coff,
                                                  unsigned zoff, f32x4 (&xa)[4], f32x4 (&xb)[4], f32x4 (&xna)[4], f32x4 (&xnb)[4]) {
+    constexpr bool RB = RM != 0;
     // cw0 / zw0 / xw0 / part0: wave-uniform pointers to (first row of the wave's 64, its first column) of C / z / the residual / the
     // statistics slot; coff / zoff / xoff (store phase: row l4, 16-B piece l15) and xlo (MFMA layout: row frow, columns 8 fq) are the
     // lane's 32-bit element offsets -- four registers instead of four 64-bit per-lane pointers (the kernel sits at the 256-register limit)
@@ -594,11 +601,16 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw
             const u32x4 r = __builtin_bit_cast(u32x4, xa[j]);
             a[j] += (f32x4){bf16_lo_to_f32(r[0]), bf16_hi_to_f32(r[0]), bf16_lo_to_f32(r[1]), bf16_hi_to_f32(r[1])};
             b[j] += (f32x4){bf16_lo_to_f32(r[2]), bf16_hi_to_f32(r[2]), bf16_lo_to_f32(r[3]), bf16_hi_to_f32(r[3])};
+            if constexpr (RM == 2) {                       // the low halves of the pair stream
+                const u32x4 q = __builtin_bit_cast(u32x4, xb[j]);
+                a[j] += (f32x4){bf16_lo_to_f32(q[0]), bf16_hi_to_f32(q[0]), bf16_lo_to_f32(q[1]), bf16_hi_to_f32(q[1])};
+                b[j] += (f32x4){bf16_lo_to_f32(q[2]), bf16_hi_to_f32(q[2]), bf16_lo_to_f32(q[3]), bf16_hi_to_f32(q[3])};
+            }
         } else { a[j] += xa[j]; b[j] += xb[j]; }
         s4 += a[j]; s4 += b[j];
         q4 += a[j] * a[j]; q4 += b[j] * b[j];
     }
-    if constexpr (IDX + 2 < w4_groups<TR>()) w4p_zload<IDX + 2, TR, RB>(xw0, xlo, xa, xb, p.e.z_ldr);      // (xa / xb are consumed: re-targeted right away)
+    if constexpr (IDX + 2 < w4_groups<TR>()) w4p_zload<IDX + 2, TR, RM>(xw0, xl0, xlo, xa, xb, p.e.z_ldr);      // (xa / xb are consumed: re-targeted right away)
     if (!RB && p.e.z_update) {
         // x <- x + branch in place (the rows this lane loaded xa / xb from).  Straight from the MFMA layout a store instruction would
         // cover 16 rows x 4 pieces of 16 B at a 32-B stride (measured: fc2 + 228 us per launch, most of it these 64 stores per tile);
@@ -630,7 +642,20 @@ __device__ __forceinline__ void w4p_store_tile_z(const GemmParams& p, bf16_t* cw
     bf16_t* zw = zw0 + (int64_t)w4_rowoff<TR>(IDX) * p.e.z_ldc;
 #pragma unroll
     for (int q = 0; q < 4; ++q) W4_ST((u32x4*)(zw + (int64_t)(4 * q) * p.e.z_ldc + zoff), rd[q]);
-    if constexpr (IDX + 1 < w4_groups<TR>()) w4p_store_tile_z<IDX + 1, TR, RB>(p, cw0, zw0, part0, scr, frow, fq, l15, l4, bias_l, xw0, xoff, xlo, coff, zoff, xna, xnb, xa, xb);
+    if constexpr (RM == 2) {
+        // pair stream: lo' = bf16(x' - hi'), same route (z_ldr == z_ldc: the two halves have one geometry); a / b become the remainders in place
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned h0 = pack_bf16(a[j][0], a[j][1]), h1 = pack_bf16(a[j][2], a[j][3]), h2 = pack_bf16(b[j][0], b[j][1]), h3 = pack_bf16(b[j][2], b[j][3]);
+            a[j] -= (f32x4){bf16_lo_to_f32(h0), bf16_hi_to_f32(h0), bf16_lo_to_f32(h1), bf16_hi_to_f32(h1)};
+            b[j] -= (f32x4){bf16_lo_to_f32(h2), bf16_hi_to_f32(h2), bf16_lo_to_f32(h3), bf16_hi_to_f32(h3)};
+        }
+        w4p_lds_rows(scr, frow, fq, l15, l4, a, b, rd);
+        bf16_t* lw = xl0 + (int64_t)w4_rowoff<TR>(IDX) * p.e.z_ldc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) W4_ST((u32x4*)(lw + (int64_t)(4 * q) * p.e.z_ldc + zoff), rd[q]);
+    }
+    if constexpr (IDX + 1 < w4_groups<TR>()) w4p_store_tile_z<IDX + 1, TR, RM>(p, cw0, zw0, part0, scr, frow, fq, l15, l4, bias_l, xw0, xl0, xoff, xlo, coff, zoff, xna, xnb, xa, xb);
 }
 
 // Dynamic tile walk: per stream slot (runtime.cpp: hh_stream_slot) 8 per-XCD tile counters + the count of finished workgroups; the last
@@ -648,9 +673,10 @@ __device__ unsigned g_w4_tile_cnt[32][16];
 template <bool OUT_BF16, int EPI, int TR = 256>
 __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
     static_assert(TR == 256 || (TR == 224 && OUT_BF16 && (EPI == 0 || EPI == 4)), "224-row tiles: bf16 bias-only and LayerNorm-fold producer epilogues");
-    constexpr bool PRODUCER = EPI == 4 || EPI == 7;          // LayerNorm fold, producer side; 7 = with bf16 residual rows (z_resid_dtype HH_BF16)
+    constexpr bool PRODUCER = EPI == 4 || EPI == 7 || EPI == 8;          // LayerNorm fold, producer side; 7 = bf16 residual rows (z_resid_dtype HH_BF16), 8 = bf16 pair stream (z_resid_lo)
     constexpr bool CONSUMER = EPI == 5 || EPI == 6;
-    constexpr bool RB = EPI == 7;
+    constexpr bool RB = EPI == 7 || EPI == 8;
+    constexpr int RM = EPI == 8 ? 2 : EPI == 7 ? 1 : 0;
     constexpr int WROWS = TR == 224 ? 112 : 64;              // tile row of wave row 1's first A-lo row
     // global_store_dwordx4 per wave and tile in the epilogue that are younger than every load of it (checked in the ISA); the producer
     // side of the LayerNorm fold (EPI 4) waits for its residual loads group by group: only the last group's z stores are certain to trail
@@ -891,9 +917,10 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
                 const unsigned coff = l4u * (unsigned)p.ldc + 8u * l15u, zoff = l4u * (unsigned)e.z_ldc + 8u * l15u;      // store phase, bf16 rows
                 const unsigned xlo = l15u * (unsigned)e.z_ldr + 8u * l4u;                     // MFMA layout: row frow = lane & 15, columns 8 fq
                 f32x4 xa[4], xb[4], xna[4], xnb[4];
-                w4p_zload<0, TR, RB>(xw0, xlo, xa, xb, e.z_ldr);
-                w4p_zload<1, TR, RB>(xw0, xlo, xna, xnb, e.z_ldr);
-                w4p_store_tile_z<0, TR, RB>(p, cw0, zw0, part0, scr, frow_, fq_, l15, l4, bias_z, xw0, xoff, xlo, coff, zoff, xa, xb, xna, xnb);
+                bf16_t* xl0 = RM == 2 ? (bf16_t*)e.z_resid_lo + row0 * e.z_ldr + col0 : nullptr;
+                w4p_zload<0, TR, RM>(xw0, xl0, xlo, xa, xb, e.z_ldr);
+                w4p_zload<1, TR, RM>(xw0, xl0, xlo, xna, xnb, e.z_ldr);
+                w4p_store_tile_z<0, TR, RM>(p, cw0, zw0, part0, scr, frow_, fq_, l15, l4, bias_z, xw0, xl0, xoff, xlo, coff, zoff, xa, xb, xna, xnb);
             } else if constexpr (OUT_BF16 && EPI != 2 && EPI != 6) {
                 // through this wave's 4 KB of LDS: a lane finishes 4 x 16 B of one row (MFMA layout), the wave then stores 4 rows x 256 B
                 // per instruction.  A store instruction covering 16 rows x 64 B takes ~270 cycles on the CU's store path, 4 rows x 256 B
@@ -926,7 +953,7 @@ static int g_w4_ln_ext = 1;         // hh_set_tuning("gemm_ln_w4", 0): keep Laye
 void hh_gemm256w4p_set_ln_ext(int v) { g_w4_ln_ext = v; }
 int hh_gemm256w4p_ln_epi(const hh_gemm_epilogue& e) {
     if (e.c_dtype != HH_BF16) return -1;
-    if (e.z_out) return (e.ln_stats == nullptr && e.act == HH_ACT_NONE && e.colscale_cols == 0 && e.c_block_stride == 0) ? (e.z_resid_dtype == HH_BF16 ? 7 : 4) : -1;
+    if (e.z_out) return (e.ln_stats == nullptr && e.act == HH_ACT_NONE && e.colscale_cols == 0 && e.c_block_stride == 0) ? (e.z_resid_lo ? 8 : e.z_resid_dtype == HH_BF16 ? 7 : 4) : -1;
     if (e.ln_stats) {                        // (callers check N >= 2048: the two epilogue records live where the N-float bias vector is)
         if (e.act == HH_ACT_NONE && e.colscale_cols > 0 && e.colscale_cols % 128 == 0) return 5;
         if (e.act == HH_ACT_QUICKGELU && e.colscale_cols == 0) return 6;
@@ -952,7 +979,7 @@ int hh_gemm256w4p_launch(const GemmParams& p, int epi, unsigned pg, hipStream_t 
     if (!attr_done) {
 #define ATTRP(BF, E) hipFuncSetAttribute((const void*)gemm256w4p_kernel<BF, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096))
         ATTRP(true, 0); ATTRP(false, 0); ATTRP(true, 1); ATTRP(false, 1); ATTRP(true, 2); ATTRP(false, 2); ATTRP(true, 3); ATTRP(false, 3);
-        ATTRP(true, 4); ATTRP(true, 5); ATTRP(true, 6); ATTRP(true, 7);
+        ATTRP(true, 4); ATTRP(true, 5); ATTRP(true, 6); ATTRP(true, 7); ATTRP(true, 8);
 #undef ATTRP
         hipFuncSetAttribute((const void*)gemm256w4p_kernel<true, 0, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096));
         hipFuncSetAttribute((const void*)gemm256w4p_kernel<true, 4, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096));
@@ -969,7 +996,7 @@ int hh_gemm256w4p_launch(const GemmParams& p, int epi, unsigned pg, hipStream_t 
     }
     if (epi >= 4) {
         if (!bf) { hh_set_error("hh_gemm_bf16: the LayerNorm-fold epilogues of the persistent kernel write bf16"); return HH_ERR_UNSUPPORTED; }
-        if (epi == 4) LAUNCHP(true, 4); else if (epi == 5) LAUNCHP(true, 5); else if (epi == 6) LAUNCHP(true, 6); else LAUNCHP(true, 7);
+        if (epi == 4) LAUNCHP(true, 4); else if (epi == 5) LAUNCHP(true, 5); else if (epi == 6) LAUNCHP(true, 6); else if (epi == 7) LAUNCHP(true, 7); else LAUNCHP(true, 8);
         g_w4_ts_last = true;
         return hh_check_launch("hh_gemm_bf16(256x256 persistent, 4 waves, LayerNorm fold)");
     }

@@ -58,6 +58,17 @@ __device__ __forceinline__ void gemm_store4(const hh_gemm_epilogue& e, char* Cba
     if (e.resid) v += *(const f32x4*)(e.resid + orow * e.ldr + n);
     if (e.z_out) {
         f32x4 z;
+        if (e.z_resid_lo) {                           // bf16 pair stream: x = hi + lo, both halves updated in place; hi' is the z of the next LayerNorm
+            const u32x2 r = *(const u32x2*)((const bf16_t*)e.z_resid + orow * e.z_ldr + n);
+            const u32x2 q = *(const u32x2*)((const bf16_t*)e.z_resid_lo + orow * e.z_ldr + n);
+            z = (f32x4){bf16_lo_to_f32(r[0]) + bf16_lo_to_f32(q[0]), bf16_hi_to_f32(r[0]) + bf16_hi_to_f32(q[0]),
+                        bf16_lo_to_f32(r[1]) + bf16_lo_to_f32(q[1]), bf16_hi_to_f32(r[1]) + bf16_hi_to_f32(q[1])} + v;
+            const u32x2 h = {pack_bf16(z[0], z[1]), pack_bf16(z[2], z[3])};
+            const u32x2 l = {pack_bf16(z[0] - bf16_lo_to_f32(h[0]), z[1] - bf16_hi_to_f32(h[0])), pack_bf16(z[2] - bf16_lo_to_f32(h[1]), z[3] - bf16_hi_to_f32(h[1]))};
+            *(u32x2*)((bf16_t*)e.z_resid + orow * e.z_ldr + n) = h;
+            *(u32x2*)((bf16_t*)e.z_resid_lo + orow * e.z_ldr + n) = l;
+            return;
+        }
         if (e.z_resid_dtype == HH_BF16) {
             const u32x2 r = *(const u32x2*)((const bf16_t*)e.z_resid + orow * e.z_ldr + n);
             z = (f32x4){bf16_lo_to_f32(r[0]), bf16_hi_to_f32(r[0]), bf16_lo_to_f32(r[1]), bf16_hi_to_f32(r[1])} + v;

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      int64_t rows, int cols, float eps,
                                                      TOUT* __restrict__ y2, const float* __restrict__ pos, int pos_rows,
-                                                     TOUT* __restrict__ y_cls = nullptr, int split_n = 0) {
+                                                     TOUT* __restrict__ y_cls = nullptr, int split_n = 0, const bf16_t* __restrict__ x_lo = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -44,6 +44,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIN* __restrict__ x, 
     }
     float v[NV][4];
     load_row<NV, TIN>(x + row * cols, cols, lane, v);
+    if (x_lo != nullptr) {                         // bf16 pair stream (hh_layernorm_split_cls_fwd): the row is x + x_lo
+        float w[NV][4];
+        load_row<NV, bf16_t>(x_lo + row * cols, cols, lane, w);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] += w[i][j];
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -328,16 +336,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIN* __restrict__ x, 
 template <int NV>
 static int ln_fwd_dispatch(const void* x, int xd, const float* g, const float* b, void* y, int yd, float* mo, float* ro,
                            int64_t rows, int cols, float eps, hipStream_t s, void* y2 = nullptr, const float* pos = nullptr, int pos_rows = 1,
-                           void* y_cls = nullptr, int split_n = 0) {
+                           void* y_cls = nullptr, int split_n = 0, const void* x_lo = nullptr) {
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if (xd == HH_F32 && yd == HH_BF16)
         hipLaunchKernelGGL((ln_fwd_kernel<NV, float, bf16_t>), grid, block, 0, s, (const float*)x, g, b, (bf16_t*)y, mo, ro, rows, cols, eps, (bf16_t*)y2, pos, pos_rows, (bf16_t*)y_cls, split_n);
     else if (xd == HH_F32 && yd == HH_F32)
         hipLaunchKernelGGL((ln_fwd_kernel<NV, float, float>), grid, block, 0, s, (const float*)x, g, b, (float*)y, mo, ro, rows, cols, eps, (float*)y2, pos, pos_rows, (float*)y_cls, split_n);
     else if (xd == HH_BF16 && yd == HH_BF16)
-        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, g, b, (bf16_t*)y, mo, ro, rows, cols, eps, (bf16_t*)y2, pos, pos_rows, (bf16_t*)y_cls, split_n);
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)x, g, b, (bf16_t*)y, mo, ro, rows, cols, eps, (bf16_t*)y2, pos, pos_rows, (bf16_t*)y_cls, split_n, (const bf16_t*)x_lo);
     else
-        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, float>), grid, block, 0, s, (const bf16_t*)x, g, b, (float*)y, mo, ro, rows, cols, eps, (float*)y2, pos, pos_rows, (float*)y_cls, split_n);
+        hipLaunchKernelGGL((ln_fwd_kernel<NV, bf16_t, float>), grid, block, 0, s, (const bf16_t*)x, g, b, (float*)y, mo, ro, rows, cols, eps, (float*)y2, pos, pos_rows, (float*)y_cls, split_n, (const bf16_t*)x_lo);
     return hh_check_launch("hh_layernorm_fwd");
 }
 
@@ -356,7 +364,8 @@ extern "C" int hh_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
 }
 
 extern "C" int hh_layernorm_split_cls_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y_patches, void* y_cls, int y_dtype,
-                                          int64_t clips, int tokens_per_clip, int cols, float eps, hh_stream_t stream) {
+                                          int64_t clips, int tokens_per_clip, int cols, float eps, const void* x_lo, hh_stream_t stream) {
+    HH_REQUIRE(x_lo == nullptr || (x_dtype == HH_BF16 && HH_ALIGNED16(x_lo)), HH_ERR_DTYPE, "hh_layernorm_split_cls_fwd: x_lo (bf16 pair stream) needs x_dtype = HH_BF16");
     HH_REQUIRE(clips >= 0 && tokens_per_clip >= 2 && cols > 0 && cols % 8 == 0 && cols <= 2048, HH_ERR_SHAPE,
                "hh_layernorm_split_cls_fwd: cols=%d must be a multiple of 8 and <= 2048, tokens_per_clip >= 2", cols);
     HH_REQUIRE((x_dtype == HH_F32 || x_dtype == HH_BF16) && (y_dtype == HH_F32 || y_dtype == HH_BF16), HH_ERR_DTYPE, "hh_layernorm_split_cls_fwd: bad dtype");
@@ -366,9 +375,9 @@ extern "C" int hh_layernorm_split_cls_fwd(const void* x, int x_dtype, const floa
     hipStream_t s = (hipStream_t)stream;
     const int64_t rows = clips * tokens_per_clip;
     const int nv = (cols + 255) / 256;
-    if (nv <= 2) return ln_fwd_dispatch<2>(x, x_dtype, gamma, beta, y_patches, y_dtype, nullptr, nullptr, rows, cols, eps, s, nullptr, nullptr, 1, y_cls, tokens_per_clip);
-    if (nv <= 4) return ln_fwd_dispatch<4>(x, x_dtype, gamma, beta, y_patches, y_dtype, nullptr, nullptr, rows, cols, eps, s, nullptr, nullptr, 1, y_cls, tokens_per_clip);
-    return ln_fwd_dispatch<8>(x, x_dtype, gamma, beta, y_patches, y_dtype, nullptr, nullptr, rows, cols, eps, s, nullptr, nullptr, 1, y_cls, tokens_per_clip);
+    if (nv <= 2) return ln_fwd_dispatch<2>(x, x_dtype, gamma, beta, y_patches, y_dtype, nullptr, nullptr, rows, cols, eps, s, nullptr, nullptr, 1, y_cls, tokens_per_clip, x_lo);
+    if (nv <= 4) return ln_fwd_dispatch<4>(x, x_dtype, gamma, beta, y_patches, y_dtype, nullptr, nullptr, rows, cols, eps, s, nullptr, nullptr, 1, y_cls, tokens_per_clip, x_lo);
+    return ln_fwd_dispatch<8>(x, x_dtype, gamma, beta, y_patches, y_dtype, nullptr, nullptr, rows, cols, eps, s, nullptr, nullptr, 1, y_cls, tokens_per_clip, x_lo);
 }
 
 extern "C" int hh_layernorm_pos_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, void* y_plus_pos, int y_dtype,

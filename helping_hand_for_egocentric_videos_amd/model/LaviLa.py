@@ -100,6 +100,9 @@ LN_FOLD = True
 TIME_PROJ_READS_Z3 = True          # False: the time projection's epilogue reads the fp32 residual rows (round 4; A/B measurements)
 # every large kernel of a tower block walks its rows opposite to its predecessor (SpaceTimeBlock.fused); False: all first to last (rounds 1-4)
 WALK_ALTERNATE = True
+# the residual stream as a PAIR of bf16 tensors x = hi + lo (hi is the z every LayerNorm-fold consumer reads; hh_gemm_epilogue.z_resid_lo):
+# the branch-ending GEMMs move 8 instead of 10 bytes per element.  False: fp32 stream + separate z (rounds 4-5)
+STREAM_PAIR = True
 
 
 class VarAttention(nn.Module):
@@ -213,6 +216,20 @@ class SpaceTimeBlock(nn.Module):
         LN_FOLD False: the fused add+LayerNorm kernels; `pending` / the result are then the (space branch, MLP branch) bf16 outputs
         that the next add+LayerNorm adds to x (x = (x + space) + mlp written once per block)."""
         pk = self.packed()
+        if "qkv_n1" in pk and isinstance(x, tuple):
+            # bf16 pair stream (STREAM_PAIR): x = (hi, lo); hi is z3 on entry, z2 after the space projection, the next block's z3 after fc2
+            xh, xl = x
+            eps3, eps1, eps2 = pk["n3"][2], pk["n1"][2], pk["n2"][2]
+            _, st3 = pending
+            alt = WALK_ALTERNATE
+            a = self.timeattn.core(xh, pk["time"], B, T, n, "time", ln=(st3, pk["qkv_n3"]), rev_gemm=False, rev_attn=alt)
+            _, z1, st1 = ops.gemm(a, pk["time"]["wproj"], pk["time"]["bproj"], z=(xh, eps1, False))             # z1 = bf16(hi + t): feeds norm1 only
+            a = self.attn.core(z1, pk["space"], B, T, n, "space", ln=(st1, pk["qkv_n1"]), rev_gemm=alt, rev_attn=False)
+            _, _, st2 = ops.gemm(a, pk["space"]["wproj"], pk["space"]["bproj"], zpair=(xh, xl, eps2), reverse=alt)     # x <- x + s; hi = z2
+            wf, cs, bf = pk["fc1_n2"]
+            h = ops.gemm(xh, wf, bf, act=ops.ACT_QUICKGELU, ln=(st2, cs))
+            _, _, st3n = ops.gemm(h, pk["w2"], pk["b2"], zpair=(xh, xl, eps3), reverse=alt)                      # x <- x + m; hi = next z3
+            return xh, st3n
         if "qkv_n1" in pk:
             eps3, eps1, eps2 = pk["n3"][2], pk["n1"][2], pk["n2"][2]
             if pending is None:
@@ -354,6 +371,20 @@ class SpaceTimeTransformer(nn.Module):
         tok = ops.gemm(patches, pk["wpatch"], out_dtype=torch.float32)
         fold = bool(LN_FOLD) and len(self.blocks) > 0
         pending = None
+        if fold and STREAM_PAIR and "qkv_n1" in self.blocks[0].packed():
+            # bf16 pair stream x = hi + lo (hh_gemm_epilogue.z_resid_lo): hi = bf16(x) is block 0's norm3 input and every later LayerNorm input, the
+            # branch-ending GEMMs update both halves in place, the final norm reads their sum -- no fp32 copy of the stream exists
+            xh, xl, st0 = ops.embed_ln_pre(tok, pk["cls"], pk["pos"], pk["tmp"], *pk["ln_pre"][:2], B, T, n, pk["ln_pre"][2], z_eps=self.blocks[0].norm3.eps, pair=True)
+            del patches, tok
+            pending = (xh, st0)
+            for blk in self.blocks:
+                pending = blk.fused((xh, xl), B, T, n, pending)
+            if split_cls:
+                cls, pat = ops.layernorm_split_cls(xh, *pk["norm"], clips=B, out_dtype=out_dtype, x_lo=xl)
+                return self.pre_logits(cls), pat
+            xs = xh.float().add_(xl.float())
+            out = ops.layernorm(xs, *pk["norm"], out_dtype=out_dtype).view(B, 1 + T * n, D)
+            return self.pre_logits(out[:, 0]), out
         if fold:      # z = bf16(x) and its row statistics for block 0's folded norm3 ride in the same pass (no cast + hh_ln_rowstats launches)
             xs, z0, st0 = ops.embed_ln_pre(tok, pk["cls"], pk["pos"], pk["tmp"], *pk["ln_pre"][:2], B, T, n, pk["ln_pre"][2], z_eps=self.blocks[0].norm3.eps)
             pending = (z0, st0)

@@ -250,7 +250,7 @@ def fold_layernorm_into_linear(weight, bias, gamma, beta):
 
 
 def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, resid=None, colscale=1.0,
-         colscale_cols=0, remap=None, out_rows=None, splitk=1, col_blocked=False, ln=None, z=None, reverse=False):
+         colscale_cols=0, remap=None, out_rows=None, splitk=1, col_blocked=False, ln=None, z=None, reverse=False, zpair=None):
     """C = epilogue(A @ W^T).  a bf16 [M,K], w bf16 [N,K] (nn.Linear weight layout), bias fp32 [N].
 
     LayerNorm fold (include/hh.h):  ln=(stats fp32 [M,2], colsum fp32 [N]) -- consumer side: `a` holds un-normalised rows, `w` / `bias`
@@ -262,6 +262,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
     col_blocked=True returns C as N/64 planes [N/64, M, 64] (plane j = columns 64j .. 64j+63; include/hh.h c_block_stride):
     the QKV projection written this way is the head-major buffer of divided_attention.
     reverse: the persistent kernel walks its m-tiles last to first (hh_gemm_epilogue.walk_reverse; same results).
+    zpair=(hi, lo, eps): producer side on the bf16 PAIR residual stream x = hi + lo (both updated in place; returns (None, hi, stats of hi)).
     """
     _chk(bias)
     for t in (a, w, resid, out):                     # 2-D operands may be row-strided views (unit inner stride)
@@ -305,6 +306,23 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
     zt = st = None
     keep_c = True
     update = False
+    if zpair is not None:
+        # bf16 pair stream (hh_gemm_epilogue.z_resid_lo): x = hi + lo updated in place; hi is the next LayerNorm's input z
+        xh, xl, eps = zpair
+        _chk(xh, xl)
+        if z is not None or ln is not None or xh.dtype != torch.bfloat16 or xl.dtype != torch.bfloat16 or tuple(xh.shape) != (M, N) or tuple(xl.shape) != (M, N) \
+                or not xh.is_contiguous() or not xl.is_contiguous():
+            raise TypeError("gemm: zpair=(hi, lo, eps) needs contiguous bf16 [M, N] halves and no z= / ln=")
+        st = torch.empty((M, 2), dtype=torch.float32, device=a.device)
+        part = _workspace("gemm_zstats", M, N, device=a.device)
+        e = GemmEpilogue()
+        e.walk_reverse = int(bool(reverse))
+        e.z_resid, e.z_ldr, e.z_out, e.z_ldc, e.z_stats, e.z_partials = xh.data_ptr(), N, xh.data_ptr(), N, st.data_ptr(), part.data_ptr()
+        e.z_eps, e.skip_c, e.z_update, e.z_resid_dtype, e.z_resid_lo = float(eps), 1, 1, BF16, xl.data_ptr()
+        e.bias = bias.data_ptr() if bias is not None else None
+        e.colscale, e.c_dtype = 1.0, BF16
+        _lib.check(_lib.lib().hh_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(xh), N, M, N, K, ctypes.byref(e), _stream()), "hh_gemm_bf16")
+        return None, xh, st
     if z is not None:
         x, eps, keep_c = z[:3]
         update = bool(z[3]) if len(z) > 3 else False
@@ -410,25 +428,35 @@ def patch_im2col_u8(video, patch, kpad, mean=NORM_MEAN, std=NORM_STD):
     return out
 
 
-def embed_ln_pre(tok, cls, pos, temporal, gamma, beta, B, T, n, eps=1e-5, z_eps=None):
+def embed_ln_pre(tok, cls, pos, temporal, gamma, beta, B, T, n, eps=1e-5, z_eps=None, pair=False):
     """x fp32 [B, 1+T*n, D] = ln_pre(cat[cls, tok] + pos + temporal) (LaviLa.py:548-559).  z_eps (the next LayerNorm's eps): also returns
-    z = bf16(x) [rows, D] and its row statistics fp32 [rows, 2] -- the operands of the first block's folded norm3 -- from the same pass."""
+    z = bf16(x) [rows, D] and its row statistics fp32 [rows, 2] -- the operands of the first block's folded norm3 -- from the same pass.
+    pair (with z_eps): the bf16 pair stream instead of x -- returns (z, z_lo = bf16(x - z), stats); the fp32 rows are not written."""
     _chk(tok, cls, pos, temporal, gamma, beta)
     D = tok.shape[-1]
-    x = torch.empty((B, 1 + T * n, D), dtype=torch.float32, device=tok.device)
-    z = st = None
+    rows = B * (1 + T * n)
+    if pair and z_eps is None:
+        raise ValueError("embed_ln_pre: pair=True needs z_eps")
+    x = None if pair else torch.empty((B, 1 + T * n, D), dtype=torch.float32, device=tok.device)
+    z = st = zl = None
     if z_eps is not None:
-        z = torch.empty((B * (1 + T * n), D), dtype=torch.bfloat16, device=tok.device)
-        st = torch.empty((B * (1 + T * n), 2), dtype=torch.float32, device=tok.device)
+        z = torch.empty((rows, D), dtype=torch.bfloat16, device=tok.device)
+        st = torch.empty((rows, 2), dtype=torch.float32, device=tok.device)
+        zl = torch.empty((rows, D), dtype=torch.bfloat16, device=tok.device) if pair else None
     _lib.check(_lib.lib().hh_embed_ln_pre(_p(tok), _p(cls), _p(pos), _p(temporal), _p(gamma), _p(beta), _p(x), B, T, n, D,
-                                          float(eps), _p(z), _p(st), float(z_eps or 0.0), _stream()), "hh_embed_ln_pre")
+                                          float(eps), _p(z), _p(st), float(z_eps or 0.0), _p(zl), _stream()), "hh_embed_ln_pre")
+    if pair:
+        return z, zl, st
     return x if z_eps is None else (x, z, st)
 
 
-def layernorm_split_cls(x, gamma, beta, eps, clips, out_dtype=torch.bfloat16):
+def layernorm_split_cls(x, gamma, beta, eps, clips, out_dtype=torch.bfloat16, x_lo=None):
     """LayerNorm of `clips` clips of N = rows / clips token rows each, CLS first: -> (cls [clips, D], patches [clips, N - 1, D]) -- the
-    tower's final norm written straight into the decoder's grid (include/hh.h: hh_layernorm_split_cls_fwd)."""
-    _chk(x, gamma, beta)
+    tower's final norm written straight into the decoder's grid (include/hh.h: hh_layernorm_split_cls_fwd).  x_lo: the low halves of a bf16
+    pair stream (x then holds the high halves): the rows are x + x_lo."""
+    _chk(x, gamma, beta, x_lo)
+    if x_lo is not None and (x.dtype != torch.bfloat16 or x_lo.dtype != torch.bfloat16 or x_lo.shape != x.shape):
+        raise TypeError("layernorm_split_cls: x_lo needs bf16 x / x_lo of one shape")
     cols = x.shape[-1]
     rows = x.numel() // cols
     if clips <= 0 or rows % clips or rows // clips < 2:
@@ -436,7 +464,7 @@ def layernorm_split_cls(x, gamma, beta, eps, clips, out_dtype=torch.bfloat16):
     N = rows // clips
     ycls = torch.empty((clips, cols), dtype=out_dtype, device=x.device)
     ypat = torch.empty((clips, N - 1, cols), dtype=out_dtype, device=x.device)
-    _lib.check(_lib.lib().hh_layernorm_split_cls_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(ypat), _p(ycls), _dt(ypat), clips, N, cols, float(eps), _stream()),
+    _lib.check(_lib.lib().hh_layernorm_split_cls_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(ypat), _p(ycls), _dt(ypat), clips, N, cols, float(eps), _p(x_lo), _stream()),
                "hh_layernorm_split_cls_fwd")
     return ycls, ypat
 

@@ -195,6 +195,10 @@ typedef struct hh_gemm_epilogue {
     int z_resid_dtype;        /* HH_F32 (0, default) or HH_BF16 (round 5): z_resid holds bf16 rows -- the producer that only feeds a LayerNorm
                                  (the time branch: z1 = x + t goes to norm1 alone, LaviLa.py:372) reads the 2-byte z = bf16(x) its own block's
                                  norm3 consumed instead of the 4-byte fp32 stream; no z_update with it */
+    void* z_resid_lo;         /* != NULL (round 5, with z_out == z_resid, z_resid_dtype = HH_BF16, z_update != 0, z_ldr == z_ldc): the residual stream is
+                                 kept as a PAIR of bf16 rows x = hi + lo (z_resid = hi, which IS the LayerNorm input z of the next GEMM; z_resid_lo
+                                 = lo): the epilogue reads both (4 B), adds acc + bias in fp32, and writes hi' = bf16(x'), lo' = bf16(x' - hi')
+                                 back IN PLACE (4 B) -- 8 bytes per element instead of the 10 of fp32 x + separate z, ~17 significant bits */
     int walk_reverse;         /* != 0 (round 5): the persistent kernel walks its m-tiles last to first (same tiles, same arithmetic, same results):
                                  the tower alternates the direction from kernel to kernel so that each one starts on the rows its predecessor
                                  wrote last -- the part of its input still in the Infinity Cache (model/LaviLa.py: SpaceTimeBlock.fused) */
@@ -227,7 +231,9 @@ int hh_patch_im2col_u8(const uint8_t* video, void* patches, int64_t frames, int 
  * (rstd, -rstd * mean) fp32 [rows, 2] with eps z_eps -- the operands of the first block's folded LayerNorm (hh_gemm_epilogue.ln_stats). */
 int hh_embed_ln_pre(const float* tok, const float* cls, const float* pos, const float* temporal,
                     const float* gamma, const float* beta, float* x, int B, int T, int n, int D, float eps,
-                    void* z_out, float* z_stats, float z_eps, hh_stream_t stream);
+                    void* z_out, float* z_stats, float z_eps,
+                    void* z_lo /* NULL, or bf16 [rows, D]: x - z_out rounded to bf16 (the pair stream x = z_out + z_lo; x itself may then be NULL) */,
+                    hh_stream_t stream);
 
 /* ---- weight-gradient GEMM in its natural layout (backward of the nn.Linear layers of tfm_decoder.py:156,438-441):
  * partials[s, m, n] (fp32, [splits, M, N]) = sum over the s-th token slice of At[k, m] * Bt[k, n]; At bf16 [K, M] (row stride lda),
@@ -356,7 +362,8 @@ int hh_qself_attn_bwd(const float* qkv, const float* dout, float* dqkv, int B, i
  * y_cls [clips, cols], the other rows, clip after clip, to y_patches [clips * (tokens_per_clip - 1), cols] -- the decoder's [B, T*n, D] grid
  * (tfm_decoder.py:200-205) without a strided copy of the feature map. */
 int hh_layernorm_split_cls_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y_patches, void* y_cls, int y_dtype,
-                               int64_t clips, int tokens_per_clip, int cols, float eps, hh_stream_t stream);
+                               int64_t clips, int tokens_per_clip, int cols, float eps,
+                              const void* x_lo /* NULL, or (x_dtype = HH_BF16) the low halves of a bf16 pair stream: the rows are x + x_lo */, hh_stream_t stream);
 /* LayerNorm with a second output y_plus_pos = LN(x) + pos[row % pos_rows] (pos fp32 [pos_rows, cols]): the operands of an attention
  * whose keys / queries carry a positional embedding and whose values do not (tfm_decoder.py:431-441: q = k = x + query_pos, v = x;
  * key = memory + pos, value = memory) come out of ONE pass.  Same dtypes / limits as hh_layernorm_fwd. */

@@ -1136,6 +1136,35 @@ def test_gemm_ln_fold_producer(M, N, K, keep_c):
     assert (st[:, 1] + rstd * mean).abs().max().item() <= 4e-3 * (1.0 + (rstd * mean).abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(256 * 40 + 32, 1024, 1024), (256 * 33 + 7, 1024, 4096), (300, 128, 128), (4097, 1024, 1024)])
+def test_gemm_ln_fold_producer_on_the_bf16_pair_stream(M, N, K):
+    """hh_gemm_epilogue.z_resid_lo (round 5): the residual stream as a pair of bf16 rows x = hi + lo, both updated in place; hi' = bf16(x') is
+    the next LayerNorm's input, lo' = bf16(x' - hi').  Against fp64: hi' is the bf16 rounding of the fp32 sum, hi' + lo' holds x' to ~2^-16,
+    the row statistics are those of x'; persistent kernel (+ in-kernel row tail), generic kernels, both walk directions bit-identical."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K + 11)
+    a = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    x = torch.randn(M, N, device=DEV, generator=g) * 2.0 + 0.3
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    x0 = hi.double() + lo.double()                                      # what the pair holds on entry
+    want = x0 + a.double() @ w.double().t() + bias.double()
+    h1, l1 = hi.clone(), lo.clone()
+    _, z, st = ops.gemm(a, w, bias, zpair=(h1, l1, 1e-6))
+    assert z.data_ptr() == h1.data_ptr()
+    scale = want.abs().max().item()
+    got = h1.double() + l1.double()
+    assert (got - want).abs().max().item() <= 3e-5 * scale + 2e-3 * 0      # ~2^-16 of the value + the GEMM's fp32 accumulation order
+    assert (h1.double() - want).abs().max().item() <= 4.1e-3 * scale      # hi alone: one bf16 rounding
+    assert (l1.double().abs() <= 4.0e-3 * (h1.double().abs() + 1e-30) + 1e-30).all()      # lo is a remainder of hi
+    rstd = (want.var(1, unbiased=False) + 1e-6).rsqrt()
+    assert ((st[:, 0].double() - rstd) / rstd).abs().max().item() <= 2e-3
+    h2, l2 = hi.clone(), lo.clone()
+    ops.gemm(a, w, bias, zpair=(h2, l2, 1e-6), reverse=True)
+    assert torch.equal(h1, h2) and torch.equal(l1, l2)
+
+
 @pytest.mark.parametrize("offset_sigma", [10.0, 50.0])
 def test_gemm_ln_fold_producer_statistics_with_a_large_row_mean(offset_sigma):
     """rows inside persistent-GEMM tiles get their statistics from one-pass fp32 partial sums of the UNROUNDED z, the row tail
