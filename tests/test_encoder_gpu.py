@@ -77,6 +77,40 @@ def test_block_by_block_drift_is_bounded():
             assert ((st3[:, 0] - rstd) / rstd).abs().max().item() <= 2e-3
 
 
+def test_pair_stream_block_by_block():
+    """Round 5: the residual stream as a pair of bf16 tensors x = hi + lo (LaviLa.STREAM_PAIR; hh_gemm_epilogue.z_resid_lo).  Block by block at
+    TINY16: hi + lo stays within the oracle bound, hi is the bf16 rounding of hi + lo (it IS the next LayerNorm's input), lo is a remainder
+    of hi, and the hand-off statistics are those of the stream."""
+    cfg = TINY16
+    sd = synth.encoder_state(cfg, seed=3, with_text=False)
+    video = synth.make_batch(cfg, 1, seed=3)["video"]
+    vis = LaviLa.build_backbone(cfg, None).visual
+    vis.load_state_dict({k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}, strict=True)
+    vis = vis.cuda()
+    _, _, inter = OE.vision_forward(video, sd, cfg, return_blocks=True)
+    from helping_hand_for_egocentric_videos_amd import ops
+    pk = vis.packed()
+    B, T, n, D = 1, cfg.num_frames, cfg.patches_per_frame, cfg.embed_dim
+    patches = ops.patch_im2col(video.cuda(), cfg.patch_size, vis.patch_embed.kpad())
+    tok = ops.gemm(patches, pk["wpatch"], out_dtype=torch.float32)
+    xs = ops.embed_ln_pre(tok, pk["cls"], pk["pos"], pk["tmp"], *pk["ln_pre"][:2], B, T, n, pk["ln_pre"][2]).view(-1, D)
+    xh, xl, st = ops.embed_ln_pre(tok, pk["cls"], pk["pos"], pk["tmp"], *pk["ln_pre"][:2], B, T, n, pk["ln_pre"][2], z_eps=vis.blocks[0].norm3.eps, pair=True)
+    assert torch.equal(xh, xs.to(torch.bfloat16)) and torch.equal(xl, (xs - xh.float()).to(torch.bfloat16))
+    pending = (xh, st)
+    for i, blk in enumerate(vis.blocks):
+        pending = blk.fused((xh, xl), B, T, n, pending)
+        full = xh.float() + xl.float()
+        check("pair_stream", f"hi + lo after block {i} rel-L2 vs oracle", rel_l2(full.view(1, -1, D), inter[i + 1]), 4.4e-3)
+        assert pending[0] is xh
+        # hi is the rounding of the stream it heads -- up to the rare tie that lo's own rounding pushes across (one ulp, a handful of elements)
+        rnd = full.to(torch.bfloat16)
+        assert (xh != rnd).float().mean().item() < 1e-3
+        assert ((xh.float() - rnd.float()).abs() <= 2.0 ** -7 * xh.float().abs() + 1e-30).all()
+        assert (xl.float().abs() <= 2.0 ** -8 * xh.float().abs() + 1e-30).all()
+        rstd = (full.var(1, unbiased=False) + 1e-6).rsqrt()
+        assert ((pending[1][:, 0] - rstd) / rstd).abs().max().item() <= 2e-3
+
+
 def test_layernorm_fold_equals_the_standalone_layernorm_route():
     """The same tower with norm3 / norm1 / norm2 folded into the GEMMs (default) and with the stand-alone fused add+LayerNorm kernels:
     both within the oracle bound, and within bf16-operand distance of each other (two valid roundings of the same function)."""
@@ -86,18 +120,19 @@ def test_layernorm_fold_equals_the_standalone_layernorm_route():
     with torch.no_grad():
         _, rx = OE.vision_forward(video, sd, cfg)
     outs = {}
-    was = LaviLa.LN_FOLD
+    was, was_pair = LaviLa.LN_FOLD, LaviLa.STREAM_PAIR
     try:
-        for fold in (True, False):
-            LaviLa.LN_FOLD = fold
+        for fold, pair in ((True, True), (True, False), (False, False)):      # fold on the bf16 pair stream (default), fold on the fp32 stream, stand-alone
+            LaviLa.LN_FOLD, LaviLa.STREAM_PAIR = fold, pair
             vis = LaviLa.build_backbone(cfg, None).visual
             vis.load_state_dict({k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}, strict=True)
             _, gx = vis.cuda()(video.cuda())
-            outs[fold] = gx
-            check("ln_fold_vs_standalone", "feature map rel-L2 vs oracle (fold=%s)" % fold, rel_l2(gx, rx), 4.4e-3)
+            outs[(fold, pair)] = gx
+            check("ln_fold_vs_standalone", "feature map rel-L2 vs oracle (fold=%s, pair stream=%s)" % (fold, pair), rel_l2(gx, rx), 4.4e-3)
     finally:
-        LaviLa.LN_FOLD = was
-    check("ln_fold_vs_standalone", "fold vs stand-alone route rel-L2", rel_l2(outs[True], outs[False]), 4.4e-3)
+        LaviLa.LN_FOLD, LaviLa.STREAM_PAIR = was, was_pair
+    check("ln_fold_vs_standalone", "fold vs stand-alone route rel-L2", rel_l2(outs[(True, False)], outs[(False, False)]), 4.4e-3)
+    check("ln_fold_vs_standalone", "pair stream vs fp32 stream (both folded) rel-L2", rel_l2(outs[(True, True)], outs[(True, False)]), 4.4e-3)
 
 
 def test_ln_fold_flag_is_honoured_after_a_forward():
