@@ -376,6 +376,13 @@ def test_layernorm_split_cls(clips, N, cols, xdt, ydt):
     cls, pat = ops.layernorm_split_cls(x, g, b, 1e-6, clips, out_dtype=ydt)
     assert cls.shape == (clips, cols) and pat.shape == (clips, N - 1, cols) and pat.is_contiguous()
     assert torch.equal(cls, full[:, 0]) and torch.equal(pat, full[:, 1:])
+    # round 5: the input as a bf16 pair (the tower's residual stream x = hi + lo): the same bits as the LayerNorm of the fp32 sum
+    xf = x.float()
+    hi = xf.to(torch.bfloat16)
+    lo = (xf - hi.float()).to(torch.bfloat16)
+    want = ops.layernorm(hi.float() + lo.float(), g, b, 1e-6, out_dtype=ydt).view(clips, N, cols)
+    cls2, pat2 = ops.layernorm_split_cls(hi, g, b, 1e-6, clips, out_dtype=ydt, x_lo=lo)
+    assert torch.equal(cls2, want[:, 0]) and torch.equal(pat2, want[:, 1:])
 
 
 @pytest.mark.parametrize("channels_last", [False, True])
