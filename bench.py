@@ -552,6 +552,7 @@ def main():
     ap.add_argument("--kv-proj", action="store_true", help="A/B: the decoder's round-1..4 cross-attention (one K/V in-projection of all memory tokens for the six layers + hh_xattn_*) "
                                                            "instead of the memory-space attention (csrc/mattn.hip)")
     ap.add_argument("--token-major-qkv", action="store_true", help="A/B: the QKV projections write nn.Linear's token-major [B*N, 3D] instead of head-major planes")
+    ap.add_argument("--stream-priorities", default=None, metavar="ENC,TEXT", help="A/B: HIP stream priorities of the vision-tower and text-tower streams (0 default, -1 high)")
     ap.add_argument("--stream-fp32", action="store_true", help="A/B: the tower's residual stream in fp32 with a separate bf16 LayerNorm input (rounds 4-5) instead of the bf16 pair hi + lo (LaviLa.STREAM_PAIR)")
     ap.add_argument("--walk-forward", action="store_true", help="A/B: every kernel of a tower block walks its rows first to last (rounds 1-4) instead of opposite to its predecessor (LaviLa.WALK_ALTERNATE)")
     ap.add_argument("--time-proj-fp32", action="store_true", help="A/B: the time projection's epilogue re-reads the fp32 residual rows (round 4) instead of z3 = bf16(x)")
@@ -595,6 +596,9 @@ def main():
         LaviLa.WALK_ALTERNATE = False
     if args.stream_fp32:
         LaviLa.STREAM_PAIR = False
+    if args.stream_priorities:
+        from helping_hand_for_egocentric_videos_amd import step as _step
+        _step.STREAM_PRIORITIES[:] = [int(v) for v in args.stream_priorities.split(",")]
     cfg, cfg_name = CONFIGS[args.config]
     B = args.batch or {"c2": 32, "c4": 4, "c1": 2}[args.config]
     torch.manual_seed(0)

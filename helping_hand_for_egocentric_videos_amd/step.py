@@ -20,6 +20,10 @@ DP_ENC_CUS = 0                                    # default encoder-stream CU bu
 WEIGHT_DICT = {"loss_bbox_hand_boxes": 5, "loss_bbox_obj_boxes": 5, "loss_giou_hand_boxes": 2, "loss_giou_obj_boxes": 2}
 
 
+# HIP stream priorities of (the vision-tower stream, the text-tower stream); 0 = default, -1 = high (A/B knob: bench.py --stream-priorities)
+STREAM_PRIORITIES = [0, 0]
+
+
 def finishes_last(name: str) -> bool:
     """Decoder parameters whose gradient is written by the memory side's backward (model/tfm_decoder.py _MemorySide), the last node
     of the step's backward: FlatArena lays them out last so that every earlier all-reduce bucket can overlap it."""
@@ -91,7 +95,7 @@ class TrainStep:
         n = self.cfg.patches_per_frame
         cur = torch.cuda.current_stream()
         if self._text_stream is None:
-            self._text_stream = torch.cuda.Stream()
+            self._text_stream = torch.cuda.Stream(priority=STREAM_PRIORITIES[1])
         side = self._text_stream if self.text_on_side_stream else cur
         side.wait_stream(cur)
         with torch.no_grad():
@@ -107,7 +111,7 @@ class TrainStep:
         of step i+1 does not depend on step i's optimizer update, so it overlaps step i's decoder forward/backward, whose
         13-row query-side kernels leave most CUs idle).  The result is picked up by the next step(batch)."""
         if self.enc_stream is None:
-            self.enc_stream = torch.cuda.Stream()
+            self.enc_stream = torch.cuda.Stream(priority=STREAM_PRIORITIES[0])
             if self.enc_cus > 0:
                 ops.set_stream_cu_budget(self.enc_stream, self.enc_cus)
         main = torch.cuda.current_stream()
