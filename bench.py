@@ -213,10 +213,10 @@ while True:
         w = [float(r[1]) for r in rows if t0 <= float(r[0]) <= t1 and r[1] != "nan"]
         mhz = [float(r[2]) for r in rows if t0 <= float(r[0]) <= t1 and r[2] != "nan"]
         if not w:
-            return {"samples": 0, "rows_seen": len(rows), "note": "rocm-smi gave no power sample inside the timed region on this box (cap: 1400 W; other runs: profiles/r4_bench_line.json)"}
+            return {"samples": 0, "rows_seen": len(rows), "note": "rocm-smi gave no power sample inside the timed region on this box (cap: 1400 W; other runs: profiles/r5_bench_500_steps.json)"}
         return {"package_power_w_mean": round(sum(w) / len(w), 1), "package_power_w_max": max(w), "samples": len(w),
                 "sclk_mhz_mean_reported": round(sum(mhz) / len(mhz), 1) if mhz else None,
-                "source": "rocm-smi --showpower --showclocks sampled by a child process during the timed region (cap: 1400 W)"}
+                "source": "rocm-smi --showpower --showclocks sampled by a child process during the timed region and the statistics steps behind it (cap: 1400 W)"}
 
 
 def cpu_baseline(cfg, enc_sd, dec_sd, seed):
@@ -312,7 +312,8 @@ def barrier(world):
     torch.cuda.synchronize()
 
 
-LAST_REGION = [0.0, 0.0]     # wall-clock bounds (time.time()) of the last timed region: the power samples are cut to it
+LAST_REGION = [0.0, 0.0, 0.0]     # wall-clock bounds (time.time()) of the last timed region [0], [1] and the end of the statistics steps that
+                                  # follow it [2] (same workload, back to back): the power samples are cut to [0] + 15 % .. [2]
 STATS_STEPS = 50     # per-step statistics are taken over at least this many steps: the K contract steps + extra ones run after the timed region
 
 
@@ -345,6 +346,7 @@ def timed_region(run, steps, warmup, world, timers, stats_steps=0):
         ev.append(e)
     if extra:
         barrier(world)
+    LAST_REGION[2] = time.time() if extra else LAST_REGION[1]
     per = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps + extra)]
     return dt, per, region, out
 
@@ -632,7 +634,7 @@ def main():
         metric = "train clips/sec (%d-frame %dp, nq=%d)" % (cfg.num_frames, cfg.img_size, cfg.num_queries)
         if power:
             power.start()
-        ts, batch, dt, per, region, iso, out, phases, (w0, w1) = bench_train(cfg, backbone, decoder, B, args.steps, args.warmup, world, rank, dev, args, timers)
+        ts, batch, dt, per, region, iso, out, phases, (w0, w1, w2) = bench_train(cfg, backbone, decoder, B, args.steps, args.warmup, world, rank, dev, args, timers)
     else:
         items = args.mcq_items
         mcq = synth.make_mcq_item(cfg, items, seed=1000 + rank)
@@ -645,11 +647,13 @@ def main():
         if power:
             power.start()
         dt, per, region, out = timed_region(run, args.steps, args.warmup, world, timers)
-        w0, w1 = LAST_REGION
+        w0, w1, w2 = LAST_REGION
         iso = phases = None
         if timers:
             prof_enable(0)
-    power_rec = power.stop(w0 + 0.15 * (w1 - w0), w1) if power else None      # the timed region itself (its first 15 % left out: the chip settles into its steady power state)
+    # the timed region (its first 15 % left out: the chip settles into its steady power state) and the statistics steps right behind it --
+    # the same workload back to back; a 20-step region alone (2 s) holds 0-5 rocm-smi samples
+    power_rec = power.stop(w0 + 0.15 * (w1 - w0), max(w1, w2)) if power else None
     dts = torch.tensor([dt], device=dev, dtype=torch.float64)
     per_rank = None
     if world > 1:
