@@ -31,6 +31,7 @@ class QGemmOpts(ctypes.Structure):
 # name -> argtypes (restype is int unless listed in _RESTYPES); must list every symbol of include/hh.h
 SIGNATURES = {
     "hh_version": [],
+    "hh_abi_sizeof": [ctypes.c_char_p],
     "hh_last_error_string": [],
     "hh_set_tuning": [ctypes.c_char_p, c_int],
     "hh_debug_gemm_timeline": [c_vp, c_int],
@@ -118,6 +119,10 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, c_int)
+        for cname, cls in ((b"hh_gemm_epilogue", GemmEpilogue), (b"hh_qgemm_opts", QGemmOpts)):
+            if L.hh_abi_sizeof(cname) != ctypes.sizeof(cls):
+                raise RuntimeError("libhh.so was built from another include/hh.h: sizeof(%s) is %d there, %d in this binding -- rebuild it "
+                                   "(`python -m helping_hand_for_egocentric_videos_amd.build --force`)" % (cname.decode(), L.hh_abi_sizeof(cname), ctypes.sizeof(cls)))
         _lib = L
     return _lib
 

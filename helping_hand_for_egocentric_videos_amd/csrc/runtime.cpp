@@ -1,5 +1,6 @@
 // Host-side runtime bits of libhh: version, thread-local error string, launch check.
 #include "common.h"
+#include <cstring>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -23,6 +24,13 @@ int hh_check_launch(const char* what) {
 }
 
 extern "C" int hh_version(void) { return 100; }
+// sizeof of the option structs of the ABI as THIS library was compiled: a binding compares it with its own declaration when it loads the
+// library (the structs grow by appended fields from round to round; a stale binding would hand the kernels garbage)
+extern "C" int hh_abi_sizeof(const char* name) {
+    if (name && !strcmp(name, "hh_gemm_epilogue")) return (int)sizeof(hh_gemm_epilogue);
+    if (name && !strcmp(name, "hh_qgemm_opts")) return (int)sizeof(hh_qgemm_opts);
+    return -1;
+}
 extern "C" const char* hh_last_error_string(void) { return g_err; }
 
 // ---- per-stream CU budget.  The pipelined training step runs the frozen towers of batch i+1 on one stream while the decoder

@@ -37,6 +37,9 @@ enum hh_qkv_layout { HH_QKV_TOKEN_MAJOR = 0, HH_QKV_HEAD_MAJOR = 1 };
 #define HH_QKV_WALK_REVERSE 2
 
 int hh_version(void);
+/* sizeof(hh_gemm_epilogue) / sizeof(hh_qgemm_opts) as the library was compiled (name = the struct's name; -1: unknown): the binding's own
+ * declaration must agree (helping_hand_for_egocentric_videos_amd/_lib.py checks it at load time) */
+int hh_abi_sizeof(const char* name);
 /* Performance knobs for A/B measurements (never change results).  Together with the per-stream CU budget below this is the
  * library's ONLY process-global mutable state; no entry point reads the environment.
  *   "gemm256"       0 = 128x128 kernel only, 1 = 256x256 one tile per block, 2 = + wave-row stagger, 3 = persistent 8-wave kernel,

@@ -28,6 +28,11 @@ def test_library_builds_and_exports_every_declared_symbol():
     L = _lib.lib()
     assert L.hh_version() >= 100
     assert isinstance(L.hh_last_error_string(), bytes)
+    # the option structs of the binding are the ones the library was compiled with (they grow by appended fields: a stale binding would hand
+    # the kernels garbage; _lib.lib() raises on a mismatch at load time)
+    assert L.hh_abi_sizeof(b"hh_gemm_epilogue") == ctypes.sizeof(_lib.GemmEpilogue) > 0
+    assert L.hh_abi_sizeof(b"hh_qgemm_opts") == ctypes.sizeof(_lib.QGemmOpts) > 0
+    assert L.hh_abi_sizeof(b"no_such_struct") == -1
 
 
 def test_host_side_argument_validation_needs_no_gpu():
