@@ -1,6 +1,7 @@
 """Benchmark of the hot path: train clips/sec (16-frame 224p, nq=12) -- BASELINE.json's metric -- on N GPUs.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus N --steps K --warmup W            (plain: starts its own N ranks as a child `torch.distributed.run`, self_launch())
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -83,23 +84,31 @@ def prof_snapshot():
     return snap
 
 
-def pmc_traffic(kernel_substr, cfg_tag="", tag_order=("r5", "r4", "r3", "r2", "r1")):
-    """HBM-side bytes per launch of a kernel from the COMMITTED PMC passes of the same configuration (profiles/<round>_[c4_]pmc_summary.json:
+VISION_GEMMS = ("gemm256w4p_kernel<true, 5,", "gemm256w4p_kernel<true, 6,", "gemm256w4p_kernel<true, 7,", "gemm256w4p_kernel<true, 8,")
+# the vision tower's instantiations of the persistent GEMM with the LayerNorm fold: <5> = qkv (consumer), <6> = fc1 (consumer, QuickGELU),
+# <7> = time projection (producer, reads z3), <8> = space projection and fc2 (producers on the bf16 pair stream).  <true, 0|1|2> are the text
+# tower's / small shapes and are NOT part of `roofline` (their 110-170 MiB launches used to dilute the mean)
+
+
+def pmc_traffic(kernel_substrs, cfg_tag="", tag_order=("r6", "r5", "r4", "r3", "r2", "r1")):
+    """HBM-side bytes per launch from the COMMITTED PMC passes of the same configuration (profiles/<round>_[c4_]pmc_summary.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction); launch-weighted mean over the
-    template instantiations whose name contains `kernel_substr`.  NOT measured in this run.  Returns (bytes, file) or (None, None)."""
+    template instantiations whose name contains one of `kernel_substrs`.  NOT measured in this run.  Returns (bytes, file) or (None, None)."""
+    if isinstance(kernel_substrs, str):
+        kernel_substrs = (kernel_substrs,)
     for tag in tag_order:
         path = os.path.join(ROOT, "profiles", tag + "_" + cfg_tag + "pmc_summary.json")
         if not os.path.exists(path):
             continue
         with open(path) as f:
-            rows = [v for k, v in json.load(f).items() if kernel_substr in k]
+            rows = [v for k, v in json.load(f).items() if any(t in k for t in kernel_substrs)]
         n = sum(v["launches"] for v in rows)
         if n:
             return int(sum(v["traffic_bytes_per_launch"] * v["launches"] for v in rows) / n), os.path.basename(path)
     return None, None
 
 
-def rocprof_committed(kernel_substr, cfg_tag="", pipelined=True, tag_order=("r5", "r4", "r3")):
+def rocprof_committed(kernel_substr, cfg_tag="", pipelined=True, tag_order=("r6", "r5", "r4", "r3")):
     """Average duration per launch (us) and launch count of the kernels whose name contains `kernel_substr` in the committed rocprofv3
     --kernel-trace --stats CSV of the same bench command (profiles/<round>_[c4_]{bench,unpipelined}_kernel_stats.csv).  -> dict or None."""
     import csv
@@ -117,22 +126,27 @@ def rocprof_committed(kernel_substr, cfg_tag="", pipelined=True, tag_order=("r5"
     return None
 
 
-def gemm_algorithmic_bytes(cfg, B, ln_fold=True):
-    """Operand + result bytes of the vision tower's six GEMMs per block, launch-weighted mean per launch -- what the PMC traffic of the
-    persistent GEMM is compared with.  bf16 A [M,K] and W [N,K] read once, bf16 C [M,N] written once; with the LayerNorm fold the three
-    branch-ending GEMMs (time proj, space proj, fc2) write no C but read the fp32 residual rows (4 B), write z (2 B) and -- space proj and
-    fc2 -- the fp32 residual rows back (4 B)."""
+def gemm_algorithmic_table(cfg, B, ln_fold=True, pair=True, z3=True):
+    """Operand + result bytes of the vision tower's six GEMMs of a block, one entry per launch -- what the PMC traffic of the persistent GEMM
+    is compared with.  bf16 A [M,K] and W [N,K] read once; the consumers (qkv x2, fc1) write bf16 C [M,N]; with the LayerNorm fold the three
+    branch-ending GEMMs write no C: per element of [M, D] the time projection reads its residual input (z3 = bf16 image: 2 B; fp32: 4 B) and
+    writes z (2 B); space projection and fc2 read and write the residual stream -- the bf16 pair hi + lo (4 B read, 4 B written: hi' IS the
+    next consumer's z) or, on the fp32 stream, 4 B read, 4 B written + 2 B of z.  (Row statistics: 8 B per row and 128 columns, < 0.1 %.)"""
     M, D = B * cfg.tokens, cfg.embed_dim
     aw = lambda N, K: 2 * (M * K + N * K)
     if not ln_fold:
-        shapes = [(3 * D, D)] * 2 + [(D, D)] * 2 + [(4 * D, D), (D, 4 * D)]      # (N, K): qkv x2, proj x2, fc1, fc2
-        return int(sum(aw(N, K) + 2 * M * N for N, K in shapes) / len(shapes))
-    tot = 2 * (aw(3 * D, D) + 2 * M * 3 * D)                                      # qkv (time), qkv (space): consumer side, C = q|k|v planes
-    tot += aw(D, D) + M * D * (4 + 2)                                             # time proj: + x read, z written
-    tot += aw(D, D) + M * D * (4 + 4 + 2)                                         # space proj: + x read, x and z written
-    tot += aw(4 * D, D) + 2 * M * 4 * D                                           # fc1: consumer side
-    tot += aw(D, 4 * D) + M * D * (4 + 4 + 2)                                     # fc2
-    return int(tot / 6)
+        return {k: aw(N, K) + 2 * M * N for k, (N, K) in {"qkv_time": (3 * D, D), "qkv_space": (3 * D, D), "proj_time": (D, D), "proj_space": (D, D),
+                                                          "fc1": (4 * D, D), "fc2": (D, 4 * D)}.items()}
+    upd = (4 + 4) if pair else (4 + 4 + 2)
+    return {"qkv_time": aw(3 * D, D) + 2 * M * 3 * D, "qkv_space": aw(3 * D, D) + 2 * M * 3 * D,
+            "proj_time": aw(D, D) + M * D * ((2 if z3 else 4) + 2), "proj_space": aw(D, D) + M * D * upd,
+            "fc1": aw(4 * D, D) + 2 * M * 4 * D, "fc2": aw(D, 4 * D) + M * D * upd}
+
+
+def gemm_algorithmic_bytes(cfg, B, ln_fold=True, pair=True, z3=True):
+    """Launch-weighted mean of gemm_algorithmic_table over the six GEMMs of a block (C2, B = 32, pair stream: 1.30 GB)."""
+    t = gemm_algorithmic_table(cfg, B, ln_fold, pair, z3)
+    return int(sum(t.values()) / len(t))
 
 
 def _read_timeline():
@@ -397,14 +411,15 @@ def roofline_records(region, iso, dt_ms, pipelined, cfg, B, steps):
     have_profile = cfg_tag == "c4_" or (cfg.num_frames == 16 and cfg.img_size == 224)
     main = _stream_rec(vis, "gemm256", steps)
     if main is not None:
-        traffic, src = pmc_traffic("gemm256w4p_kernel<true", cfg_tag) if have_profile else (None, None)
-        alg_bytes = gemm_algorithmic_bytes(cfg, B, LaviLa.LN_FOLD)
+        default_build = bool(LaviLa.LN_FOLD and LaviLa.STREAM_PAIR and LaviLa.TIME_PROJ_READS_Z3)     # what the committed PMC passes profiled
+        traffic, src = pmc_traffic(VISION_GEMMS, cfg_tag) if (have_profile and default_build) else (None, None)
+        alg_bytes = gemm_algorithmic_bytes(cfg, B, LaviLa.LN_FOLD, LaviLa.STREAM_PAIR, LaviLa.TIME_PROJ_READS_Z3)
         step_ms = dt_ms / max(steps, 1)
         roof = {"kernel": "gemm256w4p_kernel, vision-tower launches (persistent 256x256x64 bf16 MFMA GEMM, LayerNorms folded in)",
                 "bound": "mfma", "achieved": main["achieved"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(main["achieved"] / PEAK_BF16_TFLOPS, 4),
                 "launches_in_region": main["launches_in_region"], "launches_timed": main["launches_timed"], "avg_launch_us": main["avg_launch_us"],
                 "stream_ms_per_step": main["ms_per_step"], "ms_per_step": round(step_ms, 2), "stream_time_le_step": bool(main["ms_per_step"] <= step_ms),
-                "traffic": traffic, "traffic_source": ("committed PMC passes, profiles/%s (not measured in this run)" % src) if src else None,
+                "traffic": traffic, "traffic_source": ("committed PMC passes, profiles/%s, vision-tower instantiations <true, 5|6|7|8> only (not measured in this run)" % src) if src else None,
                 "algorithmic_bytes_per_launch": alg_bytes, "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
                 "ln_fold": bool(LaviLa.LN_FOLD), "last_dispatched": names.get("gemm256", ""),
                 "region": "timed region, pipelined" if pipelined else "timed region, un-pipelined"}
@@ -431,13 +446,15 @@ def roofline_records(region, iso, dt_ms, pipelined, cfg, B, steps):
             if i2 is not None:
                 roof["isolated"] = {"achieved": i2["achieved"], "frac": round(i2["achieved"] / PEAK_BF16_TFLOPS, 4), "avg_launch_us": i2["avg_launch_us"],
                                     "note": "2 un-pipelined steps outside the timed region: the tower alone on the chip"}
+                roof["isolated_frac"] = roof["isolated"]["frac"]          # (flat copy: the driver's record keeps scalars)
         roof["notes"] = {
             "timing": "library-side HIP events on the launch stream around every %dth launch of the class and role (hh_prof_enable / hh_prof_set_role); "
                       "agrees with rocprofv3 --kernel-trace of the same run (round 4: 511 vs 504 us)" % STRIDE,
             "work": "2*M*N*K of the full 256-row tiles of each launch; norm3 / norm1 / norm2 of every block run inside these launches (DESIGN.md 4.6), "
                     "their time counts here",
-            "bytes": "A [M,K] + W [N,K] read, C [M,N] written, bf16, mean over the six GEMMs of a block at M = %d; the branch-ending GEMMs read the fp32 "
-                     "residual rows and write z (bf16) / the fp32 rows instead of C" % (B * cfg.tokens)}
+            "bytes": "A [M,K] + W [N,K] read, C [M,N] written, bf16, mean over the six GEMMs of a block at M = %d; the branch-ending GEMMs write no C: "
+                     "time proj reads z3 (2 B) and writes z (2 B), space proj / fc2 read and write the bf16 pair stream (4 + 4 B) per element of [M, D] "
+                     "(bench.py: gemm_algorithmic_table)" % (B * cfg.tokens)}
     for key in ("space_attn", "time_attn"):
         rec = _stream_rec(vis, key, steps, 1e9)
         if rec is None:
@@ -479,8 +496,8 @@ def bench_train(cfg, backbone, decoder, B, steps, warmup, world, rank, dev, args
     if timers:
         prof_enable(0)          # (the extra statistics steps are not part of the kernel-timer region: the snapshot was taken before them)
     phases = None
-    if timers and want_iso and world == 1:
-        phases = phase_times(ts, batch, run, pipelined)
+    if timers and want_iso:
+        phases = phase_times(ts, batch, run, pipelined)          # (every rank runs it -- the steps hold collectives at N > 1; rank 0's numbers are printed)
     iso = None
     if timers and pipelined and want_iso:
         # outside the timed region: two un-pipelined steps, so that every kernel is also timed alone on the chip (no decoder kernels
@@ -521,6 +538,21 @@ def phase_times(ts, batch, run, pipelined, reps=3):
         torch.cuda.synchronize()
         alone.append(span(lambda: ts.step(batch)))
     rec["decoder_alone_ms"] = round(min(alone[1:]), 2)
+    # host-side launch cost: the time the host needs to ISSUE one un-pipelined step (device idle at the start, no synchronisation inside the
+    # step, so the call returns when everything is enqueued) over the library calls it made (hh_call_count: every launching hh_* entry point)
+    from helping_hand_for_egocentric_videos_amd import _lib
+    issue = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        c0, t0 = _lib.lib().hh_call_count(), time.perf_counter()
+        ts.step(batch)
+        t1, c1 = time.perf_counter(), _lib.lib().hh_call_count()
+        torch.cuda.synchronize()
+        issue.append(((t1 - t0) * 1e3, c1 - c0))
+    ms, calls = min(issue)
+    rec["host_issue_ms_per_step"] = round(ms, 2)
+    rec["libhh_calls_per_step"] = int(calls)
+    rec["host_us_per_libhh_call"] = round(ms * 1e3 / max(calls, 1), 2)
     if pipelined:
         ts.span_log = []
         for _ in range(reps + 2):
@@ -531,6 +563,45 @@ def phase_times(ts, batch, run, pipelined, reps=3):
         if spans:
             rec["decoder_in_step_ms"] = round(sum(spans) / len(spans), 2)
     return rec
+
+
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` typed plainly (no WORLD_SIZE in the environment): this process becomes the launcher.  BEFORE any GPU
+    call it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same args>` as a FRESH CHILD process group
+    (never os.exec*: a process that has touched the GPU must not be replaced, and this one has not touched it), relays the children's
+    stdout -- rank 0's one JSON line -- and returns the launcher's exit code; the whole group is killed when HH_BENCH_LAUNCH_TIMEOUT
+    seconds (default 3600) pass.  Fewer than N visible devices: one line on stderr, exit code 2.  (run/train.py:372-412,579-586 of the
+    reference is launched by torchrun the same way.)"""
+    import signal
+    import socket
+    assert not torch.cuda.is_initialized(), "self_launch must run before anything touches the GPU"
+    same_device = os.environ.get("HH_BENCH_SAME_DEVICE") == "1"          # test hook: every rank on cuda:0 (see main())
+    ndev = torch.cuda.device_count()                                     # (counting devices does not initialise the GPU)
+    need = 1 if same_device else n_gpus
+    if ndev < need:
+        sys.stderr.write("bench.py: --gpus %d needs %d visible GPU(s), this host shows %d\n" % (n_gpus, need, ndev))
+        return 2
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+        s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    limit = float(os.environ.get("HH_BENCH_LAUNCH_TIMEOUT", 3600))
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT, start_new_session=True)      # stdout / stderr inherited: the line goes straight through
+    try:
+        return child.wait(timeout=limit)
+    except (subprocess.TimeoutExpired, KeyboardInterrupt) as e:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)                         # the launcher's own process group (start_new_session): exact, not a pattern
+        except ProcessLookupError:
+            pass
+        child.wait()
+        sys.stderr.write("bench.py: the %d-rank run was killed (%s)\n" % (n_gpus, "timeout after %.0f s" % limit if isinstance(e, subprocess.TimeoutExpired) else "interrupted"))
+        return 124
 
 
 def main():
@@ -565,6 +636,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder forward with this step's decoder")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -574,7 +648,8 @@ def main():
     backend = os.environ.get("HH_BENCH_BACKEND", "nccl")
     same_device = os.environ.get("HH_BENCH_SAME_DEVICE") == "1"
     if args.gpus > 1 or world > 1:
-        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        if world != args.gpus:
+            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or plainly without WORLD_SIZE set)" % (args.gpus, world, args.gpus))
         if same_device:
             local = 0
         torch.cuda.set_device(local)
@@ -783,6 +858,27 @@ def main():
                 "step_stats": step_stats(per, drop_first=bool(train and not args.no_pipeline)),
                 "end_to_end_mfma_frac": round(value * tf / (world * PEAK_BF16_TFLOPS), 4),
                 "roofline": roof}
+        # flat scalars the driver's stored record keeps (it cuts nested sub-records): second half of BASELINE.json's metric, config 4, power, margins
+        cfgd = line["config"]
+        cfgd["end_to_end_mfma_frac"] = line["end_to_end_mfma_frac"]
+        if mcq_rec is not None:
+            cfgd["mcq_clips_per_s"] = mcq_rec["value"]
+        if c4_rec is not None:
+            cfgd["c4_clips_per_s"] = c4_rec["value"]
+            if c4_rec.get("roofline"):
+                cfgd["c4_roofline_frac"] = c4_rec["roofline"]["frac"]
+        if power_rec and power_rec.get("package_power_w_mean") is not None:
+            cfgd["power_w_mean"] = power_rec["package_power_w_mean"]
+        if phases:
+            for k in ("host_issue_ms_per_step", "libhh_calls_per_step", "host_us_per_libhh_call", "decoder_in_step_ms", "decoder_alone_ms", "towers_alone_ms"):
+                if k in phases:
+                    cfgd[k] = phases[k]
+            if "decoder_in_step_ms" in phases:
+                cfgd["decoder_in_step_frac"] = round(phases["decoder_in_step_ms"] / (dt / args.steps * 1e3), 3)
+        if att:
+            for k, short in (("space_attn", "space_attn_hbm_frac"), ("time_attn", "time_attn_hbm_frac")):
+                if k in att:
+                    cfgd[short] = att[k]["frac"]
         if att:
             line["attention_roofline"] = att
         if power_rec:

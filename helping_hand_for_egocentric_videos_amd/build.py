@@ -16,6 +16,9 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libhh.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value"]
+# per-file additions.  attn_space32.hip: VGPR-form MFMAs -- its persistent kernel may use 512 registers per wave, for which hipcc otherwise
+# selects the AGPR form of every MFMA and the score tiles land in AGPRs that v_exp_f32 cannot read (csrc/attn_space32.hip, header)
+EXTRA_FLAGS = {"attn_space32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wno-pass-failed"]}
 
 
 def sources():
@@ -35,7 +38,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src + ".o")
         if force or _newer(s, o) or os.path.getmtime(o) < hdr_m:
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
             jobs.append(cmd)
 
     def run(cmd):

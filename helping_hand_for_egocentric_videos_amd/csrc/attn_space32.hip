@@ -1,0 +1,505 @@
+// Space attention on v_mfma_f32_32x32x16_bf16 (round 6): see the block comments below.  Built with -mllvm -amdgpu-mfma-vgpr-form=1 (build.py):
+// the persistent kernel is allowed 512 registers (one wave per SIMD), for which hipcc otherwise selects the AGPR form of every MFMA -- the
+// score tiles would then sit in AGPRs, which v_exp_f32 cannot read (16 v_accvgpr_read per half-step and a bunched schedule).
+#include "attn_space_dev.h"
+
+// ---- 32-query blocks on v_mfma_f32_32x32x16_bf16, software-pipelined INSIDE the wave (round 6) ----------------------
+// Why: the joint-block kernel above runs a chunk as three serial phases per in-order wave (score MFMAs -> exponentials -> PV MFMAs) and a
+// 16x16x32 MFMA holds the SIMD's vector issue for 8 of its 16 cycles (MI355X_MICROARCH.md, cycle constants): 36 MFMAs + 32 v_exp_f32 + 16
+// v_cvt_pk per 64-query x 32-key chunk are 288 + 256 + 72 issue cycles against 576 cycles of matrix-core time -- issue-bound even when
+// perfectly overlapped, and measured at ~2200 cycles per chunk and wave (MFMA busy 34 %).  Here
+//   * every product is a 32x32x16 MFMA (8 of 32 cycles of issue): S^T[32 keys][32 queries] = K . Q^T (4 MFMAs over d = 64), the
+//     probabilities stay on the lane of their query (16 registers = 16 keys), and P^T IS the B operand of O^T[32 d][32 queries] += V^T . P^T
+//     with the key order of the contraction chosen to match the accumulator layout (registers 8m..8m+7 of lane-half hh = keys 16m + 4hh + 0..3
+//     and 16m + 8 + 4hh + 0..3: two ds_read_b64_tr_b16 per V^T fragment); row sums = a third product against an all-ones operand;
+//   * a wave owns TWO 32-query blocks a, b whose chains QK -> exp -> PV run half a chunk apart, so that each half-step holds 10 independent
+//     MFMAs (QK of one block + PV of the same block's previous chunk: 320 cycles) and the 16 exponentials + 8 conversions of the OTHER
+//     block (128 + 36 issue cycles + 80 of the MFMAs' own): the exponentials hide under the matrix core inside ONE wave, no partner needed;
+//   * no reference maximum: scores are base-2 logits and fp32 / bf16 carry them from 2^-126 to 2^127, the softmax is shift-invariant, so
+//     P = exp2(s) is used as it is and a block whose row sum leaves [2^-100, 2^100] (a row maximum outside about [-100, +92], i.e. natural
+//     logits outside [-69, +64]) is redone on the running-maximum path (space16_chunk) -- the accumulator initialiser of a 32x32 product
+//     would cost 16 registers per block that the pipeline needs for the second block;
+//   * same LDS images and swizzles as above (both 32x32 fragment reads are conflict-free on them: DESIGN.md 4.2), whole chunk loop unrolled so
+//     that every fragment address is a lane constant + immediate;
+//   * the output leaves through LDS (the K tile is dead after the last chunk): O^T has the query on the lane and 4 consecutive d per register
+//     group, rows are rebuilt with ds_write_b64 / ds_read_b128 and stored as 8 full 128-B lines per instruction.
+#define NW32 4
+__device__ __forceinline__ void sp32_qk(const char* const (&kb)[4], int ci, const bf16x8 (&q)[4], f32x16& s) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(kb[ks] + ci * 4096);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, q[ks], ks == 0 ? z : s, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void sp32_exp(const f32x16& s, bf16x8 (&p)[2]) {
+    float e[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e[i] = __builtin_amdgcn_exp2f(s[i]);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+        p[m] = (bf16x8){(bf16_t)e[8 * m], (bf16_t)e[8 * m + 1], (bf16_t)e[8 * m + 2], (bf16_t)e[8 * m + 3],
+                        (bf16_t)e[8 * m + 4], (bf16_t)e[8 * m + 5], (bf16_t)e[8 * m + 6], (bf16_t)e[8 * m + 7]};
+}
+// the CLS chunk: only its row 0 (accumulator register 0 of lanes 0..31) is a key
+__device__ __forceinline__ void sp32_exp_cls(const f32x16& s, bf16x8 (&p)[2], int lane) {
+    const float e = lane < 32 ? __builtin_amdgcn_exp2f(s[0]) : 0.f;
+    const bf16_t zb = (bf16_t)0.f;
+    p[0] = (bf16x8){(bf16_t)e, zb, zb, zb, zb, zb, zb, zb};
+    p[1] = (bf16x8){zb, zb, zb, zb, zb, zb, zb, zb};
+}
+template <bool CLS>
+__device__ __forceinline__ void sp32_pv(const char* const (&vb)[2], int ci, const bf16x8 (&p)[2], f32x16 (&o)[2], f32x16& ol) {
+    const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
+    // the row-sum products first: their operands are in registers when the half-step starts, so they cover the LDS latency of the fragments
+#pragma unroll
+    for (int m = 0; m < (CLS ? 1 : 2); ++m) ol = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, p[m], ol, 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < (CLS ? 1 : 2); ++m) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const bf16x4 a0 = lds_tr4(vb[dt] + ci * 4096 + m * 2048), a1 = lds_tr4(vb[dt] + ci * 4096 + m * 2048 + 1024);
+            const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, p[m], o[dt], 0, 0, 0);
+        }
+    }
+}
+// One steady-state half-step: row sums + PV of block Z (chunk cz, probabilities from the previous half-step), scores of block Z's NEXT chunk
+// (10 MFMAs = 320 cycles of the matrix core), and under them the 16 exponentials + 8 conversions of block Y.  The group barriers pin the
+// interleave the scheduler would otherwise bunch (all exponentials after the first MFMA: 7 per gap): per MFMA gap 2 v_exp_f32 + 1
+// v_cvt_pk_bf16_f32 (= 8 + 16 + 4 issue cycles of the gap's 32), the 12 fragment reads in the first three gaps.
+__device__ __forceinline__ void sp32_half_step(const char* const (&kb)[4], const char* const (&vb)[2], int cz, const bf16x8 (&qz)[4], f32x16& sz,
+                                               const bf16x8 (&pz)[2], f32x16 (&oz)[2], f32x16& olz, const f32x16& sy, bf16x8 (&py)[2], bool has_pv) {
+    // MFMA order: the two row-sum products (operands in registers: they cover the LDS latency of the K fragments), the score chain (done four
+    // MFMAs = 128 cycles before the half-step ends, so the next half-step's first exponentials do not wait for it), the four PV products
+    const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
+    if (has_pv) {
+        olz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pz[0], olz, 0, 0, 0);
+        olz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pz[1], olz, 0, 0, 0);
+    }
+    sp32_qk(kb, cz + 1, qz, sz);
+    if (has_pv) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const bf16x4 a0 = lds_tr4(vb[dt] + cz * 4096 + m * 2048), a1 = lds_tr4(vb[dt] + cz * 4096 + m * 2048 + 1024);
+                const bf16x8 af = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                oz[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pz[m], oz[dt], 0, 0, 0);
+            }
+    }
+    sp32_exp(sy, py);
+    asm volatile("" : "+v"(py[0]), "+v"(py[1]));     // the probabilities are made HERE (LLVM otherwise sinks them to their use in the next half-step)
+#ifndef HH_SP32_NO_GROUPS
+    if (has_pv) {
+#pragma unroll
+        for (int g = 0; g < 10; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // MFMA
+            if (g < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);         // DS read
+            if (g >= 1 && g <= 8) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);     // VALU: the conversion of the previous gap's pair
+            if (g < 8) __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);         // TRANS
+        }
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+}
+// O^T of one 32-query block -> the wave's LDS rows (row q: 128 B, 16-B chunk c at position c ^ (q & 7)), normalised, bf16
+__device__ __forceinline__ void sp32_o_to_lds(char* rows, const f32x16 (&o)[2], float l, int r, int hh) {
+    const float inv = 1.f / l;
+    char* row = rows + r * 128 + 8 * hh;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const u32x2 w = {pack_bf16(o[dt][4 * k4] * inv, o[dt][4 * k4 + 1] * inv), pack_bf16(o[dt][4 * k4 + 2] * inv, o[dt][4 * k4 + 3] * inv)};
+            *(u32x2*)(row + (((4 * dt + k4) ^ (r & 7)) << 4)) = w;
+        }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(64 * NW32, 2) void space_attn32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                   float* __restrict__ cls_partial, int B, int T, int heads, int dbg, int layout) {
+    constexpr int n = NCH * 32, KP = n + 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + (size_t)KP * 128;
+    float* scratch = (float*)(smem + (size_t)KP * 256);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = heads * 64;
+    const int N = 1 + T * n;
+    const int rev = layout >> 1;                       // (bit 1, HH_QKV_WALK_REVERSE: the problems last to first)
+    layout &= 1;
+    const int64_t ld = layout ? 64 : 3 * (int64_t)D;
+    const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
+    int bid = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int head = bid % heads; bid /= heads;
+    const int f = bid % T;
+    const int b = bid / T;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + head * hs;
+    const bf16_t* q_ptr = base + (int64_t)(1 + f * n) * ld;
+    const int r = lane & 31, hh = lane >> 5;
+    bf16x8 qa[4], qb[4];
+    auto load_q = [&](int q0) {
+        const bf16_t* ra = q_ptr + (int64_t)(q0 + r) * ld + 8 * hh;
+        const bf16_t* rb = ra + 32 * ld;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qa[ks] = *(const bf16x8*)(ra + 16 * ks); qb[ks] = *(const bf16x8*)(rb + 16 * ks); }
+    };
+    const int q0 = wave * 64;                          // this wave's 64 queries (n <= 256: at most one group per wave)
+    const bool active = q0 < n;
+    // debug mode 3: cls_partial is a [workgroups, 8] uint64 buffer of s_memtime stamps of wave 0 (start / staged / chunks done / K, V free / done)
+    unsigned long long* stamps = dbg == 3 ? (unsigned long long*)cls_partial + (int64_t)blockIdx.x * 8 : nullptr;
+    if (dbg == 3) { cls_partial = nullptr; if (tid == 0) stamps[0] = __builtin_readcyclecounter(); }
+    if (active) load_q(q0);                            // in flight together with the K / V staging
+    if (dbg != 2) space_stage<NW32>(Ks, Vs, base, q_ptr, ld, ws, n, KP, lane, wave);
+    else for (int i = tid * 16; i < KP * 256; i += 64 * NW32 * 16) *(u32x4*)(smem + i) = (u32x4){0u, 0u, 0u, 0u};     // (compute only: finite operands)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (dbg == 3 && tid == 0) stamps[1] = __builtin_readcyclecounter();
+    if (dbg == 1) {                                    // debug: memory traffic only
+        if (active) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                *(bf16x8*)(out + ((int64_t)b * N + 1 + f * n + q0 + r) * D + head * 64 + 16 * ks + 8 * hh) = qa[ks];
+                *(bf16x8*)(out + ((int64_t)b * N + 1 + f * n + q0 + 32 + r) * D + head * 64 + 16 * ks + 8 * hh) = qb[ks];
+            }
+        }
+        return;
+    }
+    // lane-constant fragment addresses of chunk 0 (the swizzle keys use row bits 0-3 / 1 only: the same for every chunk)
+    const int kz = (r & 7) ^ ((r >> 3) & 1);
+    const char* kb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kb[ks] = Ks + r * 128 + (((2 * ks + hh) ^ kz) << 4);
+    const int i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, e16 = (lane >> 4) & 1, vz = ((q4 >> 1) & 1) << 2;
+    const char* vb[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) vb[dt] = Vs + (4 * hh + q4) * 128 + (((4 * dt + 2 * e16 + (pp >> 1)) ^ vz) << 4) + 8 * (pp & 1);
+    const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x16 oa[2] = {z16, z16}, ob[2] = {z16, z16};
+    float la = 1.f, lb = 1.f;
+    bool bad_a = false, bad_b = false;
+    if (active) {
+        f32x16 sa, sb, ola = z16, olb = z16;
+        bf16x8 pa[2], pb[2];
+        sp32_qk(kb, 0, qa, sa);
+#pragma unroll
+        for (int ci = 0; ci < NCH; ++ci) {
+            // half-step A: PV of b (chunk ci - 1) + scores of b (chunk ci) | probabilities of a (chunk ci)
+            sp32_half_step(kb, vb, ci - 1, qb, sb, pb, ob, olb, sa, pa, ci > 0);
+            // half-step B: PV of a (chunk ci) + scores of a (chunk ci + 1; the last one is the CLS chunk) | probabilities of b (chunk ci)
+            sp32_half_step(kb, vb, ci, qa, sa, pa, oa, ola, sb, pb, true);
+        }
+        sp32_pv<false>(vb, NCH - 1, pb, ob, olb);
+        sp32_qk(kb, NCH, qb, sb);
+        sp32_exp_cls(sa, pa, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        sp32_exp_cls(sb, pb, lane);
+        sp32_pv<true>(vb, NCH, pa, oa, ola);
+        sp32_pv<true>(vb, NCH, pb, ob, olb);
+        if (dbg == 3 && tid == 0) stamps[2] = __builtin_readcyclecounter();
+        // ---- a row sum outside [2^-100, 2^100]: that block is redone on the running-maximum path (16-query routines, K / V still resident)
+        la = ola[0]; lb = olb[0];
+        bad_a = __builtin_amdgcn_ballot_w64(!(la >= 7.9e-31f && la <= 1.2e30f)) != 0;
+        bad_b = __builtin_amdgcn_ballot_w64(!(lb >= 7.9e-31f && lb <= 1.2e30f)) != 0;
+        if (bad_a || bad_b) {
+            const int c = lane & 15, g = lane >> 4, nt = (n >> 4) + 1;
+#pragma unroll 1
+            for (int sub = 0; sub < 4; ++sub) {
+                if (!(sub < 2 ? bad_a : bad_b)) continue;
+                const int row0 = q0 + 16 * sub;
+                const bf16_t* qrow = q_ptr + (int64_t)(row0 + c) * ld + 8 * g;
+                bf16x8 q16[2];
+                q16[0] = *(const bf16x8*)(qrow);
+                q16[1] = *(const bf16x8*)(qrow + 32);
+                f32x4 o2[4] = {z4, z4, z4, z4};
+                float m_run = -INFINITY, l_run = 0.f;
+                for (int t = 0; t + 1 < nt; ++t) space16_chunk<1, false>(Ks, Vs, q16, t, lane, o2, m_run, l_run);
+                space16_chunk<1, true>(Ks, Vs, q16, nt - 1, lane, o2, m_run, l_run);
+                space_store_block(o2, l_run, out + ((int64_t)b * N + 1 + f * n + row0 + c) * D + head * 64 + 16 * g, c, D);
+            }
+        }
+    }
+    // ---- the CLS query's partial over this frame's keys needs K / V: it runs BEFORE the rows go through the K tile
+    if (cls_partial != nullptr) {
+        bf16x8 qc[2];
+        qc[0] = *(const bf16x8*)(base + 8 * (lane >> 4));
+        qc[1] = *(const bf16x8*)(base + 8 * (lane >> 4) + 32);
+        space16_cls_wave<NW32>(Ks, Vs, scratch, qc, n, f == 0, lane, wave);
+    }
+    __syncthreads();                                   // every wave is done with K / V
+    if (dbg == 3 && tid == 0) stamps[3] = __builtin_readcyclecounter();
+    if (cls_partial != nullptr && tid < 64)
+        space16_cls_merge<NW32>(scratch, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, tid);
+    if (!active) return;
+    char* rows = Ks + wave * 8192;                     // the wave's 64 output rows, in the dead K tile (KP * 128 >= 4 * 8192 needs n >= 224;
+                                                       // smaller n: fewer active waves, same bound per wave: q0 + 64 <= n <= KP)
+    if (!bad_a) sp32_o_to_lds(rows, oa, la, r, hh);
+    if (!bad_b) sp32_o_to_lds(rows + 32 * 128, ob, lb, r, hh);
+    // 8 rows x 128 B per instruction: lane l takes chunk l & 7 of row 8 t + (l >> 3)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if ((t < 4 ? bad_a : bad_b)) continue;         // (wave-uniform)
+        const int row = 8 * t + (lane >> 3);
+        const u32x4 v = *(const u32x4*)(rows + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+        *(u32x4*)(out + ((int64_t)b * N + 1 + f * n + q0 + row) * D + head * 64 + 8 * (lane & 7)) = v;
+    }
+    if (dbg == 3 && tid == 0) { stamps[4] = __builtin_readcyclecounter(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[5] = __builtin_readcyclecounter(); }
+}
+
+
+// ---- the same chunk pipeline in a PERSISTENT, WAVE-SPECIALISED workgroup, one per CU (round 6, second step).  Timeline of the kernel above
+// (debug mode 3, B = 32): a workgroup lives 19 us -- 9.4 us waiting for its K / V / Q, 4.8-6.3 us in the chunk loop, 3.3-4.4 us until its stores
+// are taken -- i.e. with two workgroups per CU nothing is in flight for a CU while its workgroups compute, and the chip's memory system (the
+// kernel's real bound: 1074 MB per call) idles a quarter of the time.  A first persistent form (4 waves, one per SIMD, 512 registers, the next
+// problem's K / V / Q requested into parked registers before the chunk loop) was built and measured at 315-367 us: a wave that issues 26
+// loads + 8 stores into a saturated memory system is BLOCKED in the issue of those instructions for about the memory time of a problem,
+// and with one wave per SIMD nothing else runs -- memory time and compute time add up (10.8 us per problem).  Hence two roles:
+//   * waves 0-3 (one per SIMD) only compute: Q fragments from LDS, the chunk loop above, the running-maximum redo, the CLS partial, their 64
+//     output rows into LDS -- no vector-memory instruction on the normal path;
+//   * waves 4-7 (the second wave of each SIMD) only move data: while problem i is computed they store the rows of problem i - 1 from LDS,
+//     request K / V / Q of problem i + 1 into their registers (26 x 16 B per lane, 104 KB in flight per CU), and between the two workgroup
+//     barriers of a problem boundary write them to LDS (the image the LDS-DMA of the kernels above writes: lane l of piece pc at pc * 1024 +
+//     16 l) -- plain loads and ds_write, so hipcc's own counted waits apply (an LDS-DMA in flight would turn them into vmcnt(0)).
+// Two barriers per problem: A = "K / V / Q of problem i are dead" (loaders then overwrite them, compute waves write their rows), B = "K / V / Q
+// of problem i + 1 are visible, rows of problem i are complete".
+#define NW32P 8
+template <int NCH>
+__global__ __launch_bounds__(64 * NW32P, 1) void space_attn32p_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                     float* __restrict__ cls_partial, int B, int T, int heads, int dbg, int layout) {
+    constexpr int n = NCH * 32, KP = n + 32, PIECES = KP / 8, PPW = PIECES / 4, QPW = n / 8 / 4;
+    static_assert(n == 256, "four compute waves x 64 queries");
+    static_assert(PIECES % 4 == 0 && (n / 8) % 4 == 0, "every loader wave moves the same number of pieces");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + (size_t)KP * 128;
+    char* Qs = smem + (size_t)KP * 256;
+    char* rows_all = Qs + (size_t)n * 128;
+    float* scratch = (float*)(rows_all + 4 * 8192);                 // two sets of 4 CLS records (the merge of problem i - 1 runs while problem i is computed)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = heads * 64;
+    const int N = 1 + T * n;
+    const int rev = layout >> 1;                       // (bit 1, HH_QKV_WALK_REVERSE: the problems last to first)
+    layout &= 1;
+    const int64_t ld = layout ? 64 : 3 * (int64_t)D;
+    const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
+    const int P = B * T * heads;
+    auto problem = [&](int i, int& b, int& f, int& head) { int bid = rev ? P - 1 - i : i; head = bid % heads; bid /= heads; f = bid % T; b = bid / T; };
+    const int first = blockIdx.x, step = gridDim.x;
+    if (first >= P) return;
+    unsigned long long* stamps = dbg == 3 ? (unsigned long long*)cls_partial + (int64_t)blockIdx.x * 8 : nullptr;
+    if (dbg == 3) cls_partial = nullptr;
+    const bool stamp_wave = dbg == 3 && tid == 0;
+
+    if (wave >= 4) {
+        // ================================================================ loader waves
+        const int lw = wave - 4;
+        // piece j of this wave = rows 8 (lw + 4 j) + (lane >> 3): row & 7 = lane >> 3 and (row >> 3) & 1 = lw & 1 for every j, so a stream's
+        // swizzled chunk is one lane constant; K / V pieces 0 .. PPW-2 hold frame keys, the last one the CLS row (rows n .. n + 31)
+        const unsigned ck = (unsigned)((lane & 7) ^ (lane >> 3) ^ (lw & 1)), cv = (unsigned)((lane & 7) ^ (((lane >> 4) & 1) << 2));
+        const unsigned ld_b = (unsigned)ld * 2u;
+        const unsigned rowoff = (unsigned)(lw * 8 + (lane >> 3)) * ld_b;
+        const unsigned voff_k = rowoff + ck * 16u, voff_v = rowoff + cv * 16u;
+        const unsigned voff_o = ((unsigned)(lane >> 3) * (unsigned)D + 8u * (unsigned)(lane & 7)) * 2u;
+        u32x4 kreg[PPW], vreg[PPW], qreg[QPW];
+        auto request = [&](int i) {
+            int b, f, head;
+            problem(i, b, f, head);
+            const char* base = (const char*)(qkv + (int64_t)b * N * ld + head * hs);       // the clip's row 0 (CLS) of this head's q plane
+            const char* q_ptr = base + (int64_t)(1 + f * n) * ld * 2;
+#pragma unroll
+            for (int j = 0; j < QPW; ++j) qreg[j] = *(const u32x4*)(q_ptr + (int64_t)(32 * j) * ld_b + (size_t)voff_k);     // Q rows: the K swizzle
+#pragma unroll
+            for (int j = 0; j < PPW - 1; ++j) {
+                kreg[j] = *(const u32x4*)(q_ptr + (int64_t)(32 * j) * ld_b + ws * 2 + (size_t)voff_k);
+                vreg[j] = *(const u32x4*)(q_ptr + (int64_t)(32 * j) * ld_b + ws * 4 + (size_t)voff_v);
+            }
+            kreg[PPW - 1] = *(const u32x4*)(base + ws * 2 + (size_t)(ck * 16u));
+            vreg[PPW - 1] = *(const u32x4*)(base + ws * 4 + (size_t)(cv * 16u));
+        };
+        auto to_lds = [&]() {
+#pragma unroll
+            for (int j = 0; j < QPW; ++j) *(u32x4*)(Qs + (lw + 4 * j) * 1024 + lane * 16) = qreg[j];
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                *(u32x4*)(Ks + (lw + 4 * j) * 1024 + lane * 16) = kreg[j];
+                *(u32x4*)(Vs + (lw + 4 * j) * 1024 + lane * 16) = vreg[j];
+            }
+        };
+        // rows of problem ip (compute wave w's 64 rows at rows_all + 8192 w; this loader wave stores those of compute wave lw) + its CLS record
+        auto flush = [&](int ip, int par_prev, unsigned bad_mask) {
+            int b, f, head;
+            problem(ip, b, f, head);
+            const char* rows = rows_all + lw * 8192;
+            u32x4 v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int row = 8 * t + (lane >> 3);
+                v[t] = *(const u32x4*)(rows + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+            }
+            if (cls_partial != nullptr && lw == 0)
+                space16_cls_merge<4>(scratch + par_prev * (4 * CLS_REC), cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, lane);
+            char* orow = (char*)(out + ((int64_t)b * N + 1 + f * n + lw * 64) * D + head * 64);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if ((bad_mask >> (2 * lw + (t >> 2))) & 1u) continue;       // (wave-uniform: a redone block was stored by its compute wave)
+                *(u32x4*)(orow + (int64_t)(8 * t) * D * 2 + (size_t)voff_o) = v[t];
+            }
+        };
+        volatile unsigned* bad_flags = (volatile unsigned*)(scratch + 2 * 4 * CLS_REC);      // [2 sets][4 compute waves]: bit 0 / 1 = block a / b was redone
+        request(first);
+        to_lds();
+        __syncthreads();                               // B(first)
+        int par = 0, prev = -1;
+        for (int i = first; i < P; i += step) {
+            if (prev >= 0) {
+                unsigned bm = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) bm |= (bad_flags[(par ^ 1) * 4 + w] & 3u) << (2 * w);
+                flush(prev, par ^ 1, (unsigned)__builtin_amdgcn_readfirstlane((int)bm));
+            }
+            const int inext = i + step;
+            if (inext < P) request(inext);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                           // A(i): the compute waves are done with K / V / Q of problem i
+            if (inext < P) to_lds();
+            __syncthreads();                           // B(next): K / V / Q of the next problem visible, rows of problem i complete
+            prev = i; par ^= 1;
+        }
+        {
+            unsigned bm = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) bm |= (bad_flags[(par ^ 1) * 4 + w] & 3u) << (2 * w);
+            flush(prev, par ^ 1, (unsigned)__builtin_amdgcn_readfirstlane((int)bm));
+        }
+        return;
+    }
+
+    // ==================================================================== compute waves
+    const int r = lane & 31, hh = lane >> 5;
+    const int q0 = wave * 64;
+    const int kz = (r & 7) ^ ((r >> 3) & 1);
+    const char* kb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kb[ks] = Ks + r * 128 + (((2 * ks + hh) ^ kz) << 4);
+    const int i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3, e16 = (lane >> 4) & 1, vz = ((q4 >> 1) & 1) << 2;
+    const char* vb[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) vb[dt] = Vs + (4 * hh + q4) * 128 + (((4 * dt + 2 * e16 + (pp >> 1)) ^ vz) << 4) + 8 * (pp & 1);
+    const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    char* rows = rows_all + wave * 8192;
+    unsigned* bad_flags = (unsigned*)(scratch + 2 * 4 * CLS_REC);
+    __syncthreads();                                   // B(first)
+    int par = 0;
+    for (int i = first; i < P; i += step) {
+        int b, f, head;
+        problem(i, b, f, head);
+        const bool st = stamp_wave && i == first + step;
+        if (st) stamps[0] = __builtin_readcyclecounter();
+        // (an opaque copy of the lane index per problem: everything addressed from it -- Q fragments, the rows, the redo path -- is recomputed
+        // here instead of being hoisted out of the problem loop, where ~35 loop-invariant address registers took the chunk loop's arch VGPRs to
+        // the 256 cap and the scheduler gave up the pinned interleave)
+        int lane_i = lane;
+        asm volatile("" : "+v"(lane_i));
+        const int r_i = lane_i & 31, hh_i = lane_i >> 5, kz_i = (r_i & 7) ^ ((r_i >> 3) & 1);
+        bf16x8 qa[4], qb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qa[ks] = *(const bf16x8*)(Qs + (q0 + r_i) * 128 + (((2 * ks + hh_i) ^ kz_i) << 4));
+            qb[ks] = *(const bf16x8*)(Qs + (q0 + 32 + r_i) * 128 + (((2 * ks + hh_i) ^ kz_i) << 4));
+        }
+        f32x16 oa[2] = {z16, z16}, ob[2] = {z16, z16}, sa, sb, ola = z16, olb = z16;
+        bf16x8 pa[2], pb[2];
+        sp32_qk(kb, 0, qa, sa);
+#pragma unroll
+        for (int ci = 0; ci < NCH; ++ci) {
+            sp32_half_step(kb, vb, ci - 1, qb, sb, pb, ob, olb, sa, pa, ci > 0);
+            sp32_half_step(kb, vb, ci, qa, sa, pa, oa, ola, sb, pb, true);
+        }
+        sp32_pv<false>(vb, NCH - 1, pb, ob, olb);
+        sp32_qk(kb, NCH, qb, sb);
+        sp32_exp_cls(sa, pa, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        sp32_exp_cls(sb, pb, lane);
+        sp32_pv<true>(vb, NCH, pa, oa, ola);
+        sp32_pv<true>(vb, NCH, pb, ob, olb);
+        if (st) stamps[1] = __builtin_readcyclecounter();
+        const float la = ola[0], lb = olb[0];
+        const bool bad_a = __builtin_amdgcn_ballot_w64(!(la >= 7.9e-31f && la <= 1.2e30f)) != 0;
+        const bool bad_b = __builtin_amdgcn_ballot_w64(!(lb >= 7.9e-31f && lb <= 1.2e30f)) != 0;
+        const bf16_t* base = qkv + (int64_t)b * N * ld + head * hs;
+        if (bad_a || bad_b) {
+            const bf16_t* q_ptr = base + (int64_t)(1 + f * n) * ld;
+            bf16_t* orow = out + ((int64_t)b * N + 1 + f * n + q0) * D + head * 64;
+            const int c = lane_i & 15, g = lane_i >> 4, nt = (n >> 4) + 1;
+#pragma unroll 1
+            for (int sub = 0; sub < 4; ++sub) {
+                if (!(sub < 2 ? bad_a : bad_b)) continue;
+                const bf16_t* qrow = q_ptr + (int64_t)(q0 + 16 * sub + c) * ld + 8 * g;
+                bf16x8 q16[2];
+                q16[0] = *(const bf16x8*)(qrow);
+                q16[1] = *(const bf16x8*)(qrow + 32);
+                f32x4 o2[4] = {z4, z4, z4, z4};
+                float m_run = -INFINITY, l_run = 0.f;
+                for (int t = 0; t + 1 < nt; ++t) space16_chunk<1, false>(Ks, Vs, q16, t, lane_i, o2, m_run, l_run);
+                space16_chunk<1, true>(Ks, Vs, q16, nt - 1, lane_i, o2, m_run, l_run);
+                space_store_block(o2, l_run, orow + (int64_t)(16 * sub + c) * D + 16 * g, c, D);
+            }
+        }
+        if (lane == 0) bad_flags[par * 4 + wave] = (bad_a ? 1u : 0u) | (bad_b ? 2u : 0u);
+        if (cls_partial != nullptr) {
+            bf16x8 qc[2];                             // the CLS query = row 0 of the clip: one 128-B row, read through the scalar / vector cache
+            qc[0] = *(const bf16x8*)(base + 8 * (lane_i >> 4));
+            qc[1] = *(const bf16x8*)(base + 8 * (lane_i >> 4) + 32);
+            space16_cls_wave<4>(Ks, Vs, scratch + par * (4 * CLS_REC), qc, n, f == 0, lane_i, wave);
+        }
+        __syncthreads();                               // A(i)
+        if (st) stamps[2] = __builtin_readcyclecounter();
+        if (!bad_a) sp32_o_to_lds(rows, oa, la, r_i, hh_i);
+        if (!bad_b) sp32_o_to_lds(rows + 32 * 128, ob, lb, r_i, hh_i);
+        __syncthreads();                               // B(next)
+        if (st) stamps[3] = __builtin_readcyclecounter();
+        par ^= 1;
+    }
+}
+
+
+// mode: hh_set_tuning("space_mfma32"): 1 = the persistent kernel where n == 256 (else the one-problem-per-workgroup kernel), 2 = always the latter
+int hh_space_attn32_launch(const void* qkv, int layout_rev, void* out, float* cls_partial, int B, int T, int n, int heads, int mode, int dbg, hipStream_t stream) {
+    typedef void (*k32_t)(const bf16_t*, bf16_t*, float*, int, int, int, int, int);
+    const int nch = n / 32, KP = n + 32;
+    HH_REQUIRE(n % 64 == 0 && n >= 64 && n <= 256, HH_ERR_UNSUPPORTED, "hh_space_attn_fwd: the 32x32x16 kernels take n in {64, 128, 192, 256}, got %d", n);
+    if (n == 256 && mode == 1 && dbg != 1 && dbg != 2) {
+        // persistent form: one workgroup per CU walks the problems, the next problem's K / V / Q are requested before the current chunk loop
+        const k32_t kp = (k32_t)space_attn32p_kernel<8>;
+        const size_t ldsp = (size_t)KP * 256 + (size_t)n * 128 + 4 * 8192 + ((size_t)2 * 4 * CLS_REC + 64) * 4;
+        static size_t attrp32 = 0;
+        if (ldsp > attrp32) {
+            hipError_t e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+            HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", ldsp);
+            attrp32 = ldsp;
+        }
+        const int64_t P = (int64_t)B * T * heads;
+        const int cus = hh_stream_cu_count(stream);
+        hh_prof_note_kernel(HH_PROF_SPACE_ATTN, "space_attn32p_kernel<8>");
+        hipLaunchKernelGGL(kp, dim3((unsigned)(P < cus ? P : cus)), dim3(64 * NW32P), ldsp, stream,
+                           (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, heads, dbg, layout_rev);
+        return hh_check_launch("hh_space_attn_fwd");
+    }
+    const size_t lds = (size_t)KP * 256 + ((size_t)KP + 12 * CLS_REC + 24) * 4;          // (the same size as the 16x16x32 kernels reserve)
+    const k32_t k32 = nch == 8 ? (k32_t)space_attn32_kernel<8> : nch == 6 ? (k32_t)space_attn32_kernel<6> : nch == 4 ? (k32_t)space_attn32_kernel<4> : (k32_t)space_attn32_kernel<2>;
+    static size_t attr32[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (lds > attr32[nch]) {
+        hipError_t e = hipFuncSetAttribute((const void*)k32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds);
+        attr32[nch] = lds;
+    }
+    hh_prof_note_kernel(HH_PROF_SPACE_ATTN, nch == 8 ? "space_attn32_kernel<8>" : nch == 6 ? "space_attn32_kernel<6>" : nch == 4 ? "space_attn32_kernel<4>" : "space_attn32_kernel<2>");
+    hipLaunchKernelGGL(k32, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW32), lds, stream,
+                       (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, heads, dbg, layout_rev);
+    return hh_check_launch("hh_space_attn_fwd");
+}

@@ -29,6 +29,13 @@ struct HHProfScope {
     hipStream_t stream_;
 };
 
+// per-device once-guards for hipFuncSetAttribute (dynamic LDS sizes are a per-device function attribute): `mask` is the call site's static
+// bit set of devices already done.  hh_attr_needed: true until hh_attr_done() was called for the CURRENT device (set the bit only after every
+// attribute call of the site succeeded).  Thread-safe; devices >= 64 are simply set every time.
+#include <atomic>
+bool hh_attr_needed(const std::atomic<uint64_t>& mask);
+void hh_attr_done(std::atomic<uint64_t>& mask);
+
 void hh_prof_note_kernel(int klass, const char* name);    // runtime.cpp: the kernel a launch site dispatched for a profiled class (hh_prof_kernel_name)
 
 #define HH_REQUIRE(cond, code, ...)                 \

@@ -332,13 +332,14 @@ static int gemm_bf16_impl(const void* A, int64_t lda, const void* W, int64_t ldw
     const int groups = (per_xcd_mt + GROUP_M - 1) / GROUP_M;
     const unsigned grid = p.Mt < 8 ? (unsigned)(p.Mt * p.Nt) : 8u * (unsigned)groups * GROUP_M * (unsigned)p.Nt;
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        attr_done = true;
+    static std::atomic<uint64_t> attr_mask{0};
+    if (hh_attr_needed(attr_mask)) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_gemm_bf16: cannot reserve 128 KB of LDS for the 128x128 kernel: %s", hipGetErrorString(e));
+        hh_attr_done(attr_mask);
     }
     const unsigned splits = epi->splitk > 1 ? (unsigned)epi->splitk : 1u;
     HH_REQUIRE(splits <= 1024, HH_ERR_SHAPE, "hh_gemm_bf16: splitk too large");

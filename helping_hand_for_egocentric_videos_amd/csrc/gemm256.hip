@@ -591,6 +591,10 @@ static int g_space_waves = 0;      // waves per workgroup of the joint space ker
 int hh_tuning_space_waves() { return g_space_waves; }
 static int g_space_prog = 1;       // 1 = progressive K / V staging where a specialised kernel exists (n = 576)
 int hh_tuning_space_prog() { return g_space_prog; }
+static int g_space_mfma32 = 1;     // "space_mfma32": 1 = space attention on the 32x32x16 software-pipelined kernel where n <= 256 and n % 64 == 0 (round 6); 0 = the joint-block kernel
+int hh_tuning_space_mfma32() { return g_space_mfma32; }
+static int g_mattn_no_ticket = 0;  // "mattn_no_ticket": tests only -- hh_mattn_* behave as if the stream-slot table were full (one key slice per unit)
+int hh_tuning_mattn_no_ticket() { return g_mattn_no_ticket; }
 
 
 
@@ -600,6 +604,8 @@ extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "space_debug")) { g_space_dbg = value; return HH_OK; }
     if (name && !strcmp(name, "space_joint")) { g_space_joint = value; return HH_OK; }
     if (name && !strcmp(name, "space_prog") && value >= 0 && value <= 2) { g_space_prog = value; return HH_OK; }
+    if (name && !strcmp(name, "space_mfma32") && value >= 0 && value <= 2) { g_space_mfma32 = value; return HH_OK; }
+    if (name && !strcmp(name, "mattn_no_ticket") && (value == 0 || value == 1)) { g_mattn_no_ticket = value; return HH_OK; }
     if (name && !strcmp(name, "space_waves") && (value == 0 || value == 4 || value == 12)) { g_space_waves = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_skew")) { g_skew = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_pskew") && value >= 0 && value <= 64) { g_pskew = value; return HH_OK; }
@@ -655,16 +661,17 @@ int hh_gemm256_tile_rows(const GemmParams& p, hipStream_t s) {
 
 int hh_gemm256_launch(const GemmParams& pin, hipStream_t s, bool* tail_done) {
     if (tail_done) *tail_done = false;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)gemm256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
-        hipFuncSetAttribute((const void*)gemm256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
-        hipFuncSetAttribute((const void*)gemm256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
-        hipFuncSetAttribute((const void*)gemm256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
-#define ATTRD(BF, E) hipFuncSetAttribute((const void*)gemm256d_kernel<BF, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192))
+    static std::atomic<uint64_t> attr_mask{0};
+    if (hh_attr_needed(attr_mask)) {
+        hipError_t e = hipSuccess;
+#define ATTR1(...) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm256_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES)
+#define ATTRD(...) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm256d_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS(8192))
+        ATTR1(true, true); ATTR1(false, true); ATTR1(true, false); ATTR1(false, false);
         ATTRD(true, 0); ATTRD(false, 0); ATTRD(true, 1); ATTRD(false, 1); ATTRD(true, 2); ATTRD(false, 2); ATTRD(true, 3); ATTRD(false, 3);
+#undef ATTR1
 #undef ATTRD
-        attr_done = true;
+        HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_gemm_bf16: cannot reserve %d B of LDS for the 256x256 kernels: %s", (int)P_LDS(8192), hipGetErrorString(e));
+        hh_attr_done(attr_mask);
     }
     const int stagger = g_mode != 1;
     GemmParams p = pin;

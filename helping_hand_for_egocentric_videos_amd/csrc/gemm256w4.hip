@@ -260,7 +260,7 @@ __device__ __forceinline__ void w4_ldsread(bf16x8& r, unsigned a) {
 // one 16-B-per-lane LDS-DMA piece: global address = scalar base + lane offset, LDS destination = wave base + IMM (through M0)
 template <int IMM>
 __device__ __forceinline__ void w4_dma(unsigned voff, const char* sbase, unsigned wave_lds) {
-    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(wave_lds), "n"(IMM) : "memory", "scc");
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(wave_lds), "n"(IMM) : "memory", "scc", "m0");
 }
 // closes a quadrant: the eight fragment registers read under it are valid, the half-tile read in the next quadrant has landed
 // (VM younger DMA / store instructions may stay in flight), every wave is done with the half-tile read in this one
@@ -288,7 +288,7 @@ __device__ __forceinline__ void w4q(const bf16x8 (&AF)[4][2], const bf16x8 (&WF)
     }
     if constexpr (DMA_ON && I >= 16 && I < 24) {                   // M0 in one MFMA gap, the load in the next (the MFMA between them covers the M0 hazard)
         constexpr int i = (I - 16) / 2;
-        if constexpr (I % 2 == 0) asm volatile("s_add_u32 m0, %0, %1" :: "s"(wave_lds), "n"(DIMM + i * 1024) : "scc");
+        if constexpr (I % 2 == 0) asm volatile("s_add_u32 m0, %0, %1" :: "s"(wave_lds), "n"(DIMM + i * 1024) : "scc", "m0");
         else asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(voff[i]), "s"(src) : "memory");
     }
     if constexpr (I + 1 < 32) w4q<TR, MH, NH, ZERO, RIMM, DIMM, DMA_ON, I + 1>(AF, WF, RD, raddr, voff, src, wave_lds);
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4p_kernel(GemmParams p) {
                                     : (const char*)(p.e.ln_stats + 2 * tm0) + (wave - 2) * 1024;
         unsigned dst = w4_lds_u32(smem + 2 * W4_BUF) + (unsigned)par * W4_LNREC + (unsigned)wave * 1024u;
         asm volatile("" : "+s"(src), "+s"(dst));
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane16), "s"(src), "s"(dst) : "memory");
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane16), "s"(src), "s"(dst) : "memory", "m0");
     };
     if (p.skew_iters > 0) {
         // start skew: workgroups of an XCD begin `skew_iters` sleeps apart (P phases, or a 32-step ramp).  The tiles of a launch take equal
@@ -975,15 +975,16 @@ int hh_gemm256w4_timeline(unsigned long long* out, int blocks) {
 
 #define W4P_LDS(N) (2 * W4_BUF + (size_t)(N) * 4 + 4 * 4096)      // staging ring + bias vector + 4 KB of epilogue scratch per wave
 int hh_gemm256w4p_launch(const GemmParams& p, int epi, unsigned pg, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-#define ATTRP(BF, E) hipFuncSetAttribute((const void*)gemm256w4p_kernel<BF, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096))
+    static std::atomic<uint64_t> attr_mask{0};
+    if (hh_attr_needed(attr_mask)) {
+        hipError_t e = hipSuccess;
+#define ATTRP(...) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm256w4p_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096))
         ATTRP(true, 0); ATTRP(false, 0); ATTRP(true, 1); ATTRP(false, 1); ATTRP(true, 2); ATTRP(false, 2); ATTRP(true, 3); ATTRP(false, 3);
         ATTRP(true, 4); ATTRP(true, 5); ATTRP(true, 6); ATTRP(true, 7); ATTRP(true, 8);
+        ATTRP(true, 0, 224); ATTRP(true, 4, 224);
 #undef ATTRP
-        hipFuncSetAttribute((const void*)gemm256w4p_kernel<true, 0, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096));
-        hipFuncSetAttribute((const void*)gemm256w4p_kernel<true, 4, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4P_LDS(4096));
-        attr_done = true;
+        HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_gemm_bf16: cannot reserve %d B of LDS for the persistent 4-wave kernel: %s", (int)W4P_LDS(4096), hipGetErrorString(e));
+        hh_attr_done(attr_mask);
     }
     const bool bf = p.e.c_dtype == HH_BF16;
 #define LAUNCHP(BF, E) hipLaunchKernelGGL((gemm256w4p_kernel<BF, E>), dim3(pg), dim3(256), W4P_LDS(p.N), s, p)
@@ -1016,11 +1017,12 @@ int hh_gemm256w4p_launch(const GemmParams& p, int epi, unsigned pg, hipStream_t 
 }
 
 int hh_gemm256w4_launch(const GemmParams& p, unsigned grid, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)gemm256w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W4_BUF);
-        hipFuncSetAttribute((const void*)gemm256w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W4_BUF);
-        attr_done = true;
+    static std::atomic<uint64_t> attr_mask{0};
+    if (hh_attr_needed(attr_mask)) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W4_BUF);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm256w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W4_BUF);
+        HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_gemm_bf16: cannot reserve %d B of LDS for the 4-wave kernel: %s", (int)(2 * W4_BUF), hipGetErrorString(e));
+        hh_attr_done(attr_mask);
     }
     if (p.e.c_dtype == HH_BF16) hipLaunchKernelGGL((gemm256w4_kernel<true>), dim3(grid), dim3(256), 2 * W4_BUF, s, p);
     else hipLaunchKernelGGL((gemm256w4_kernel<false>), dim3(grid), dim3(256), 2 * W4_BUF, s, p);

@@ -79,7 +79,7 @@ __device__ __forceinline__ bf16x4 ma_tr4(unsigned a) {
 __device__ __forceinline__ void ma_dma_row(const bf16_t* src, unsigned voff, unsigned dst) {
     // (s_nop 4: the scalar operands may come straight out of a v_readfirstlane -- VALU writes SGPR -> VMEM reads it needs 5 wait states, and
     // the compiler's hazard recogniser does not look inside inline asm; scripts/check_isa_hazards.py)
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src), "s"(dst) : "memory");
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src), "s"(dst) : "memory", "m0");
 }
 
 // reductions over the four 16-lane groups of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same query): two register swaps on the
@@ -477,6 +477,8 @@ static void ma_slicing(int M, int* slices, int* per) {
     *slices = (chunks + cps - 1) / cps;
 }
 
+int hh_tuning_mattn_no_ticket();          // gemm256.hip (the tuning table)
+
 extern "C" int hh_mattn_slices(int M, int slices) {
     if (M <= 0 || M % MA_KC != 0 || slices < 1) return -1;
     int per;
@@ -506,15 +508,21 @@ extern "C" int hh_mattn_fwd(const float* qt, const void* mp, const void* mem, in
     p.c.seed = seed;
     HH_REQUIRE(p.c.slices == 1 || workspace != nullptr, HH_ERR_SHAPE, "hh_mattn_fwd: slices > 1 needs hh_workspace_bytes_mattn_fwd() bytes of workspace");
     p.qt = qt; p.pooled = pooled; p.lse2 = lse2; p.rsum = rsum;
+    p.slot = hh_tuning_mattn_no_ticket() ? -1 : hh_stream_slot((hipStream_t)stream);
+    if (p.c.slices > 1 && (p.slot < 0 || 2 * B > MA_TICKET_UNITS)) {
+        // no ticket row for the last-arriver fold (more than 32 launch streams seen in this process, or B too large): one slice per (clip, head
+        // group) -- slower at small B, same results up to the fp32 re-association of the fold; the workspace stays unused
+        p.c.slices = 1;
+        ma_slicing(M, &p.c.slices, &p.c.keys_per_slice);
+    }
     const int64_t rows_h = (int64_t)B * Q * MA_H;
     p.o_part = workspace;
     p.st_part = p.c.slices == 1 ? nullptr : workspace + (int64_t)p.c.slices * rows_h * MA_C;
-    p.slot = hh_stream_slot((hipStream_t)stream);
-    HH_REQUIRE(p.c.slices == 1 || (p.slot >= 0 && 2 * B <= MA_TICKET_UNITS), HH_ERR_UNSUPPORTED, "hh_mattn_fwd: key slices need a ticket row (<= 32 launch streams, B <= %d)", MA_TICKET_UNITS / 2);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)mattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MA_XOFF + 8 * 2048);
-        attr_done = true;
+    static std::atomic<uint64_t> attr_mask{0};
+    if (hh_attr_needed(attr_mask)) {
+        hipError_t e = hipFuncSetAttribute((const void*)mattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MA_XOFF + 8 * 2048);
+        HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_mattn_fwd: cannot reserve %d B of LDS: %s", (int)(MA_XOFF + 8 * 2048), hipGetErrorString(e));
+        hh_attr_done(attr_mask);
     }
     const int units = B * p.c.slices;
     const unsigned grid = 16u * (unsigned)((units + 7) / 8);
@@ -703,16 +711,22 @@ extern "C" int hh_mattn_bwd(const float* qt, const float* dpooled, const float* 
     p.c.slices = slices;
     ma_slicing(M, &p.c.slices, &p.c.keys_per_slice);
     HH_REQUIRE(p.c.slices == 1 || workspace != nullptr, HH_ERR_SHAPE, "hh_mattn_bwd: slices > 1 needs hh_workspace_bytes_mattn_bwd() bytes of workspace");
-    p.slot = hh_stream_slot((hipStream_t)stream);
-    HH_REQUIRE(p.c.slices == 1 || (p.slot >= 0 && 2 * B <= MA_TICKET_UNITS), HH_ERR_UNSUPPORTED, "hh_mattn_bwd: key slices need a ticket row (<= 32 launch streams, B <= %d)", MA_TICKET_UNITS / 2);
+    p.slot = hh_tuning_mattn_no_ticket() ? -1 : hh_stream_slot((hipStream_t)stream);
+    if (p.c.slices > 1 && (p.slot < 0 || 2 * B > MA_TICKET_UNITS)) {
+        // no ticket row for the last-arriver fold (more than 32 launch streams seen in this process, or B too large): one slice per (clip, head
+        // group) -- slower at small B, same results up to the fp32 re-association of the fold; the workspace stays unused
+        p.c.slices = 1;
+        ma_slicing(M, &p.c.slices, &p.c.keys_per_slice);
+    }
     ma_drop_params(dropout_p, &p.c.drop_thresh, &p.c.drop_scale);
     p.c.seed = seed;
     p.qt = qt; p.dpooled = dpooled; p.lse2 = lse2; p.dca = dca; p.ca = ca; p.bv = bv; p.dqt_part = workspace; p.dqt = dqt;
     p.pdT = (bf16_t*)pdT; p.dsT = (bf16_t*)dsT; p.qt16 = (bf16_t*)qt16; p.dp16 = (bf16_t*)dp16; p.rows_total = rows_total; p.row_off = row_off;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)mattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MA_XOFF + 8 * 4096);
-        attr_done = true;
+    static std::atomic<uint64_t> attr_mask{0};
+    if (hh_attr_needed(attr_mask)) {
+        hipError_t e = hipFuncSetAttribute((const void*)mattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MA_XOFF + 8 * 4096);
+        HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_mattn_bwd: cannot reserve %d B of LDS: %s", (int)(MA_XOFF + 8 * 4096), hipGetErrorString(e));
+        hh_attr_done(attr_mask);
     }
     const int units = B * p.c.slices;
     const unsigned grid = 16u * (unsigned)((units + 7) / 8);

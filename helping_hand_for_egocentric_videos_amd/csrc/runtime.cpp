@@ -14,13 +14,26 @@ void hh_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static std::atomic<long long> g_calls{0};       // launching entry points that reached their launch check (hh_call_count)
+
 int hh_check_launch(const char* what) {
+    g_calls.fetch_add(1, std::memory_order_relaxed);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         hh_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
         return HH_ERR_LAUNCH;
     }
     return HH_OK;
+}
+
+static int current_device() { int d = 0; return hipGetDevice(&d) == hipSuccess ? d : 0; }
+bool hh_attr_needed(const std::atomic<uint64_t>& mask) {
+    const int d = current_device();
+    return d >= 64 || !((mask.load(std::memory_order_acquire) >> d) & 1u);
+}
+void hh_attr_done(std::atomic<uint64_t>& mask) {
+    const int d = current_device();
+    if (d < 64) mask.fetch_or(1ull << d, std::memory_order_release);
 }
 
 extern "C" int hh_version(void) { return 100; }
@@ -32,6 +45,7 @@ extern "C" int hh_abi_sizeof(const char* name) {
     return -1;
 }
 extern "C" const char* hh_last_error_string(void) { return g_err; }
+extern "C" int64_t hh_call_count(void) { return (int64_t)g_calls.load(std::memory_order_relaxed); }
 
 // ---- per-stream CU budget.  The pipelined training step runs the frozen towers of batch i+1 on one stream while the decoder
 // forward/backward of batch i runs on another.  The persistent 256x256 GEMM normally puts one workgroup on every CU (LDS and

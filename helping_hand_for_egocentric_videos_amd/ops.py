@@ -64,14 +64,20 @@ class prof_role:
     """`with ops.prof_role(ops.PROF_ROLE_VISION): ...` -- names the part of the step whose kernels the host launches inside the block, for
     the library's per-kernel timers (include/hh.h: hh_prof_set_role).  Costs one relaxed store; never changes results."""
 
+    current = PROF_ROLE_DECODER          # host-side shadow of the library's role (the only writer is this class), so that blocks nest
+
     def __init__(self, role):
         self.role = int(role)
+        self.prev = PROF_ROLE_DECODER
 
     def __enter__(self):
+        self.prev = prof_role.current
+        prof_role.current = self.role
         _lib.lib().hh_prof_set_role(self.role)
 
     def __exit__(self, *exc):
-        _lib.lib().hh_prof_set_role(PROF_ROLE_DECODER)
+        prof_role.current = self.prev
+        _lib.lib().hh_prof_set_role(self.prev)
         return False
 
 

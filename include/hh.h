@@ -68,6 +68,10 @@ int hh_abi_sizeof(const char* name);
  *                   segment while the rest is in flight) where a specialised kernel exists: n = 576; 0 = off; 2 = also n = 256 (experiment: within
  *                   +-0.1 % at step level).  (Round 4's persistent cross-problem-prefetch variant, value 3, was slower and is removed: DESIGN.md 4.2);
  *                   "space_debug" 0 / 1 / 2: full kernel / memory traffic only / no staging
+ *   "space_mfma32"  1 (default) = space attention with n <= 256, n % 64 == 0 on the 32x32x16-MFMA kernel whose exponentials are software-pipelined
+ *                   under the matrix core inside each wave (round 6); 0 = the joint-block 16x16x32 kernel (rounds 2-5)
+ *   "mattn_no_ticket" 0 (default) / 1: tests only -- hh_mattn_fwd / _bwd act as if no ticket row were free (more than 32 launch streams seen):
+ *                   they then run ONE key slice per (clip, head group) instead of failing; same results up to fp32 re-association
  *   "gemm256_debug_ts", "gemm256_debug_nostore": diagnostics (timeline recording; skip the epilogue stores) */
 int hh_set_tuning(const char* name, int value);
 const char* hh_last_error_string(void);
@@ -102,6 +106,9 @@ enum hh_prof_class {
     HH_PROF_XATTN_BWD = 7,    /* decoder cross-attention backward: K,V read + dK,dV written */
     HH_PROF_CLASSES = 8
 };
+/* number of launching entry-point calls this process has made so far (every hh_* call that enqueued at least one kernel; monotonic).
+ * bench.py divides the host time of issuing one step by the difference over that step: host microseconds per library call. */
+int64_t hh_call_count(void);
 int hh_prof_enable(int stride);
 int hh_prof_read(int klass, int64_t* launches_timed, int64_t* launches_seen, double* total_ms, double* total_work);
 /* roles (round 5): the host names the part of the step it is launching -- 0 = decoder / losses / optimizer (default), 1 = vision tower,

@@ -1,0 +1,77 @@
+"""Round 6: space attention on 32x32x16 MFMAs (space_attn32_kernel, hh_set_tuning("space_mfma32", 1)) against the joint-block 16x16x32 kernel:
+max |diff|, time per call alone (B = 32 and B = 2), memory-only / compute-only variants of both."""
+import os, sys, torch, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from helping_hand_for_egocentric_videos_amd import ops, _lib
+B, T, n, heads = 32, 16, 256, 16
+if len(sys.argv) > 1:
+    B, T, n = (int(v) for v in sys.argv[1:4])
+N, D = 1 + T * n, heads * 64
+g = torch.Generator(device="cuda").manual_seed(0)
+qkv = torch.randn(B * N, 3 * D, device="cuda", generator=g)
+qkv[:, :D] *= 0.5
+qkv = qkv.to(torch.bfloat16)
+planes = qkv.view(B * N, 3 * heads, 64).transpose(0, 1).contiguous()
+out = torch.zeros(B * N, D, dtype=torch.bfloat16, device="cuda")
+part = torch.zeros(B * heads * T * 68, device="cuda")
+patch = (torch.arange(B * N, device="cuda") % N) != 0
+L = _lib.lib()
+def run(): _lib.check(L.hh_space_attn_fwd(ctypes.c_void_p(planes.data_ptr()), 1, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(part.data_ptr()), B, T, n, heads, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "x")
+def t(reps=20):
+    for _ in range(3): run()
+    torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(reps): run()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+res = {}
+for rnd in range(3):
+    for k in (0, 2, 1):
+        ops.set_tuning("space_mfma32", k)
+        res.setdefault(k, []).append(t())
+        if rnd == 0:
+            res["out%d" % k] = out.clone(); res["part%d" % k] = part.clone()
+print("joint 16x16x32 kernel: %s us    32x32x16 kernel, one problem per workgroup: %s us    32x32x16 persistent: %s us" % tuple(" ".join("%.1f" % v for v in res[k]) for k in (0, 2, 1)))
+for k in (2, 1):
+    d = (res["out%d" % k][patch].float() - res["out0"][patch].float()).abs()
+    print("mfma32=%d vs joint: max |diff| rows %.3e (scale %.3f), mean %.3e; CLS partial records max |diff| %.3e" % (k, d.max().item(), res["out0"].float().abs().max().item(), d.mean().item(), (res["part%d" % k] - res["part0"]).abs().max().item()))
+print("persistent vs one-per-workgroup: rows equal %s, CLS records equal %s" % (torch.equal(res["out1"][patch], res["out2"][patch]), torch.equal(res["part1"], res["part2"])))
+for k in (0, 2):
+    ops.set_tuning("space_mfma32", k)
+    for dbg, name in ((1, "memory only"), (2, "compute only (no K/V staging)")):
+        ops.set_tuning("space_debug", dbg)
+        print("mfma32=%d  %-32s %7.1f us" % (k, name, t()))
+    ops.set_tuning("space_debug", 0)
+ops.set_tuning("space_mfma32", 2)
+# ---- per-workgroup timeline of the 32x32 kernel (debug mode 3: s_memtime stamps of wave 0)
+stamps = torch.zeros(B * T * heads, 8, dtype=torch.int64, device="cuda")
+ops.set_tuning("space_debug", 3)
+_lib.check(L.hh_space_attn_fwd(ctypes.c_void_p(planes.data_ptr()), 1, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stamps.data_ptr()), B, T, n, heads, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "x")
+torch.cuda.synchronize(); ops.set_tuning("space_debug", 0)
+st = stamps.double().cpu()
+life = (st[:, 5] - st[:, 0]).mean()
+dur = t()
+rounds = B * T * heads / 512.0
+tick = dur / rounds / float(life)
+print("32x32 kernel, per-workgroup timeline of wave 0 (%.1f us kernel / %.0f rounds -> %.2f us mean lifetime; %.0f stamp ticks):" % (dur, rounds, dur / rounds, float(life)))
+for name, a, b_ in (("launch -> K / V / Q landed + barrier", 0, 1), ("chunk loop", 1, 2), ("redo check + CLS partial + barrier", 2, 3), ("rows through LDS, stores issued", 3, 4), ("stores acknowledged", 4, 5)):
+    d = (st[:, b_] - st[:, a])
+    print("   %-40s %5.1f %% of the lifetime  (~%5.2f us, %6.0f ticks; p10 %5.2f, p90 %5.2f us)" % (name, 100 * float(d.mean() / life), float(d.mean()) * tick, float(d.mean()), float(d.quantile(0.1)) * tick, float(d.quantile(0.9)) * tick))
+
+# ---- persistent kernel: stamps of each workgroup's SECOND problem (wave 0)
+if n == 256:
+    ops.set_tuning("space_mfma32", 1)
+    stamps.zero_()
+    ops.set_tuning("space_debug", 3)
+    _lib.check(L.hh_space_attn_fwd(ctypes.c_void_p(planes.data_ptr()), 1, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stamps.data_ptr()), B, T, n, heads, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "x")
+    torch.cuda.synchronize(); ops.set_tuning("space_debug", 0)
+    st = stamps[:256].double().cpu()
+    st = st[st[:, 3] > 0]
+    dur = t()
+    per = dur / (B * T * heads / 256.0)
+    life = float((st[:, 3] - st[:, 0]).mean())
+    print("persistent kernel %.1f us / %.0f problems per CU = %.2f us per problem; second problem of each workgroup, compute wave 0, %.0f ticks per problem:" % (dur, B * T * heads / 256.0, per, life))
+    for name, a, b_ in (("Q fragments from LDS + chunk loop", 0, 1), ("redo check + CLS partial + barrier A (waits for the loaders' requests)", 1, 2), ("rows -> LDS + barrier B (loaders write K / V / Q)", 2, 3)):
+        d = (st[:, b_] - st[:, a])
+        print("   %-72s %5.1f %%  (%6.0f ticks; p10 %6.0f, p90 %6.0f)" % (name, 100 * float(d.mean()) / life, float(d.mean()), float(d.quantile(0.1)), float(d.quantile(0.9))))
+ops.set_tuning("space_mfma32", 1)

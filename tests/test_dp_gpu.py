@@ -197,3 +197,32 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     nb = comm["collectives_per_step"]["all_reduce_gradient_buckets"]
     assert counted == [[1, nb + 1, nb + 2]] * 2, counted
     assert "cpu_baseline" not in line and "c4" not in line          # rank-0-at-N=1-only records
+
+
+def test_bench_plain_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` typed PLAINLY, as the driver types the N = 1 line (no torch.distributed.run around it, no WORLD_SIZE): the
+    parent must start the two ranks itself as a fresh child process group before touching the GPU (bench.py: self_launch), relay rank 0's
+    JSON line and the exit code.  Same gloo / same-device hooks as above (one GPU on this box); run/train.py:372-412,579-586 is what the
+    ranks replace."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HH_BENCH_BACKEND="gloo", HH_BENCH_SAME_DEVICE="1", HH_BENCH_LAUNCH_TIMEOUT="850")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "c1", "--batch", "2", "--no-power"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0's)"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["config"]["global_clips"] == 4 and line["config"]["parallelism"] == "dp2"
+    assert line["rccl"]["rccl_ranks"] == 2
+    comm = line["comm"]
+    nb = comm["collectives_per_step"]["all_reduce_gradient_buckets"]
+    counted = list(comm["collectives_counted_per_rank"].values())[0]
+    assert counted == [[1, nb + 1, nb + 2]] * 2, counted
+    # the per-rank margins the N > 1 line carries: host issue cost per library call and the decoder stream's share of the step
+    c = line["config"]
+    assert c["libhh_calls_per_step"] > 100 and 0 < c["host_us_per_libhh_call"] < 1000 and c["host_issue_ms_per_step"] > 0
+    assert 0 < c["decoder_in_step_frac"]

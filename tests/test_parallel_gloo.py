@@ -257,3 +257,21 @@ def test_arena_groups_follow_the_reference_optim_policy():
     comm = BucketedAllReduce(arena)
     assert not comm.enabled
     comm.finish()
+
+
+def test_bench_plain_multi_gpu_command_fails_with_one_line_when_devices_are_missing():
+    """`python bench.py --gpus N` without torch.distributed.run self-launches its ranks (bench.py: self_launch); with fewer than N visible
+    devices it must exit non-zero with ONE line on stderr before anything touches a GPU -- not die on an assert, not hang in a rendezvous."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HH_BENCH_SAME_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    msg = [l for l in r.stderr.splitlines() if l.startswith("bench.py:")]
+    assert len(msg) == 1 and "--gpus 64 needs 64 visible GPU(s)" in msg[0], r.stderr[-500:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # under a launcher whose world size disagrees with --gpus: also one line, non-zero
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
