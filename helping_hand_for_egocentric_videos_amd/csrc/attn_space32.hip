@@ -1,6 +1,7 @@
-// Space attention on v_mfma_f32_32x32x16_bf16 (round 6): see the block comments below.  Built with -mllvm -amdgpu-mfma-vgpr-form=1 (build.py):
-// the persistent kernel is allowed 512 registers (one wave per SIMD), for which hipcc otherwise selects the AGPR form of every MFMA -- the
-// score tiles would then sit in AGPRs, which v_exp_f32 cannot read (16 v_accvgpr_read per half-step and a bunched schedule).
+// Space attention on v_mfma_f32_32x32x16_bf16 (round 6): see the block comments below.  Both kernels stay within 256 registers per wave (two
+// waves per SIMD), so hipcc selects the VGPR form of every MFMA: the score tiles must sit in arch VGPRs -- v_exp_f32 cannot read an AGPR.  (A
+// 512-register one-wave-per-SIMD variant got the AGPR form: 16 v_accvgpr_read per half-step and a bunched schedule; -mllvm
+// -amdgpu-mfma-vgpr-form=1 cured that, the variant lost for another reason -- see the persistent kernel's comment.)
 #include "attn_space_dev.h"
 
 // ---- 32-query blocks on v_mfma_f32_32x32x16_bf16, software-pipelined INSIDE the wave (round 6) ----------------------
@@ -67,17 +68,31 @@ __device__ __forceinline__ void sp32_pv(const char* const (&vb)[2], int ci, cons
 // One steady-state half-step: row sums + PV of block Z (chunk cz, probabilities from the previous half-step), scores of block Z's NEXT chunk
 // (10 MFMAs = 320 cycles of the matrix core), and under them the 16 exponentials + 8 conversions of block Y.  The group barriers pin the
 // interleave the scheduler would otherwise bunch (all exponentials after the first MFMA: 7 per gap): per MFMA gap 2 v_exp_f32 + 1
-// v_cvt_pk_bf16_f32 (= 8 + 16 + 4 issue cycles of the gap's 32), the 12 fragment reads in the first three gaps.
-__device__ __forceinline__ void sp32_half_step(const char* const (&kb)[4], const char* const (&vb)[2], int cz, const bf16x8 (&qz)[4], f32x16& sz,
-                                               const bf16x8 (&pz)[2], f32x16 (&oz)[2], f32x16& olz, const f32x16& sy, bf16x8 (&py)[2], bool has_pv) {
-    // MFMA order: the two row-sum products (operands in registers: they cover the LDS latency of the K fragments), the score chain (done four
-    // MFMAs = 128 cycles before the half-step ends, so the next half-step's first exponentials do not wait for it), the four PV products
+// v_cvt_pk_bf16_f32 (= 8 + 16 + 4 issue cycles of the gap's 32), the fragment reads in the first gaps.
+// K fragments: chunk c feeds the scores of block a (half-step B of chunk c - 1) and of block b (half-step A of chunk c), so they are read
+// ONCE, a whole half-step before their first use (LOADK: half-step A of chunk c - 1 reads chunk c + ... see the callers) and kept for both
+// -- 4 KB less LDS traffic per chunk and wave and no LDS latency in front of the score chain.
+__device__ __forceinline__ void sp32_load_k(const char* const (&kb)[4], int ci, bf16x8 (&kf)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8*)(kb[ks] + ci * 4096);
+}
+__device__ __forceinline__ void sp32_qk_regs(const bf16x8 (&kf)[4], const bf16x8 (&q)[4], f32x16& s) {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], q[ks], ks == 0 ? z : s, 0, 0, 0);
+}
+template <bool LOADK>
+__device__ __forceinline__ void sp32_half_step(const char* const (&kb)[4], const char* const (&vb)[2], int cz, const bf16x8 (&kf)[4], int cn, bf16x8 (&kfn)[4],
+                                               const bf16x8 (&qz)[4], f32x16& sz, const bf16x8 (&pz)[2], f32x16 (&oz)[2], f32x16& olz, const f32x16& sy,
+                                               bf16x8 (&py)[2], bool has_pv) {
+    // MFMA order: the two row-sum products, the score chain (done four MFMAs = 128 cycles before the half-step ends, so the next half-step's
+    // first exponentials do not wait for it), the four PV products (their V^T fragments are read under the first six MFMAs)
     const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
     if (has_pv) {
         olz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pz[0], olz, 0, 0, 0);
         olz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pz[1], olz, 0, 0, 0);
     }
-    sp32_qk(kb, cz + 1, qz, sz);
+    sp32_qk_regs(kf, qz, sz);
     if (has_pv) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -88,14 +103,16 @@ __device__ __forceinline__ void sp32_half_step(const char* const (&kb)[4], const
                 oz[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pz[m], oz[dt], 0, 0, 0);
             }
     }
+    if (LOADK) sp32_load_k(kb, cn, kfn);
     sp32_exp(sy, py);
     asm volatile("" : "+v"(py[0]), "+v"(py[1]));     // the probabilities are made HERE (LLVM otherwise sinks them to their use in the next half-step)
+    if (LOADK) asm volatile("" : "+v"(kfn[0]), "+v"(kfn[1]), "+v"(kfn[2]), "+v"(kfn[3]));       // ... and so are the next chunk's K fragments
 #ifndef HH_SP32_NO_GROUPS
     if (has_pv) {
 #pragma unroll
         for (int g = 0; g < 10; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // MFMA
-            if (g < 3) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);         // DS read
+            if (g < 2 || (LOADK && g == 6)) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);         // DS reads: V^T under MFMAs 0-1, the next K under MFMA 6
             if (g >= 1 && g <= 8) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);     // VALU: the conversion of the previous gap's pair
             if (g < 8) __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);         // TRANS
         }
@@ -184,16 +201,18 @@ __global__ __launch_bounds__(64 * NW32, 2) void space_attn32_kernel(const bf16_t
     if (active) {
         f32x16 sa, sb, ola = z16, olb = z16;
         bf16x8 pa[2], pb[2];
-        sp32_qk(kb, 0, qa, sa);
+        bf16x8 kf[2][4];                               // K fragments of chunk c in kf[c & 1]
+        sp32_load_k(kb, 0, kf[0]);
+        sp32_qk_regs(kf[0], qa, sa);
 #pragma unroll
         for (int ci = 0; ci < NCH; ++ci) {
-            // half-step A: PV of b (chunk ci - 1) + scores of b (chunk ci) | probabilities of a (chunk ci)
-            sp32_half_step(kb, vb, ci - 1, qb, sb, pb, ob, olb, sa, pa, ci > 0);
+            // half-step A: PV of b (chunk ci - 1) + scores of b (chunk ci) | probabilities of a (chunk ci) | reads K of chunk ci + 1
+            sp32_half_step<true>(kb, vb, ci - 1, kf[ci & 1], ci + 1, kf[(ci + 1) & 1], qb, sb, pb, ob, olb, sa, pa, ci > 0);
             // half-step B: PV of a (chunk ci) + scores of a (chunk ci + 1; the last one is the CLS chunk) | probabilities of b (chunk ci)
-            sp32_half_step(kb, vb, ci, qa, sa, pa, oa, ola, sb, pb, true);
+            sp32_half_step<false>(kb, vb, ci, kf[(ci + 1) & 1], 0, kf[ci & 1], qa, sa, pa, oa, ola, sb, pb, true);
         }
         sp32_pv<false>(vb, NCH - 1, pb, ob, olb);
-        sp32_qk(kb, NCH, qb, sb);
+        sp32_qk_regs(kf[NCH & 1], qb, sb);
         sp32_exp_cls(sa, pa, lane);
         __builtin_amdgcn_sched_barrier(0);
         sp32_exp_cls(sb, pb, lane);
@@ -287,9 +306,24 @@ __global__ __launch_bounds__(64 * NW32P, 1) void space_attn32p_kernel(const bf16
     const int64_t ld = layout ? 64 : 3 * (int64_t)D;
     const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
     const int P = B * T * heads;
-    auto problem = [&](int i, int& b, int& f, int& head) { int bid = rev ? P - 1 - i : i; head = bid % heads; bid /= heads; f = bid % T; b = bid / T; };
     const int first = blockIdx.x, step = gridDim.x;
     if (first >= P) return;
+    // (clip, frame, head) of problem i, advanced by `step` problems with carries: the three integer divisions of a direct decode cost ~1500
+    // cycles per problem on the scalar unit (measured: the gap between two problems' stamps), serial to everything
+    struct Walk { int b, f, head; };
+    auto decode = [&](int i) { Walk w; int bid = rev ? P - 1 - i : i; w.head = bid % heads; bid /= heads; w.f = bid % T; w.b = bid / T; return w; };
+    const int dh = step % heads, df = (step / heads) % T, db = step / heads / T;
+    auto advance = [&](Walk& w) {
+        if (!rev) {
+            w.head += dh; int c = w.head >= heads; w.head -= c ? heads : 0;
+            w.f += df + c; c = w.f >= T; w.f -= c ? T : 0;
+            w.b += db + c;
+        } else {
+            w.head -= dh; int c = w.head < 0; w.head += c ? heads : 0;
+            w.f -= df + c; c = w.f < 0; w.f += c ? T : 0;
+            w.b -= db + c;
+        }
+    };
     unsigned long long* stamps = dbg == 3 ? (unsigned long long*)cls_partial + (int64_t)blockIdx.x * 8 : nullptr;
     if (dbg == 3) cls_partial = nullptr;
     const bool stamp_wave = dbg == 3 && tid == 0;
@@ -304,77 +338,111 @@ __global__ __launch_bounds__(64 * NW32P, 1) void space_attn32p_kernel(const bf16
         const unsigned rowoff = (unsigned)(lw * 8 + (lane >> 3)) * ld_b;
         const unsigned voff_k = rowoff + ck * 16u, voff_v = rowoff + cv * 16u;
         const unsigned voff_o = ((unsigned)(lane >> 3) * (unsigned)D + 8u * (unsigned)(lane & 7)) * 2u;
-        u32x4 kreg[PPW], vreg[PPW], qreg[QPW];
-        auto request = [&](int i) {
-            int b, f, head;
-            problem(i, b, f, head);
+        // TWO register sets: while problem i is computed, set `cur` holds problem i + 1 (requested one problem ago, written to LDS at the next
+        // boundary) and set `oth` receives problem i + 2 -- two problems' worth of requests (208 KB per CU) stay in flight, also across the
+        // boundary itself.  (One set: the requests of problem i + 1 were issued only after barrier B and took 12 200 cycles against a 7 600-cycle
+        // chunk loop -- every compute wave waited 4 500 cycles at barrier A, the CU had nothing in flight during the 1 900-cycle boundary.)
+        struct Regs { u32x4 k[PPW], v[PPW], q[QPW]; };
+        Regs X, Y;
+        // The requests are inline asm and the waits manual: with compiler-visible loads hipcc allocated address temporaries inside the other
+        // set's destination registers and made the ds_writes of `cur` wait for the requests of `oth` issued a moment earlier (vmcnt(25) .. (0) at
+        // the boundary: a full memory latency per problem).  Nothing reads a set between its request and the landed() that follows a whole
+        // problem later (scripts/check_isa_hazards.py scans for it).
+        auto request = [&](const Walk& w, Regs& R) {
+            const int b = w.b, f = w.f, head = w.head;
             const char* base = (const char*)(qkv + (int64_t)b * N * ld + head * hs);       // the clip's row 0 (CLS) of this head's q plane
             const char* q_ptr = base + (int64_t)(1 + f * n) * ld * 2;
+#define SP32_LD(DST, VOFF, SBASE) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(DST) : "v"(VOFF), "s"(SBASE))
 #pragma unroll
-            for (int j = 0; j < QPW; ++j) qreg[j] = *(const u32x4*)(q_ptr + (int64_t)(32 * j) * ld_b + (size_t)voff_k);     // Q rows: the K swizzle
+            for (int j = 0; j < QPW; ++j) { const char* sb = q_ptr + (int64_t)(32 * j) * ld_b; SP32_LD(R.q[j], voff_k, sb); }     // Q rows: the K swizzle
 #pragma unroll
             for (int j = 0; j < PPW - 1; ++j) {
-                kreg[j] = *(const u32x4*)(q_ptr + (int64_t)(32 * j) * ld_b + ws * 2 + (size_t)voff_k);
-                vreg[j] = *(const u32x4*)(q_ptr + (int64_t)(32 * j) * ld_b + ws * 4 + (size_t)voff_v);
+                const char* sk = q_ptr + (int64_t)(32 * j) * ld_b + ws * 2;
+                const char* sv = q_ptr + (int64_t)(32 * j) * ld_b + ws * 4;
+                SP32_LD(R.k[j], voff_k, sk);
+                SP32_LD(R.v[j], voff_v, sv);
             }
-            kreg[PPW - 1] = *(const u32x4*)(base + ws * 2 + (size_t)(ck * 16u));
-            vreg[PPW - 1] = *(const u32x4*)(base + ws * 4 + (size_t)(cv * 16u));
+            const char* sk = base + ws * 2;
+            const char* sv = base + ws * 4;
+            const unsigned ok = ck * 16u, ov = cv * 16u;
+            SP32_LD(R.k[PPW - 1], ok, sk);
+            SP32_LD(R.v[PPW - 1], ov, sv);
+#undef SP32_LD
         };
-        auto to_lds = [&]() {
+        // `younger` = vector-memory instructions this wave issued AFTER the set's request (0, or the 2 PPW + QPW loads of the other set)
+        auto landed = [&](Regs& R, bool other_requested) {
+            if (other_requested) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PPW + QPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int j = 0; j < QPW; ++j) *(u32x4*)(Qs + (lw + 4 * j) * 1024 + lane * 16) = qreg[j];
+            for (int j = 0; j < QPW; ++j) asm volatile("" : "+v"(R.q[j]));
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) asm volatile("" : "+v"(R.k[j]), "+v"(R.v[j]));
+        };
+        auto to_lds = [&](const Regs& R) {
+#pragma unroll
+            for (int j = 0; j < QPW; ++j) *(u32x4*)(Qs + (lw + 4 * j) * 1024 + lane * 16) = R.q[j];
 #pragma unroll
             for (int j = 0; j < PPW; ++j) {
-                *(u32x4*)(Ks + (lw + 4 * j) * 1024 + lane * 16) = kreg[j];
-                *(u32x4*)(Vs + (lw + 4 * j) * 1024 + lane * 16) = vreg[j];
+                *(u32x4*)(Ks + (lw + 4 * j) * 1024 + lane * 16) = R.k[j];
+                *(u32x4*)(Vs + (lw + 4 * j) * 1024 + lane * 16) = R.v[j];
             }
         };
+        // [2 sets][4 compute waves]: bit 0 / 1 = block a / b was redone.  (A plain LDS pointer: as `volatile unsigned*` it became a generic pointer,
+        // i.e. flat_load + s_waitcnt vmcnt(0) -- which waits for every request in flight.  The barriers order the accesses.)
+        const unsigned* bad_flags = (const unsigned*)(scratch + 2 * 4 * CLS_REC);
         // rows of problem ip (compute wave w's 64 rows at rows_all + 8192 w; this loader wave stores those of compute wave lw) + its CLS record
-        auto flush = [&](int ip, int par_prev, unsigned bad_mask) {
-            int b, f, head;
-            problem(ip, b, f, head);
-            const char* rows = rows_all + lw * 8192;
-            u32x4 v[8];
+        auto flush = [&](const Walk& w, int par_prev) {
+            unsigned bm = 0;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int row = 8 * t + (lane >> 3);
-                v[t] = *(const u32x4*)(rows + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
-            }
+            for (int w = 0; w < 4; ++w) bm |= (bad_flags[par_prev * 4 + w] & 3u) << (2 * w);
+            const unsigned bad_mask = (unsigned)__builtin_amdgcn_readfirstlane((int)bm);
+            const int b = w.b, f = w.f, head = w.head;
+            const char* rows = rows_all + lw * 8192;
             if (cls_partial != nullptr && lw == 0)
                 space16_cls_merge<4>(scratch + par_prev * (4 * CLS_REC), cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, lane);
             char* orow = (char*)(out + ((int64_t)b * N + 1 + f * n + lw * 64) * D + head * 64);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if ((bad_mask >> (2 * lw + (t >> 2))) & 1u) continue;       // (wave-uniform: a redone block was stored by its compute wave)
-                *(u32x4*)(orow + (int64_t)(8 * t) * D * 2 + (size_t)voff_o) = v[t];
+            for (int half = 0; half < 2; ++half) {
+                if ((bad_mask >> (2 * lw + half)) & 1u) continue;       // (wave-uniform: a redone block was stored by its compute wave)
+                u32x4 v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = 8 * (4 * half + t) + (lane >> 3);
+                    v[t] = *(const u32x4*)(rows + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) *(u32x4*)(orow + (int64_t)(8 * (4 * half + t)) * D * 2 + (size_t)voff_o) = v[t];
             }
         };
-        volatile unsigned* bad_flags = (volatile unsigned*)(scratch + 2 * 4 * CLS_REC);      // [2 sets][4 compute waves]: bit 0 / 1 = block a / b was redone
-        request(first);
-        to_lds();
-        __syncthreads();                               // B(first)
-        int par = 0, prev = -1;
-        for (int i = first; i < P; i += step) {
-            if (prev >= 0) {
-                unsigned bm = 0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) bm |= (bad_flags[(par ^ 1) * 4 + w] & 3u) << (2 * w);
-                flush(prev, par ^ 1, (unsigned)__builtin_amdgcn_readfirstlane((int)bm));
-            }
-            const int inext = i + step;
-            if (inext < P) request(inext);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int par = 0;
+        bool have_prev = false;
+        Walk wcur = decode(first), wprev = wcur, wreq = wcur;       // problems i, i - step (once have_prev), i + 2 step
+        auto body = [&](int i, Regs& cur, Regs& oth) {
+            if (have_prev) flush(wprev, par ^ 1);
+            const bool req = i + 2 * step < P;
+            if (req) request(wreq, oth);
+            if (i + step < P) landed(cur, req);        // (requested a whole problem ago; the stores of flush() are older than the new requests)
             __syncthreads();                           // A(i): the compute waves are done with K / V / Q of problem i
-            if (inext < P) to_lds();
+            if (i + step < P) to_lds(cur);
             __syncthreads();                           // B(next): K / V / Q of the next problem visible, rows of problem i complete
-            prev = i; par ^= 1;
+            wprev = wcur; have_prev = true; par ^= 1;
+            advance(wcur); advance(wreq);
+        };
+        request(wreq, X);
+        landed(X, false);
+        to_lds(X);
+        __syncthreads();                               // B(first)
+        advance(wreq);
+        if (first + step < P) request(wreq, X);
+        advance(wreq);
+        for (int i = first; i < P;) {
+            body(i, X, Y);
+            i += step;
+            if (i >= P) break;
+            body(i, Y, X);
+            i += step;
         }
-        {
-            unsigned bm = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) bm |= (bad_flags[(par ^ 1) * 4 + w] & 3u) << (2 * w);
-            flush(prev, par ^ 1, (unsigned)__builtin_amdgcn_readfirstlane((int)bm));
-        }
+        flush(wprev, par ^ 1);
         return;
     }
 
@@ -393,13 +461,16 @@ __global__ __launch_bounds__(64 * NW32P, 1) void space_attn32p_kernel(const bf16
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     char* rows = rows_all + wave * 8192;
     unsigned* bad_flags = (unsigned*)(scratch + 2 * 4 * CLS_REC);
+    if (stamp_wave) stamps[6] = __builtin_amdgcn_s_memrealtime();          // (100 MHz: absolute time of the workgroup's start)
     __syncthreads();                                   // B(first)
     int par = 0;
+    Walk wc = decode(first);
     for (int i = first; i < P; i += step) {
-        int b, f, head;
-        problem(i, b, f, head);
-        const bool st = stamp_wave && i == first + step;
-        if (st) stamps[0] = __builtin_readcyclecounter();
+        const int b = wc.b, f = wc.f, head = wc.head;
+        advance(wc);
+        const bool st = stamp_wave;                     // debug mode 3: per-phase cycle totals over all problems of this workgroup (compute wave 0)
+        unsigned long long t0 = 0, t1 = 0, t2 = 0;
+        if (st) t0 = __builtin_readcyclecounter();
         // (an opaque copy of the lane index per problem: everything addressed from it -- Q fragments, the rows, the redo path -- is recomputed
         // here instead of being hoisted out of the problem loop, where ~35 loop-invariant address registers took the chunk loop's arch VGPRs to
         // the 256 cap and the scheduler gave up the pinned interleave)
@@ -414,20 +485,22 @@ __global__ __launch_bounds__(64 * NW32P, 1) void space_attn32p_kernel(const bf16
         }
         f32x16 oa[2] = {z16, z16}, ob[2] = {z16, z16}, sa, sb, ola = z16, olb = z16;
         bf16x8 pa[2], pb[2];
-        sp32_qk(kb, 0, qa, sa);
+        bf16x8 kf[2][4];                               // K fragments of chunk c in kf[c & 1]
+        sp32_load_k(kb, 0, kf[0]);
+        sp32_qk_regs(kf[0], qa, sa);
 #pragma unroll
         for (int ci = 0; ci < NCH; ++ci) {
-            sp32_half_step(kb, vb, ci - 1, qb, sb, pb, ob, olb, sa, pa, ci > 0);
-            sp32_half_step(kb, vb, ci, qa, sa, pa, oa, ola, sb, pb, true);
+            sp32_half_step<true>(kb, vb, ci - 1, kf[ci & 1], ci + 1, kf[(ci + 1) & 1], qb, sb, pb, ob, olb, sa, pa, ci > 0);
+            sp32_half_step<false>(kb, vb, ci, kf[(ci + 1) & 1], 0, kf[ci & 1], qa, sa, pa, oa, ola, sb, pb, true);
         }
         sp32_pv<false>(vb, NCH - 1, pb, ob, olb);
-        sp32_qk(kb, NCH, qb, sb);
+        sp32_qk_regs(kf[NCH & 1], qb, sb);
         sp32_exp_cls(sa, pa, lane);
         __builtin_amdgcn_sched_barrier(0);
         sp32_exp_cls(sb, pb, lane);
         sp32_pv<true>(vb, NCH, pa, oa, ola);
         sp32_pv<true>(vb, NCH, pb, ob, olb);
-        if (st) stamps[1] = __builtin_readcyclecounter();
+        if (st) t1 = __builtin_readcyclecounter();
         const float la = ola[0], lb = olb[0];
         const bool bad_a = __builtin_amdgcn_ballot_w64(!(la >= 7.9e-31f && la <= 1.2e30f)) != 0;
         const bool bad_b = __builtin_amdgcn_ballot_w64(!(lb >= 7.9e-31f && lb <= 1.2e30f)) != 0;
@@ -458,11 +531,17 @@ __global__ __launch_bounds__(64 * NW32P, 1) void space_attn32p_kernel(const bf16
             space16_cls_wave<4>(Ks, Vs, scratch + par * (4 * CLS_REC), qc, n, f == 0, lane_i, wave);
         }
         __syncthreads();                               // A(i)
-        if (st) stamps[2] = __builtin_readcyclecounter();
+        if (st) t2 = __builtin_readcyclecounter();
         if (!bad_a) sp32_o_to_lds(rows, oa, la, r_i, hh_i);
         if (!bad_b) sp32_o_to_lds(rows + 32 * 128, ob, lb, r_i, hh_i);
         __syncthreads();                               // B(next)
-        if (st) stamps[3] = __builtin_readcyclecounter();
+        if (st) {
+            const unsigned long long t3 = __builtin_readcyclecounter();
+            stamps[0] += t1 - t0; stamps[1] += t2 - t1; stamps[2] += t3 - t2; stamps[3] += 1;
+            if (i == first) stamps[4] = t0;
+            stamps[5] = t3;
+            stamps[7] = __builtin_amdgcn_s_memrealtime();
+        }
         par ^= 1;
     }
 }

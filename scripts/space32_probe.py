@@ -17,8 +17,8 @@ part = torch.zeros(B * heads * T * 68, device="cuda")
 patch = (torch.arange(B * N, device="cuda") % N) != 0
 L = _lib.lib()
 def run(): _lib.check(L.hh_space_attn_fwd(ctypes.c_void_p(planes.data_ptr()), 1, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(part.data_ptr()), B, T, n, heads, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "x")
-def t(reps=20):
-    for _ in range(3): run()
+def t(reps=200):
+    for _ in range(20): run()
     torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
     e0.record()
     for _ in range(reps): run()
@@ -68,10 +68,15 @@ if n == 256:
     st = stamps[:256].double().cpu()
     st = st[st[:, 3] > 0]
     dur = t()
-    per = dur / (B * T * heads / 256.0)
-    life = float((st[:, 3] - st[:, 0]).mean())
-    print("persistent kernel %.1f us / %.0f problems per CU = %.2f us per problem; second problem of each workgroup, compute wave 0, %.0f ticks per problem:" % (dur, B * T * heads / 256.0, per, life))
-    for name, a, b_ in (("Q fragments from LDS + chunk loop", 0, 1), ("redo check + CLS partial + barrier A (waits for the loaders' requests)", 1, 2), ("rows -> LDS + barrier B (loaders write K / V / Q)", 2, 3)):
-        d = (st[:, b_] - st[:, a])
-        print("   %-72s %5.1f %%  (%6.0f ticks; p10 %6.0f, p90 %6.0f)" % (name, 100 * float(d.mean()) / life, float(d.mean()), float(d.quantile(0.1)), float(d.quantile(0.9))))
+    cnt = float(st[:, 3].mean())
+    tot = float((st[:, 0] + st[:, 1] + st[:, 2]).mean())
+    span = float((st[:, 5] - st[:, 4]).mean())
+    real = (st[:, 7] - st[:, 6]) / 100.0                 # us, workgroup start -> end of its last problem (100 MHz counter)
+    t_first = float((st[:, 6] - st[:, 6].min()).max()) / 100.0
+    t_end = float((st[:, 7] - st[:, 6].min()).max()) / 100.0
+    print("persistent kernel %.1f us, %.1f problems per workgroup; compute wave 0: %.0f cycles per problem in its three phases, %.0f cycles from the first top to the last bottom;" % (dur, cnt, tot / cnt, span))
+    print("   workgroup start -> end of its last problem %.1f us mean (%.1f .. %.1f); last workgroup starts %.1f us after the first; last problem ends %.1f us after the first start" % (float(real.mean()), float(real.min()), float(real.max()), t_first, t_end))
+    for name, c in (("Q fragments from LDS + chunk loop", 0), ("redo check + CLS partial + barrier A (waits for the loaders' requests)", 1), ("rows -> LDS + barrier B (loaders write K / V / Q)", 2)):
+        d = st[:, c] / st[:, 3]
+        print("   %-72s %5.1f %%  (%6.0f cycles per problem; p10 %6.0f, p90 %6.0f over workgroups)" % (name, 100 * float(st[:, c].mean()) / tot, float(d.mean()), float(d.quantile(0.1)), float(d.quantile(0.9))))
 ops.set_tuning("space_mfma32", 1)

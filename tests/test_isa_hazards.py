@@ -23,3 +23,6 @@ def test_no_sgpr_reload_to_inline_asm_vmem_hazard():
     # round 5: destinations of asm-issued vector loads (the Q fragments of the progressive space-attention kernel) are not touched -- copied,
     # spilled, overwritten -- before a vmcnt wait has made them valid
     assert "attn_space.hip: 0 hazard(s)" in r.stdout and "mattn.hip: 0 hazard(s)" in r.stdout, r.stdout
+    # round 6: the loader waves of the persistent 32x32x16 space-attention kernel request two problems' K / V / Q by inline asm into two register
+    # sets and wait with a counted vmcnt a whole problem later
+    assert "attn_space32.hip: 0 hazard(s)" in r.stdout, r.stdout

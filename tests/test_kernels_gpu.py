@@ -462,9 +462,12 @@ def test_space_attention_joint_blocks_equal_the_16_query_kernel(n, blocks_per_wa
     try:
         ops.set_tuning("space_joint", 0)
         generic = ops.divided_attention(qkv, B, T, n, heads, "space")
+        ops.set_tuning("space_joint", 1)
+        ops.set_tuning("space_mfma32", 0)          # (round 6: n <= 256 defaults to the 32x32x16 kernels, tested below)
+        joint = ops.divided_attention(qkv, B, T, n, heads, "space")
     finally:
         ops.set_tuning("space_joint", 1)
-    joint = ops.divided_attention(qkv, B, T, n, heads, "space")
+        ops.set_tuning("space_mfma32", 1)
     # (the CLS rows also merge 4 instead of 8 per-wave partial softmax records; at n = 128 the 16-query kernel has no fast path --
     # its first chunk would hold the CLS tile -- and runs the running-maximum softmax: probabilities round differently)
     assert_close_bf16(joint, generic, 8e-3, "joint vs 16-query")
@@ -481,21 +484,60 @@ def test_space_attention_joint_kernel_many_problems():
     qkv = rnd(B * N, 3 * D, seed=77)
     qkv[:, :D] *= 0.5 * ops.LOG2E
     qkv = bf(qkv).to(DEV)
-    out = ops.divided_attention(qkv, B, T, n, heads, "space")
     try:
+        ops.set_tuning("space_mfma32", 0)
+        out = ops.divided_attention(qkv, B, T, n, heads, "space")
         ops.set_tuning("space_joint", 0)
         generic = ops.divided_attention(qkv, B, T, n, heads, "space")
     finally:
         ops.set_tuning("space_joint", 1)
+        ops.set_tuning("space_mfma32", 1)
     assert_close_bf16(out, generic, 8e-3, "joint, many problems")
     torch.testing.assert_close(out.float(), generic.float(), rtol=2.0 ** -7, atol=1e-3 * float(generic.float().abs().max()))
 
 
-@pytest.mark.parametrize("joint", [1, 0])
-def test_space_attention_redo_path_when_the_reference_maximum_is_exceeded(joint):
-    """The fast path of the space kernel fixes one reference maximum per 16-query block (from the first 32 keys) and redoes the block
-    with a running maximum when a later score exceeds it by more than 2^127: plant such keys and compare with the fp32 reference."""
+@pytest.mark.parametrize("n", [256, 192, 128, 64])
+def test_space_attention_32x32_kernels_vs_fp32_and_vs_the_16_query_kernel(n):
+    """Round 6: n <= 256 (n % 64 == 0) runs on v_mfma_f32_32x32x16_bf16 with the exponentials software-pipelined under the matrix core and
+    NO reference maximum (base-2 logits, P = exp2(s); csrc/attn_space32.hip) -- hh_set_tuning("space_mfma32", 2) = one problem per workgroup,
+    1 (default) = the persistent wave-specialised kernel at n = 256.  Against the fp32 reference (same bound as every space kernel), against the
+    16-query kernel (different rounding of P: a reference maximum there, none here -- one bf16 ulp of the output), the two 32x32 forms
+    bit-identical (same arithmetic, different data movement), and 288 problems so that persistent workgroups walk more than one."""
+    B, T, heads = 3, 6, 16
+    N, D = 1 + T * n, heads * 64
+    qkv = rnd(B * N, 3 * D, seed=n + 5)
+    qkv[:, :D] *= 0.6 * ops.LOG2E
+    qkv[7, :64] += 5.0
+    qkv = bf(qkv).to(DEV)
+    try:
+        ops.set_tuning("space_joint", 0)
+        generic = ops.divided_attention(qkv, B, T, n, heads, "space")
+        ops.set_tuning("space_joint", 1)
+        ops.set_tuning("space_mfma32", 2)
+        one = ops.divided_attention(qkv, B, T, n, heads, "space")
+        ops.set_tuning("space_mfma32", 1)
+        per = ops.divided_attention(qkv, B, T, n, heads, "space")
+        rev = ops.divided_attention(qkv, B, T, n, heads, "space", reverse=True)
+        planes = qkv.view(B * N, 3 * heads, 64).transpose(0, 1).contiguous()
+        per_planes = ops.divided_attention(planes, B, T, n, heads, "space")
+    finally:
+        ops.set_tuning("space_joint", 1)
+        ops.set_tuning("space_mfma32", 1)
+    assert torch.equal(one, per) and torch.equal(per, rev) and torch.equal(per, per_planes)
+    ref = _ref_divided(qkv.cpu(), B, T, n, heads, "space")
+    assert_close_bf16(per, ref, 1.2e-2, "attn-space-32x32")
+    err = (per.float().cpu() - ref).abs().amax(1)
+    assert (err / (ref.abs().amax(1) + 1e-3)).max() < 5e-2
+    assert_close_bf16(per, generic, 8e-3, "32x32 vs 16-query")
+
+
+@pytest.mark.parametrize("joint,mfma32", [(1, 1), (1, 2), (1, 0), (0, 0)])
+def test_space_attention_redo_path_when_the_reference_maximum_is_exceeded(joint, mfma32):
+    """The fast path of the 16x16x32 space kernels fixes one reference maximum per 16-query block (from the first 32 keys) and redoes the block
+    with a running maximum when a later score exceeds it by more than 2^127; the 32x32x16 kernels use no reference and redo a 32-query block
+    whose row sum leaves [2^-100, 2^100]: plant such keys / queries and compare with the fp32 reference."""
     ops.set_tuning("space_joint", joint)
+    ops.set_tuning("space_mfma32", mfma32)
     B, T, n, heads = 1, 2, 256, 2
     N, D = 1 + T * n, heads * 64
     qkv = rnd(B * N, 3 * D, seed=3)
@@ -503,11 +545,14 @@ def test_space_attention_redo_path_when_the_reference_maximum_is_exceeded(joint)
     q0 = qkv[1 + 40, :64].clone()                                  # query 40 of frame 0, head 0
     qkv[1 + 200, D:D + 64] = q0 * (160.0 / float(q0 @ q0))        # key 200 (beyond the first chunk): logit ~ +160 for that query
     qkv[1 + n + 7, :64] *= 30.0                                    # frame 1: a query with huge logits everywhere
+    qkv[1 + n + 100, :64] *= 30.0                                  # ... and a second one, whose whole score row is then shifted to about -600:
+    qkv[1 + n + 100, :64] -= 12.0 * qkv[1 + n:1 + 2 * n, D:D + 64].mean(0) / float((qkv[1 + n:1 + 2 * n, D:D + 64].mean(0) ** 2).sum()) ** 0.5
     qkv[:, :D] *= ops.LOG2E
     qkv = bf(qkv)
     out = ops.divided_attention(qkv.to(DEV), B, T, n, heads, "space")
     ref = _ref_divided(qkv, B, T, n, heads, "space")
     ops.set_tuning("space_joint", 1)
+    ops.set_tuning("space_mfma32", 1)
     assert torch.isfinite(out.float()).all()
     assert_close_bf16(out, ref, 1.2e-2, "attn-space-redo")
     err = (out.float().cpu() - ref).abs().amax(1)
