@@ -80,3 +80,16 @@ if n == 256:
         d = st[:, c] / st[:, 3]
         print("   %-72s %5.1f %%  (%6.0f cycles per problem; p10 %6.0f, p90 %6.0f over workgroups)" % (name, 100 * float(st[:, c].mean()) / tot, float(d.mean()), float(d.quantile(0.1)), float(d.quantile(0.9))))
 ops.set_tuning("space_mfma32", 1)
+# ---- one launch at a time with the chip idle in between (no sustained load: the clock the power management allows a lone 250-us kernel)
+import time
+for k, name in ((0, "joint 16x16x32"), (2, "32x32x16 one problem per workgroup"), (1, "32x32x16 persistent")):
+    ops.set_tuning("space_mfma32", k)
+    ts = []
+    for _ in range(12):
+        torch.cuda.synchronize(); time.sleep(0.02)
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        e0.record(); run(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    print("single launches, 20 ms idle between: %-36s median %.1f us (min %.1f, max %.1f)" % (name, ts[len(ts) // 2], ts[0], ts[-1]))
+ops.set_tuning("space_mfma32", 1)
