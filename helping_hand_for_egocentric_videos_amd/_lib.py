@@ -38,6 +38,7 @@ SIGNATURES = {
     "hh_stream_set_cu_budget": [c_vp, c_int],
     "hh_stream_get_cu_budget": [c_vp, ctypes.POINTER(c_int)],
     "hh_call_count": [],
+    "hh_debug_space_redo_count": [c_int],
     "hh_prof_enable": [c_int],
     "hh_prof_kernel_name": [c_int],
     "hh_prof_read": [c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
@@ -100,7 +101,7 @@ SIGNATURES = {
     "hh_adamw_arena_step": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_float, c_float, c_float, c_float,
                             c_float, c_int, c_vp],
 }
-_RESTYPES = {"hh_last_error_string": ctypes.c_char_p, "hh_call_count": c_i64, "hh_prof_kernel_name": ctypes.c_char_p, "hh_workspace_bytes_gemm_splitk": c_i64, "hh_workspace_bytes_gemm_tn": c_i64, "hh_workspace_bytes_gemm_zstats": c_i64,
+_RESTYPES = {"hh_last_error_string": ctypes.c_char_p, "hh_call_count": c_i64, "hh_debug_space_redo_count": c_i64, "hh_prof_kernel_name": ctypes.c_char_p, "hh_workspace_bytes_gemm_splitk": c_i64, "hh_workspace_bytes_gemm_tn": c_i64, "hh_workspace_bytes_gemm_zstats": c_i64,
              "hh_workspace_bytes_xattn_bwd": c_i64, "hh_workspace_bytes_xattn_fwd": c_i64, "hh_workspace_bytes_attn_cls_partial": c_i64, "hh_workspace_bytes_egonce": c_i64,
              "hh_workspace_bytes_mattn_fwd": c_i64, "hh_workspace_bytes_mattn_bwd": c_i64}
 

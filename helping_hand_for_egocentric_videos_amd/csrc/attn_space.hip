@@ -13,6 +13,8 @@
 
 #include "attn_space_dev.h"
 
+HH_SPACE_REDO_COUNTER(g_space_redo);
+
 // One 16-query block of one (clip, frame, head) problem against the nt key tiles staged in LDS: fast path, running-maximum redo, store.
 __device__ __forceinline__ void space16_block(const char* Ks, const char* Vs, const bf16x8 (&q)[2], int nt, int lane, bf16_t* op) {
     const int c = lane & 15, g = lane >> 4;
@@ -57,6 +59,7 @@ __device__ __forceinline__ void space16_block(const char* Ks, const char* Vs, co
         redo = __builtin_amdgcn_ballot_w64(!(l_run <= 3.0e38f)) != 0;
     }
     if (redo) {
+        if (fast) HH_SPACE_REDO_NOTE(g_space_redo, lane);      // (short frames always run this path: not a redo)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = z4;
         float m_run = -INFINITY;
@@ -306,6 +309,7 @@ __global__ __launch_bounds__(64 * NWV, WPS) void space_attnj_kernel(const bf16_t
             float l_run = ol[j][0];
             // a score more than 2^127 above the block's reference maximum: l is not finite -> redo this block with the running maximum
             if (__builtin_amdgcn_ballot_w64(!(l_run <= 3.0e38f)) != 0) {
+                HH_SPACE_REDO_NOTE(g_space_redo, lane);
                 f32x4 o2[4] = {z4, z4, z4, z4};
                 float m_run = -INFINITY;
                 l_run = 0.f;
@@ -569,6 +573,7 @@ __global__ __launch_bounds__(64 * NWV, WPS) void space_attnp_kernel(const bf16_t
         float l_run = ol[j][0];
         // a score more than 2^127 above the block's reference maximum: l is not finite -> redo this block with the running maximum
         if (__builtin_amdgcn_ballot_w64(!(l_run <= 3.0e38f)) != 0) {
+            HH_SPACE_REDO_NOTE(g_space_redo, lane);
             f32x4 o2[4] = {z4, z4, z4, z4};
             float m_run = -INFINITY;
             l_run = 0.f;
@@ -625,6 +630,15 @@ extern "C" int hh_cls_combine(const float* partial, int G, void* out, int B, int
     if (B == 0) return HH_OK;
     hipLaunchKernelGGL(cls_combine_kernel, dim3((unsigned)(B * heads)), dim3(64), 0, (hipStream_t)stream, partial, G, (bf16_t*)out, N, heads);
     return hh_check_launch("hh_cls_combine");
+}
+
+unsigned long long hh_space32_redo_read(int reset);      // attn_space32.hip
+// blocks redone on the running-maximum path since the last reset (all space-attention kernels); synchronises the device
+extern "C" int64_t hh_debug_space_redo_count(int reset) {
+    unsigned long long v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_space_redo), sizeof(v)) != hipSuccess) return -1;
+    if (reset) { const unsigned long long z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_space_redo), &z, sizeof(z)) != hipSuccess) return -1; }
+    return (int64_t)(v + hh_space32_redo_read(reset));
 }
 
 int hh_tuning_space_debug();

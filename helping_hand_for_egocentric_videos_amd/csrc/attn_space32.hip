@@ -4,6 +4,8 @@
 // -amdgpu-mfma-vgpr-form=1 cured that, the variant lost for another reason -- see the persistent kernel's comment.)
 #include "attn_space_dev.h"
 
+HH_SPACE_REDO_COUNTER(g_space32_redo);
+
 // ---- 32-query blocks on v_mfma_f32_32x32x16_bf16, software-pipelined INSIDE the wave (round 6) ----------------------
 // Why: the joint-block kernel above runs a chunk as three serial phases per in-order wave (score MFMAs -> exponentials -> PV MFMAs) and a
 // 16x16x32 MFMA holds the SIMD's vector issue for 8 of its 16 cycles (MI355X_MICROARCH.md, cycle constants): 36 MFMAs + 32 v_exp_f32 + 16
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(64 * NW32, 2) void space_attn32_kernel(const bf16_t
 #pragma unroll 1
             for (int sub = 0; sub < 4; ++sub) {
                 if (!(sub < 2 ? bad_a : bad_b)) continue;
+                if ((sub & 1) == 0) HH_SPACE_REDO_NOTE(g_space32_redo, lane);          // (one count per 32-query block)
                 const int row0 = q0 + 16 * sub;
                 const bf16_t* qrow = q_ptr + (int64_t)(row0 + c) * ld + 8 * g;
                 bf16x8 q16[2];
@@ -512,6 +515,7 @@ __global__ __launch_bounds__(64 * NW32P, 1) void space_attn32p_kernel(const bf16
 #pragma unroll 1
             for (int sub = 0; sub < 4; ++sub) {
                 if (!(sub < 2 ? bad_a : bad_b)) continue;
+                if ((sub & 1) == 0) HH_SPACE_REDO_NOTE(g_space32_redo, lane);          // (one count per 32-query block)
                 const bf16_t* qrow = q_ptr + (int64_t)(q0 + 16 * sub + c) * ld + 8 * g;
                 bf16x8 q16[2];
                 q16[0] = *(const bf16x8*)(qrow);
@@ -581,4 +585,11 @@ int hh_space_attn32_launch(const void* qkv, int layout_rev, void* out, float* cl
     hipLaunchKernelGGL(k32, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW32), lds, stream,
                        (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, heads, dbg, layout_rev);
     return hh_check_launch("hh_space_attn_fwd");
+}
+
+unsigned long long hh_space32_redo_read(int reset) {
+    unsigned long long v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_space32_redo), sizeof(v)) != hipSuccess) return 0;
+    if (reset) { const unsigned long long z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_space32_redo), &z, sizeof(z)); }
+    return v;
 }

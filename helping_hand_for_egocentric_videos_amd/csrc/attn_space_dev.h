@@ -18,6 +18,11 @@ __device__ __forceinline__ bf16x4 lds_tr4(const char* addr) {
     return __builtin_bit_cast(bf16x4, r);
 }
 
+// debug / test counter: query blocks that took the running-maximum redo path (one atomic per redone block: the path is rare).  Each translation
+// unit owns one counter (no relocatable device code); hh_debug_space_redo_count() sums them.
+#define HH_SPACE_REDO_COUNTER(NAME) __device__ unsigned long long NAME = 0ull
+#define HH_SPACE_REDO_NOTE(NAME, LANE) do { if ((LANE) == 0) atomicAdd(&NAME, 1ull); } while (0)
+
 // layout of one CLS partial record: [m, l, 0, 0, o[64]] fp32
 #define CLS_REC 68
 

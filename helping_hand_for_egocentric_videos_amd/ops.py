@@ -57,6 +57,15 @@ def set_tuning(name, value):
     _lib.check(_lib.lib().hh_set_tuning(name.encode(), int(value)), "hh_set_tuning")
 
 
+def space_redo_count(reset=False):
+    """Debug / tests: query blocks the space-attention kernels have redone on their running-maximum path since the last reset
+    (include/hh.h: hh_debug_space_redo_count; synchronises the device)."""
+    v = _lib.lib().hh_debug_space_redo_count(1 if reset else 0)
+    if v < 0:
+        raise RuntimeError("hh_debug_space_redo_count failed")
+    return int(v)
+
+
 PROF_ROLE_DECODER, PROF_ROLE_VISION, PROF_ROLE_TEXT = 0, 1, 2
 
 

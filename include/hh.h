@@ -259,6 +259,11 @@ int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int64_t ldb, fl
 int hh_gemm_tn_bf16_batched2(const void* At, const void* Bt, const void* At2, const void* Bt2, int64_t lda, int64_t ldb, int64_t stride_a,
                              int64_t stride_b, float* C, int64_t stride_c, int M, int N, int64_t K, int batch, hh_stream_t stream);
 
+/* Debug / tests: number of query blocks the space-attention kernels have redone on their running-maximum path since the last reset (a 16-query
+ * block of the 16x16x32 kernels: a score more than 2^127 above its reference maximum; a 32-query block of the 32x32x16 kernels: a row sum outside
+ * [2^-100, 2^100]).  Synchronises the device; reset != 0 zeroes the counters.  -1 on error. */
+int64_t hh_debug_space_redo_count(int reset);
+
 /* ---- divided space-time attention cores (model/LaviLa.py:246-283, attn() :194-198)
  * qkv bf16 [B, N=1+T*n, 3*D] (q|k|v, head-major inside D) or its head-major planes (qkv_layout: enum hh_qkv_layout), out bf16
  * [B, N, D] token-major in both cases; head dim 64.  The q columns are PRE-SCALED by the

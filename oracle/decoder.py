@@ -66,7 +66,7 @@ def memory_kv(features, sd, cfg):
     return torch.stack(Ks), torch.stack(Vs)
 
 
-def decoder_layer(tgt, memory, pos, qpos, sd, b, heads, kv=None, rows=None, relu_mask=None):
+def decoder_layer(tgt, memory, pos, qpos, sd, b, heads, kv=None, rows=None, relu_mask=None, relu_trace=None):
     """TransformerDecoderLayer.forward_pre, sa_first -- tfm_decoder.py:430-461 (all LN eps 1e-5).  kv = (K, V) of this layer
     replaces the in-layer key/value projection of (memory + pos, memory); rows = (memory, memory_plus_pos) replaces the two operands
     of that projection (lets a test feed the oracle the very memory rows another implementation attends over); relu_mask [B,Q,ffn]
@@ -83,6 +83,8 @@ def decoder_layer(tgt, memory, pos, qpos, sd, b, heads, kv=None, rows=None, relu
         tgt = tgt + mha(c + qpos, memory + pos, memory, sd, b + "multihead_attn", heads)
     e = _ln(tgt, sd, b + "norm3")
     h1 = F.linear(e, sd[b + "linear1.weight"], sd[b + "linear1.bias"])
+    if relu_trace is not None:
+        relu_trace.append((h1 > 0).detach())         # the branch THIS evaluation takes (tests count how many units another implementation flipped)
     ff = F.linear(F.relu(h1) if relu_mask is None else h1 * relu_mask.to(h1.dtype), sd[b + "linear2.weight"], sd[b + "linear2.bias"])
     return tgt + ff
 
@@ -110,7 +112,7 @@ def cross_attention_forward(src, mask, query_embed, pos_embed, sd, cfg, prefix="
     return torch.stack(inter), memory.transpose(1, 2).reshape(B, C, T, n)
 
 
-def objdecoder_forward(features, sd, cfg, compute_logits=True, kv=None, rows=None, relu_masks=None):
+def objdecoder_forward(features, sd, cfg, compute_logits=True, kv=None, rows=None, relu_masks=None, relu_trace=None):
     """ObjDecoder.forward -- tfm_decoder.py:183-233 (+ Cross_Attention.forward :76-93,
     TransformerDecoder.forward :255-295).
 
@@ -118,7 +120,7 @@ def objdecoder_forward(features, sd, cfg, compute_logits=True, kv=None, rows=Non
     out['pred_logits'] [B*T,Q,classes+1], out['aux_outputs'] for layers 0..L-2.
     kv = (K, V) [L,B,M,C]: run the query side on these key/value projections (see mha_given_kv) instead of the memory side's.
     rows = (memory, memory + pos) [B,M,C] each: run every layer's key / value projection on these rows instead of the memory side's.
-    relu_masks: per layer [B,Q,ffn] bool, see decoder_layer.
+    relu_masks: per layer [B,Q,ffn] bool, see decoder_layer.  relu_trace: a list that receives every layer's own (pre-activation > 0) mask.
     """
     B, T, n, _ = features.shape
     C, heads, L = cfg.dec_dim, cfg.dec_heads, cfg.dec_layers
@@ -130,7 +132,7 @@ def objdecoder_forward(features, sd, cfg, compute_logits=True, kv=None, rows=Non
     inter = []
     for l in range(L):
         tgt = decoder_layer(tgt, memory, pos, qpos, sd, f"transformer.decoder.layers.{l}.", heads,
-                            None if kv is None else (kv[0][l], kv[1][l]), rows, None if relu_masks is None else relu_masks[l])
+                            None if kv is None else (kv[0][l], kv[1][l]), rows, None if relu_masks is None else relu_masks[l], relu_trace)
         inter.append(_ln(tgt, sd, "transformer.decoder.norm"))
     hs = torch.stack(inter)                                                   # [L,B,Q,C]
     Q = hs.shape[2]

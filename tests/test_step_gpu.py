@@ -7,7 +7,7 @@ Stated tolerances (north_star: "decoder loss within 1e-3 rel of CPU reference, b
   * gradients: (1) with the oracle fed the GPU path's OWN bf16 K/V (query side) and the GPU's own dK/dV (memory side), so that
     both sides differentiate the same function at the same point: relative L2 per tensor <= 5e-3 (heads <= 1e-2)
     (test_decoder_gradients_on_shared_kv); (2) end to end against the fp32 oracle / the reference golden, where the bf16 rounding
-    of K/V flips single ReLU units of the FFN (B*Q ~ 10 rows feed a weight row): per tensor <= 1.5e-1, median <= 5e-2, and the
+    of K/V flips single ReLU units of the FFN (B*Q ~ 10 rows feed a weight row): per tensor <= 9.5e-2, median <= 4.4e-2 (2x measured), and the
     fixture's gradient samples <= 1e-1 relative L2.  This loose bound is the price of storing K/V in bf16 (half the bytes of the 1.6 GB
     buffer the cross-attention streams six times per step); measured on MI355X (profiles/r3_parity_measured.json): worst tensor
     `temporal_embed` 5.7e-2 (T = 4) / `frame_index.weight` 5.5e-2 (T = 16), median 2.4e-2 -- (1) is the real evidence;
@@ -94,12 +94,13 @@ def test_decoder_forward_backward_vs_oracle(cfg):
         rel[name] = float((gg - rg).norm() / (rg.norm() + 1e-12))
     worst = sorted(rel.items(), key=lambda kv: -kv[1])[:4]
     print("decoder grad rel-L2: median %.2e, worst %s" % (float(np.median(list(rel.values()))), worst))
-    record("decoder_fwd_bwd_T%d" % cfg.num_frames, "end-to-end gradient rel-L2 vs fp32 oracle: worst tensor (%s)" % worst[0][0], worst[0][1], 1.5e-1)
-    record("decoder_fwd_bwd_T%d" % cfg.num_frames, "end-to-end gradient rel-L2 vs fp32 oracle: median", float(np.median(list(rel.values()))), 5e-2)
+    record("decoder_fwd_bwd_T%d" % cfg.num_frames, "end-to-end gradient rel-L2 vs fp32 oracle: worst tensor (%s)" % worst[0][0], worst[0][1], 9.5e-2)
+    record("decoder_fwd_bwd_T%d" % cfg.num_frames, "end-to-end gradient rel-L2 vs fp32 oracle: median", float(np.median(list(rel.values()))), 4.4e-2)
     assert len(rel) > 100
-    # ReLU-gated FFN weights can flip single hidden units under bf16 noise (few query rows) -> bound on rel-L2, not max
-    assert max(rel.values()) < 1.5e-1, worst
-    assert float(np.median(list(rel.values()))) < 5e-2
+    # ReLU-gated FFN weights can flip single hidden units under bf16 noise (few query rows) -> bound on rel-L2, not max.  Round 6: both
+    # bounds at 2x the measurement (4.8e-2 / 4.7e-2 worst tensor, 2.2e-2 / 1.9e-2 median at T = 4 / 16) instead of 3x
+    assert max(rel.values()) < 9.5e-2, worst
+    assert float(np.median(list(rel.values()))) < 4.4e-2
 
 
 def test_losses_vs_oracle_on_identical_inputs():
@@ -526,10 +527,16 @@ def test_decoder_gradients_on_shared_memory_rows(cfg):
     # unit would cost every gradient below it ~2e-3 -- measured -- although both sides are fp32-grade)
     Qn = hs.shape[2]
     masks = [m.cpu().view(B, Qn, -1) for m in kept["relu_masks"]]
+    own_masks = []
     with torch.no_grad():
-        _, free = OD.objdecoder_forward(feats, dsd, cfg, compute_logits=False, rows=(mem.detach(), mp.detach()))
+        _, free = OD.objdecoder_forward(feats, dsd, cfg, compute_logits=False, rows=(mem.detach(), mp.detach()), relu_trace=own_masks)
     _, rhs = OD.objdecoder_forward(feats, params, cfg, compute_logits=False, rows=(mem, mp), relu_masks=masks)
     assert _rel(rhs, free) < 1e-5                                          # the imposed branch is the oracle's own, up to units at the kink
+    # ... COUNTED: the units on which the imposed masks differ from the branch the oracle takes by itself -- a handful of ~3e5
+    flips = sum(int((a.bool() != b_.bool()).sum()) for a, b_ in zip(masks, own_masks))
+    units = sum(a.numel() for a in masks)
+    record("decoder_shared_rows_T%d" % T, "statistic: FFN units whose ReLU branch was imposed against the oracle's own (of %d)" % units, flips, 16)
+    assert len(own_masks) == len(masks) == L and flips <= 16, (flips, units)
     check_hs = _rel(hs, rhs)
     record("decoder_shared_rows_T%d" % T, "hs rel-L2 vs oracle on the same memory rows", check_hs, 1e-4)
     assert check_hs < 1e-4                                                # same rows -> hs agrees to fp32-grade kernels
@@ -1118,3 +1125,26 @@ def test_fused_box_tail_equals_the_two_compute_box_loss_calls():
         torch.testing.assert_close(a[2][k].float(), b[2][k].float(), rtol=1e-6, atol=1e-7, msg=k)
     torch.testing.assert_close(a[3], b[3], rtol=1e-5, atol=1e-8)
     assert float(a[2]["cardinality_error_hand_boxes"]) > 0 and float(a[3].abs().max()) > 0
+
+
+def test_c5_egomcq_item_at_full_width_vs_oracle():
+    """BASELINE config 5 at FULL width (C5 was pinned at TINY width and through a self-comparison only): one EgoMCQ item -- 5
+    candidate clips of 16 x 224 px + 1 query text -- through mcq_forward against oracle.step.mcq_forward on this box's host cores
+    (run/test_EgoMCQ.py:56-83): similarity scores within 5e-3 absolute, the predicted answer equal."""
+    from helping_hand_for_egocentric_videos_amd import C2
+    cfg = C2
+    esd, dsd = synth.encoder_state(cfg, seed=3), synth.decoder_state(cfg, seed=3)
+    item = synth.make_mcq_item(cfg, 1, seed=31)
+    backbone = LaviLa.build_backbone(cfg, esd)
+    dec = tfm_decoder.build_decoder(cfg, dsd).eval()
+    with torch.no_grad():
+        got = mcq_forward(backbone, dec, item["video"].cuda(), item["text"].cuda(), cfg).float().cpu()
+        want = OS.mcq_forward(esd, dsd, item["video"], item["text"], cfg)
+    assert got.shape == want.shape == (1, 5)
+    err = float((got - want).abs().max())
+    top2 = want[0].topk(2).values
+    record("c5_full_width_mcq", "max |score - oracle| (cosine similarities)", err, 5e-3)
+    record("c5_full_width_mcq", "statistic: oracle's top-2 score margin", float(top2[0] - top2[1]), 0.0)
+    assert err <= 5e-3, (got, want)
+    if float(top2[0] - top2[1]) > 2 * 5e-3:                       # (an untrained model's five scores can tie within the bound)
+        assert int(got.argmax(-1)) == int(want.argmax(-1))
