@@ -54,9 +54,9 @@ SIGNATURES = {
     "hh_workspace_bytes_mattn_fwd": [c_int, c_int, c_int],
     "hh_workspace_bytes_mattn_bwd": [c_int, c_int, c_int],
     "hh_mattn_slices": [c_int, c_int],
-    "hh_mattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
+    "hh_mattn_fwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_int, c_vp],
     "hh_mattn_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
-                     c_int, c_int, c_float, ctypes.c_uint32, c_vp],
+                     c_int, c_int, c_float, ctypes.c_uint32, c_int, c_vp],
     "hh_gemm_tn_bf16_batched2": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_int, c_int, c_i64, c_int, c_vp],
     "hh_layernorm_fwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_float, c_vp],
     "hh_add_layernorm_fwd": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_float, c_vp],

@@ -53,16 +53,19 @@ __device__ __forceinline__ unsigned lds_u32(const char* p) { return (unsigned)(s
 // loads have been issued, i.e. it waits for the prefetch it is supposed to overlap with.
 #define HH_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (7 << 4) | (15 << 8) | (((N) >> 4) << 14))
 
-template <int T>
+// Round 6: any frame count.  T is the tile's frame SLOT count (a power of two); PAD = the clip has Tr < T real frames (Tr = 3, 5, 12 ...): rows
+// r with r % T >= Tr are padding -- their loads are clamped to the last real frame (valid memory), their keys masked, their queries never
+// stored, the CLS query does not see them.  PAD = false compiles to exactly the round-5 kernel.
+template <int T, bool PAD>
 __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                             float* __restrict__ cls_partial, int B, int n, int heads, int layout) {
+                                                             float* __restrict__ cls_partial, int B, int n, int heads, int layout, int Tr) {
     constexpr int P = 128 / T;         // patch locations per wave (= per CLS partial record)
     constexpr int PT = 16 / T;         // patch locations per 16-row tile
     __shared__ __attribute__((aligned(16))) char Vsm[4 * 2 * 2048];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = heads * 64;
-    const int N = 1 + T * n;
+    const int N = 1 + (PAD ? Tr : T) * n;
     // qkv layout (include/hh.h, hh_qkv_layout): element (row, which, head, d) at row * ld + which * ws + head * hs + d
     const int rev = layout >> 1;                       // (bit 1 of the layout argument, HH_QKV_WALK_REVERSE: the problems last to first)
     layout &= 1;
@@ -85,7 +88,8 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
     // token row of tile t, tile row r; patches beyond n are clamped (their keys only meet their own, never stored, queries)
     auto tokrow = [&](int t, int r) -> int64_t {
         const int patch = min(p0 + t * PT + r / T, n - 1);
-        return 1 + (int64_t)(r % T) * n + patch;
+        const int fr = PAD ? min(r % T, Tr - 1) : r % T;
+        return 1 + (int64_t)fr * n + patch;
     };
     auto issue = [&](int t, bf16x8 (&qq)[2], bf16x8 (&kk)[2]) {
         char* dst = vbuf + (t & 1) * 2048;
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
     auto compute = [&](int t, const f32x4& s, const f32x4& sc, const f32x4& s3, const bf16x4 (&vf)[4]) {
         float x[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = (T == 16 || ((4 * g + j) / T) == (c / T)) ? s[j] : -INFINITY;
+        for (int j = 0; j < 4; ++j) x[j] = ((T == 16 || ((4 * g + j) / T) == (c / T)) && (!PAD || (4 * g + j) % T < Tr)) ? s[j] : -INFINITY;
         float m = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -175,10 +179,10 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
             hh_fullline_swap(w0, w1, x, y);
             if (p0 + t * PT < n) {
                 const int64_t col = head * 64 + 16 * g + 8 * (c >> 3);
-                *(u32x4*)(out + ((int64_t)b * N + tokrow(t, c & 7)) * D + col) = x;
-                *(u32x4*)(out + ((int64_t)b * N + tokrow(t, 8 + (c & 7))) * D + col) = y;
+                if (!PAD || (c & 7) < Tr) *(u32x4*)(out + ((int64_t)b * N + tokrow(t, c & 7)) * D + col) = x;
+                if (!PAD || 8 + (c & 7) < Tr) *(u32x4*)(out + ((int64_t)b * N + tokrow(t, 8 + (c & 7))) * D + col) = y;
             }
-        } else if (p0 + t * PT + c / T < n) {
+        } else if (p0 + t * PT + c / T < n && (!PAD || c % T < Tr)) {
             bf16_t* op = out + ((int64_t)b * N + tokrow(t, c)) * D + head * 64 + 16 * g;
             *(u32x4*)(op) = w0;
             *(u32x4*)(op + 8) = w1;
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
         // ---- CLS query over this tile's keys (lane (c, g) register j = key row 4g+j, identical for every c)
         float y[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = (p0 + t * PT + (4 * g + j) / T < n) ? s3[j] : -INFINITY;
+        for (int j = 0; j < 4; ++j) y[j] = (p0 + t * PT + (4 * g + j) / T < n && (!PAD || (4 * g + j) % T < Tr)) ? s3[j] : -INFINITY;
         float gm = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
         gm = fmaxf(gm, __shfl_xor(gm, 16, 64));
         gm = fmaxf(gm, __shfl_xor(gm, 32, 64));
@@ -252,14 +256,16 @@ __global__ __launch_bounds__(256) void time_attn_mfma_kernel(const bf16_t* __res
 // (= 128 tokens = one CLS record, as above).  Scores are four 16x16 blocks per patch (2 key tiles x 2 query tiles); the PV
 // product of a query tile contracts over all 32 frame keys in ONE 16x16x32 MFMA (k-slots jj < 4 -> key row 4g+jj of tile 0,
 // jj >= 4 -> key row 16+4g+jj-4 of tile 1) and takes the CLS key in a second MFMA whose only non-zero k-slot is slot 0 of g = 0.
+// Round 6: PAD = 16 < Tr < 32 real frames: the second key / query tile is ragged (same rules as above).
+template <bool PAD>
 __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                               float* __restrict__ cls_partial, int B, int n, int heads, int layout) {
+                                                               float* __restrict__ cls_partial, int B, int n, int heads, int layout, int Tr) {
     constexpr int T = 32, P = 4;
     __shared__ __attribute__((aligned(16))) char Vsm[4 * 2 * 4096];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = heads * 64;
-    const int N = 1 + T * n;
+    const int N = 1 + (PAD ? Tr : T) * n;
     // qkv layout (include/hh.h, hh_qkv_layout): element (row, which, head, d) at row * ld + which * ws + head * hs + d
     const int rev = layout >> 1;                       // (bit 1 of the layout argument, HH_QKV_WALK_REVERSE: the problems last to first)
     layout &= 1;
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
     const int c = lane & 15, g = lane >> 4;
     const float LOG2E = 1.4426950408889634f;
     char* vbuf = Vsm + wave * 8192;
-    auto tok = [&](int u, int fr) -> int64_t { return 1 + (int64_t)fr * n + p0 + u; };
+    auto tok = [&](int u, int fr) -> int64_t { return 1 + (int64_t)(PAD ? min(fr, Tr - 1) : fr) * n + p0 + u; };
     auto issue = [&](int u, bf16x8 (&qq)[2][2], bf16x8 (&kk)[2][2]) {
         char* dst = vbuf + (u & 1) * 4096;
 #pragma unroll
@@ -351,7 +357,12 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
         }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            const f32x4 s0 = r.s0[qt], s1 = r.s1[qt], sc = r.sc[qt];
+            const f32x4 s0 = r.s0[qt], sc = r.sc[qt];
+            f32x4 s1 = r.s1[qt];
+            if (PAD) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s1[j] = 16 + 4 * g + j < Tr ? s1[j] : -INFINITY;     // padded frames of the second key tile
+            }
             float m = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
             m = fmaxf(m, __shfl_xor(m, 16, 64));
             m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -384,11 +395,16 @@ __global__ __launch_bounds__(256) void time_attn_mfma32_kernel(const bf16_t* __r
             u32x4 x, y;                                                  // 8 full 128-B lines per store (common.h: hh_fullline_swap)
             hh_fullline_swap(w0, w1, x, y);
             const int64_t col = head * 64 + 16 * g + 8 * (c >> 3);
-            *(u32x4*)(out + ((int64_t)b * N + tok(u, 16 * qt + (c & 7))) * D + col) = x;
-            *(u32x4*)(out + ((int64_t)b * N + tok(u, 16 * qt + 8 + (c & 7))) * D + col) = y;
+            if (!PAD || 16 * qt + (c & 7) < Tr) *(u32x4*)(out + ((int64_t)b * N + tok(u, 16 * qt + (c & 7))) * D + col) = x;
+            if (!PAD || 16 * qt + 8 + (c & 7) < Tr) *(u32x4*)(out + ((int64_t)b * N + tok(u, 16 * qt + 8 + (c & 7))) * D + col) = y;
         }
         if (cls_partial == nullptr) return;
-        const f32x4 y0 = r.y0, y1 = r.y1;
+        const f32x4 y0 = r.y0;
+        f32x4 y1 = r.y1;
+        if (PAD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y1[j] = 16 + 4 * g + j < Tr ? y1[j] : -INFINITY;
+        }
         float gm = fmaxf(fmaxf(fmaxf(y0[0], y0[1]), fmaxf(y0[2], y0[3])), fmaxf(fmaxf(y1[0], y1[1]), fmaxf(y1[2], y1[3])));
         gm = fmaxf(gm, __shfl_xor(gm, 16, 64));
         gm = fmaxf(gm, __shfl_xor(gm, 32, 64));
@@ -460,30 +476,33 @@ extern "C" int hh_time_attn_fwd(const void* qkv, int qkv_layout, void* out, floa
     qkv_layout &= ~HH_QKV_WALK_REVERSE;
     HH_REQUIRE(qkv_layout == HH_QKV_TOKEN_MAJOR || qkv_layout == HH_QKV_HEAD_MAJOR, HH_ERR_SHAPE, "hh_time_attn_fwd: bad qkv_layout");
     HH_REQUIRE(B >= 0 && n > 0 && heads > 0, HH_ERR_SHAPE, "hh_time_attn_fwd: bad shape");
-    HH_REQUIRE(T == 1 || T == 2 || T == 4 || T == 8 || T == 16 || T == 32, HH_ERR_UNSUPPORTED,
-               "hh_time_attn_fwd: num_frames=%d unsupported (1,2,4,8,16,32)", T);
+    HH_REQUIRE(T >= 1 && T <= 32, HH_ERR_UNSUPPORTED, "hh_time_attn_fwd: num_frames=%d unsupported (1 .. 32)", T);
     HH_REQUIRE(HH_ALIGNED16(qkv) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_time_attn_fwd: pointers must be 16-byte aligned");
     if (B == 0) return HH_OK;
-    const int P = 128 / T;
+    int TP = 1;                                                  // frame slots of a tile: the next power of two (padding rows are masked)
+    while (TP < T) TP *= 2;
+    const bool pad = TP != T;
+    const int P = 128 / TP;
     const int64_t blocks = (int64_t)B * heads * ((n + P - 1) / P);
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* in = (const bf16_t*)qkv;
     bf16_t* o = (bf16_t*)out;
     HHProfScope prof(HH_PROF_TIME_ATTN, 8.0 * B * (1.0 + (double)T * n) * heads * 64, s);
-    if (T == 32) {
-        hh_prof_note_kernel(HH_PROF_TIME_ATTN, "time_attn_mfma32_kernel");
-        hipLaunchKernelGGL(time_attn_mfma32_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout | walk_rev);
+    const unsigned wg = (unsigned)((blocks + 3) / 4);           // one wave per record, four waves per workgroup
+    if (TP == 32) {
+        hh_prof_note_kernel(HH_PROF_TIME_ATTN, pad ? "time_attn_mfma32_kernel<true>" : "time_attn_mfma32_kernel<false>");
+        if (pad) hipLaunchKernelGGL(time_attn_mfma32_kernel<true>, dim3(wg), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout | walk_rev, T);
+        else hipLaunchKernelGGL(time_attn_mfma32_kernel<false>, dim3(wg), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout | walk_rev, T);
         return hh_check_launch("hh_time_attn_fwd(T=32)");
     }
-    const unsigned wg = (unsigned)((blocks + 3) / 4);           // one wave per record, four waves per workgroup
-#define LAUNCHM(TT) do { hh_prof_note_kernel(HH_PROF_TIME_ATTN, "time_attn_mfma_kernel<" #TT ">"); \
-                         hipLaunchKernelGGL(time_attn_mfma_kernel<TT>, dim3(wg), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout | walk_rev); } while (0)
-    switch (T) {
-        case 1: LAUNCHM(1); break;
-        case 2: LAUNCHM(2); break;
-        case 4: LAUNCHM(4); break;
-        case 8: LAUNCHM(8); break;
-        default: LAUNCHM(16); break;
+#define LAUNCHM(TT, PD) do { hh_prof_note_kernel(HH_PROF_TIME_ATTN, "time_attn_mfma_kernel<" #TT ", " #PD ">"); \
+                         hipLaunchKernelGGL((time_attn_mfma_kernel<TT, PD>), dim3(wg), dim3(256), 0, s, in, o, cls_partial, B, n, heads, qkv_layout | walk_rev, T); } while (0)
+    switch (TP) {
+        case 1: LAUNCHM(1, false); break;
+        case 2: LAUNCHM(2, false); break;
+        case 4: if (pad) LAUNCHM(4, true); else LAUNCHM(4, false); break;
+        case 8: if (pad) LAUNCHM(8, true); else LAUNCHM(8, false); break;
+        default: if (pad) LAUNCHM(16, true); else LAUNCHM(16, false); break;
     }
 #undef LAUNCHM
     return hh_check_launch("hh_time_attn_fwd");

@@ -100,6 +100,7 @@ __device__ __forceinline__ float ma_sum_groups(float v) {
 struct MaCommon {
     const bf16_t* mp; const bf16_t* mem; int64_t ld;     // [B, M, ld] bf16 (ld >= 512)
     int B, Q, M, slices, keys_per_slice;
+    int Mv;                                              // keys [Mv, M) are padding (rows of zeros): masked out of every softmax (round 6: any memory length)
     unsigned drop_thresh; float drop_scale; unsigned seed;
 };
 
@@ -356,6 +357,12 @@ __global__ __launch_bounds__(512) void mattn_fwd_kernel(MaFwd p) {
         float t[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { t[r] = s[0][r] * MA_LOG2E; t[4 + r] = s[1][r] * MA_LOG2E; }
+        const bool ragged = k_begin + (c + 1) * MA_KC > p.c.Mv;          // (wave-uniform: the chunk holds padding keys)
+        if (ragged) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k_begin + c * MA_KC + 4 * g + 16 * (j >> 2) + (j & 3) >= p.c.Mv) t[j] = -INFINITY;
+        }
         float mx = fmaxf(fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])), fmaxf(fmaxf(t[4], t[5]), fmaxf(t[6], t[7])));
         mx = ma_max_groups(mx);
         if (more) ma_stage_part<2>(p.c, b, kn, wave, voff, sn);
@@ -373,6 +380,7 @@ __global__ __launch_bounds__(512) void mattn_fwd_kernel(MaFwd p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float pv = __builtin_amdgcn_exp2f(t[j] - m_run);
+            if (ragged && t[j] == -INFINITY) pv = 0.f;                      // (a slice of padding only: m_run is still -inf, exp2(-inf + inf) is NaN)
             l_run += pv;
             if (p.c.drop_thresh) pv = ma_keep(p.c.seed, bh, (unsigned)ql, (unsigned)(kbase + 16 * (j >> 2) + (j & 3)), p.c.drop_thresh) ? pv * p.c.drop_scale : 0.f;
             rs_run += pv;
@@ -493,15 +501,17 @@ extern "C" int64_t hh_workspace_bytes_mattn_fwd(int B, int Q, int slices) {
 }
 
 extern "C" int hh_mattn_fwd(const float* qt, const void* mp, const void* mem, int64_t ld, float* pooled, float* lse2, float* rsum, float* workspace,
-                            int slices, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, hh_stream_t stream) {
+                            int slices, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, int keys_valid, hh_stream_t stream) {
     int rc = ma_check("hh_mattn_fwd", B, Q, M, heads, C, ld, slices);
     if (rc) return rc;
+    HH_REQUIRE(keys_valid <= M, HH_ERR_SHAPE, "hh_mattn_fwd: keys_valid = %d > M = %d", keys_valid, M);
     HH_REQUIRE(HH_ALIGNED16(qt) && HH_ALIGNED16(mp) && HH_ALIGNED16(mem) && HH_ALIGNED16(pooled) && HH_ALIGNED16(workspace), HH_ERR_ALIGN,
                "hh_mattn_fwd: pointers must be 16-byte aligned");
     HH_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, HH_ERR_SHAPE, "hh_mattn_fwd: dropout_p must be in [0,1)");
     if (B == 0) return HH_OK;
     MaFwd p;
     p.c.mp = (const bf16_t*)mp; p.c.mem = (const bf16_t*)mem; p.c.ld = ld; p.c.B = B; p.c.Q = Q; p.c.M = M;
+    p.c.Mv = keys_valid > 0 ? keys_valid : M;
     p.c.slices = slices;
     ma_slicing(M, &p.c.slices, &p.c.keys_per_slice);
     ma_drop_params(dropout_p, &p.c.drop_thresh, &p.c.drop_scale);
@@ -642,7 +652,7 @@ __global__ __launch_bounds__(512) void mattn_bwd_kernel(MaBwd p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float sv = j < 4 ? s[0][j] : s[1][j - 4], dv = j < 4 ? dp[0][j] : dp[1][j - 4];
-            const float pv = live ? __builtin_amdgcn_exp2f(sv * MA_LOG2E - lse) : 0.f;
+            const float pv = (live && kbase + 16 * (j >> 2) + (j & 3) < p.c.Mv) ? __builtin_amdgcn_exp2f(sv * MA_LOG2E - lse) : 0.f;
             // (delta = dO . O contains the value-bias term rsum * cb, so cb belongs to dP with or without dropout)
             float pd = pv, dpm = dv + cb;
             if (p.c.drop_thresh) {
@@ -696,9 +706,10 @@ extern "C" int64_t hh_workspace_bytes_mattn_bwd(int B, int Q, int slices) {
 
 extern "C" int hh_mattn_bwd(const float* qt, const float* dpooled, const float* lse2, const float* dca, const float* ca, const float* bv,
                             const void* mp, const void* mem, int64_t ld, float* dqt, float* workspace, int slices, void* pdT, void* dsT, void* qt16, void* dp16,
-                            int rows_total, int row_off, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, hh_stream_t stream) {
+                            int rows_total, int row_off, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, int keys_valid, hh_stream_t stream) {
     int rc = ma_check("hh_mattn_bwd", B, Q, M, heads, C, ld, slices);
     if (rc) return rc;
+    HH_REQUIRE(keys_valid <= M, HH_ERR_SHAPE, "hh_mattn_bwd: keys_valid = %d > M = %d", keys_valid, M);
     HH_REQUIRE(HH_ALIGNED16(qt) && HH_ALIGNED16(dpooled) && HH_ALIGNED16(dca) && HH_ALIGNED16(ca) && HH_ALIGNED16(bv) && HH_ALIGNED16(mp) && HH_ALIGNED16(mem) &&
                HH_ALIGNED16(dqt) && HH_ALIGNED16(workspace) && HH_ALIGNED16(pdT) && HH_ALIGNED16(dsT) && HH_ALIGNED16(qt16) && HH_ALIGNED16(dp16), HH_ERR_ALIGN,
                "hh_mattn_bwd: pointers must be 16-byte aligned");
@@ -708,6 +719,7 @@ extern "C" int hh_mattn_bwd(const float* qt, const float* dpooled, const float* 
     if (B == 0) return HH_OK;
     MaBwd p;
     p.c.mp = (const bf16_t*)mp; p.c.mem = (const bf16_t*)mem; p.c.ld = ld; p.c.B = B; p.c.Q = Q; p.c.M = M;
+    p.c.Mv = keys_valid > 0 ? keys_valid : M;
     p.c.slices = slices;
     ma_slicing(M, &p.c.slices, &p.c.keys_per_slice);
     HH_REQUIRE(p.c.slices == 1 || workspace != nullptr, HH_ERR_SHAPE, "hh_mattn_bwd: slices > 1 needs hh_workspace_bytes_mattn_bwd() bytes of workspace");

@@ -139,8 +139,10 @@ extern "C" int64_t hh_workspace_bytes_xattn_fwd(int B, int Q, int heads, int spl
     return (B < 0 || Q <= 0 || heads <= 0 || splits < 1) ? -1 : (int64_t)splits * B * Q * heads * (64 + 1) * 4;   // out planes, then lse planes
 }
 extern "C" int64_t hh_workspace_bytes_attn_cls_partial(int B, int T, int n, int heads, int time_mode) {
-    if (B < 0 || T <= 0 || n <= 0 || heads <= 0 || (time_mode && T > 128)) return -1;
-    const int64_t G = time_mode ? (n + (128 / T) - 1) / (128 / T) : T;                         // key groups per (clip, head)
+    if (B < 0 || T <= 0 || n <= 0 || heads <= 0 || (time_mode && T > 32)) return -1;
+    int TP = 1;                                                                                // time kernel: frame slots per tile = next power of two
+    while (TP < T) TP *= 2;
+    const int64_t G = time_mode ? (n + (128 / TP) - 1) / (128 / TP) : T;                       // key groups per (clip, head)
     return (int64_t)B * heads * G * 68 * 4;                                                    // records {m, l, 0, 0, o[64]} fp32
 }
 

@@ -167,7 +167,7 @@ class QueryStack(torch.autograd.Function):
                 # scores q_h.(mp Wk_h^T + bk_h) = (q_h Wk_h).mp + const: map the 13 rows of every head into memory space, attend over the
                 # un-projected rows, apply Wv_h / bv_h to the 13 pooled rows (tfm_decoder.py:438-441; csrc/mattn.hip)
                 qt = ops.head_map_in(q, wi_c[C:2 * C])                                                      # [R, heads * C]
-                pooled, lse, rsum = ops.mattn_fwd(qt, holder.mp, holder.mem, Q, p, sd("x"))
+                pooled, lse, rsum = ops.mattn_fwd(qt, holder.mp, holder.mem, Q, p, sd("x"), keys_valid=holder.Mv)
                 ca = ops.head_map_out(pooled, wi_c[2 * C:], bias=bi_c[2 * C:], rowscale=rsum if p > 0 else None)
                 xs = (qt, pooled, rsum)
             else:
@@ -271,7 +271,7 @@ class QueryStack(torch.autograd.Function):
                 dpooled = ops.head_map_in(dca, wi_c[2 * C:])
                 ops.head_map_wgrad(dca, pooled, gw_c[2 * C:], colsum=gb_c[2 * C:], rowscale=rs)
                 # attention core in memory space: d qt; Pd^T / dS^T of this layer for _MemorySideKVFree's batched d-memory GEMM
-                dqt = ops.mattn_bwd(qt, dpooled, lse, dca, ca, bi_c[2 * C:], h.mp, h.mem, Q, pdT, dsT, qt16, dp16, l * 128, p, sd("x"))
+                dqt = ops.mattn_bwd(qt, dpooled, lse, dca, ca, bi_c[2 * C:], h.mp, h.mem, Q, pdT, dsT, qt16, dp16, l * 128, p, sd("x"), keys_valid=h.Mv)
                 # qt_h = q_h Wk_h:  d q, d Wk (key rows); the key bias drops out of the softmax -- its gradient is exactly 0 (the rows stay zero)
                 dq = ops.head_map_out(dqt, wi_c[C:2 * C])
                 ops.head_map_wgrad(q, dqt, gw_c[C:2 * C])

@@ -40,8 +40,8 @@ class _KVHolder:
     kv_free (default, round 5): `mem` = pre_norm(proj(x)) and `mp` = mem + pos, bf16 [B, M, C] -- the un-projected rows every layer and
     head attends over (csrc/mattn.hip); the backward of the layers leaves Pd^T / dS^T (`pdT`, `dsT`: bf16 [B, L*128, M]) and the bf16
     mapped queries / pooled-row gradients (`qt16`, `dp16`: bf16 [B, L*128, C]) for ONE batched GEMM in _MemorySideKVFree.backward.
-    Otherwise (the round-1..4 path, kept for A/B measurements and for M % 128 != 0): K/V of all layers [B*M, 2*L*C] bf16 (K columns
-    first) and its gradient buffer."""
+    Otherwise (the round-1..4 path, kept for A/B measurements and for decoders other than 512 / 8 heads): K/V of all layers
+    [B*M, 2*L*C] bf16 (K columns first) and its gradient buffer."""
 
     def __init__(self):
         self.kv = None
@@ -49,6 +49,7 @@ class _KVHolder:
         self.mem = self.mp = None
         self.pdT = self.dsT = self.qt16 = self.dp16 = None
         self.B = self.M = self.C = self.L = 0
+        self.Mv = 0                      # kv_free: the clip's real memory length T * n when M was rounded up to a multiple of 128 (else 0 = all M rows are keys)
         self.seed = 0
         self.keep, self.kept = False, None
         self.relu_masks = []             # keep only: per layer, the active units of the FFN hidden layer [B*Q, ffn] (tests/test_step_gpu.py)
@@ -171,8 +172,20 @@ class _MemorySideKVFree(torch.autograd.Function):
         mem0 = ops.gemm(feat_b, ops.to_bf16(w_proj.detach()), out_dtype=torch.float32)                   # [BM, C]
         memory, mem_pos, mean, rstd = ops.layernorm_pos(mem0, g_pre.detach().float(), b_pre.detach().float(), eps,
                                                         pos.detach().float().contiguous(), out_dtype=torch.bfloat16, save_stats=True)
-        holder.mem, holder.mp = memory.view(B, M, C), mem_pos.view(B, M, C)
-        holder.B, holder.M, holder.C, holder.L = B, M, C, L
+        Mp = (M + 127) // 128 * 128
+        if Mp == M:
+            holder.mem, holder.mp, holder.Mv = memory.view(B, M, C), mem_pos.view(B, M, C), 0
+        else:
+            # any memory length (round 6; e.g. patch 16 -> n = 196, M = 3136): the rows are rounded up to the 128-row tile of the batched
+            # d-memory GEMM with ZERO rows that hh_mattn_* masks out of every softmax (keys_valid) -- one more copy of the rows, paid only
+            # by shapes that are not multiples of 128; their Pd^T / dS^T columns are exact zeros, their d memory rows are dropped below
+            holder.mem = torch.zeros((B, Mp, C), dtype=torch.bfloat16, device=feat_b.device)
+            holder.mp = torch.zeros_like(holder.mem)
+            holder.mem[:, :M].copy_(memory.view(B, M, C))
+            holder.mp[:, :M].copy_(mem_pos.view(B, M, C))
+            holder.Mv = M
+        holder.B, holder.M, holder.C, holder.L = B, Mp, C, L
+        ctx.M_valid = M
         ctx.holder = holder
         ctx.param_objs = (w_proj, g_pre, b_pre)
         ctx.save_for_backward(feat_b, mem0, mean, rstd, g_pre)
@@ -182,13 +195,17 @@ class _MemorySideKVFree(torch.autograd.Function):
     def backward(ctx, _gtoken):
         feat_b, mem0, mean, rstd, g_pre = ctx.saved_tensors
         h = ctx.holder
-        B, M, C, L = h.B, h.M, h.C, h.L
+        B, Mp, C, L = h.B, h.M, h.C, h.L
+        M = ctx.M_valid
         if h.pdT is None:                      # no cross-attention gradient reached us
             dmem = torch.zeros((B * M, C), dtype=torch.float32, device=feat_b.device)
             dpos = torch.zeros((M, C), dtype=torch.float32, device=feat_b.device)
         else:
-            dmem = ops.gemm_tn_batched2(h.pdT, h.dp16, h.dsT, h.qt16).view(B * M, C)                     # d(memory) incl. the key path
-            dpos = ops.gemm_tn(h.dsT.view(B * L * 128, M), h.qt16.view(B * L * 128, C))                  # d(pos) = sum over clips of the key path
+            dmem = ops.gemm_tn_batched2(h.pdT, h.dp16, h.dsT, h.qt16)                                    # d(memory) incl. the key path  [B, Mp, C]
+            dpos = ops.gemm_tn(h.dsT.view(B * L * 128, Mp), h.qt16.view(B * L * 128, C))                 # d(pos) = sum over clips of the key path
+            if Mp != M:                        # (padding rows: exact zeros)
+                dmem, dpos = dmem[:, :M].contiguous(), dpos[:M].contiguous()
+            dmem = dmem.view(B * M, C)
         # gradient sinks (parallel._GradSink): the LayerNorm reductions accumulate into, and the projection's split-K partials are summed
         # into, the parameters' (zeroed) slices of the gradient arena -- no zero fills, no copies, no AccumulateGrad adds
         sinks = [getattr(t, "_hh_sink", None) for t in ctx.param_objs]
@@ -200,7 +217,7 @@ class _MemorySideKVFree(torch.autograd.Function):
                                           db=sinks[2].view if sunk else None)
         dw_proj = ops.gemm_tn(ops.to_bf16(dmem0), feat_b, out=sinks[0].view if sunk else None)             # [C, F]
         if h.keep:
-            h.kept = {"mem": h.mem, "mp": h.mp, "dmem": dmem, "dpos": dpos, "relu_masks": h.relu_masks}        # test hook (Cross_Attention.debug_keep_kv)
+            h.kept = {"mem": h.mem[:, :M], "mp": h.mp[:, :M], "dmem": dmem, "dpos": dpos, "relu_masks": h.relu_masks}        # test hook (Cross_Attention.debug_keep_kv)
         h.mem = h.mp = h.pdT = h.dsT = h.qt16 = h.dp16 = None
         if sunk:
             for s_ in sinks:
@@ -576,9 +593,10 @@ class Cross_Attention(nn.Module):
         self._reset_parameters()
         self.d_model, self.nhead = d_model, nhead
         self.dec_layers, self.enc_layers = num_decoder_layers, num_encoder_layers
-        # kv_free (default): the cross-attention runs in memory space (csrc/mattn.hip) -- no K/V projection of the memory tokens.  False:
-        # the round-1..4 path (one batched K/V in-projection for all layers + hh_xattn_*), kept for same-session A/B measurements; it is
-        # also what runs when the clip's token count is not a multiple of 128 (the batched d-memory GEMM's tile)
+        # kv_free (default): the cross-attention runs in memory space (csrc/mattn.hip) -- no K/V projection of the memory tokens -- for EVERY
+        # memory length (round 6: rows padded to a multiple of 128 and masked).  False: the round-1..4 path (one batched K/V in-projection for
+        # all layers + hh_xattn_*), kept for same-session A/B measurements; it also serves decoders that are not the reference's 512 / 8 heads /
+        # <= 16 queries, which hh_mattn_* is built for (tfm_decoder.py:51)
         self.kv_free = True
         self.debug_keep_kv, self.last_holder = False, None        # tests: keep the memory rows / K/V and their gradients after backward
         self._seed = None            # dropout-mask stream of the cross-attention kernels; see next_dropout_seed()
@@ -606,7 +624,7 @@ class Cross_Attention(nn.Module):
         holder.keep = self.debug_keep_kv
         self.last_holder = holder if self.debug_keep_kv else None
         layers = self.decoder.layers
-        kv_free = self.kv_free and pos.shape[0] % 128 == 0
+        kv_free = self.kv_free and self.d_model == ops.MATTN_C and self.nhead == ops.MATTN_H and query_embed.shape[0] <= 16
         if kv_free:
             token = _MemorySideKVFree.apply(feat_b, w_proj, self.pre_norm.weight, self.pre_norm.bias, pos, holder, self.pre_norm.eps, len(layers))
         else:

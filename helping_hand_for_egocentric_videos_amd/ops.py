@@ -553,7 +553,8 @@ def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True, revers
     L = _lib.lib()
     part, G = None, 0
     if fold_cls:
-        G = T if mode == "space" else (n + (128 // T) - 1) // (128 // T)
+        tp = 1 << max(0, (T - 1).bit_length())          # the time kernel's tile holds the next power of two of frame slots
+        G = T if mode == "space" else (n + (128 // tp) - 1) // (128 // tp)
         part = _workspace("attn_cls_partial", B, T, n, heads, int(mode == "time"), device=qkv.device).view(B, heads, G, 68)
     else:
         _lib.check(L.hh_cls_attn_fwd(_p(qkv), lay, _p(out), B, N, heads, int(mode == "space"), _stream()), "hh_cls_attn_fwd")
@@ -667,8 +668,9 @@ def _mattn_mem(mp, mem):
         raise RuntimeError("mattn: mp and mem must share shape and row stride")
 
 
-def mattn_fwd(qt, mp, mem, Q, dropout_p=0.0, seed=0, slices=None):
-    """qt fp32 [B*Q, 8*512] (mapped queries), mp / mem bf16 [B, M, 512] -> (pooled fp32 [B*Q, 8*512], lse2 fp32 [B*Q, 8], rsum fp32 [B*Q, 8])."""
+def mattn_fwd(qt, mp, mem, Q, dropout_p=0.0, seed=0, slices=None, keys_valid=0):
+    """qt fp32 [B*Q, 8*512] (mapped queries), mp / mem bf16 [B, M, 512] -> (pooled fp32 [B*Q, 8*512], lse2 fp32 [B*Q, 8], rsum fp32 [B*Q, 8]).
+    keys_valid: rows [keys_valid, M) of mp / mem are padding (finite) that the softmax does not see (0: none)."""
     _chk(qt)
     _mattn_mem(mp, mem)
     B, M, _ = mp.shape
@@ -680,11 +682,11 @@ def mattn_fwd(qt, mp, mem, Q, dropout_p=0.0, seed=0, slices=None):
     rsum = torch.empty_like(lse2)
     ws = _workspace("mattn_fwd", B, Q, S, device=qt.device) if S > 1 else None
     _lib.check(_lib.lib().hh_mattn_fwd(_p(qt), _p(mp), _p(mem), mp.stride(1), _p(pooled), _p(lse2), _p(rsum), _p(ws), S, B, Q, M, MATTN_H, MATTN_C,
-                                       float(dropout_p), int(seed) & 0xFFFFFFFF, _stream()), "hh_mattn_fwd")
+                                       float(dropout_p), int(seed) & 0xFFFFFFFF, int(keys_valid), _stream()), "hh_mattn_fwd")
     return pooled, lse2, rsum
 
 
-def mattn_bwd(qt, dpooled, lse2, dca, ca, bv, mp, mem, Q, pdT, dsT, qt16, dp16, row_off, dropout_p=0.0, seed=0, slices=None):
+def mattn_bwd(qt, dpooled, lse2, dca, ca, bv, mp, mem, Q, pdT, dsT, qt16, dp16, row_off, dropout_p=0.0, seed=0, slices=None, keys_valid=0):
     """Backward of mattn_fwd for one layer: returns dqt fp32 [B*Q, 8*512]; writes this layer's 128 rows (row_off + head*16 + query) of
     pdT / dsT (bf16 [B, rows, M]) and of qt16 / dp16 (bf16 [B, rows, 512]) -- the operands of gemm_tn_batched2."""
     _chk(qt, dpooled, lse2, dca, ca, bv, pdT, dsT, qt16, dp16)
@@ -698,7 +700,7 @@ def mattn_bwd(qt, dpooled, lse2, dca, ca, bv, mp, mem, Q, pdT, dsT, qt16, dp16, 
     ws = _workspace("mattn_bwd", B, Q, S, device=qt.device) if S > 1 else None
     _lib.check(_lib.lib().hh_mattn_bwd(_p(qt), _p(dpooled), _p(lse2), _p(dca), _p(ca), _p(bv), _p(mp), _p(mem), mp.stride(1), _p(dqt), _p(ws), S, _p(pdT), _p(dsT),
                                        _p(qt16), _p(dp16), rows, int(row_off), B, Q, M, MATTN_H, MATTN_C, float(dropout_p), int(seed) & 0xFFFFFFFF,
-                                       _stream()), "hh_mattn_bwd")
+                                       int(keys_valid), _stream()), "hh_mattn_bwd")
     return dqt
 
 

@@ -319,13 +319,16 @@ int hh_xattn_bwd(const float* q, const void* k, const void* v, int64_t ldkv, con
  *             the head outputs, bv fp32 [512] the layer's value bias);  pdT / dsT bf16 [B, rows_total, M]: rows [row_off, row_off + 128)
  *             (row_off + head*16 + query) receive Pd^T and dS^T, keys contiguous -- the operands of hh_gemm_tn_bf16_batched2, which makes
  *             d mem + d mp for all layers at once;  qt16 / dp16 (optional, bf16 [B, rows_total, 512]): the same rows of bf16(qt) / bf16(dpooled),
- *             the other operands of that GEMM.  Same dropout mask as the forward for the same seed. */
+ *             the other operands of that GEMM.  Same dropout mask as the forward for the same seed.
+ *   keys_valid (round 6): 0 < keys_valid <= M -- keys [keys_valid, M) are PADDING rows (finite, e.g. zeros) that no softmax sees: their
+ *             probabilities, Pd^T and dS^T columns are exact zeros.  Lets a caller round any memory length up to the 32-key chunk / the 128-row
+ *             tile of hh_gemm_tn_bf16_batched2 (model/tfm_decoder.py pads M = T * n to a multiple of 128).  <= 0: all M keys are valid. */
 int hh_mattn_slices(int M, int slices);
 int hh_mattn_fwd(const float* qt, const void* mp, const void* mem, int64_t ld, float* pooled, float* lse2, float* rsum, float* workspace,
-                 int slices, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, hh_stream_t stream);
+                 int slices, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, int keys_valid, hh_stream_t stream);
 int hh_mattn_bwd(const float* qt, const float* dpooled, const float* lse2, const float* dca, const float* ca, const float* bv,
                  const void* mp, const void* mem, int64_t ld, float* dqt, float* workspace, int slices, void* pdT, void* dsT, void* qt16, void* dp16,
-                 int rows_total, int row_off, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, hh_stream_t stream);
+                 int rows_total, int row_off, int B, int Q, int M, int heads, int C, float dropout_p, uint32_t seed, int keys_valid, hh_stream_t stream);
 
 /* ---- query side of the decoder (model/tfm_decoder.py:430-461 forward_pre on the 13 object queries, :208-233 heads, and the
  * txt_proj / obj_proj projections of run/train.py:124-125,187-189): fp32 operands, bf16 matrix cores at fp32-grade accuracy.

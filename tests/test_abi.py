@@ -44,7 +44,7 @@ def test_host_side_argument_validation_needs_no_gpu():
     assert rc == -1 and b"hh_gemm_bf16" in L.hh_last_error_string()
     assert L.hh_space_attn_fwd(None, 0, None, None, 1, 4, 250, 2, None) == -1
     assert L.hh_space_attn_fwd(None, 7, None, None, 1, 4, 256, 2, None) == -1          # unknown qkv layout
-    assert L.hh_time_attn_fwd(None, 1, None, None, 1, 5, 256, 2, None) == -3
+    assert L.hh_time_attn_fwd(None, 1, None, None, 1, 33, 256, 2, None) == -3         # (round 6: every T <= 32 is supported)
     assert L.hh_xattn_fwd(None, None, None, 512, None, None, 1, 17, 4096, 8, 0.0, 0, None) == -1
     assert L.hh_adamw_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None) == -1
     # query-side entry points (round 2)

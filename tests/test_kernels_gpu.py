@@ -422,8 +422,6 @@ def _ref_divided(qkv, B, T, n, heads, mode):
 @pytest.mark.parametrize("mode", ["space", "time"])
 @pytest.mark.parametrize("B,T,n,heads", [(2, 4, 256, 2), (1, 16, 256, 16), (1, 2, 576, 2), (1, 32, 64, 2), (1, 3, 160, 2), (1, 2, 128, 1)])
 def test_divided_attention(mode, B, T, n, heads):
-    if mode == "time" and T not in (1, 2, 4, 8, 16, 32):
-        pytest.skip("hh_time_attn_fwd: num_frames in {1,2,4,8,16,32}")
     N, D = 1 + T * n, heads * 64
     qkv = rnd(B * N, 3 * D, seed=T + n)
     qkv[:, :D] *= 0.6            # realistic logits (|s| up to ~15)
@@ -559,6 +557,32 @@ def test_space_attention_redo_path_when_the_reference_maximum_is_exceeded(joint,
     assert (err / (ref.abs().amax(1) + 1e-3)).max() < 5e-2
 
 
+@pytest.mark.parametrize("B,T,n,heads", [(2, 3, 64, 2), (1, 5, 100, 1), (2, 12, 256, 2), (1, 7, 33, 3), (1, 9, 196, 2), (1, 20, 64, 2), (2, 24, 37, 1), (1, 31, 196, 2), (1, 17, 5, 1)])
+def test_time_attention_any_frame_count(B, T, n, heads):
+    """Round 6: hh_time_attn_fwd for every T <= 32, not only powers of two -- the tile holds the next power of two of frame
+    slots, the padding rows' keys are masked, their queries never stored, the CLS query's folded partial skips them.  Against the fp32
+    reference, token-major and head-major planes, forward and reversed walk, folded and stand-alone CLS row; rows the kernel must not
+    write (there are none besides row 0 of each clip, which hh_cls_combine writes) are checked through a poisoned output buffer."""
+    N, D = 1 + T * n, heads * 64
+    qkv = rnd(B * N, 3 * D, seed=300 + T + n)
+    qkv[:, :D] *= 0.6
+    qkv[3, :64] += 5.0
+    qkv = bf(qkv)
+    ref = _ref_divided(qkv, B, T, n, heads, "time")
+    poison = torch.full((B * N, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    out = ops.divided_attention(qkv.to(DEV), B, T, n, heads, "time", out=poison.clone())
+    assert torch.isfinite(out.float()).all()
+    assert_close_bf16(out, ref, 1.2e-2, f"attn-time-T{T}")
+    err = (out.float().cpu() - ref).abs().amax(1)
+    assert (err / (ref.abs().amax(1) + 1e-3)).max() < 5e-2
+    planes = qkv.view(B * N, 3 * heads, 64).transpose(0, 1).contiguous().to(DEV)
+    assert torch.equal(ops.divided_attention(planes, B, T, n, heads, "time"), out)
+    assert torch.equal(ops.divided_attention(qkv.to(DEV), B, T, n, heads, "time", reverse=True), out)
+    sep = ops.divided_attention(qkv.to(DEV), B, T, n, heads, "time", fold_cls=False)
+    assert torch.equal(sep.view(B, N, D)[:, 1:], out.view(B, N, D)[:, 1:])
+    assert_close_bf16(sep.view(B, N, D)[:, 0], out.view(B, N, D)[:, 0], 8e-3, "cls folded vs stand-alone")
+
+
 @pytest.mark.parametrize("B,T,n,heads", [(2, 4, 50, 2), (1, 16, 37, 1), (2, 8, 96, 3), (1, 1, 70, 2), (1, 2, 5, 1), (3, 16, 256, 2),
                                           (2, 32, 30, 2), (1, 32, 7, 1), (1, 32, 576, 2)])
 def test_time_attention_ragged_patch_counts(B, T, n, heads):
@@ -686,6 +710,52 @@ def test_mattn_fwd_bwd_vs_torch(B, Q, M, slices):
         assert_close_bf16(dmp, L * mpr.grad, 8e-3, "mattn d(mp)")
         one = ops.gemm_tn_batched2(pdT[:, :128].contiguous(), dp16[:, :128].contiguous())
         assert_close_bf16(one, memr.grad, 8e-3, "mattn d(mem), one layer")
+
+
+@pytest.mark.parametrize("B,Q,M,Mv,slices", [(2, 13, 640, 588, None), (1, 13, 512, 500, 16), (2, 5, 3200, 3136, None), (1, 16, 128, 97, 1)])
+def test_mattn_masks_padding_keys(B, Q, M, Mv, slices):
+    """Round 6: keys [keys_valid, M) are padding rows (any finite content -- here large values that would dominate the softmax if they were
+    seen): pooled / lse2 / dqt equal the fp64 reference over the first keys_valid keys, the padding columns of Pd^T / dS^T are exact zeros
+    (so the batched d-memory GEMM gives their rows exact zeros), also when a whole key slice is padding (M = 512, 16 slices of 32 keys)."""
+    H, C = 8, 512
+    R = B * Q
+    qt = rnd(R, H * C, seed=31, scale=0.08)
+    mpm = bf(rnd(2, B, M, C, seed=32))
+    mpm[:, :, Mv:] = 3.0                                   # padding rows: must not be seen
+    wv, bv = rnd(C, C, seed=33, scale=0.05), rnd(C, seed=34, scale=0.1)
+    G = rnd(R, C, seed=35)
+    mp, mem = mpm[0].to(DEV), mpm[1].to(DEV)
+    pooled, lse2, rsum = ops.mattn_fwd(qt.to(DEV), mp, mem, Q, slices=slices, keys_valid=Mv)
+    qr = qt.double().requires_grad_(True)
+    mpr, memr = mpm[0][:, :Mv].double().requires_grad_(True), mpm[1][:, :Mv].double().requires_grad_(True)
+    rp, rl, rca = _mattn_ref(qr, mpr, memr, wv.double(), bv.double(), Q)
+    assert torch.isfinite(pooled).all() and torch.isfinite(lse2).all()
+    assert_close_bf16(pooled, rp.detach(), 3e-5, "mattn pooled, masked padding")
+    torch.testing.assert_close(lse2.cpu().double(), rl.detach(), rtol=0, atol=2e-4)
+    ca = ops.head_map_out(pooled, wv.to(DEV), bias=bv.to(DEV))
+    (rca * G.double()).sum().backward()
+    dca = G.to(DEV)
+    dpooled = ops.head_map_in(dca, wv.to(DEV))
+    pdT = torch.full((B, 128, M), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dsT = torch.full_like(pdT, float("nan"))
+    qt16 = torch.full((B, 128, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dp16 = torch.full_like(qt16, float("nan"))
+    dqt = ops.mattn_bwd(qt.to(DEV), dpooled, lse2, dca, ca, bv.to(DEV), mp, mem, Q, pdT, dsT, qt16, dp16, 0, slices=slices, keys_valid=Mv)
+    assert_close_bf16(dqt, qr.grad, 1e-4, "mattn dqt, masked padding")
+    assert float(pdT[:, :, Mv:].float().abs().max()) == 0.0 and float(dsT[:, :, Mv:].float().abs().max()) == 0.0
+    if M % 128 == 0:
+        dmem = ops.gemm_tn_batched2(pdT, dp16, dsT, qt16)
+        assert float(dmem[:, Mv:].abs().max()) == 0.0
+        assert_close_bf16(dmem[:, :Mv], mpr.grad + memr.grad, 8e-3, "mattn d(mem) + d(mp), masked padding")
+    # ADVICE r5: no ticket row for the last-arriver fold (more than 32 launch streams in the process) -> one slice, not an error
+    try:
+        ops.set_tuning("mattn_no_ticket", 1)
+        p1, l1, _ = ops.mattn_fwd(qt.to(DEV), mp, mem, Q, slices=slices, keys_valid=Mv)
+        d1 = ops.mattn_bwd(qt.to(DEV), dpooled, lse2, dca, ca, bv.to(DEV), mp, mem, Q, pdT, dsT, qt16, dp16, 0, slices=slices, keys_valid=Mv)
+    finally:
+        ops.set_tuning("mattn_no_ticket", 0)
+    assert_close_bf16(p1, pooled, 2e-5, "mattn one slice (no ticket row)")
+    assert_close_bf16(d1, dqt, 2e-5, "mattn bwd one slice (no ticket row)")
 
 
 def test_mattn_key_slices_and_dropout():

@@ -1148,3 +1148,53 @@ def test_c5_egomcq_item_at_full_width_vs_oracle():
     assert err <= 5e-3, (got, want)
     if float(top2[0] - top2[1]) > 2 * 5e-3:                       # (an untrained model's five scores can tie within the bound)
         assert int(got.argmax(-1)) == int(want.argmax(-1))
+
+
+@pytest.mark.parametrize("T,img", [(3, 196), (16, 224 - 28), (5, 140)], ids=["M588", "M3136", "M500"])
+def test_decoder_any_memory_length_on_the_kv_free_path(T, img):
+    """Round 6: the memory-space cross-attention for EVERY memory length -- M = T * n is rounded up to a multiple of 128
+    with zero rows that hh_mattn_fwd / _bwd mask out of the softmax (keys_valid); no silent fall-back to the projected-K/V route.  Patch-16-like
+    grids (n = 196: M = 588 and 3136) and M = 500 (not even a multiple of the 32-key chunk): forward and every parameter gradient against the fp32
+    oracle within the bounds of test_decoder_forward_backward_vs_oracle, and against the legacy projected-K/V path on the same inputs."""
+    cfg = TINY4.with_(num_frames=T, img_size=img)
+    n = cfg.patches_per_frame
+    assert (T * n) % 128 != 0
+    dsd = synth.decoder_state(cfg, seed=3)
+    dec = tfm_decoder.build_decoder(cfg, dsd).eval()
+    assert dec.transformer.kv_free
+    B = 2
+    feats = torch.randn(B, T, n, cfg.embed_dim, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).float()
+    out, hs, _, _ = dec(feats.cuda())
+    params = {k: v.clone().requires_grad_(True) for k, v in dsd.items()}
+    ro, rhs = OD.objdecoder_forward(feats, params, cfg)
+    e_hs = scaled_err(hs, rhs)
+    record("decoder_any_M_%d" % (T * n), "hs scaled error vs fp32 oracle", e_hs, 2e-2)
+    assert e_hs < 2e-2
+    assert float((out["pred_boxes"].detach().cpu() - ro["pred_boxes"]).abs().max()) < 5e-3
+    g = torch.Generator().manual_seed(1)
+    w, wb = torch.randn(rhs.shape, generator=g), torch.randn(ro["pred_boxes"].shape, generator=g)
+    ((hs * w.cuda()).sum() + (out["pred_boxes"] * wb.cuda()).sum()).backward()
+    ((rhs * w).sum() + (ro["pred_boxes"] * wb).sum()).backward()
+    rel = {}
+    for name, p_ in dec.named_parameters():
+        rg = params[name].grad
+        if rg is None:
+            continue
+        gg = p_.grad.detach().cpu()
+        if "multihead_attn.in_proj_bias" in name:
+            C = cfg.dec_dim
+            sel = torch.cat([torch.arange(0, C), torch.arange(2 * C, 3 * C)])
+            gg, rg = gg[sel], rg[sel]
+        rel[name] = float((gg - rg).norm() / (rg.norm() + 1e-12))
+    worst = sorted(rel.items(), key=lambda kv: -kv[1])[:3]
+    med = float(np.median(list(rel.values())))
+    record("decoder_any_M_%d" % (T * n), "end-to-end gradient rel-L2 vs fp32 oracle: worst tensor (%s)" % worst[0][0], worst[0][1], 9.5e-2)
+    record("decoder_any_M_%d" % (T * n), "end-to-end gradient rel-L2 vs fp32 oracle: median", med, 4.4e-2)
+    assert len(rel) > 100 and max(rel.values()) < 9.5e-2 and med < 4.4e-2, worst
+    # the legacy projected-K/V route on the same inputs (an independent implementation of the same layer; hh_xattn_* needs M % 32 == 0)
+    if (T * n) % 32:
+        return
+    dec2 = tfm_decoder.build_decoder(cfg, dsd).eval()
+    dec2.transformer.kv_free = False
+    out2, hs2, _, _ = dec2(feats.cuda())
+    assert scaled_err(hs, hs2) < 1e-2 and float((out["pred_boxes"] - out2["pred_boxes"]).abs().max()) < 5e-3
