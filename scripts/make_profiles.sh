@@ -96,6 +96,46 @@ M = ["# " + TAG + " -- HBM-side traffic from PMC counters (rocprofv3 --pmc, sepa
      "The counters sit on the L2's fabric side, so Infinity-Cache hits are included.  Per-launch averages, " + WHAT + ".", "",
      "| kernel | launches | fetch (corrected) MiB | write MiB | traffic / launch MiB |", "|---|---|---|---|---|"]
 M += [r for _, r in sorted(rows, reverse=True)]
+# ---- per-GEMM table of the vision tower: the persistent kernel's instantiations <true, 5> = qkv (time and space), <6> = fc1,
+# <7> = time projection, <8> = space projection AND fc2 -- told apart by dispatch order (they alternate: proj, fc2 per block)
+try:
+    import re as _re
+    c4 = "c4" in EXTRA
+    Mrows, Dm = (4 * 18433, 1024) if c4 else (32 * 4097, 1024)
+    aw = lambda N, K: 2 * (Mrows * K + N * K)
+    alg = {"qkv (time + space)": aw(3 * Dm, Dm) + 2 * Mrows * 3 * Dm, "time proj": aw(Dm, Dm) + Mrows * Dm * 4, "space proj": aw(Dm, Dm) + Mrows * Dm * 8,
+           "fc1": aw(4 * Dm, Dm) + 2 * Mrows * 4 * Dm, "fc2": aw(Dm, 4 * Dm) + Mrows * Dm * 8}
+    per = {k: {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]} for k in alg}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        rowsc = []
+        for f in glob.glob(R + "/gpurun_out/pmc_%s/**/*counter_collection.csv" % cname, recursive=True):
+            rowsc += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == cname and "gemm256w4p_kernel<true," in r["Kernel_Name"]]
+        rowsc.sort(key=lambda r: int(r["Dispatch_Id"]))
+        n8 = 0
+        for r in rowsc:
+            m = _re.search(r"gemm256w4p_kernel<true, (\d+),", r["Kernel_Name"])
+            e = int(m.group(1)) if m else -1
+            key = {5: "qkv (time + space)", 6: "fc1", 7: "time proj"}.get(e)
+            if e == 8:
+                key = "space proj" if n8 % 2 == 0 else "fc2"
+                n8 += 1
+            if key:
+                per[key][cname][0] += float(r["Counter_Value"]) * 1024.0 * (2.0 if cname == "FETCH_SIZE" else 1.0)
+                per[key][cname][1] += 1
+    M += ["", "## Vision-tower GEMMs one by one (bytes per launch; algorithmic = bench.py: gemm_algorithmic_table, the bf16 pair stream)", "",
+          "| GEMM | launches | fetch (corrected) MiB | write MiB | traffic MiB | algorithmic MiB | traffic / algorithmic |", "|---|---|---|---|---|---|---|"]
+    tot_t = tot_a = tot_n = 0
+    for k in alg:
+        nf, nw = per[k]["FETCH_SIZE"][1], per[k]["WRITE_SIZE"][1]
+        if not nf or not nw: continue
+        fe, wr = per[k]["FETCH_SIZE"][0] / nf, per[k]["WRITE_SIZE"][0] / nw
+        M.append("| %s | %d | %.0f | %.0f | %.0f | %.0f | %.2f |" % (k, nf, fe / 2**20, wr / 2**20, (fe + wr) / 2**20, alg[k] / 2**20, (fe + wr) / alg[k]))
+        tot_t += (fe + wr) * nf; tot_a += alg[k] * nf; tot_n += nf
+    if tot_n:
+        M.append("| launch-weighted mean | %d | | | %.0f | %.0f | **%.2f** |" % (tot_n, tot_t / tot_n / 2**20, tot_a / tot_n / 2**20, tot_t / tot_a))
+        M += ["", "(`roofline.traffic` / `roofline.algorithmic_bytes_per_launch` of bench.py's line are these two means; the counters sit on L2's fabric side and include Infinity-Cache hits.)"]
+except Exception as _e:
+    M += ["", "(per-GEMM table not produced: %r)" % (_e,)]
 open(OUT + TAG + "_pmc_summary.md", "w").write("\n".join(M) + "\n")
 print("\n".join(M[-len(rows):]))
 # ---- SQ counters: MFMA / VALU busy share per kernel
