@@ -286,7 +286,8 @@ __global__ __launch_bounds__(64 * NW32, 2) void space_attn32_kernel(const bf16_t
 //     barriers of a problem boundary write them to LDS (the image the LDS-DMA of the kernels above writes: lane l of piece pc at pc * 1024 +
 //     16 l) -- plain loads and ds_write, so hipcc's own counted waits apply (an LDS-DMA in flight would turn them into vmcnt(0)).
 // Two barriers per problem: A = "K / V / Q of problem i are dead" (loaders then overwrite them, compute waves write their rows), B = "K / V / Q
-// of problem i + 1 are visible, rows of problem i are complete".
+// of problem i + 1 are visible, rows of problem i complete".  (A third barrier that frees the Q tile right after the fragment reads, so that
+// the next Q rows -- 32 of the 104 KB -- go to LDS under the chunk loop, was measured SLOWER: 11 300 instead of 9 500 cycles per problem.)
 #define NW32P 8
 template <int NCH>
 __global__ __launch_bounds__(64 * NW32P, 1) void space_attn32p_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
@@ -381,9 +382,11 @@ __global__ __launch_bounds__(64 * NW32P, 1) void space_attn32p_kernel(const bf16
 #pragma unroll
             for (int j = 0; j < PPW; ++j) asm volatile("" : "+v"(R.k[j]), "+v"(R.v[j]));
         };
-        auto to_lds = [&](const Regs& R) {
+        auto q_to_lds = [&](const Regs& R) {
 #pragma unroll
             for (int j = 0; j < QPW; ++j) *(u32x4*)(Qs + (lw + 4 * j) * 1024 + lane * 16) = R.q[j];
+        };
+        auto kv_to_lds = [&](const Regs& R) {
 #pragma unroll
             for (int j = 0; j < PPW; ++j) {
                 *(u32x4*)(Ks + (lw + 4 * j) * 1024 + lane * 16) = R.k[j];
@@ -426,14 +429,15 @@ __global__ __launch_bounds__(64 * NW32P, 1) void space_attn32p_kernel(const bf16
             if (req) request(wreq, oth);
             if (i + step < P) landed(cur, req);        // (requested a whole problem ago; the stores of flush() are older than the new requests)
             __syncthreads();                           // A(i): the compute waves are done with K / V / Q of problem i
-            if (i + step < P) to_lds(cur);
+            if (i + step < P) { q_to_lds(cur); kv_to_lds(cur); }
             __syncthreads();                           // B(next): K / V / Q of the next problem visible, rows of problem i complete
             wprev = wcur; have_prev = true; par ^= 1;
             advance(wcur); advance(wreq);
         };
         request(wreq, X);
         landed(X, false);
-        to_lds(X);
+        q_to_lds(X);
+        kv_to_lds(X);
         __syncthreads();                               // B(first)
         advance(wreq);
         if (first + step < P) request(wreq, X);
@@ -551,12 +555,183 @@ __global__ __launch_bounds__(64 * NW32P, 1) void space_attn32p_kernel(const bf16
 }
 
 
-// mode: hh_set_tuning("space_mfma32"): 1 = the persistent kernel where n == 256 (else the one-problem-per-workgroup kernel), 2 = always the latter
+// ---- the same idea on 16x16x32 MFMAs for frames whose 32-query blocks do not split evenly over the SIMDs (round 6: n = 576, config 4).
+// The progressive kernel of attn_space.hip runs a chunk of a wave's three 16-query blocks as three serial phases (12 score MFMAs -> 24
+// exponentials -> 15 PV MFMAs): ~4000 cycles per chunk for a SIMD's three waves against 1296 of matrix-core time.  Here the three blocks of
+// a wave run their chains QK -> exp -> PV a THIRD of a chunk apart: third-step u holds the scores of block u % 3 (chunk u / 3: 4 MFMAs),
+// the probabilities of block (u + 2) % 3 (8 v_exp_f32 + 4 v_cvt_pk) and the PV + row-sum products of block (u + 1) % 3 (5 MFMAs) -- nine
+// independent MFMAs and the exponentials of ANOTHER block in every third-step, no second score buffer (a block's scores are overwritten two
+// third-steps after their exponentials), K / V^T fragments of a chunk read once and used by all three blocks.  No reference maximum (see
+// above); plain K / V staging (the fragment reads stay compiler-visible so that the group barriers can place them).
+#define NW16P 12
+template <int U, int NC>       // third-step U of a wave's walk over NC chunks (the last chunk holds only the CLS key, in row 0 of its first tile)
+__device__ __forceinline__ void sp16_third_step(const char* kb0, const char* kb1, const char* vb0, const char* vb2, const bf16x8 (&q)[3][2], f32x4 (&s)[3][2],
+                                                bf16x8 (&pf)[3], f32x4 (&o)[3][4], f32x4 (&ol)[3], bf16x8 (&kf)[2][2], bf16x8 (&vf)[4], int lane) {
+    constexpr int X = U % 3, CQ = U / 3;                     // scores: block X, chunk CQ
+    constexpr int Y = (U + 2) % 3, CE = (U - 1) / 3;         // probabilities: block Y, chunk CE (U >= 1)
+    constexpr int Z = (U + 1) % 3, CP = (U - 2) / 3;         // PV: block Z, chunk CP (U >= 2)
+    constexpr bool QK = CQ < NC, EX = U >= 1 && CE < NC, PV = U >= 2 && CP < NC;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
+    if constexpr (PV) {
+        if constexpr (Z == 2 - 2 || (U - 2) % 3 == 0) {      // first PV third-step of chunk CP: its V^T fragments (two key tiles per operand)
+            constexpr int OB = CP == NC - 1 ? 0 : 2048;      // (the CLS chunk has one tile: the second half re-reads it, its probabilities are 0)
+#define SP16_V(DT, VC, SUB) do { const bf16x4 a = lds_tr4(VC + CP * 4096 + SUB), b = lds_tr4(VC + CP * 4096 + OB + SUB); \
+                                 vf[DT] = (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; } while (0)
+            SP16_V(0, vb0, 0); SP16_V(1, vb0, 8); SP16_V(2, vb2, 0); SP16_V(3, vb2, 8);
+#undef SP16_V
+        }
+        ol[Z] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[Z], ol[Z], 0, 0, 0);
+    }
+    if constexpr (QK) {
+        if constexpr (X == 0) {                              // first score third-step of chunk CQ: its K fragments
+            kf[0][0] = *(const bf16x8*)(kb0 + CQ * 4096); kf[0][1] = *(const bf16x8*)(kb1 + CQ * 4096);
+            if constexpr (CQ < NC - 1) { kf[1][0] = *(const bf16x8*)(kb0 + CQ * 4096 + 2048); kf[1][1] = *(const bf16x8*)(kb1 + CQ * 4096 + 2048); }
+        }
+        s[X][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0][0], q[X][0], z4, 0, 0, 0);
+        s[X][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0][1], q[X][1], s[X][0], 0, 0, 0);
+        if constexpr (CQ < NC - 1) {
+            s[X][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1][0], q[X][0], z4, 0, 0, 0);
+            s[X][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1][1], q[X][1], s[X][1], 0, 0, 0);
+        }
+    }
+    if constexpr (PV) {
+        o[Z][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], pf[Z], o[Z][0], 0, 0, 0);
+        o[Z][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[1], pf[Z], o[Z][1], 0, 0, 0);
+        o[Z][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[2], pf[Z], o[Z][2], 0, 0, 0);
+        o[Z][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[3], pf[Z], o[Z][3], 0, 0, 0);
+    }
+    if constexpr (EX) {
+        const bf16_t zb = (bf16_t)0.f;
+        if constexpr (CE < NC - 1) {
+            float e[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(s[Y][0][r]); e[4 + r] = __builtin_amdgcn_exp2f(s[Y][1][r]); }
+            pf[Y] = (bf16x8){(bf16_t)e[0], (bf16_t)e[1], (bf16_t)e[2], (bf16_t)e[3], (bf16_t)e[4], (bf16_t)e[5], (bf16_t)e[6], (bf16_t)e[7]};
+        } else {
+            const float e0 = (lane >> 4) == 0 ? __builtin_amdgcn_exp2f(s[Y][0][0]) : 0.f;      // the CLS key: row 0 of the tile = register 0 of lanes 0..15
+            pf[Y] = (bf16x8){(bf16_t)e0, zb, zb, zb, zb, zb, zb, zb};
+        }
+        asm volatile("" : "+v"(pf[Y]));                      // made HERE (LLVM otherwise sinks the exponentials to their use, a third-step later)
+    }
+#ifndef HH_SP16_NO_GROUPS
+    if constexpr (QK && EX && PV && CQ < NC - 1 && CE < NC - 1) {        // the steady state: 9 MFMAs, 8 exponentials, 4 conversions
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // MFMA
+            if (g == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);              // this third-step's fragment reads (0, 4 or 8)
+            if (g >= 1 && (g & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // VALU: a conversion of finished exponentials
+            if (g < 8) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);               // TRANS: one exponential per 16-cycle gap
+        }
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NC, int U0, int U1>
+struct Sp16Walk {
+    template <typename... A> __device__ __forceinline__ static void run(A&... a) {
+        if constexpr (U0 < U1) { sp16_third_step<U0, NC>(a...); Sp16Walk<NC, U0 + 1, U1>::run(a...); }
+    }
+};
+
+template <int NQB>            // n = 16 * NQB keys per frame = NW16P waves x 3 blocks
+__global__ __launch_bounds__(64 * NW16P, 1) void space_attn16p_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                      float* __restrict__ cls_partial, int B, int T, int heads, int layout) {
+    constexpr int n = NQB * 16, nt = NQB + 1, KP = ((n + 1 + 31) / 32) * 32, NC = NQB / 2 + 1;
+    static_assert(NQB == NW16P * 3 && NQB % 2 == 0, "one group of three blocks per wave, chunks of two key tiles");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + (size_t)KP * 128;
+    float* scratch = (float*)(smem + (size_t)KP * 256);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = heads * 64;
+    const int N = 1 + T * n;
+    const int rev = layout >> 1;
+    layout &= 1;
+    const int64_t ld = layout ? 64 : 3 * (int64_t)D;
+    const int64_t hs = layout ? (int64_t)B * N * 64 : 64, ws = (int64_t)heads * hs;
+    int bid = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int head = bid % heads; bid /= heads;
+    const int f = bid % T;
+    const int b = bid / T;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + head * hs;
+    const bf16_t* q_ptr = base + (int64_t)(1 + f * n) * ld;
+    const int c = lane & 15, g = lane >> 4;
+    const int gb = wave * 3;
+    bf16x8 q[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const bf16_t* qrow = q_ptr + (int64_t)((gb + j) * 16 + c) * ld + 8 * g;
+        q[j][0] = *(const bf16x8*)(qrow);
+        q[j][1] = *(const bf16x8*)(qrow + 32);
+    }
+    space_stage<NW16P>(Ks, Vs, base, q_ptr, ld, ws, n, KP, lane, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int kz = (c & 7) ^ (c >> 3), trq = c >> 2, trp = c & 3, vz = ((trq >> 1) & 1) << 2;
+    const char* kb0 = Ks + c * 128 + ((g ^ kz) << 4);
+    const char* kb1 = Ks + c * 128 + (((g + 4) ^ kz) << 4);
+    const char* vb0 = Vs + (4 * g + trq) * 128 + (((2 * trp) ^ vz) << 4);
+    const char* vb2 = Vs + (4 * g + trq) * 128 + (((2 * trp + 1) ^ vz) << 4);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s[3][2], o[3][4], ol[3];
+    bf16x8 pf[3], kf[2][2], vf[4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        ol[j] = z4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[j][dt] = z4;
+    }
+    Sp16Walk<NC, 0, 3 * NC + 2>::run(kb0, kb1, vb0, vb2, q, s, pf, o, ol, kf, vf, lane);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        bf16_t* op = out + ((int64_t)b * N + 1 + f * n + (gb + j) * 16 + c) * D + head * 64 + 16 * g;
+        float l_run = ol[j][0];
+        // a row sum outside [2^-100, 2^100] (no reference maximum here): the block is redone on the running-maximum path
+        if (__builtin_amdgcn_ballot_w64(!(l_run >= 7.9e-31f && l_run <= 1.2e30f)) != 0) {
+            HH_SPACE_REDO_NOTE(g_space32_redo, lane);
+            f32x4 o2[4] = {z4, z4, z4, z4};
+            float m_run = -INFINITY;
+            l_run = 0.f;
+            for (int t = 0; t + 1 < nt; ++t) space16_chunk<1, false>(Ks, Vs, q[j], t, lane, o2, m_run, l_run);
+            space16_chunk<1, true>(Ks, Vs, q[j], nt - 1, lane, o2, m_run, l_run);
+            space_store_block(o2, l_run, op, c, D);
+        } else {
+            space_store_block(o[j], l_run, op, c, D);
+        }
+    }
+    if (cls_partial == nullptr) return;
+    space16_cls_partial<NW16P>(Ks, Vs, scratch, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
+}
+
+int hh_space_attn16p_launch(const void* qkv, int layout_rev, void* out, float* cls_partial, int B, int T, int n, int heads, hipStream_t stream) {
+    typedef void (*k_t)(const bf16_t*, bf16_t*, float*, int, int, int, int);
+    HH_REQUIRE(n == 576, HH_ERR_UNSUPPORTED, "hh_space_attn_fwd: the third-step pipelined 16x16x32 kernel is built for n = 576 (got %d)", n);
+    const k_t k = (k_t)space_attn16p_kernel<36>;
+    const int KP = ((n + 1 + 31) / 32) * 32;
+    const size_t lds = (size_t)KP * 256 + ((size_t)KP + 12 * CLS_REC + 24) * 4;
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds);
+        attr = lds;
+    }
+    hh_prof_note_kernel(HH_PROF_SPACE_ATTN, "space_attn16p_kernel<36>");
+    hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW16P), lds, stream, (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, heads, layout_rev);
+    return hh_check_launch("hh_space_attn_fwd");
+}
+
+// mode: hh_set_tuning("space_mfma32"): 1 (default) = one problem per workgroup, 2 = the persistent wave-specialised kernel where n == 256.  The
+// persistent kernel is NOT the default although it is the fastest of the three inside the step (286-300 us against 294-312): it holds every
+// CU for its whole duration, and the decoder stream's span inside the pipelined step grows from 0.74 to 0.92 of the step (79 -> 97-100 ms,
+// profiles/r6_space_instep.txt) at unchanged clips/s -- the margin that eight ranks with RCCL kernels will need
 int hh_space_attn32_launch(const void* qkv, int layout_rev, void* out, float* cls_partial, int B, int T, int n, int heads, int mode, int dbg, hipStream_t stream) {
     typedef void (*k32_t)(const bf16_t*, bf16_t*, float*, int, int, int, int, int);
     const int nch = n / 32, KP = n + 32;
     HH_REQUIRE(n % 64 == 0 && n >= 64 && n <= 256, HH_ERR_UNSUPPORTED, "hh_space_attn_fwd: the 32x32x16 kernels take n in {64, 128, 192, 256}, got %d", n);
-    if (n == 256 && mode == 1 && dbg != 1 && dbg != 2) {
+    if (n == 256 && mode == 2 && dbg != 1 && dbg != 2) {
         // persistent form: one workgroup per CU walks the problems, the next problem's K / V / Q are requested before the current chunk loop
         const k32_t kp = (k32_t)space_attn32p_kernel<8>;
         const size_t ldsp = (size_t)KP * 256 + (size_t)n * 128 + 4 * 8192 + ((size_t)2 * 4 * CLS_REC + 64) * 4;

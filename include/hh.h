@@ -69,7 +69,10 @@ int hh_abi_sizeof(const char* name);
  *                   +-0.1 % at step level).  (Round 4's persistent cross-problem-prefetch variant, value 3, was slower and is removed: DESIGN.md 4.2);
  *                   "space_debug" 0 / 1 / 2: full kernel / memory traffic only / no staging
  *   "space_mfma32"  1 (default) = space attention with n <= 256, n % 64 == 0 on the 32x32x16-MFMA kernel whose exponentials are software-pipelined
- *                   under the matrix core inside each wave (round 6); 0 = the joint-block 16x16x32 kernel (rounds 2-5)
+ *                   under the matrix core inside each wave (round 6), one problem per workgroup; 2 = n = 256 on the persistent wave-specialised
+ *                   form (4 compute + 4 loader waves per CU: fastest in the step, but it holds every CU for its whole duration and stretches
+ *                   the decoder stream) and n = 576 on the third-step pipelined 16x16x32 kernel (equal in time to the default progressive
+ *                   one); 0 = the 16x16x32 kernels of rounds 2-5
  *   "mattn_no_ticket" 0 (default) / 1: tests only -- hh_mattn_fwd / _bwd act as if no ticket row were free (more than 32 launch streams seen):
  *                   they then run ONE key slice per (clip, head group) instead of failing; same results up to fp32 re-association
  *   "gemm256_debug_ts", "gemm256_debug_nostore": diagnostics (timeline recording; skip the epilogue stores) */

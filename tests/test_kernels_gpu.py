@@ -497,8 +497,8 @@ def test_space_attention_joint_kernel_many_problems():
 @pytest.mark.parametrize("n", [256, 192, 128, 64])
 def test_space_attention_32x32_kernels_vs_fp32_and_vs_the_16_query_kernel(n):
     """Round 6: n <= 256 (n % 64 == 0) runs on v_mfma_f32_32x32x16_bf16 with the exponentials software-pipelined under the matrix core and
-    NO reference maximum (base-2 logits, P = exp2(s); csrc/attn_space32.hip) -- hh_set_tuning("space_mfma32", 2) = one problem per workgroup,
-    1 (default) = the persistent wave-specialised kernel at n = 256.  Against the fp32 reference (same bound as every space kernel), against the
+    NO reference maximum (base-2 logits, P = exp2(s); csrc/attn_space32.hip) -- hh_set_tuning("space_mfma32", 1) (default) = one problem per
+    workgroup, 2 = the persistent wave-specialised kernel at n = 256.  Against the fp32 reference (same bound as every space kernel), against the
     16-query kernel (different rounding of P: a reference maximum there, none here -- one bf16 ulp of the output), the two 32x32 forms
     bit-identical (same arithmetic, different data movement), and 288 problems so that persistent workgroups walk more than one."""
     B, T, heads = 3, 6, 16
@@ -511,9 +511,10 @@ def test_space_attention_32x32_kernels_vs_fp32_and_vs_the_16_query_kernel(n):
         ops.set_tuning("space_joint", 0)
         generic = ops.divided_attention(qkv, B, T, n, heads, "space")
         ops.set_tuning("space_joint", 1)
-        ops.set_tuning("space_mfma32", 2)
-        one = ops.divided_attention(qkv, B, T, n, heads, "space")
         ops.set_tuning("space_mfma32", 1)
+        one = ops.divided_attention(qkv, B, T, n, heads, "space")
+        one_rev = ops.divided_attention(qkv, B, T, n, heads, "space", reverse=True)
+        ops.set_tuning("space_mfma32", 2)
         per = ops.divided_attention(qkv, B, T, n, heads, "space")
         rev = ops.divided_attention(qkv, B, T, n, heads, "space", reverse=True)
         planes = qkv.view(B * N, 3 * heads, 64).transpose(0, 1).contiguous()
@@ -521,12 +522,42 @@ def test_space_attention_32x32_kernels_vs_fp32_and_vs_the_16_query_kernel(n):
     finally:
         ops.set_tuning("space_joint", 1)
         ops.set_tuning("space_mfma32", 1)
-    assert torch.equal(one, per) and torch.equal(per, rev) and torch.equal(per, per_planes)
+    assert torch.equal(one, per) and torch.equal(per, rev) and torch.equal(per, per_planes) and torch.equal(one, one_rev)
     ref = _ref_divided(qkv.cpu(), B, T, n, heads, "space")
     assert_close_bf16(per, ref, 1.2e-2, "attn-space-32x32")
     err = (per.float().cpu() - ref).abs().amax(1)
     assert (err / (ref.abs().amax(1) + 1e-3)).max() < 5e-2
     assert_close_bf16(per, generic, 8e-3, "32x32 vs 16-query")
+
+
+def test_space_attention_third_step_kernel_n576():
+    """Round 6, opt-in (hh_set_tuning("space_mfma32", 2)): config 4's n = 576 on the third-step pipelined 16x16x32 kernel -- three 16-query blocks
+    per wave whose QK -> exp -> PV chains run a third of a chunk apart, no reference maximum -- against the fp32 reference and the default
+    progressive kernel (one bf16 ulp: P is rounded without / with a reference maximum), CLS records bit-equal (same partial routine), and
+    its running-maximum redo."""
+    B, T, n, heads = 2, 3, 576, 2
+    N, D = 1 + T * n, heads * 64
+    qkv = rnd(B * N, 3 * D, seed=57)
+    qkv[:, :D] *= 0.6 * ops.LOG2E
+    qkv[9, :64] += 5.0
+    qkv[1 + n + 7, :64] *= 40.0                                    # a query whose logits leave what exp2 carries without a reference
+    qkv = bf(qkv).to(DEV)
+    dflt = ops.divided_attention(qkv, B, T, n, heads, "space")
+    try:
+        ops.set_tuning("space_mfma32", 2)
+        ops.space_redo_count(reset=True)
+        third = ops.divided_attention(qkv, B, T, n, heads, "space")
+        rev = ops.divided_attention(qkv, B, T, n, heads, "space", reverse=True)
+        redone = ops.space_redo_count(reset=True)
+    finally:
+        ops.set_tuning("space_mfma32", 1)
+    assert redone >= 1 and torch.equal(third, rev)
+    ref = _ref_divided(qkv.cpu(), B, T, n, heads, "space")
+    assert_close_bf16(third, ref, 1.2e-2, "attn-space-third-step")
+    err = (third.float().cpu() - ref).abs().amax(1)
+    assert (err / (ref.abs().amax(1) + 1e-3)).max() < 5e-2
+    assert_close_bf16(third, dflt, 8e-3, "third-step vs progressive")
+    assert torch.equal(third.view(B, N, D)[:, 0], dflt.view(B, N, D)[:, 0])
 
 
 @pytest.mark.parametrize("joint,mfma32", [(1, 1), (1, 2), (1, 0), (0, 0)])
