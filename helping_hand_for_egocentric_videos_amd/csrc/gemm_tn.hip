@@ -6,7 +6,9 @@
 // 128 x 128 tile per workgroup (4 waves as 2 x 2, wave tile 64 x 64 = 4 x 4 v_mfma_f32_16x16x32_bf16), BK = 64 tokens.  Tiles are
 // staged k-major in LDS by LDS-DMA (row = 128 columns = 256 B = 16 lanes x 16 B); an MFMA operand wants 8 consecutive k per lane,
 // which the hardware-transposing ds_read_b64_tr_b16 delivers from the k-major tile (two reads of 4 k each).  16-B chunk c of row
-// r lives at position c ^ (2 (r & 3)) so that the 4 rows x 32 B a 16-lane group touches per read land in different banks.
+// r lives at position c ^ tn_key(r), tn_key(r) = 2 (r & 3) + 8 ((r >> 3) & 1): the transposing read is banked per 32-lane half = two 16-lane
+// groups 8 rows apart, each touching 4 rows x 32 B -- row bits 0-1 spread a group's rows, row bit 3 keeps the two groups apart (round 6;
+// without it the halves collided 2-way: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 2.0, profiles/r5_mattn_pmc.txt).
 // Split-K over the token dimension: blockIdx.y owns a 64-aligned slice and writes its fp32 partial tile; rows beyond K read a
 // zero line.  Operands are swapped as in gemm.hip (accumulator = C^T tile) so that a lane owns 4 consecutive n of one m.
 #include "common.h"
@@ -18,6 +20,7 @@ __device__ __forceinline__ void tn_glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+__device__ __forceinline__ int tn_key(int r) { return (2 * (r & 3)) | (((r >> 3) & 1) << 3); }
 __device__ __forceinline__ bf16x4 tn_tr4(const char* addr) {
     s16x4_tn r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_tn*)addr);
     return __builtin_bit_cast(bf16x4, r);
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = wave * 16 + 4 * i + srow;                      // row inside the k-tile
-            const int c = schunk ^ (2 * (r & 3));                         // logical chunk that lives at this lane's position
+            const int c = schunk ^ tn_key(r);                             // logical chunk that lives at this lane's position
             const int64_t k = k_begin + (int64_t)kt * 64 + r;
             const bool ok = k < k_end;
             tn_glds16(ok ? (const void*)(Ap + k * p.lda + m0 + c * 8) : (const void*)g_tn_zero, dA + i * 1024);
@@ -78,8 +81,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
     auto frag = [&](const char* tile, int col0, int ks) -> bf16x8 {     // col0: first column of the 16-wide MFMA tile
         const int r0 = 32 * ks + 8 * g + q, r1 = r0 + 4;
         const int ch = (col0 >> 3) + (pc >> 1);                           // 16-B chunk of this lane's 8-B piece
-        const bf16x4 a = tn_tr4(tile + r0 * 256 + ((ch ^ (2 * (r0 & 3))) << 4) + (pc & 1) * 8);
-        const bf16x4 b = tn_tr4(tile + r1 * 256 + ((ch ^ (2 * (r1 & 3))) << 4) + (pc & 1) * 8);
+        const bf16x4 a = tn_tr4(tile + r0 * 256 + ((ch ^ tn_key(r0)) << 4) + (pc & 1) * 8);
+        const bf16x4 b = tn_tr4(tile + r1 * 256 + ((ch ^ tn_key(r1)) << 4) + (pc & 1) * 8);
         return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     };
 
