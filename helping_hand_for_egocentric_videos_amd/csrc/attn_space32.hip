@@ -609,7 +609,11 @@ __device__ __forceinline__ void sp16_third_step(const char* kb0, const char* kb1
             for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(s[Y][0][r]); e[4 + r] = __builtin_amdgcn_exp2f(s[Y][1][r]); }
             pf[Y] = (bf16x8){(bf16_t)e[0], (bf16_t)e[1], (bf16_t)e[2], (bf16_t)e[3], (bf16_t)e[4], (bf16_t)e[5], (bf16_t)e[6], (bf16_t)e[7]};
         } else {
-            const float e0 = (lane >> 4) == 0 ? __builtin_amdgcn_exp2f(s[Y][0][0]) : 0.f;      // the CLS key: row 0 of the tile = register 0 of lanes 0..15
+            // the CLS key: row 0 of the tile = register 0 of lanes 0..15 (the lane index is recomputed here -- v_mbcnt -- instead of living in a
+            // register across the walk: the kernel sits at the 168-register cap of three waves per SIMD)
+            (void)lane;
+            const unsigned lid = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            const float e0 = lid < 16u ? __builtin_amdgcn_exp2f(s[Y][0][0]) : 0.f;
             pf[Y] = (bf16x8){(bf16_t)e0, zb, zb, zb, zb, zb, zb, zb};
         }
         asm volatile("" : "+v"(pf[Y]));                      // made HERE (LLVM otherwise sinks the exponentials to their use, a third-step later)
@@ -628,14 +632,39 @@ __device__ __forceinline__ void sp16_third_step(const char* kb0, const char* kb1
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NC, int U0, int U1>
+// progressive staging (PROG): the K / V rows are requested in four segments in key order (S0 + S1 + S2 + S3 pieces of 8 rows; E0 / E1 / E2 =
+// the chunks at which segments 1 / 2 / 3 begin) and the walk starts on segment 0 while the rest is in flight: a counted s_waitcnt vmcnt +
+// raw s_barrier in front of the third-step that first touches a segment's K rows (its V rows are touched two third-steps later).  Every
+// vector-memory instruction of the kernel is inline asm (the Q loads, the LDS-DMA), so hipcc's own wait-count pass inserts nothing -- with a
+// compiler-visible LDS-DMA it would put vmcnt(0) in front of every LDS read (DESIGN_HISTORY 4.2) -- and the fragment reads stay plain loads
+// that the group barriers can place; the memory clobber of the wait keeps them below it.
+template <int BASE>
+__device__ __forceinline__ void sp16_wait(int c3) {      // vmcnt(BASE + 2 c3), c3 in {1, 2} wave-uniform: this wave's LDS-DMAs of the ragged last segment
+    if (c3 == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(BASE + 4) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(BASE + 2) : "memory");
+}
+template <int NC, int U0, int U1, bool PROG, int E0, int E1, int E2>
 struct Sp16Walk {
-    template <typename... A> __device__ __forceinline__ static void run(A&... a) {
-        if constexpr (U0 < U1) { sp16_third_step<U0, NC>(a...); Sp16Walk<NC, U0 + 1, U1>::run(a...); }
+    template <typename... A> __device__ __forceinline__ static void run(int c3, A&... a) {
+        if constexpr (U0 < U1) {
+            if constexpr (PROG && U0 == 3 * E0) sp16_wait<4>(c3);            // segment 1 landed everywhere (segments 2, 3 may be in flight: 2 + 2 + ... per tile pair)
+            if constexpr (PROG && U0 == 3 * E1) sp16_wait<0>(c3);            // segment 2
+            if constexpr (PROG && U0 == 3 * E2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // segment 3
+            sp16_third_step<U0, NC>(a...);
+            Sp16Walk<NC, U0 + 1, U1, PROG, E0, E1, E2>::run(c3, a...);
+        }
     }
 };
+__device__ __forceinline__ void sp16_dma(const char* sbase, unsigned voff, unsigned dst_lds) {       // one 1-KB piece: lane l's 16 B at sbase + voff -> LDS dst + 16 l
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(dst_lds) : "memory", "m0");
+}
+__device__ __forceinline__ bf16x8 sp16_gld128(const bf16_t* ptr) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr));
+    return __builtin_bit_cast(bf16x8, r);
+}
 
-template <int NQB>            // n = 16 * NQB keys per frame = NW16P waves x 3 blocks
+template <int NQB, bool PROG>            // n = 16 * NQB keys per frame = NW16P waves x 3 blocks
 __global__ __launch_bounds__(64 * NW16P, 1) void space_attn16p_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                       float* __restrict__ cls_partial, int B, int T, int heads, int layout) {
     constexpr int n = NQB * 16, nt = NQB + 1, KP = ((n + 1 + 31) / 32) * 32, NC = NQB / 2 + 1;
@@ -661,15 +690,44 @@ __global__ __launch_bounds__(64 * NW16P, 1) void space_attn16p_kernel(const bf16
     const int c = lane & 15, g = lane >> 4;
     const int gb = wave * 3;
     bf16x8 q[3][2];
+    // segments of 12 / 24 / 24 / 16 pieces (the progressive kernel's split): every wave stages 1 / 2 / 2 pieces per tile of segments 0-2 and 2
+    // (waves 0-3) or 1 of the last
+    constexpr int S0 = 12, S1 = 24, S2 = 24, S3 = KP / 8 - 60, E0 = S0 / 4, E1 = E0 + S1 / 4, E2 = E1 + S2 / 4;
+    static_assert(!PROG || (NW16P == 12 && S3 > 12 && S3 <= 24), "segment plan of n = 576");
+    const int c3 = (wave < S3 - NW16P) ? 2 : 1;
+    if constexpr (PROG) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const bf16_t* qrow = q_ptr + (int64_t)((gb + j) * 16 + c) * ld + 8 * g;
-        q[j][0] = *(const bf16x8*)(qrow);
-        q[j][1] = *(const bf16x8*)(qrow + 32);
+        for (int j = 0; j < 3; ++j) {
+            const bf16_t* qrow = q_ptr + (int64_t)((gb + j) * 16 + c) * ld + 8 * g;
+            q[j][0] = sp16_gld128(qrow);
+            q[j][1] = sp16_gld128(qrow + 32);
+        }
+        const char* kbase = (const char*)(base + ws);
+        const char* vbase = (const char*)(base + 2 * ws);
+        const unsigned ld_b = (unsigned)ld * 2u;
+        auto seg = [&](int p0, int cnt) {
+            for (int which = 0; which < 2; ++which)
+                for (int i = wave; i < cnt; i += NW16P) {          // (wave-uniform trip counts)
+                    const int pc = p0 + i, row = pc * 8 + (lane >> 3);
+                    const unsigned rowidx = row < n ? (unsigned)(1 + f * n + row) : 0u;      // rows >= n take the CLS row (key n; the rest is masked)
+                    const unsigned ch = (unsigned)((lane & 7) ^ (which == 0 ? kswz(row) : vswz(row)));
+                    sp16_dma(which == 0 ? kbase : vbase, rowidx * ld_b + ch * 16u, (unsigned)(size_t)(__attribute__((address_space(3))) char*)((which == 0 ? Ks : Vs) + pc * 1024));
+                }
+        };
+        seg(0, S0); seg(S0, S1); seg(S0 + S1, S2); seg(S0 + S1 + S2, S3);
+        sp16_wait<8>(c3);                                  // the Q rows (older than every LDS-DMA) and segment 0 have landed everywhere
+        asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[2][0]), "+v"(q[2][1]));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const bf16_t* qrow = q_ptr + (int64_t)((gb + j) * 16 + c) * ld + 8 * g;
+            q[j][0] = *(const bf16x8*)(qrow);
+            q[j][1] = *(const bf16x8*)(qrow + 32);
+        }
+        space_stage<NW16P>(Ks, Vs, base, q_ptr, ld, ws, n, KP, lane, wave);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
-    space_stage<NW16P>(Ks, Vs, base, q_ptr, ld, ws, n, KP, lane, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     const int kz = (c & 7) ^ (c >> 3), trq = c >> 2, trp = c & 3, vz = ((trq >> 1) & 1) << 2;
     const char* kb0 = Ks + c * 128 + ((g ^ kz) << 4);
     const char* kb1 = Ks + c * 128 + (((g + 4) ^ kz) << 4);
@@ -684,7 +742,7 @@ __global__ __launch_bounds__(64 * NW16P, 1) void space_attn16p_kernel(const bf16
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[j][dt] = z4;
     }
-    Sp16Walk<NC, 0, 3 * NC + 2>::run(kb0, kb1, vb0, vb2, q, s, pf, o, ol, kf, vf, lane);
+    Sp16Walk<NC, 0, 3 * NC + 2, PROG, E0, E1, E2>::run(c3, kb0, kb1, vb0, vb2, q, s, pf, o, ol, kf, vf, lane);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         bf16_t* op = out + ((int64_t)b * N + 1 + f * n + (gb + j) * 16 + c) * D + head * 64 + 16 * g;
@@ -706,19 +764,19 @@ __global__ __launch_bounds__(64 * NW16P, 1) void space_attn16p_kernel(const bf16
     space16_cls_partial<NW16P>(Ks, Vs, scratch, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
 }
 
-int hh_space_attn16p_launch(const void* qkv, int layout_rev, void* out, float* cls_partial, int B, int T, int n, int heads, hipStream_t stream) {
+int hh_space_attn16p_launch(const void* qkv, int layout_rev, void* out, float* cls_partial, int B, int T, int n, int heads, int progressive, hipStream_t stream) {
     typedef void (*k_t)(const bf16_t*, bf16_t*, float*, int, int, int, int);
     HH_REQUIRE(n == 576, HH_ERR_UNSUPPORTED, "hh_space_attn_fwd: the third-step pipelined 16x16x32 kernel is built for n = 576 (got %d)", n);
-    const k_t k = (k_t)space_attn16p_kernel<36>;
+    const k_t k = progressive ? (k_t)space_attn16p_kernel<36, true> : (k_t)space_attn16p_kernel<36, false>;
     const int KP = ((n + 1 + 31) / 32) * 32;
     const size_t lds = (size_t)KP * 256 + ((size_t)KP + 12 * CLS_REC + 24) * 4;
-    static size_t attr = 0;
-    if (lds > attr) {
+    static size_t attr[2] = {0, 0};
+    if (lds > attr[progressive ? 1 : 0]) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         HH_REQUIRE(e == hipSuccess, HH_ERR_LAUNCH, "hh_space_attn_fwd: cannot reserve %zu B of LDS", lds);
-        attr = lds;
+        attr[progressive ? 1 : 0] = lds;
     }
-    hh_prof_note_kernel(HH_PROF_SPACE_ATTN, "space_attn16p_kernel<36>");
+    hh_prof_note_kernel(HH_PROF_SPACE_ATTN, progressive ? "space_attn16p_kernel<36, true>" : "space_attn16p_kernel<36, false>");
     hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW16P), lds, stream, (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, heads, layout_rev);
     return hh_check_launch("hh_space_attn_fwd");
 }

@@ -604,7 +604,7 @@ extern "C" int hh_set_tuning(const char* name, int value) {
     if (name && !strcmp(name, "space_debug")) { g_space_dbg = value; return HH_OK; }
     if (name && !strcmp(name, "space_joint")) { g_space_joint = value; return HH_OK; }
     if (name && !strcmp(name, "space_prog") && value >= 0 && value <= 2) { g_space_prog = value; return HH_OK; }
-    if (name && !strcmp(name, "space_mfma32") && value >= 0 && value <= 2) { g_space_mfma32 = value; return HH_OK; }
+    if (name && !strcmp(name, "space_mfma32") && value >= 0 && value <= 3) { g_space_mfma32 = value; return HH_OK; }
     if (name && !strcmp(name, "mattn_no_ticket") && (value == 0 || value == 1)) { g_mattn_no_ticket = value; return HH_OK; }
     if (name && !strcmp(name, "space_waves") && (value == 0 || value == 4 || value == 12)) { g_space_waves = value; return HH_OK; }
     if (name && !strcmp(name, "gemm256_skew")) { g_skew = value; return HH_OK; }

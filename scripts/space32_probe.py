@@ -25,6 +25,20 @@ def t(reps=200):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 res = {}
+if n == 576:        # config 4: 0 / 1 = the progressive 16x16x32 kernel (default), 2 = third-step pipelined + progressive staging, 3 = third-step, plain staging
+    for rnd in range(3):
+        for k in (0, 2, 3):
+            ops.set_tuning("space_mfma32", k)
+            res.setdefault(k, []).append(t())
+            if rnd == 0:
+                res["out%d" % k] = out.clone(); res["part%d" % k] = part.clone()
+    print("n = 576: progressive 16x16x32 kernel (default): %s us    third-step pipelined + progressive staging: %s us    third-step, plain staging: %s us" % tuple(" ".join("%.1f" % v for v in res[k]) for k in (0, 2, 3)))
+    for k in (2, 3):
+        d = (res["out%d" % k][patch].float() - res["out0"][patch].float()).abs()
+        print("mfma32=%d vs default: max |diff| rows %.3e (scale %.3f), mean %.3e; CLS partial records max |diff| %.3e" % (k, d.max().item(), res["out0"].float().abs().max().item(), d.mean().item(), (res["part%d" % k] - res["part0"]).abs().max().item()))
+    print("progressive vs plain staging of the third-step kernel: rows equal %s" % torch.equal(res["out2"][patch], res["out3"][patch]))
+    ops.set_tuning("space_mfma32", 1)
+    sys.exit(0)
 for rnd in range(3):
     for k in (0, 1, 2):
         ops.set_tuning("space_mfma32", k)

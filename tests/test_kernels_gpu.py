@@ -531,7 +531,7 @@ def test_space_attention_32x32_kernels_vs_fp32_and_vs_the_16_query_kernel(n):
 
 
 def test_space_attention_third_step_kernel_n576():
-    """Round 6, opt-in (hh_set_tuning("space_mfma32", 2)): config 4's n = 576 on the third-step pipelined 16x16x32 kernel -- three 16-query blocks
+    """Round 6, opt-in (hh_set_tuning("space_mfma32", 2 | 3)): config 4's n = 576 on the third-step pipelined 16x16x32 kernel -- three 16-query blocks
     per wave whose QK -> exp -> PV chains run a third of a chunk apart, no reference maximum -- against the fp32 reference and the default
     progressive kernel (one bf16 ulp: P is rounded without / with a reference maximum), CLS records bit-equal (same partial routine), and
     its running-maximum redo."""
@@ -544,14 +544,20 @@ def test_space_attention_third_step_kernel_n576():
     qkv = bf(qkv).to(DEV)
     dflt = ops.divided_attention(qkv, B, T, n, heads, "space")
     try:
-        ops.set_tuning("space_mfma32", 2)
+        ops.set_tuning("space_mfma32", 2)                     # progressive staging: the walk starts on the first key segment while the rest is in flight
         ops.space_redo_count(reset=True)
         third = ops.divided_attention(qkv, B, T, n, heads, "space")
         rev = ops.divided_attention(qkv, B, T, n, heads, "space", reverse=True)
         redone = ops.space_redo_count(reset=True)
+        planes = qkv.view(B * N, 3 * heads, 64).transpose(0, 1).contiguous()
+        third_planes = ops.divided_attention(planes, B, T, n, heads, "space")
+        again = [ops.divided_attention(planes, B, T, n, heads, "space") for _ in range(8)]     # (a race on a segment boundary would be timing-dependent)
+        ops.set_tuning("space_mfma32", 3)                     # plain staging: the same arithmetic
+        plain = ops.divided_attention(qkv, B, T, n, heads, "space")
     finally:
         ops.set_tuning("space_mfma32", 1)
-    assert redone >= 1 and torch.equal(third, rev)
+    assert redone >= 1 and torch.equal(third, rev) and torch.equal(third, third_planes) and torch.equal(third, plain)
+    assert all(torch.equal(a, third) for a in again)
     ref = _ref_divided(qkv.cpu(), B, T, n, heads, "space")
     assert_close_bf16(third, ref, 1.2e-2, "attn-space-third-step")
     err = (third.float().cpu() - ref).abs().amax(1)
