@@ -646,7 +646,7 @@ int hh_tuning_space_joint();
 int hh_tuning_space_waves();
 int hh_tuning_space_prog();
 int hh_tuning_space_mfma32();
-int hh_space_attn16p_launch(const void* qkv, int layout_rev, void* out, float* cls_partial, int B, int T, int n, int heads, int progressive, hipStream_t stream);   // attn_space32.hip
+int hh_space_attn16p_launch(const void* qkv, int layout_rev, void* out, float* cls_partial, int B, int T, int n, int heads, int progressive, int dbg, hipStream_t stream);   // attn_space32.hip
 int hh_space_attn32_launch(const void* qkv, int layout_rev, void* out, float* cls_partial, int B, int T, int n, int heads, int mode, int dbg, hipStream_t stream);   // attn_space32.hip
 #ifndef JNT4
 #define JNT4 2          // key tiles per chunk of the joint kernel at 4 / 3 / 2 query blocks per wave
@@ -678,9 +678,9 @@ extern "C" int hh_space_attn_fwd(const void* qkv, int qkv_layout, void* out, flo
     }
     HHProfScope prof(HH_PROF_SPACE_ATTN, 8.0 * B * (1.0 + (double)T * n) * heads * 64, (hipStream_t)stream);
     const int nqb = n >> 4, joint = hh_tuning_space_joint();
-    if (joint && hh_tuning_space_mfma32() >= 2 && n == 576 && hh_tuning_space_debug() == 0)     // round 6, opt-in: third-step pipelined 16x16x32 kernel (attn_space32.hip);
+    if (joint && hh_tuning_space_mfma32() >= 2 && n == 576 && hh_tuning_space_debug() <= 2)     // round 6, opt-in: third-step pipelined 16x16x32 kernel (attn_space32.hip);
         return hh_space_attn16p_launch(qkv, qkv_layout | walk_rev, out, cls_partial, B, T, n, heads,       // 2 = with progressive staging, 3 = plain staging
-                                       hh_tuning_space_mfma32() == 2, (hipStream_t)stream);
+                                       hh_tuning_space_mfma32() == 2, hh_tuning_space_debug(), (hipStream_t)stream);
     if (joint && hh_tuning_space_mfma32() && n % 64 == 0 && n <= 256)          // round 6: 32x32x16 MFMAs (attn_space32.hip)
         return hh_space_attn32_launch(qkv, qkv_layout | walk_rev, out, cls_partial, B, T, n, heads, hh_tuning_space_mfma32(), hh_tuning_space_debug(), (hipStream_t)stream);
     int jb = !joint ? 0 : nqb % (NWJ * 4) == 0 ? 4 : nqb % (NWJ * 3) == 0 ? 3 : nqb % (NWJ * 2) == 0 ? 2 : 0;

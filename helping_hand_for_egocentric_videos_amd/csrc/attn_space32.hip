@@ -666,7 +666,7 @@ __device__ __forceinline__ bf16x8 sp16_gld128(const bf16_t* ptr) {
 
 template <int NQB, bool PROG>            // n = 16 * NQB keys per frame = NW16P waves x 3 blocks
 __global__ __launch_bounds__(64 * NW16P, 1) void space_attn16p_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                      float* __restrict__ cls_partial, int B, int T, int heads, int layout) {
+                                                                      float* __restrict__ cls_partial, int B, int T, int heads, int layout, int dbg) {
     constexpr int n = NQB * 16, nt = NQB + 1, KP = ((n + 1 + 31) / 32) * 32, NC = NQB / 2 + 1;
     static_assert(NQB == NW16P * 3 && NQB % 2 == 0, "one group of three blocks per wave, chunks of two key tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -742,7 +742,17 @@ __global__ __launch_bounds__(64 * NW16P, 1) void space_attn16p_kernel(const bf16
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[j][dt] = z4;
     }
+    if (dbg == 1) {                                    // debug: memory traffic only (stage K / V, read Q, write the rows) -- hh_set_tuning("space_debug", 1)
+        if constexpr (PROG) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            bf16_t* op = out + ((int64_t)b * N + 1 + f * n + (gb + j) * 16 + c) * D + head * 64 + 16 * g;
+            *(bf16x8*)(op) = q[j][0]; *(bf16x8*)(op + 8) = q[j][1];
+        }
+        return;
+    }
     Sp16Walk<NC, 0, 3 * NC + 2, PROG, E0, E1, E2>::run(c3, kb0, kb1, vb0, vb2, q, s, pf, o, ol, kf, vf, lane);
+    if (dbg == 2) return;                              // debug: no output, no CLS partial (staging + walk only)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         bf16_t* op = out + ((int64_t)b * N + 1 + f * n + (gb + j) * 16 + c) * D + head * 64 + 16 * g;
@@ -764,8 +774,8 @@ __global__ __launch_bounds__(64 * NW16P, 1) void space_attn16p_kernel(const bf16
     space16_cls_partial<NW16P>(Ks, Vs, scratch, base, cls_partial + (((int64_t)b * heads + head) * T + f) * CLS_REC, n, f == 0, tid, lane, wave);
 }
 
-int hh_space_attn16p_launch(const void* qkv, int layout_rev, void* out, float* cls_partial, int B, int T, int n, int heads, int progressive, hipStream_t stream) {
-    typedef void (*k_t)(const bf16_t*, bf16_t*, float*, int, int, int, int);
+int hh_space_attn16p_launch(const void* qkv, int layout_rev, void* out, float* cls_partial, int B, int T, int n, int heads, int progressive, int dbg, hipStream_t stream) {
+    typedef void (*k_t)(const bf16_t*, bf16_t*, float*, int, int, int, int, int);
     HH_REQUIRE(n == 576, HH_ERR_UNSUPPORTED, "hh_space_attn_fwd: the third-step pipelined 16x16x32 kernel is built for n = 576 (got %d)", n);
     const k_t k = progressive ? (k_t)space_attn16p_kernel<36, true> : (k_t)space_attn16p_kernel<36, false>;
     const int KP = ((n + 1 + 31) / 32) * 32;
@@ -777,7 +787,7 @@ int hh_space_attn16p_launch(const void* qkv, int layout_rev, void* out, float* c
         attr[progressive ? 1 : 0] = lds;
     }
     hh_prof_note_kernel(HH_PROF_SPACE_ATTN, progressive ? "space_attn16p_kernel<36, true>" : "space_attn16p_kernel<36, false>");
-    hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW16P), lds, stream, (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, heads, layout_rev);
+    hipLaunchKernelGGL(k, dim3((unsigned)((int64_t)B * T * heads)), dim3(64 * NW16P), lds, stream, (const bf16_t*)qkv, (bf16_t*)out, cls_partial, B, T, heads, layout_rev, dbg);
     return hh_check_launch("hh_space_attn_fwd");
 }
 

@@ -37,6 +37,12 @@ if n == 576:        # config 4: 0 / 1 = the progressive 16x16x32 kernel (default
         d = (res["out%d" % k][patch].float() - res["out0"][patch].float()).abs()
         print("mfma32=%d vs default: max |diff| rows %.3e (scale %.3f), mean %.3e; CLS partial records max |diff| %.3e" % (k, d.max().item(), res["out0"].float().abs().max().item(), d.mean().item(), (res["part%d" % k] - res["part0"]).abs().max().item()))
     print("progressive vs plain staging of the third-step kernel: rows equal %s" % torch.equal(res["out2"][patch], res["out3"][patch]))
+    for k in (2, 3):
+        ops.set_tuning("space_mfma32", k)
+        for dbg, name in ((1, "memory only (stage K / V, read Q, write rows)"), (2, "staging + walk, no output / CLS partial")):
+            ops.set_tuning("space_debug", dbg)
+            print("third-step kernel, mfma32=%d  %-48s %7.1f us" % (k, name, t()))
+        ops.set_tuning("space_debug", 0)
     ops.set_tuning("space_mfma32", 1)
     sys.exit(0)
 for rnd in range(3):
