@@ -275,3 +275,30 @@ def test_bench_plain_multi_gpu_command_fails_with_one_line_when_devices_are_miss
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300,
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=root)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_roofline_accounting_matches_the_committed_pmc_summary():
+    """`roofline.traffic` must cover the vision tower's GEMM instantiations only (<true, 5|6|7|8>) and the algorithmic bytes
+    the shipped design (bf16 pair stream 4 + 4 B, time projection 2 + 2 B per element): 1.30 GB per launch at C2 / B = 32, and the ratio must be
+    recomputable by hand from profiles/r6_pmc_summary.json (no GPU needed)."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("hh_bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from helping_hand_for_egocentric_videos_amd import C2
+    tab = bench.gemm_algorithmic_table(C2, 32)
+    M, D = 32 * 4097, 1024
+    assert tab["qkv_time"] == 2 * (M * D + 3 * D * D) + 2 * M * 3 * D and tab["proj_time"] == 2 * (M * D + D * D) + M * D * 4
+    assert tab["proj_space"] == 2 * (M * D + D * D) + M * D * 8 and tab["fc2"] == 2 * (M * 4 * D + 4 * D * D) + M * D * 8
+    alg = bench.gemm_algorithmic_bytes(C2, 32)
+    assert abs(alg - 1.303e9) < 2e6
+    traffic, src = bench.pmc_traffic(bench.VISION_GEMMS)
+    assert src == "r6_pmc_summary.json"
+    rows = {k: v for k, v in json.load(open(os.path.join(root, "profiles", src))).items() if "gemm256w4p_kernel<true, " in k}
+    vis = {k: v for k, v in rows.items() if any(t in k for t in bench.VISION_GEMMS)}
+    assert len(vis) == 4 and len(rows) > len(vis)                       # the text tower's / small instantiations are NOT part of the mean
+    by_hand = sum(v["traffic_bytes_per_launch"] * v["launches"] for v in vis.values()) / sum(v["launches"] for v in vis.values())
+    assert abs(traffic - by_hand) <= 1
+    assert 1.5 < traffic / alg < 1.8                                    # 1.65 in round 6 (the round-5 record said 1.136 by averaging the wrong set)
