@@ -62,6 +62,7 @@ SIGNATURES = {
     "hh_add_layernorm_fwd": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_float, c_vp],
     "hh_layernorm_bwd": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
     "hh_gemm_bf16": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, ctypes.POINTER(GemmEpilogue), c_vp],
+    "hh_sum_partials": [c_vp, c_vp, c_int, c_i64, c_vp],
     "hh_gemm_tn_bf16": [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_i64, c_int, c_vp],
     "hh_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
     "hh_cast_bf16_to_f32": [c_vp, c_vp, c_i64, c_vp],

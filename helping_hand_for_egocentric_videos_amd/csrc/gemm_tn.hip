@@ -159,6 +159,34 @@ extern "C" int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int6
     return hh_check_launch("hh_gemm_tn_bf16");
 }
 
+// out[i] = sum_s partials[s, i]: the split-K planes of hh_gemm_tn_bf16 added up in plane order (deterministic), 16 B per lane and
+// four planes in flight; replaces the stock reduction over dim 0 (about 200 us for 64 MB of planes; this one reads them at HBM speed).
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int splits, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4* p = (const f32x4*)part + i;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {
+        const f32x4 a = __builtin_nontemporal_load(p + (int64_t)s * n4), b = __builtin_nontemporal_load(p + (int64_t)(s + 1) * n4);
+        const f32x4 c = __builtin_nontemporal_load(p + (int64_t)(s + 2) * n4), d = __builtin_nontemporal_load(p + (int64_t)(s + 3) * n4);
+        acc += a; acc += b; acc += c; acc += d;
+    }
+    for (; s < splits; ++s) acc += __builtin_nontemporal_load(p + (int64_t)s * n4);
+    ((f32x4*)out)[i] = acc;
+}
+
+extern "C" int hh_sum_partials(const float* partials, float* out, int splits, int64_t n, hh_stream_t stream) {
+    HH_REQUIRE(splits >= 1 && splits <= 4096 && n >= 0 && n % 4 == 0, HH_ERR_SHAPE, "hh_sum_partials: need 1 <= splits <= 4096 and n %% 4 == 0 (splits=%d n=%lld)",
+               splits, (long long)n);
+    HH_REQUIRE(HH_ALIGNED16(partials) && HH_ALIGNED16(out), HH_ERR_ALIGN, "hh_sum_partials: pointers must be 16-byte aligned");
+    if (n == 0) return HH_OK;
+    const int64_t n4 = n / 4, blocks = (n4 + 255) / 256;
+    HH_REQUIRE(blocks <= 0x7fffffff, HH_ERR_SHAPE, "hh_sum_partials: n too large");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partials, out, splits, n4);
+    return hh_check_launch("hh_sum_partials");
+}
+
 // C_z [M, N] fp32 = At_z^T Bt_z (+ At2_z^T Bt2_z), z = 0 .. batch - 1: the d-memory GEMM of the K/V-projection-free decoder cross-attention
 // (mattn.hip): per clip, At = the transposed probabilities Pd^T [rows, M keys], Bt = the pooled-row gradients [rows, 512]; second pair =
 // the score gradients dS^T and the mapped queries; rows = 6 layers x 128.  K (rows) is short, M (keys) long: one workgroup per 128 x 128

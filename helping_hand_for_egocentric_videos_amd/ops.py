@@ -304,7 +304,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=torch.bfloat16, act=ACT_NONE, r
         e.colscale, e.c_dtype, e.splitk, e.split_stride = 1.0, F32, int(splitk), M * N
         _lib.check(_lib.lib().hh_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(part), N, M, N, K, ctypes.byref(e),
                                            _stream()), "hh_gemm_bf16")
-        return part.sum(0)
+        return sum_partials(part)
     if col_blocked:
         if out is not None or resid is not None or remap is not None or out_rows is not None:
             raise ValueError("gemm: col_blocked takes no preallocated output / residual / row remap")
@@ -509,11 +509,26 @@ def gemm_tn(at, bt, splits=None, colsum=False, out=None):
         if splits == 1:
             out.copy_(part[0])
         else:
-            torch.sum(part, dim=0, out=out)
+            sum_partials(part, out)
     else:
-        out = part[0] if splits == 1 else part.sum(0)
+        out = part[0] if splits == 1 else sum_partials(part)
     if colsum:
-        return out, (cs[0] if splits == 1 else cs.sum(0))
+        return out, (cs[0] if splits == 1 else sum_partials(cs))
+    return out
+
+
+def sum_partials(part, out=None):
+    """part fp32 [splits, ...] (dense) -> fp32 [...] = the planes added in order (include/hh.h: hh_sum_partials); `out`: dense fp32 of that shape."""
+    if not part.is_cuda:
+        raise RuntimeError("libhh ops need GPU tensors; there is no CPU fallback")
+    if part.dtype != torch.float32 or not part.is_contiguous() or part.dim() < 2:
+        raise ValueError("sum_partials: fp32 dense [splits, ...] planes")
+    n = part[0].numel()
+    if out is None:
+        out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+    elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != n or out.device != part.device:
+        raise ValueError("sum_partials: out must be dense fp32 with one plane's element count")
+    _lib.check(_lib.lib().hh_sum_partials(_p(part), _p(out), int(part.shape[0]), n, _stream()), "hh_sum_partials")
     return out
 
 

@@ -255,6 +255,9 @@ int hh_embed_ln_pre(const float* tok, const float* cls, const float* pos, const 
  * sum over the s-th token slice of At[k, m] -- the bias gradient of the nn.Linear whose dY is At -- as a by-product. */
 int hh_gemm_tn_bf16(const void* At, int64_t lda, const void* Bt, int64_t ldb, float* partials, float* colsum_partials, int M, int N,
                     int64_t K, int splits, hh_stream_t stream);
+/* out[i] (fp32, n values) = sum over s of partials[s * n + i], planes added in order (deterministic): the sum of hh_gemm_tn_bf16's split-K
+ * planes / column-sum partials (the reference's autograd does this inside its one cuBLAS call per nn.Linear weight gradient).  n % 4 == 0. */
+int hh_sum_partials(const float* partials, float* out, int splits, int64_t n, hh_stream_t stream);
 /* batched two-pair form:  C_z [M, N] fp32 (dense, batch stride stride_c) = At_z^T Bt_z + At2_z^T Bt2_z  for z = 0 .. batch - 1; operand z
  * of a pair sits at + z * stride_a / + z * stride_b elements; both pairs share lda / ldb / K; At2 = Bt2 = NULL: one pair.  No split-K (K
  * is short here: the rows of hh_mattn_bwd's Pd^T / dS^T), K % 64 == 0 with two pairs.  The memory-side gradient of the decoder's

@@ -1489,3 +1489,22 @@ def test_round4_entry_points_accept_empty_inputs():
     assert dw.shape == (512, 256) and float(dw.abs().max()) == 0.0 and db.shape == (512,)
     assert ops.divided_attention(torch.empty(0, 3072, dtype=torch.bfloat16, device=DEV), 0, 4, 32, 16, "space").shape == (0, 1024)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("splits,shape", [(1, (128, 128)), (3, (128, 256)), (7, (512,)), (64, (512, 1024))])
+def test_sum_partials_vs_fp64(splits, shape):
+    """hh_sum_partials (the split-K planes of the weight-gradient GEMM added up in plane order) against an fp64 sum; bit-exact against the
+    same order in fp32 on the host."""
+    g = torch.Generator(device="cpu").manual_seed(splits)
+    part = (torch.randn((splits,) + shape, generator=g) * 3).cuda()
+    got = ops.sum_partials(part)
+    want = part.double().sum(0)
+    assert (got.double() - want).abs().max().item() <= 2e-6 * splits * want.abs().max().item()
+    seq = part[0].cpu().clone()
+    for s_ in range(1, splits):
+        seq += part[s_].cpu()
+    assert torch.equal(got.cpu(), seq)               # plane order, left to right (four loads in flight, one chain of adds)
+    out = torch.full(shape, 7.0, device="cuda")
+    assert ops.sum_partials(part, out=out) is out and torch.equal(out, got)          # overwrites, does not accumulate
+    with pytest.raises(ValueError):
+        ops.sum_partials(part.half())
