@@ -49,7 +49,7 @@ L += [""] + stats("prof_u", TAG + "_unpipelined", "Same build, un-pipelined step
 # ---- steady state of the un-pipelined run: the dispatches between the first and the last optimizer launch (adamw_arena_kernel = one per step), so
 # that the process's start-up (weight packing, copies, fills) does not count as "per step"
 LIBHH = ("gemm", "attn", "ln_", "add_ln", "embed", "im2col", "cast_", "transpose", "qgemm", "qself", "xattn", "lsap", "match_boxes", "box_", "rownorm", "egonce",
-         "masked_ce", "tv_accuracy", "adamw", "cls_combine", "text_flags", "_Z13ln_fwd", "accuracy", "gather_rows", "word_", "dropout_", "mattn")
+         "masked_ce", "tv_accuracy", "adamw", "cls_combine", "text_flags", "_Z13ln_fwd", "accuracy", "gather_rows", "word_", "dropout_", "mattn", "sum_partials")
 tf = glob.glob(R + "/gpurun_out/prof_u/**/*kernel_trace.csv", recursive=True)
 if tf:
     tr = sorted(csv.DictReader(open(tf[0])), key=lambda r: int(r["Start_Timestamp"]))
