@@ -28,6 +28,15 @@ class QGemmOpts(ctypes.Structure):
                 ("stride_colsum", c_i64), ("rowscale", c_vp), ("ld_rowscale", c_i64), ("stride_rowscale", c_i64)]
 
 
+class QGemmItem(ctypes.Structure):
+    """include/hh.h: hh_qgemm_item -- one product of hh_qgemm_f32x3_group (the argument list of hh_qgemm_f32x3)."""
+    _fields_ = [("A", c_vp), ("lda", c_i64), ("B", c_vp), ("ldb", c_i64), ("C", c_vp), ("ldc", c_i64),
+                ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("mode", ctypes.c_int32), ("opts", QGemmOpts)]
+
+
+QGEMM_GROUP_MAX = 12          # include/hh.h: HH_QGEMM_GROUP_MAX
+
+
 # name -> argtypes (restype is int unless listed in _RESTYPES); must list every symbol of include/hh.h
 SIGNATURES = {
     "hh_version": [],
@@ -80,6 +89,7 @@ SIGNATURES = {
     "hh_xattn_fwd_split": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
     "hh_xattn_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_float,
                      ctypes.c_uint32, c_vp],
+    "hh_qgemm_f32x3_group": [ctypes.POINTER(QGemmItem), c_int, c_vp],
     "hh_qgemm_f32x3": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_int, ctypes.POINTER(QGemmOpts), c_vp],
     "hh_qself_attn_fwd": [c_vp, c_vp, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
     "hh_qself_attn_bwd": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, ctypes.c_uint32, c_vp],
@@ -122,7 +132,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, c_int)
-        for cname, cls in ((b"hh_gemm_epilogue", GemmEpilogue), (b"hh_qgemm_opts", QGemmOpts)):
+        for cname, cls in ((b"hh_gemm_epilogue", GemmEpilogue), (b"hh_qgemm_opts", QGemmOpts), (b"hh_qgemm_item", QGemmItem)):
             if L.hh_abi_sizeof(cname) != ctypes.sizeof(cls):
                 raise RuntimeError("libhh.so was built from another include/hh.h: sizeof(%s) is %d there, %d in this binding -- rebuild it "
                                    "(`python -m helping_hand_for_egocentric_videos_amd.build --force`)" % (cname.decode(), L.hh_abi_sizeof(cname), ctypes.sizeof(cls)))

@@ -59,27 +59,29 @@ __device__ __forceinline__ void q_split(const f32x4& v, u32x2& hi, u32x2& lo) {
 //   direct     (contraction index contiguous in memory): row tid >> 2, k = 16 (tid & 3) .. + 15        -> 4 x float4 along k
 //   transposed (contraction index is the memory ROW):     k = 4 (tid >> 4) .. + 3, rows 4 (tid & 15) .. + 3 -> 4 x float4, one per k,
 //              transposed in registers so that both flavours store 4 consecutive k per row (8-byte LDS writes, no 2-byte scatter)
+// one 64 x 64 output tile: (bx, by, bz) = the block's coordinates inside ITS product's grid (tile column, tile row, split-K slice or batch
+// index), gz = that grid's z extent -- blockIdx / gridDim for a plain launch, decoded from the flat block index by qgemm_group_kernel
 template <int MODE>
-__global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
+__device__ __forceinline__ void qgemm_tile(QGemm& p, const int bx, const int by, const int bz, const int gz) {
     __shared__ __attribute__((aligned(16))) bf16_t sA[2][64][QROW];        // [hi | lo][tile row][k]
     __shared__ __attribute__((aligned(16))) bf16_t sB[2][64][QROW];
     __shared__ float scs[64];
     constexpr bool A_T = MODE == 2, B_T = MODE != 0;                         // operand stored with the contraction index as its ROW
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = by * 64, n0 = bx * 64;
     const int nk_all = (p.K + QBK - 1) / QBK;
     if (p.batch > 1) {
-        const int64_t z = blockIdx.z;
+        const int64_t z = bz;
         p.A += z * p.sA; p.B += z * p.sB; p.C += z * p.sC;
         if (p.bias) p.bias += z * p.sBias;
         if (p.colsum) p.colsum += z * p.sColsum;
         if (p.rowscale) p.rowscale += z * p.sRs;
     }
-    const int kt0 = p.batch > 1 ? 0 : blockIdx.z * p.k_per_split;
-    const int nk = min(nk_all - kt0, p.k_per_split);                          // this slice's k-steps (split-K over blockIdx.z)
-    const bool split = p.batch <= 1 && gridDim.z > 1;
-    const bool want_cs = A_T && p.colsum != nullptr && blockIdx.x == 0;
+    const int kt0 = p.batch > 1 ? 0 : bz * p.k_per_split;
+    const int nk = min(nk_all - kt0, p.k_per_split);                          // this slice's k-steps (split-K over bz)
+    const bool split = p.batch <= 1 && gz > 1;
+    const bool want_cs = A_T && p.colsum != nullptr && bx == 0;
     if (tid < 64) scs[tid] = 0.f;
 
     f32x4 ra0[4], rb0[4], ra1[4], rb1[4];           // two register stages: the global loads run TWO k-steps ahead of the MFMAs
@@ -219,6 +221,31 @@ __global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
     }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void qgemm_kernel(QGemm p) {
+    qgemm_tile<MODE>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
+}
+
+// Several independent products of ONE mode in one launch (hh_qgemm_f32x3_group): the nine weight gradients of a decoder layer, the two
+// in-projection halves of its self-attention.  Flat grid; a block finds its product by the prefix sums of the products' grids.  Every tile
+// is computed exactly as by the single launch (bit-identical results).
+struct QGroup {
+    QGemm p[HH_QGEMM_GROUP_MAX];
+    int start[HH_QGEMM_GROUP_MAX + 1];       // first flat block index of product i; start[n] = grid size
+    int gx[HH_QGEMM_GROUP_MAX], gy[HH_QGEMM_GROUP_MAX], gz[HH_QGEMM_GROUP_MAX];
+    int n;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void qgemm_group_kernel(QGroup g) {
+    const int bid = blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && bid >= g.start[i + 1]) ++i;
+    const int local = bid - g.start[i], gx = g.gx[i], gy = g.gy[i];
+    QGemm p = g.p[i];
+    qgemm_tile<MODE>(p, local % gx, (local / gx) % gy, local / (gx * gy), g.gz[i]);
+}
+
 static void q_drop_params(float p, unsigned* thresh, float* scale) {
     *thresh = 0u; *scale = 1.f;
     if (p <= 0.f) return;
@@ -228,8 +255,9 @@ static void q_drop_params(float p, unsigned* thresh, float* scale) {
     *scale = 1.f / (1.f - p);
 }
 
-extern "C" int hh_qgemm_f32x3(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
-                              int mode, const hh_qgemm_opts* o, hh_stream_t stream) {
+// argument checks + kernel parameters + grid of one product (shared by the single and the grouped launch)
+static int q_prepare(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, int mode,
+                     const hh_qgemm_opts* o, QGemm& p, dim3& grid) {
     HH_REQUIRE(o != nullptr && M >= 0 && N > 0 && K > 0 && mode >= 0 && mode <= 2, HH_ERR_SHAPE, "hh_qgemm_f32x3: bad shape / mode (M=%d N=%d K=%d mode=%d)", M, N, K, mode);
     // contiguous dimension of every operand is read / written as float4
     const int a_contig = mode == 2 ? M : K, b_contig = mode == 0 ? K : N;
@@ -240,8 +268,6 @@ extern "C" int hh_qgemm_f32x3(const float* A, int64_t lda, const float* B, int64
     HH_REQUIRE(o->colsum == nullptr || mode == 2, HH_ERR_UNSUPPORTED, "hh_qgemm_f32x3: colsum (bias gradient) is a by-product of the TN mode only");
     HH_REQUIRE(o->a_drop_p >= 0.f && o->a_drop_p < 1.f && o->drop_p >= 0.f && o->drop_p < 1.f, HH_ERR_SHAPE, "hh_qgemm_f32x3: dropout p must be in [0,1)");
     HH_REQUIRE((o->resid == nullptr || o->ldr % 4 == 0) && (o->relu_mask == nullptr || o->ldmask % 4 == 0), HH_ERR_SHAPE, "hh_qgemm_f32x3: ldr / ldmask must be multiples of 4");
-    if (M == 0) return HH_OK;
-    QGemm p;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.mode = mode;
     p.a_scale = o->a_scale == 0.f ? 1.f : o->a_scale;
     q_drop_params(o->a_drop_p, &p.a_drop_thresh, &p.a_drop_scale);
@@ -266,12 +292,51 @@ extern "C" int hh_qgemm_f32x3(const float* A, int64_t lda, const float* B, int64
                "hh_qgemm_f32x3: split-K adds partial products atomically into a zeroed C: no epilogue options");
     p.k_per_split = (nk_all + splits - 1) / splits;
     splits = (nk_all + p.k_per_split - 1) / p.k_per_split;
-    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)(p.batch > 1 ? p.batch : splits));
+    grid = dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)(p.batch > 1 ? p.batch : splits));
+    return HH_OK;
+}
+
+extern "C" int hh_qgemm_f32x3(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
+                              int mode, const hh_qgemm_opts* o, hh_stream_t stream) {
+    QGemm p;
+    dim3 grid;
+    const int rc = q_prepare(A, lda, B, ldb, C, ldc, M, N, K, mode, o, p, grid);
+    if (rc != HH_OK) return rc;
+    if (M == 0) return HH_OK;
     hipStream_t s = (hipStream_t)stream;
     if (mode == 0) hipLaunchKernelGGL(qgemm_kernel<0>, grid, dim3(256), 0, s, p);
     else if (mode == 1) hipLaunchKernelGGL(qgemm_kernel<1>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(qgemm_kernel<2>, grid, dim3(256), 0, s, p);
     return hh_check_launch("hh_qgemm_f32x3");
+}
+
+extern "C" int hh_qgemm_f32x3_group(const hh_qgemm_item* items, int n, hh_stream_t stream) {
+    HH_REQUIRE(items != nullptr && n >= 1 && n <= HH_QGEMM_GROUP_MAX, HH_ERR_SHAPE, "hh_qgemm_f32x3_group: 1 .. %d products per launch (n=%d)", HH_QGEMM_GROUP_MAX, n);
+    QGroup g;
+    int64_t blocks = 0;
+    g.n = 0;
+    const int mode = items[0].mode;
+    for (int i = 0; i < n; ++i) {
+        const hh_qgemm_item& it = items[i];
+        HH_REQUIRE(it.mode == mode, HH_ERR_UNSUPPORTED, "hh_qgemm_f32x3_group: all products of a group share one mode (product %d: %d, product 0: %d)", i, it.mode, mode);
+        dim3 grid;
+        const int rc = q_prepare(it.A, it.lda, it.B, it.ldb, it.C, it.ldc, it.M, it.N, it.K, it.mode, &it.opts, g.p[g.n], grid);
+        if (rc != HH_OK) return rc;
+        if (it.M == 0) continue;
+        g.start[g.n] = (int)blocks;
+        g.gx[g.n] = (int)grid.x; g.gy[g.n] = (int)grid.y; g.gz[g.n] = (int)grid.z;
+        blocks += (int64_t)grid.x * grid.y * grid.z;
+        HH_REQUIRE(blocks <= 0x7fffffff, HH_ERR_SHAPE, "hh_qgemm_f32x3_group: grid too large");
+        ++g.n;
+    }
+    if (g.n == 0) return HH_OK;
+    for (int i = g.n; i <= HH_QGEMM_GROUP_MAX; ++i) g.start[i] = (int)blocks;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)blocks);
+    if (mode == 0) hipLaunchKernelGGL(qgemm_group_kernel<0>, grid, dim3(256), 0, s, g);
+    else if (mode == 1) hipLaunchKernelGGL(qgemm_group_kernel<1>, grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(qgemm_group_kernel<2>, grid, dim3(256), 0, s, g);
+    return hh_check_launch("hh_qgemm_f32x3_group");
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -42,6 +42,7 @@ extern "C" int hh_version(void) { return 100; }
 extern "C" int hh_abi_sizeof(const char* name) {
     if (name && !strcmp(name, "hh_gemm_epilogue")) return (int)sizeof(hh_gemm_epilogue);
     if (name && !strcmp(name, "hh_qgemm_opts")) return (int)sizeof(hh_qgemm_opts);
+    if (name && !strcmp(name, "hh_qgemm_item")) return (int)sizeof(hh_qgemm_item);
     return -1;
 }
 extern "C" const char* hh_last_error_string(void) { return g_err; }

@@ -157,8 +157,10 @@ class QueryStack(torch.autograd.Function):
             x = tgt_all[l]
             a, aq, mean1, rstd1 = ops.layernorm_pos(x, n1w, n1b, eps, qpos, save_stats=True)
             qkv = torch.empty((R, 3 * C), dtype=torch.float32, device=dev)
-            ops.qgemm(aq, wi_s[:2 * C], ops.NT, bias=bi_s[:2 * C], out=qkv[:, :2 * C])                  # q = k = norm1(x) + query_pos
-            ops.qgemm(a, wi_s[2 * C:], ops.NT, bias=bi_s[2 * C:], out=qkv[:, 2 * C:])                   # v = norm1(x)
+            pair = ops.QGemmGroup()                                                                     # the two halves of the in-projection: one launch
+            ops.qgemm(aq, wi_s[:2 * C], ops.NT, bias=bi_s[:2 * C], out=qkv[:, :2 * C], defer=pair)      # q = k = norm1(x) + query_pos
+            ops.qgemm(a, wi_s[2 * C:], ops.NT, bias=bi_s[2 * C:], out=qkv[:, 2 * C:], defer=pair)       # v = norm1(x)
+            pair.launch()
             o = ops.qself_attn_fwd(qkv, B, Q, heads, p, sd("sa"))
             tgt1 = ops.qgemm(o, wo_s, ops.NT, bias=bo_s, drop_p=p, drop_seed=sd("d1"), resid=x)
             _, cq, mean2, rstd2 = ops.layernorm_pos(tgt1, n2w, n2b, eps, qpos, save_stats=True)
@@ -251,17 +253,20 @@ class QueryStack(torch.autograd.Function):
             elif g is None:                              # (nobody read the last layer: nothing flows into it)
                 g = torch.zeros((R, C), dtype=torch.float32, device=dev)
             drop = lambda site: dict(a_drop_p=p, a_drop_seed=sd(site), a_drop_ld=C) if p > 0 else {}
+            # the layer's nine weight gradients (TN products: they feed nothing inside this backward) are collected and go out as ONE grouped
+            # launch at the end of the layer (hh_qgemm_f32x3_group; the reference's autograd: one cuBLAS call each)
+            tn = ops.QGemmGroup()
             # FFN:  tgt3 = tgt2 + drop3(hid.W2^T + b2),  hid = drop(relu(e.W1^T + b1)),  e = norm3(tgt2)
             db2 = new(l, 17, C)
-            dw2 = ops.qgemm(g, hid, ops.TN, colsum=db2, out=sv(l, 16) if sunk else None, **drop("d3"))
+            dw2 = ops.qgemm(g, hid, ops.TN, colsum=db2, out=sv(l, 16) if sunk else None, defer=tn, **drop("d3"))
             dz = ops.qgemm(g, w2, ops.NN, relu_mask=hid, mask_scale=keep, **drop("d3"))
             db1 = new(l, 15, F_)
-            dw1 = ops.qgemm(dz, e, ops.TN, colsum=db1, out=sv(l, 14) if sunk else None)
+            dw1 = ops.qgemm(dz, e, ops.TN, colsum=db1, out=sv(l, 14) if sunk else None, defer=tn)
             de = ops.qgemm(dz, w1, ops.NN)
             g2 = ops.layernorm_bwd_add(tgt2, n3w, mean3, rstd3, de, g, ln_w(l, 2), ln_b(l, 2))
             # cross-attention:  tgt2 = tgt1 + drop2(ca.Wo^T + bo),  ca = xattn(q, K_l, V_l),  q = (cq.Wq^T + bq) / 8,  cq = norm2(tgt1) + qpos
             dbo_c = new(l, 11, C)
-            dwo_c = ops.qgemm(g2, ca.view(R, C), ops.TN, colsum=dbo_c, out=sv(l, 10) if sunk else None, **drop("d2"))
+            dwo_c = ops.qgemm(g2, ca.view(R, C), ops.TN, colsum=dbo_c, out=sv(l, 10) if sunk else None, defer=tn, **drop("d2"))
             dca = ops.qgemm(g2, wo_c, ops.NN, **drop("d2"))
             gw_c, gb_c = (sv(l, 8), sv(l, 9)) if sunk else (d_wi_c[l], d_bi_c[l])       # gradient of this layer's packed [q; k; v] in-projection
             if kv_free:
@@ -269,30 +274,31 @@ class QueryStack(torch.autograd.Function):
                 rs = rsum if p > 0 else None
                 # head output O_h = pooled_h Wv_h^T + rsum_h bv_h:  d pooled, d Wv (value rows), d bv as the TN product's column sums
                 dpooled = ops.head_map_in(dca, wi_c[2 * C:])
-                ops.head_map_wgrad(dca, pooled, gw_c[2 * C:], colsum=gb_c[2 * C:], rowscale=rs)
+                ops.head_map_wgrad(dca, pooled, gw_c[2 * C:], colsum=gb_c[2 * C:], rowscale=rs, defer=tn)
                 # attention core in memory space: d qt; Pd^T / dS^T of this layer for _MemorySideKVFree's batched d-memory GEMM
                 dqt = ops.mattn_bwd(qt, dpooled, lse, dca, ca, bi_c[2 * C:], h.mp, h.mem, Q, pdT, dsT, qt16, dp16, l * 128, p, sd("x"), keys_valid=h.Mv)
                 # qt_h = q_h Wk_h:  d q, d Wk (key rows); the key bias drops out of the softmax -- its gradient is exactly 0 (the rows stay zero)
                 dq = ops.head_map_out(dqt, wi_c[C:2 * C])
-                ops.head_map_wgrad(q, dqt, gw_c[C:2 * C])
+                ops.head_map_wgrad(q, dqt, gw_c[C:2 * C], defer=tn)
             else:
                 k, v = kvv[:, :, l * C:(l + 1) * C], kvv[:, :, (Lk + l) * C:(Lk + l + 1) * C]
                 dk, dv = dkvv[:, :, l * C:(l + 1) * C], dkvv[:, :, (Lk + l) * C:(Lk + l + 1) * C]
                 dq = ops.xattn_bwd(q.view(B, Q, C), k, v, ca, lse, dca.view(B, Q, C), dk, dv, heads, p, sd("x")).view(R, C)
             # query rows of the cross-attention in-projection (K/V path: its key / value rows are written by _MemorySide, which also
             # reports the parameter as final when both halves went straight into the arena)
-            ops.qgemm(dq, cq, ops.TN, a_scale=0.125, colsum=gb_c[:C], out=gw_c[:C])
+            ops.qgemm(dq, cq, ops.TN, a_scale=0.125, colsum=gb_c[:C], out=gw_c[:C], defer=tn)
             dcq = ops.qgemm(dq, wi_c[:C], ops.NN, a_scale=0.125)
             g1 = ops.layernorm_bwd_add(tgt1, n2w, mean2, rstd2, dcq, g2, ln_w(l, 1), ln_b(l, 1))
             # self-attention:  tgt1 = x + drop1(o.Wo^T + bo),  o = attn(q = k = aq.W[:2C], v = a.W[2C:]),  a = norm1(x), aq = a + qpos
             dbo_s = new(l, 5, C)
-            dwo_s = ops.qgemm(g1, o, ops.TN, colsum=dbo_s, out=sv(l, 4) if sunk else None, **drop("d1"))
+            dwo_s = ops.qgemm(g1, o, ops.TN, colsum=dbo_s, out=sv(l, 4) if sunk else None, defer=tn, **drop("d1"))
             do = ops.qgemm(g1, wo_s, ops.NN, **drop("d1"))
             dqkv = ops.qself_attn_bwd(qkv, do, B, Q, heads, p, sd("sa"))
             dwi_s = new(l, 2, 3 * C, C)
             dbi_s = new(l, 3, 3 * C)
-            ops.qgemm(dqkv[:, :2 * C], aq, ops.TN, colsum=dbi_s[:2 * C], out=dwi_s[:2 * C])
-            ops.qgemm(dqkv[:, 2 * C:], a, ops.TN, colsum=dbi_s[2 * C:], out=dwi_s[2 * C:])
+            ops.qgemm(dqkv[:, :2 * C], aq, ops.TN, colsum=dbi_s[:2 * C], out=dwi_s[:2 * C], defer=tn)
+            ops.qgemm(dqkv[:, 2 * C:], a, ops.TN, colsum=dbi_s[2 * C:], out=dwi_s[2 * C:], defer=tn)
+            tn.launch()
             daq = ops.qgemm(dqkv[:, :2 * C], wi_s[:2 * C], ops.NN)
             da = ops.qgemm(dqkv[:, 2 * C:], wi_s[2 * C:], ops.NN, resid=daq)
             g = ops.layernorm_bwd_add(x, n1w, mean1, rstd1, da, g1, ln_w(l, 0), ln_b(l, 0))

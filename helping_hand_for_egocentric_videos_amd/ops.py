@@ -180,8 +180,40 @@ def layernorm_bwd_add(x, gamma, mean, rstd, dy, dx_add, dgamma, dbeta, out=None)
 NT, NN, TN = 0, 1, 2
 
 
+class QGemmGroup:
+    """Independent hh_qgemm_f32x3 products of ONE mode collected for a single launch (include/hh.h: hh_qgemm_f32x3_group):
+    `qgemm(..., defer=group)` / `head_map_wgrad(..., defer=group)` record their product instead of launching it and return the output
+    tensor, whose contents exist after `group.launch()`.  The group keeps every operand alive until then.  More than
+    HH_QGEMM_GROUP_MAX products go out as several launches."""
+
+    def __init__(self):
+        self.items, self.refs = [], []
+
+    def add(self, item, *tensors):
+        if self.items and self.items[0].mode != item.mode:
+            raise ValueError("QGemmGroup: all products of a group share one mode")
+        self.items.append(item)
+        self.refs.append(tensors)
+
+    def launch(self):
+        L = _lib.lib()
+        for i0 in range(0, len(self.items), _lib.QGEMM_GROUP_MAX):
+            chunk = self.items[i0:i0 + _lib.QGEMM_GROUP_MAX]
+            arr = (_lib.QGemmItem * len(chunk))(*chunk)
+            _lib.check(L.hh_qgemm_f32x3_group(arr, len(chunk), _stream()), "hh_qgemm_f32x3_group")
+        self.items, self.refs = [], []
+
+
+def _qgemm_item(a, lda, b, ldb, c, ldc, M, N, K, mode, o):
+    it = _lib.QGemmItem()
+    it.A, it.lda, it.B, it.ldb, it.C, it.ldc = a.data_ptr(), int(lda), b.data_ptr(), int(ldb), c.data_ptr(), int(ldc)
+    it.M, it.N, it.K, it.mode = int(M), int(N), int(K), int(mode)
+    it.opts = o
+    return it
+
+
 def qgemm(a, b, mode=NT, *, out=None, bias=None, scale=0.0, scale_ncols=0, relu=False, drop_p=0.0, drop_seed=0, relu_mask=None, mask_scale=1.0,
-          resid=None, a_scale=0.0, a_drop_p=0.0, a_drop_seed=0, a_drop_ld=0, colsum=None, splitk=1):
+          resid=None, a_scale=0.0, a_drop_p=0.0, a_drop_seed=0, a_drop_ld=0, colsum=None, splitk=1, defer=None):
     """Query-side GEMM at fp32-grade accuracy on the bf16 matrix cores (include/hh.h: hh_qgemm_f32x3).  All operands fp32, 2-D with
     unit inner stride.  mode NT: a [M,K], b [N,K];  NN: a [M,K], b [K,N];  TN: a [K,M], b [K,N]  ->  out fp32 [M,N].
     splitk > 1: the contraction is split over workgroups that ADD into `out` / `colsum` atomically (both must be zero on entry; a fresh
@@ -216,6 +248,9 @@ def qgemm(a, b, mode=NT, *, out=None, bias=None, scale=0.0, scale_ncols=0, relu=
     o.resid = resid.data_ptr() if resid is not None else None
     o.ldr = resid.stride(0) if resid is not None else 0
     o.colsum = colsum.data_ptr() if colsum is not None else None
+    if defer is not None:                              # part of a grouped launch (QGemmGroup.launch)
+        defer.add(_qgemm_item(a, a.stride(0), b, b.stride(0), out, out.stride(0), M, N, K, mode, o), a, b, out, bias, relu_mask, resid, colsum)
+        return out
     _lib.check(_lib.lib().hh_qgemm_f32x3(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, int(mode), ctypes.byref(o),
                                          _stream()), "hh_qgemm_f32x3")
     return out
@@ -597,7 +632,7 @@ def text_attention(qkv, S, L, heads):
 MATTN_H, MATTN_C = 8, 512
 
 
-def _head_qgemm(mode, a, lda, sa, b, ldb, sb, c, ldc, sc, M, N, K, *, bias=None, sbias=0, rowscale=None, ld_rs=0, s_rs=0, colsum=None, scolsum=0):
+def _head_qgemm(mode, a, lda, sa, b, ldb, sb, c, ldc, sc, M, N, K, *, bias=None, sbias=0, rowscale=None, ld_rs=0, s_rs=0, colsum=None, scolsum=0, defer=None):
     o = QGemmOpts()
     o.batch = MATTN_H
     o.stride_a, o.stride_b, o.stride_c = int(sa), int(sb), int(sc)
@@ -607,6 +642,9 @@ def _head_qgemm(mode, a, lda, sa, b, ldb, sb, c, ldc, sc, M, N, K, *, bias=None,
     o.ld_rowscale, o.stride_rowscale = int(ld_rs), int(s_rs)
     o.colsum = colsum.data_ptr() if colsum is not None else None
     o.stride_colsum = int(scolsum)
+    if defer is not None:
+        defer.add(_qgemm_item(a, lda, b, ldb, c, ldc, M, N, K, mode, o), a, b, c, bias, rowscale, colsum)
+        return
     _lib.check(_lib.lib().hh_qgemm_f32x3(_p(a), int(lda), _p(b), int(ldb), _p(c), int(ldc), int(M), int(N), int(K), int(mode), ctypes.byref(o), _stream()),
                "hh_qgemm_f32x3(batched)")
 
@@ -650,7 +688,7 @@ def head_map_out(y, w, bias=None, rowscale=None, out=None):
     return out
 
 
-def head_map_wgrad(x, y, out, colsum=None, rowscale=None):
+def head_map_wgrad(x, y, out, colsum=None, rowscale=None, defer=None):
     """out[64 h + m, :] = sum_r x[r, 64 h + m] y[r, h, :]  (batched TN; the key / value rows of d in_proj_weight), optionally
     colsum[64 h + m] = sum_r x[r, 64 h + m] * rowscale[r, h] (the value-bias gradient).  x fp32 [R, 512], y fp32 [R, 8 * 512],
     out fp32 [512, 512] (row-strided view)."""
@@ -660,7 +698,7 @@ def head_map_wgrad(x, y, out, colsum=None, rowscale=None):
     if x.shape[1] != H * 64 or y.shape != (R, H * C) or tuple(out.shape) != (H * 64, C):
         raise ValueError("head_map_wgrad: x [R, 512], y [R, 8 * 512], out [512, 512]")
     _head_qgemm(TN, x, x.stride(0), 64, y, y.stride(0), C, out, out.stride(0), 64 * out.stride(0), 64, C, R, colsum=colsum, scolsum=64,
-                rowscale=rowscale if colsum is not None else None, ld_rs=rowscale.stride(0) if rowscale is not None else 0, s_rs=1)
+                rowscale=rowscale if colsum is not None else None, ld_rs=rowscale.stride(0) if rowscale is not None else 0, s_rs=1, defer=defer)
     return out
 
 

@@ -376,6 +376,20 @@ typedef struct hh_qgemm_opts {
 } hh_qgemm_opts;
 int hh_qgemm_f32x3(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, int mode,
                    const hh_qgemm_opts* opts, hh_stream_t stream);
+/* Several INDEPENDENT products of one mode in one launch (round 6): the nine weight gradients of a decoder layer's backward
+ * (tfm_decoder.py:420-461: autograd issues one cuBLAS call each), the q|k and v halves of its self-attention in-projection.  Item i is
+ * exactly the argument list of hh_qgemm_f32x3 (all forms: split-K, batched, every prologue / epilogue option); results are bit-identical
+ * to n single calls.  1 <= n <= HH_QGEMM_GROUP_MAX, all items of the same mode; products must not read what another product of the
+ * group writes. */
+#define HH_QGEMM_GROUP_MAX 12
+typedef struct hh_qgemm_item {
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    float* C; int64_t ldc;
+    int32_t M, N, K, mode;
+    hh_qgemm_opts opts;
+} hh_qgemm_item;
+int hh_qgemm_f32x3_group(const hh_qgemm_item* items, int n, hh_stream_t stream);
 /* self-attention over the Q <= 16 queries of a clip (nn.MultiheadAttention(q = k = x + query_pos, v = x), tfm_decoder.py:433-436):
  * qkv fp32 [B*Q, 3*heads*64] (q | k | v projections, not pre-scaled; the kernel applies 64^-1/2), out fp32 [B*Q, heads*64];
  * attention dropout by the same counter-based hash (probabilities and mask are recomputed in the backward). */

@@ -1508,3 +1508,57 @@ def test_sum_partials_vs_fp64(splits, shape):
     assert ops.sum_partials(part, out=out) is out and torch.equal(out, got)          # overwrites, does not accumulate
     with pytest.raises(ValueError):
         ops.sum_partials(part.half())
+
+
+@pytest.mark.parametrize("mode", [ops.NT, ops.NN, ops.TN])
+def test_qgemm_group_is_bit_identical_to_single_launches(mode):
+    """hh_qgemm_f32x3_group: several independent products of one mode in one launch (the nine weight gradients of a decoder layer) -- every
+    tile is computed exactly as by its own launch, so the results are bit-identical; ragged shapes, the bias-gradient column sums, the
+    prologue scale / dropout and the head-batched form included.  More than HH_QGEMM_GROUP_MAX products: several launches."""
+    g = torch.Generator(device="cpu").manual_seed(7 + mode)
+    rnd = lambda *sh: torch.randn(*sh, generator=g).cuda()
+    shapes = [(416, 512, 2048), (416, 2048, 512), (52, 512, 512), (416, 128, 64), (13, 1536, 512)] + [(416, 512, 512)] * 9     # (rows, a, b)
+    grp, single, grouped = ops.QGemmGroup(), [], []
+    for i, (R, a_, b_) in enumerate(shapes):
+        if mode == ops.TN:                      # dY [R, a] ^T X [R, b] -> [a, b] + column sums
+            A, B = rnd(R, a_), rnd(R, b_)
+            kw = dict(a_scale=0.125) if i == 1 else (dict(a_drop_p=0.1, a_drop_seed=99 + i, a_drop_ld=a_) if i == 2 else {})
+            cs1, cs2 = torch.empty(a_, device="cuda"), torch.empty(a_, device="cuda")
+            single.append((ops.qgemm(A, B, mode, colsum=cs1, **kw), cs1))
+            grouped.append((ops.qgemm(A, B, mode, colsum=cs2, defer=grp, **kw), cs2))
+        elif mode == ops.NT:                    # X [R, a] W [b, a]^T + bias -> [R, b]
+            A, B, bias = rnd(R, a_), rnd(b_, a_), rnd(b_)
+            kw = dict(relu=True) if i == 0 else (dict(resid=rnd(R, b_), drop_p=0.1, drop_seed=5) if i == 1 else {})
+            single.append((ops.qgemm(A, B, mode, bias=bias, **kw),))
+            grouped.append((ops.qgemm(A, B, mode, bias=bias, defer=grp, **kw),))
+        else:                                   # dY [R, a] W [a, b] -> [R, b]
+            A, B = rnd(R, a_), rnd(a_, b_)
+            single.append((ops.qgemm(A, B, mode),))
+            grouped.append((ops.qgemm(A, B, mode, defer=grp),))
+    if mode == ops.TN:                          # the head-batched weight gradient of the memory-space cross-attention + a split-K product
+        x, y, rs = rnd(416, 512), rnd(416, 8 * 512), rnd(416, 8)
+        o1, o2 = torch.empty(512, 512, device="cuda"), torch.empty(512, 512, device="cuda")
+        c1, c2 = torch.empty(512, device="cuda"), torch.empty(512, device="cuda")
+        ops.head_map_wgrad(x, y, o1, colsum=c1, rowscale=rs)
+        ops.head_map_wgrad(x, y, o2, colsum=c2, rowscale=rs, defer=grp)
+        single.append((o1, c1)); grouped.append((o2, c2))
+        A, B = rnd(6656, 512), rnd(6656, 512)
+        z1, z2 = torch.zeros(512, 512, device="cuda"), torch.zeros(512, 512, device="cuda")
+        ops.qgemm(A, B, mode, out=z1, splitk=8)
+        ops.qgemm(A, B, mode, out=z2, splitk=8, defer=grp)
+        assert len(grp.items) > 12
+    before = ops._lib.lib().hh_call_count()
+    n_items = len(grp.items)
+    grp.launch()
+    assert ops._lib.lib().hh_call_count() - before == (n_items + 11) // 12 and not grp.items
+    torch.cuda.synchronize()
+    for one, many in zip(single, grouped):
+        assert torch.equal(one[0], many[0])
+        if len(one) > 1:                        # the column sums are folded by LDS float atomics (free order): equal to rounding, not to the bit
+            assert (one[1] - many[1]).abs().max().item() <= 2e-6 * one[1].abs().max().item()
+    if mode == ops.TN:                          # (atomic split-K: the order of the adds is free)
+        assert (z1 - z2).abs().max().item() <= 1e-3 * z1.abs().max().item() and z2.abs().max().item() > 0
+    mixed = ops.QGemmGroup()
+    ops.qgemm(rnd(16, 64), rnd(64, 64), ops.NT, defer=mixed)
+    with pytest.raises(ValueError):
+        ops.qgemm(rnd(16, 64), rnd(64, 64), ops.NN, defer=mixed)
