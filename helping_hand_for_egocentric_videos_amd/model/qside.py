@@ -120,6 +120,10 @@ class LinearX3(nn.Linear):
         return _LinearX3.apply(x, self.weight, self.bias, False, getattr(self, "single_use", False))
 
 
+# A/B switch (bench.py --no-qgroup): False = every product of QueryStack is its own launch, as in rounds 2-5
+GROUP_LAUNCHES = True
+
+
 # parameters of one TransformerDecoderLayer in the order QueryStack receives them
 LAYER_PARAMS = ("norm1.weight", "norm1.bias", "self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
                 "self_attn.out_proj.bias", "norm2.weight", "norm2.bias", "multihead_attn.in_proj_weight", "multihead_attn.in_proj_bias",
@@ -157,10 +161,11 @@ class QueryStack(torch.autograd.Function):
             x = tgt_all[l]
             a, aq, mean1, rstd1 = ops.layernorm_pos(x, n1w, n1b, eps, qpos, save_stats=True)
             qkv = torch.empty((R, 3 * C), dtype=torch.float32, device=dev)
-            pair = ops.QGemmGroup()                                                                     # the two halves of the in-projection: one launch
+            pair = ops.QGemmGroup() if GROUP_LAUNCHES else None                                         # the two halves of the in-projection: one launch
             ops.qgemm(aq, wi_s[:2 * C], ops.NT, bias=bi_s[:2 * C], out=qkv[:, :2 * C], defer=pair)      # q = k = norm1(x) + query_pos
             ops.qgemm(a, wi_s[2 * C:], ops.NT, bias=bi_s[2 * C:], out=qkv[:, 2 * C:], defer=pair)       # v = norm1(x)
-            pair.launch()
+            if pair is not None:
+                pair.launch()
             o = ops.qself_attn_fwd(qkv, B, Q, heads, p, sd("sa"))
             tgt1 = ops.qgemm(o, wo_s, ops.NT, bias=bo_s, drop_p=p, drop_seed=sd("d1"), resid=x)
             _, cq, mean2, rstd2 = ops.layernorm_pos(tgt1, n2w, n2b, eps, qpos, save_stats=True)
@@ -255,7 +260,7 @@ class QueryStack(torch.autograd.Function):
             drop = lambda site: dict(a_drop_p=p, a_drop_seed=sd(site), a_drop_ld=C) if p > 0 else {}
             # the layer's nine weight gradients (TN products: they feed nothing inside this backward) are collected and go out as ONE grouped
             # launch at the end of the layer (hh_qgemm_f32x3_group; the reference's autograd: one cuBLAS call each)
-            tn = ops.QGemmGroup()
+            tn = ops.QGemmGroup() if GROUP_LAUNCHES else None
             # FFN:  tgt3 = tgt2 + drop3(hid.W2^T + b2),  hid = drop(relu(e.W1^T + b1)),  e = norm3(tgt2)
             db2 = new(l, 17, C)
             dw2 = ops.qgemm(g, hid, ops.TN, colsum=db2, out=sv(l, 16) if sunk else None, defer=tn, **drop("d3"))
@@ -298,7 +303,8 @@ class QueryStack(torch.autograd.Function):
             dbi_s = new(l, 3, 3 * C)
             ops.qgemm(dqkv[:, :2 * C], aq, ops.TN, colsum=dbi_s[:2 * C], out=dwi_s[:2 * C], defer=tn)
             ops.qgemm(dqkv[:, 2 * C:], a, ops.TN, colsum=dbi_s[2 * C:], out=dwi_s[2 * C:], defer=tn)
-            tn.launch()
+            if tn is not None:
+                tn.launch()
             daq = ops.qgemm(dqkv[:, :2 * C], wi_s[:2 * C], ops.NN)
             da = ops.qgemm(dqkv[:, 2 * C:], wi_s[2 * C:], ops.NN, resid=daq)
             g = ops.layernorm_bwd_add(x, n1w, mean1, rstd1, da, g1, ln_w(l, 0), ln_b(l, 0))
