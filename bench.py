@@ -633,6 +633,7 @@ def main():
     ap.add_argument("--space-16q", action="store_true", help="A/B: space attention on the 16-query-block kernel instead of the joint-block kernel")
     ap.add_argument("--gemm-tail", type=int, default=None, help="A/B: hh_set_tuning('gemm_tail', v): 1 (default) = row tails of <= 64 rows inside the persistent kernel, 2 = always the separate tail kernel, 0 = the 128x128 kernel; same results")
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=V", help="A/B: hh_set_tuning(NAME, V) before anything runs (repeatable)")
+    ap.add_argument("--no-text-pad", action="store_true", help="A/B: the text tower's rows as they are (S * 77: a 160-row tail per GEMM goes to a separate launch) instead of padded to 256")
     ap.add_argument("--no-qgroup", action="store_true", help="A/B: every weight gradient of the decoder's query side as its own launch (rounds 2-5) instead of one grouped launch per layer")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap the next step's frozen-encoder forward with this step's decoder")
     args = ap.parse_args()
@@ -685,6 +686,9 @@ def main():
     if args.token_major_qkv:
         from helping_hand_for_egocentric_videos_amd.model import LaviLa as _L
         _L.QKV_HEAD_MAJOR_PLANES = False
+    if args.no_text_pad:
+        from helping_hand_for_egocentric_videos_amd.model import openai_model as _om
+        _om.ROW_PAD = 0
     if args.no_qgroup:
         from helping_hand_for_egocentric_videos_amd.model import qside as _qside
         _qside.GROUP_LAUNCHES = False

@@ -38,6 +38,10 @@ class ResidualAttentionBlock(nn.Module):
         return x + self.mlp(self.ln_2(x))
 
 
+# rows of the frozen text stream are padded to a multiple of this (the persistent GEMM's row tile); 0 = off (A/B: bench.py --no-text-pad)
+ROW_PAD = 256
+
+
 class Transformer(nn.Module):
     """openai_model.py:219-232."""
 
@@ -87,11 +91,23 @@ class Transformer(nn.Module):
         xs = x.reshape(S * L, W).float().contiguous()
         if xs.data_ptr() == x.data_ptr() and not owns_x:      # the residual stream is updated in place: never the caller's own tensor
             xs = xs.clone()
+        # Row padding (round 6): the stream is carried with its row count rounded up to the persistent GEMM's 256-row tile (32 captions x 77 =
+        # 2464 -> 2560: + 3.9 % rows of a tower that runs hidden beside the vision tower), so that none of the 48 GEMMs leaves a row tail of
+        # more than 64 rows to a separate `gemm_tail_kernel` launch (36 launches per step, each waiting for free CUs inside the pipelined
+        # step).  Rows are independent in every kernel but the attention, which is handed the S * L real rows only; the padding rows start
+        # as zeros and are never read back.
+        R, Rp = S * L, ROW_PAD * ((S * L + ROW_PAD - 1) // ROW_PAD) if ROW_PAD else S * L
+        o = None
+        if Rp != R:
+            xp = torch.zeros((Rp, W), dtype=torch.float32, device=xs.device)
+            xp[:R].copy_(xs)
+            xs = xp
+            o = torch.zeros((Rp, W), dtype=torch.bfloat16, device=xs.device)      # attention output: the padding rows stay zero
         pending = None                        # bf16 branch output not yet added to the fp32 residual stream (as in SpaceTimeBlock.fused)
         for pk in self.packed():
             xn = ops.layernorm(xs, *pk["ln1"]) if pending is None else ops.add_layernorm(xs, pending, *pk["ln1"], write_x=True)
-            qkv = ops.gemm(xn, pk["win"], pk["bin"], colscale=d ** -0.5, colscale_cols=W)                  # bf16 [S*L, 3W], q scaled
-            o = ops.text_attention(qkv, S, L, h)                                                           # libhh causal attention
+            qkv = ops.gemm(xn, pk["win"], pk["bin"], colscale=d ** -0.5, colscale_cols=W)                  # bf16 [Rp, 3W], q scaled
+            o = ops.text_attention(qkv[:R], S, L, h, out=o)                                                # libhh causal attention
             a = ops.gemm(o, pk["wout"], pk["bout"])                                                        # bf16 branch
             hid = ops.gemm(ops.add_layernorm(xs, a, *pk["ln2"], write_x=True), pk["wfc"], pk["bfc"], act=ops.ACT_QUICKGELU)
             pending = ops.gemm(hid, pk["wpr"], pk["bpr"])
@@ -99,7 +115,7 @@ class Transformer(nn.Module):
             g, b, eps = final_ln
             y = ops.layernorm(xs, g, b, eps, out_dtype=torch.float32) if pending is None else \
                 ops.add_layernorm(xs, pending, g, b, eps, write_x=False, out_dtype=torch.float32)
-            return y.view(S, L, W)
+            return y[:R].view(S, L, W)
         if pending is not None:
             xs += pending.float()
-        return xs.view(S, L, W)
+        return xs[:R].view(S, L, W)

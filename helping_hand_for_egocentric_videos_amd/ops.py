@@ -617,13 +617,17 @@ def divided_attention(qkv, B, T, n, heads, mode, out=None, fold_cls=True, revers
     return out
 
 
-def text_attention(qkv, S, L, heads):
-    """Causal self-attention of the text tower: qkv bf16 [S*L, 3*heads*64] (q pre-scaled) -> bf16 [S*L, heads*64]."""
-    _chk(qkv)
+def text_attention(qkv, S, L, heads, out=None):
+    """Causal self-attention of the text tower: qkv bf16 [S*L, 3*heads*64] (q pre-scaled) -> bf16 [S*L, heads*64] (`out`: a dense bf16
+    buffer of at least S*L rows whose first S*L rows are written -- the row-padded stream of Transformer.forward_frozen)."""
+    _chk(qkv, out)
     W = heads * 64
-    if qkv.dtype != torch.bfloat16 or qkv.shape != (S * L, 3 * W):
-        raise ValueError("text_attention: qkv must be bf16 [S*L, 3*heads*64], got %s" % (tuple(qkv.shape),))
-    out = torch.empty((S * L, W), dtype=torch.bfloat16, device=qkv.device)
+    if qkv.dtype != torch.bfloat16 or qkv.shape != (S * L, 3 * W) or not qkv.is_contiguous():
+        raise ValueError("text_attention: qkv must be contiguous bf16 [S*L, 3*heads*64], got %s" % (tuple(qkv.shape),))
+    if out is None:
+        out = torch.empty((S * L, W), dtype=torch.bfloat16, device=qkv.device)
+    elif out.dtype != torch.bfloat16 or out.dim() != 2 or out.shape[1] != W or out.shape[0] < S * L or not out.is_contiguous():
+        raise ValueError("text_attention: out must be contiguous bf16 [>= S*L, heads*64]")
     _lib.check(_lib.lib().hh_text_attn_fwd(_p(qkv), _p(out), S, L, heads, _stream()), "hh_text_attn_fwd")
     return out
 

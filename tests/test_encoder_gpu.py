@@ -395,6 +395,33 @@ def test_text_tower_on_libhh_matches_oracle_and_stock_path():
     assert torch.nn.functional.cosine_similarity(gc.cpu(), rc, dim=-1).min() > 0.999
 
 
+def test_row_padded_text_stream_equals_the_unpadded_one():
+    """Transformer.forward_frozen carries the text rows padded to the persistent GEMM's 256-row tile (no separate row-tail launches): the
+    real rows must come out as from the un-padded stream -- equal up to the bf16 rounding of the rows whose GEMM tile changed kernels
+    (main kernel instead of gemm_tail_kernel: another k-summation order) -- with fewer library calls."""
+    from helping_hand_for_egocentric_videos_amd import _lib
+    from helping_hand_for_egocentric_videos_amd.model import openai_model
+    cfg = TINY16.with_(text_layers=3)
+    sd = synth.encoder_state(cfg, seed=9)
+    model = LaviLa.build_backbone(cfg, sd)
+    text = synth.make_batch(cfg, 5, seed=9)["text"].cuda()         # 5 x 77 = 385 rows -> 512
+    assert openai_model.ROW_PAD == 256
+    with torch.no_grad():
+        model.encode_text(text)                                    # (packs the frozen weights once)
+        c0 = _lib.lib().hh_call_count()
+        pc, px = model.encode_text(text)
+        c1 = _lib.lib().hh_call_count()
+        openai_model.ROW_PAD = 0
+        try:
+            uc, ux = model.encode_text(text)
+        finally:
+            openai_model.ROW_PAD = 256
+        c2 = _lib.lib().hh_call_count()
+    assert px.shape == ux.shape and pc.shape == uc.shape
+    check("text_row_pad", "padded vs un-padded text feature map rel-L2", rel_l2(px, ux), 4e-3)
+    assert torch.isfinite(px).all() and c1 - c0 <= c2 - c1
+
+
 def test_inflated_4_frame_checkpoint_through_the_16_frame_tower_f2():
     """SURVEY 8f row 2 on the GPU (run/test_egtea.py:46-96,115): a 4-frame LaViLa state ('module.'-prefixed, as the checkpoints are)
     is loaded into a T = 16 tower -- `visual.temporal_embed` inflated bilinearly by utils/checkpoint.py -- and the GPU feature map is
