@@ -50,6 +50,7 @@ class Transformer(nn.Module):
         self.width, self.layers, self.heads = width, layers, heads
         self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
         self._pack = None
+        self._opad = {}
 
     def forward(self, x: torch.Tensor, use_checkpoint=False):
         return self.resblocks(x)
@@ -57,10 +58,12 @@ class Transformer(nn.Module):
     def _load_from_state_dict(self, *a, **k):
         super()._load_from_state_dict(*a, **k)
         self._pack = None
+        self._opad = {}
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         self._pack = None
+        self._opad = {}
         return r
 
     def packed(self):
@@ -102,7 +105,13 @@ class Transformer(nn.Module):
             xp = torch.zeros((Rp, W), dtype=torch.float32, device=xs.device)
             xp[:R].copy_(xs)
             xs = xp
-            o = torch.zeros((Rp, W), dtype=torch.bfloat16, device=xs.device)      # attention output: the padding rows stay zero
+            # attention output: only its real rows are ever written, so ONE zero-filled buffer per shape serves every call (calls of a
+            # tower are serialised on its stream)
+            key = (Rp, W, xs.device)
+            o = self._opad.get(key)
+            if o is None:
+                self._opad.clear()
+                o = self._opad[key] = torch.zeros((Rp, W), dtype=torch.bfloat16, device=xs.device)
         pending = None                        # bf16 branch output not yet added to the fp32 residual stream (as in SpaceTimeBlock.fused)
         for pk in self.packed():
             xn = ops.layernorm(xs, *pk["ln1"]) if pending is None else ops.add_layernorm(xs, pending, *pk["ln1"], write_x=True)
