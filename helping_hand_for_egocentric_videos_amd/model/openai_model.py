@@ -109,9 +109,8 @@ class Transformer(nn.Module):
             # tower are serialised on its stream)
             key = (Rp, W, xs.device)
             o = self._opad.get(key)
-            if o is None:
-                self._opad.clear()
-                o = self._opad[key] = torch.zeros((Rp, W), dtype=torch.bfloat16, device=xs.device)
+            if o is None:                       # (kept per shape, never freed while the module lives: a buffer another stream may still read
+                o = self._opad[key] = torch.zeros((Rp, W), dtype=torch.bfloat16, device=xs.device)       #  must not go back to the allocator)
         pending = None                        # bf16 branch output not yet added to the fp32 residual stream (as in SpaceTimeBlock.fused)
         for pk in self.packed():
             xn = ops.layernorm(xs, *pk["ln1"]) if pending is None else ops.add_layernorm(xs, pending, *pk["ln1"], write_x=True)
