@@ -32,6 +32,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     # the kernels garbage; _lib.lib() raises on a mismatch at load time)
     assert L.hh_abi_sizeof(b"hh_gemm_epilogue") == ctypes.sizeof(_lib.GemmEpilogue) > 0
     assert L.hh_abi_sizeof(b"hh_qgemm_opts") == ctypes.sizeof(_lib.QGemmOpts) > 0
+    assert L.hh_abi_sizeof(b"hh_qgemm_item") == ctypes.sizeof(_lib.QGemmItem) > 0
     assert L.hh_abi_sizeof(b"no_such_struct") == -1
 
 
@@ -55,6 +56,18 @@ def test_host_side_argument_validation_needs_no_gpu():
     o.splitk, o.relu = 4, 1
     assert L.hh_qgemm_f32x3(None, 512, None, 512, None, 512, 16, 512, 512, 0, ctypes.byref(o), None) == -3       # split-K takes no epilogue
     assert L.hh_qself_attn_fwd(None, None, 2, 17, 8, 0.0, 0, None) == -1                                           # Q <= 16
+    # grouped products (round 6): 1 .. HH_QGEMM_GROUP_MAX items of one mode, each checked like a single call
+    items = (_lib.QGemmItem * 13)()
+    for it in items:
+        it.lda = it.ldb = it.ldc = 512
+        it.M, it.N, it.K, it.mode = 16, 512, 512, 2
+    assert L.hh_qgemm_f32x3_group(items, 0, None) == -1 and L.hh_qgemm_f32x3_group(items, 13, None) == -1
+    assert b"products per launch" in L.hh_last_error_string()
+    items[1].mode = 1
+    assert L.hh_qgemm_f32x3_group(items, 2, None) == -3 and b"share one mode" in L.hh_last_error_string()
+    items[1].mode, items[1].N = 2, 510
+    assert L.hh_qgemm_f32x3_group(items, 2, None) == -1 and b"multiples of 4" in L.hh_last_error_string()
+    assert L.hh_sum_partials(None, None, 0, 16, None) == -1 and L.hh_sum_partials(None, None, 4, 6, None) == -1
     assert L.hh_layernorm_pos_fwd(None, 0, None, None, None, None, 0, None, 13, None, None, 10, 512, 1e-5, None) == -1
     # caller-owned workspace sizes and the timing facility need no GPU
     assert L.hh_workspace_bytes_gemm_tn(512, 2048, 3) == 3 * 512 * 2048 * 4
